@@ -1,0 +1,304 @@
+// field29.h — BN254 prime-field arithmetic for gfx950 on SIGNED 9 x 29-bit limbs.
+//
+// Why this representation (measured, tools/ubench/valu_rates.hip on MI355X):
+// v_mad_u64_u32 / v_mad_i64_i32 issue at the same rate as v_add_co_u32 / v_addc_co_u32 (~4.5 cycles
+// per wave-instruction), so on this chip the cost of a 254-bit modular multiply is its INSTRUCTION
+// COUNT, and carry-flag chains cost as much as the multiplies they serve.  With 29-bit limbs the
+// 58-bit partial products of a whole product-scanning column (9 from a*b, 9 from m*p) fit one 64-bit
+// accumulator, so a Montgomery multiply is a pure chain of 162 mads + 18 shifts + 9 (mul,and) with
+// no carry flag at all, and add / sub are 9 independent 32-bit ops (the fast VALU class) with
+// normalisation deferred.  Signed limbs make subtraction free of "add k*p" corrections.
+//
+// Value of an element: sum l[j] * 2^(29 j); Montgomery radix R' = 2^261.
+//   normalised:  l[0..7] in [0, 2^29), l[8] signed (carries the sign of the value)
+//   mul/sqr:     operands need |l_a| * |l_b| < 2^59.35 per limb pair and |a * b| < 2^261 * m (~169 m^2);
+//                result is normalised and lies in (-m, 2m)
+// The bounds each formula relies on are written next to it and are CHECKED on the host by the
+// KZG_BOUND_CHECK build (tests/test_field29_host.py), which compiles this same header with g++.
+//
+// Replaces: the ark-ff 0.5 `Fp256<MontBackend>` arithmetic the reference calls through
+// `G1Projective::msm` (prover/src/kzg.rs:100,121) and `domain.fft/ifft` (primitives/src/polynomial.rs:135,246).
+#pragma once
+#include <cstdint>
+#include "field_constants.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KZG_HD __host__ __device__ __forceinline__
+#define KZG_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define KZG_HD inline
+#define KZG_HD_NOINLINE
+#endif
+
+#if defined(KZG_BOUND_CHECK)
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#endif
+
+namespace kzg {
+
+constexpr int NL = 9;
+constexpr int LB = 29;
+constexpr uint32_t LMASK = (1u << LB) - 1u;
+
+template <class F>
+struct Fe {
+    int32_t l[NL];
+};
+
+#if defined(KZG_BOUND_CHECK)
+template <class F>
+inline long double fe_approx(const Fe<F>& a) {
+    long double v = 0;
+    for (int j = NL - 1; j >= 0; --j) v = v * 536870912.0L + (long double)a.l[j];
+    return v;
+}
+template <class F>
+inline long double fe_modulus_approx() {
+    long double v = 0;
+    for (int j = NL - 1; j >= 0; --j) v = v * 536870912.0L + (long double)F::P[j];
+    return v;
+}
+template <class F>
+inline void fe_check_mul_operands(const Fe<F>& a, const Fe<F>& b, const char* what) {
+    long double ma = 0, mb = 0;
+    for (int j = 0; j < NL; ++j) {
+        ma = fmaxl(ma, fabsl((long double)a.l[j]));
+        mb = fmaxl(mb, fabsl((long double)b.l[j]));
+    }
+    const long double lim = 7.3e17L;              // (2^63 - 9*2^58)/9 = 2^59.35 = 7.366e17
+    if (ma * mb >= lim) { fprintf(stderr, "KZG_BOUND_CHECK: %s limb bound violated: %Lg * %Lg\n", what, ma, mb); abort(); }
+    long double m = fe_modulus_approx<F>();
+    long double prod = fabsl(fe_approx(a)) * fabsl(fe_approx(b));
+    if (prod >= ldexpl(1.0L, 261) * m) { fprintf(stderr, "KZG_BOUND_CHECK: %s value bound violated: |a*b| / (R m) = %Lg\n", what, prod / (ldexpl(1.0L, 261) * m)); abort(); }
+}
+#define KZG_CHECK_MUL(a, b, what) fe_check_mul_operands(a, b, what)
+#else
+#define KZG_CHECK_MUL(a, b, what) ((void)0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Montgomery product a * b * 2^-261 mod m.  Finely-integrated product scanning: column k sums
+// a_j b_(k-j) and m_j p_(k-j); its low 29 bits are cancelled by m_k p_0; the rest carries on.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+KZG_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
+    KZG_CHECK_MUL(a, b, "fe_mul");
+    int64_t acc = 0;
+    int32_t m[NL];
+    int32_t out[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+#pragma unroll
+        for (int j = 0; j <= k; ++j) acc += (int64_t)a.l[j] * (int64_t)b.l[k - j];
+#pragma unroll
+        for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
+        acc += (int64_t)m[k] * (int64_t)(int32_t)F::P[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)a.l[j] * (int64_t)b.l[k - j];
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        acc >>= LB;
+    }
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = out[j];
+}
+
+// Montgomery square: the symmetric products are taken once against the doubled limb.
+template <class F>
+KZG_HD void fe_sqr(Fe<F>& r, const Fe<F>& a) {
+    KZG_CHECK_MUL(a, a, "fe_sqr");
+    int64_t acc = 0;
+    int32_t m[NL];
+    int32_t out[NL];
+    int32_t a2[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) a2[j] = a.l[j] * 2;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+#pragma unroll
+        for (int j = 0; 2 * j < k; ++j) acc += (int64_t)a2[j] * (int64_t)a.l[k - j];
+        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * (int64_t)a.l[k / 2];
+#pragma unroll
+        for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
+        acc += (int64_t)m[k] * (int64_t)(int32_t)F::P[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+        for (int j = k - NL + 1; 2 * j < k; ++j) acc += (int64_t)a2[j] * (int64_t)a.l[k - j];
+        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * (int64_t)a.l[k / 2];
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        acc >>= LB;
+    }
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = out[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lazy limb-wise add / sub / neg / small multiples (no carry, no reduction), normalisation.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+KZG_HD void fe_add(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = a.l[j] + b.l[j];
+}
+template <class F>
+KZG_HD void fe_sub(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = a.l[j] - b.l[j];
+}
+template <class F>
+KZG_HD void fe_neg(Fe<F>& r, const Fe<F>& a) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = -a.l[j];
+}
+// r = neg ? -a : a   (neg is 0 / 1)
+template <class F>
+KZG_HD void fe_cneg(Fe<F>& r, const Fe<F>& a, uint32_t neg) {
+    int32_t s = -(int32_t)neg;                 // 0 or -1
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = (a.l[j] ^ s) - s;
+}
+template <class F>
+KZG_HD void fe_dbl(Fe<F>& r, const Fe<F>& a) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = a.l[j] * 2;
+}
+template <class F>
+KZG_HD void fe_set_zero(Fe<F>& r) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = 0;
+}
+template <class F>
+KZG_HD void fe_set_one(Fe<F>& r) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = (int32_t)F::ONE[j];
+}
+template <class F>
+KZG_HD void fe_select(Fe<F>& r, bool c, const Fe<F>& a, const Fe<F>& b) {   // r = c ? a : b
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = c ? a.l[j] : b.l[j];
+}
+// Signed carry propagation: limbs 0..7 -> [0, 2^29), limb 8 keeps the sign.  Value unchanged.
+template <class F>
+KZG_HD void fe_norm(Fe<F>& a) {
+#pragma unroll
+    for (int j = 0; j < NL - 1; ++j) {
+        int32_t c = a.l[j] >> LB;
+        a.l[j] &= (int32_t)LMASK;
+        a.l[j + 1] += c;
+    }
+}
+
+// a is a NORMALISED value in (-m, 2m) (any fe_mul / fe_sqr result): a == 0 mod m  <=>  a in {0, m}
+template <class F>
+KZG_HD bool fe_is_zero_mod(const Fe<F>& a) {
+    uint32_t z0 = 0, zp = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        z0 |= (uint32_t)a.l[j];
+        zp |= (uint32_t)a.l[j] ^ F::P[j];
+    }
+    return (z0 == 0) | (zp == 0);
+}
+template <class F>
+KZG_HD bool fe_is_literal_zero(const Fe<F>& a) {
+    uint32_t z0 = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) z0 |= (uint32_t)a.l[j];
+    return z0 == 0;
+}
+
+// normalised a in (-m, 2m)  ->  canonical [0, m)
+template <class F>
+KZG_HD void fe_canon(Fe<F>& a) {
+    Fe<F> t;
+    bool neg = a.l[NL - 1] < 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) t.l[j] = a.l[j] + (neg ? (int32_t)F::P[j] : 0);
+    fe_norm(t);
+    Fe<F> u;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) u.l[j] = t.l[j] - (int32_t)F::P[j];
+    fe_norm(u);
+    bool ge = u.l[NL - 1] >= 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) a.l[j] = ge ? u.l[j] : t.l[j];
+}
+
+// any lazy value with |a| < 169 m  ->  normalised representative in (-m, 2m)  (mont_mul by R' mod m)
+template <class F>
+KZG_HD void fe_reduce(Fe<F>& a) {
+    Fe<F> one;
+    fe_set_one(one);
+    fe_norm(a);
+    fe_mul(a, a, one);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 256-bit words <-> limbs.  w[8] little-endian u32 words of a non-negative integer < 2^256.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+KZG_HD void fe_unpack(Fe<F>& r, const uint32_t w[8]) {
+    r.l[0] = (int32_t)(w[0] & LMASK);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) r.l[j] = (int32_t)(((w[j - 1] >> (32 - 3 * j)) | (w[j] << (3 * j))) & LMASK);
+    r.l[8] = (int32_t)(w[7] >> 8);
+}
+// a canonical (limbs in [0, 2^29), value < 2^256)
+template <class F>
+KZG_HD void fe_pack(uint32_t w[8], const Fe<F>& a) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = ((uint32_t)a.l[k] >> (3 * k)) | ((uint32_t)a.l[k + 1] << (29 - 3 * k));
+}
+
+// wire (arkworks Montgomery, a * 2^256 mod m, canonical) -> internal (a * 2^261), result in (-m, 2m)
+template <class F>
+KZG_HD void fe_from_wire(Fe<F>& r, const uint32_t w[8]) {
+    Fe<F> t, k;
+    fe_unpack(t, w);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) k.l[j] = (int32_t)F::K_IN[j];
+    fe_mul(r, t, k);
+}
+// internal (normalised, |a| < 169 m) -> wire words (canonical)
+template <class F>
+KZG_HD void fe_to_wire(uint32_t w[8], const Fe<F>& a) {
+    Fe<F> t, k;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) k.l[j] = (int32_t)F::K_OUT[j];
+    fe_mul(t, a, k);
+    fe_canon(t);
+    fe_pack(w, t);
+}
+// wire -> canonical integer words (the `into_bigint()` of the reference's scalars)
+template <class F>
+KZG_HD void fe_wire_to_canonical_words(uint32_t out[8], const uint32_t w[8]) {
+    Fe<F> t, k;
+    fe_unpack(t, w);
+    fe_set_zero(k);
+    k.l[0] = 32;                                  // a*2^256 * 2^5 * 2^-261 = a
+    fe_mul(t, t, k);
+    fe_canon(t);
+    fe_pack(out, t);
+}
+
+using Fq = Fe<FqParams>;
+using Fr = Fe<FrParams>;
+
+}  // namespace kzg

@@ -1,0 +1,189 @@
+"""CPU check of the PRODUCT's device math headers (rust-kzg-bn254_amd/csrc/field29.h, curve.h).
+
+tests/hostcheck/hostcheck.cpp compiles those headers with g++ and -DKZG_BOUND_CHECK, which turns every
+lazy-reduction bound the formulas rely on (limb magnitude and |a*b| < 2^261 m) into an abort().  The
+results are compared bit for bit with the oracle.  This is a sanitizer-style build of the device math,
+not a CPU fallback: nothing in the product loads libhostcheck.so.
+"""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import pyref
+from pyref import P, R_
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+SO = os.path.join(HERE, "hostcheck", "libhostcheck.so")
+CSRC = os.path.join(ROOT, "rust-kzg-bn254_amd", "csrc")
+
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("field29.h", "curve.h", "field_constants.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DKZG_BOUND_CHECK", "-Wno-unknown-pragmas", "-fPIC",
+                               "-shared", "-I" + CSRC, "-o", SO, SRC])
+    return C.CDLL(SO)
+
+
+def w32(limbs64):
+    return np.ascontiguousarray(limbs64, dtype=np.uint64).view(np.uint32).copy()
+
+
+def _mul(hc, which, a, b, square=False):
+    a32, b32 = w32(a), w32(b)
+    out = np.zeros(8, np.uint32)
+    hc.hc_mul(which, a32.ctypes.data_as(u32p), b32.ctypes.data_as(u32p), out.ctypes.data_as(u32p), int(square))
+    return out.view(np.uint64)
+
+
+def test_field_constants_header_is_current():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_field_constants", os.path.join(ROOT, "tools", "gen_field_constants.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.limbs29(P) == [0x187cfd47, 0x010460b6, 0x1c72a34f, 0x02d522d0, 0x1585d978, 0x02db40c0, 0x00a6e141, 0x0e5c2634, 0x0030644e]
+    hdr = open(os.path.join(CSRC, "field_constants.h")).read()
+    for m in (P, R_):
+        inv = (-pow(m, -1, 1 << 29)) % (1 << 29)
+        assert f"INV = 0x{inv:08x}u" in hdr
+        for v in ((1 << 261) % m, (1 << 266) % m, (1 << 256) % m):
+            assert ", ".join(f"0x{x:08x}u" for x in mod.limbs29(v)) in hdr
+
+
+@pytest.mark.parametrize("which,mod", [(0, P), (1, R_)])
+def test_mul_sqr_vs_oracle(hc, which, mod):
+    rnd = random.Random(which)
+    vals = [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2, (1 << 253) % mod, (1 << 29) - 1, 1 << 29, (1 << 232) - 1]
+    vals += [rnd.randrange(mod) for _ in range(300)]
+    for i in range(len(vals)):
+        a = vals[i]; b = vals[(i * 7 + 3) % len(vals)]
+        am, bm = pyref.to_limbs(a * (1 << 256) % mod), pyref.to_limbs(b * (1 << 256) % mod)
+        got = _mul(hc, which, am, bm)
+        assert np.array_equal(got, orc.f_mul(which, am, bm)), (a, b)
+        assert np.array_equal(_mul(hc, which, am, am, square=True), orc.f_mul(which, am, am)), a
+
+
+@pytest.mark.parametrize("which,mod", [(0, P), (1, R_)])
+def test_lazy_signed_chain(hc, which, mod):
+    rnd = random.Random(10 + which)
+    cases = [(0, 0), (0, mod - 1), (mod - 1, 0), (mod - 1, mod - 1), (1, mod - 1)]
+    cases += [(rnd.randrange(mod), rnd.randrange(mod)) for _ in range(200)]
+    for a, b in cases:
+        am, bm = w32(pyref.to_limbs(a * (1 << 256) % mod)), w32(pyref.to_limbs(b * (1 << 256) % mod))
+        out = np.zeros(8, np.uint32)
+        hc.hc_lazy(which, am.ctypes.data_as(u32p), bm.ctypes.data_as(u32p), out.ctypes.data_as(u32p))
+        want = (2 * (a - b) - b) * (2 * a - b) % mod
+        assert pyref.from_limbs(out.view(np.uint64)) == want * (1 << 256) % mod
+
+
+def test_wire_to_canonical(hc):
+    rnd = random.Random(5)
+    for which, mod in ((0, P), (1, R_)):
+        for a in [0, 1, mod - 1] + [rnd.randrange(mod) for _ in range(50)]:
+            am = w32(pyref.to_limbs(a * (1 << 256) % mod)); out = np.zeros(8, np.uint32)
+            hc.hc_wire_to_canonical(which, am.ctypes.data_as(u32p), out.ctypes.data_as(u32p))
+            assert pyref.from_limbs(out.view(np.uint64)) == a
+
+
+def _xyzz_to_affine(out32):
+    """X, Y, ZZ, ZZZ wire -> affine python ints (None = identity)."""
+    w = out32.view(np.uint64).reshape(4, 4)
+    X, Y, ZZ, ZZZ = (pyref.fq_from_mont(w[i]) for i in range(4))
+    if ZZ == 0:
+        return None
+    assert pow(ZZ, 3, P) == pow(ZZZ, 2, P)
+    return (X * pow(ZZ, -1, P) % P, Y * pow(ZZZ, -1, P) % P)
+
+
+def _chain(hc, pts, signs):
+    wire = pyref.points_to_wire(pts).view(np.uint32).copy()
+    sg = np.array(signs, dtype=np.uint8)
+    out = np.zeros(32, np.uint32)
+    hc.hc_madd_chain(wire.ctypes.data_as(u32p), sg.ctypes.data_as(u8p), C.c_size_t(len(pts)), out.ctypes.data_as(u32p))
+    return _xyzz_to_affine(out)
+
+
+def _ref_sum(pts, signs):
+    acc = None
+    for p, s in zip(pts, signs):
+        acc = pyref.ec_add(acc, pyref.ec_neg(p) if s else p)
+    return acc
+
+
+def test_madd_chain_random_and_exceptional(hc, test_srs_points):
+    rnd = random.Random(11)
+    pts = test_srs_points[:200]
+    signs = [rnd.randrange(2) for _ in pts]
+    assert _chain(hc, pts, signs) == _ref_sum(pts, signs)
+    # long chain keeps the stored-form bounds (bound check aborts otherwise)
+    long_pts = [test_srs_points[rnd.randrange(3000)] for _ in range(3000)]
+    long_s = [rnd.randrange(2) for _ in long_pts]
+    assert _chain(hc, long_pts, long_s) == _ref_sum(long_pts, long_s)
+    a, b = test_srs_points[5], test_srs_points[9]
+    # P + P (doubling through the exceptional path), then more adds
+    assert _chain(hc, [a, a], [0, 0]) == pyref.ec_mul(2, a)
+    assert _chain(hc, [a, a, a, b], [0, 0, 0, 1]) == pyref.ec_add(pyref.ec_mul(3, a), pyref.ec_neg(b))
+    assert _chain(hc, [a, b, pyref.ec_add(a, b)], [0, 0, 0]) == pyref.ec_mul(2, pyref.ec_add(a, b))
+    # P + (-P) -> identity, then continue from the identity
+    assert _chain(hc, [a, a], [0, 1]) is None
+    assert _chain(hc, [a, a, b], [0, 1, 0]) == b
+    assert _chain(hc, [a, pyref.ec_neg(a)], [0, 0]) is None
+    # identity bases are skipped
+    assert _chain(hc, [None, a, None], [0, 0, 1]) == a
+    assert _chain(hc, [], []) is None
+    # same point many times: 1P, 2P (dbl), 3P, ...
+    assert _chain(hc, [a] * 17, [0] * 17) == pyref.ec_mul(17, a)
+    assert _chain(hc, [a] * 17, [1] * 17) == pyref.ec_mul(R_ - 17, a)
+
+
+def test_full_add_doubling_and_memory_format(hc, test_srs_points):
+    rnd = random.Random(12)
+    for trial in range(6):
+        n = [2, 3, 10, 64, 65, 200][trial]
+        pts = [test_srs_points[rnd.randrange(3000)] for _ in range(n)]
+        signs = [rnd.randrange(2) for _ in pts]
+        wire = pyref.points_to_wire(pts).view(np.uint32).copy(); sg = np.array(signs, dtype=np.uint8)
+        for dbl in (0, 1, 5):
+            out = np.zeros(32, np.uint32)
+            hc.hc_add_halves(wire.ctypes.data_as(u32p), sg.ctypes.data_as(u8p), C.c_size_t(n), dbl, out.ctypes.data_as(u32p))
+            assert _xyzz_to_affine(out) == pyref.ec_mul(1 << dbl, _ref_sum(pts, signs))
+    # a + a through the full add (exceptional -> xyzz_dbl), a + (-a) -> identity
+    a = test_srs_points[77]
+    for pts, signs, want in (([a, a], [0, 0], pyref.ec_mul(2, a)), ([a, a], [0, 1], None)):
+        wire = pyref.points_to_wire(pts).view(np.uint32).copy(); sg = np.array(signs, dtype=np.uint8)
+        out = np.zeros(32, np.uint32)
+        hc.hc_add_halves(wire.ctypes.data_as(u32p), sg.ctypes.data_as(u8p), C.c_size_t(2), 0, out.ctypes.data_as(u32p))
+        assert _xyzz_to_affine(out) == want
+
+
+def test_running_sum_shape(hc, test_srs_points):
+    pts = test_srs_points[100:140] + [None, test_srs_points[3], None]
+    wire = pyref.points_to_wire(pts).view(np.uint32).copy()
+    out = np.zeros(32, np.uint32)
+    hc.hc_running_sum(wire.ctypes.data_as(u32p), C.c_size_t(len(pts)), out.ctypes.data_as(u32p))
+    want = None
+    for k, p in enumerate(pts):
+        want = pyref.ec_add(want, pyref.ec_mul(k + 1, p))
+    assert _xyzz_to_affine(out) == want
+
+
+def test_affine_wire_to_device_format(hc, test_srs_points):
+    pt = test_srs_points[42]
+    wire = pyref.point_to_wire(pt).view(np.uint32).copy(); out = np.zeros(16, np.uint32)
+    hc.hc_affine_wire_to_device(wire.ctypes.data_as(u32p), out.ctypes.data_as(u32p))
+    got = out.view(np.uint64).reshape(2, 4)
+    assert pyref.from_limbs(got[0]) == pt[0] * (1 << 261) % P
+    assert pyref.from_limbs(got[1]) == pt[1] * (1 << 261) % P
+    zero = np.zeros(16, np.uint32); out[:] = 1
+    hc.hc_affine_wire_to_device(zero.ctypes.data_as(u32p), out.ctypes.data_as(u32p))
+    assert not out.any()
