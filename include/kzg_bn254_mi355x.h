@@ -1,0 +1,131 @@
+/*
+ * kzg_bn254_mi355x.h — C-ABI of the MI355X-native KZG-BN254 prover hot path.
+ *
+ * Drop-in boundary for Layr-Labs/rust-kzg-bn254: the reference has no FFI seam of its own; its hot
+ * path is five calls into arkworks 0.5.  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference).  INTEGRATION.md shows the Rust
+ * `extern "C"` binding a maintainer would add.
+ *
+ * Wire format (zero-copy from Rust):
+ *   Fr / Fq      4 x u64 little-endian limbs, Montgomery form a * 2^256 mod m, canonical (< m) —
+ *                arkworks' in-memory `Fp256<MontBackend<_, 4>>` (`fr.0.0`, cf. primitives/src/helpers.rs:158)
+ *   G1 affine    8 x u64 = x[4] || y[4]; the identity is all-zero (the coordinates arkworks'
+ *                `G1Affine::identity()` carries) and is also reported through `out_is_infinity`
+ *   G1 partial   16 x u64 = X || Y || ZZ || ZZZ (extended Jacobian, x = X/ZZ, y = Y/ZZZ; identity: ZZ = 0)
+ *
+ * All pointers are caller-owned; the library never frees caller memory.  Functions return a
+ * kzg_status (0 = OK, < 0 = error mirroring a `KzgError` variant, primitives/src/errors.rs:32-86).
+ * A context is bound to one GPU; calls on one context are serialised internally, different
+ * contexts may be used concurrently from different threads.  There is NO CPU fallback: without a
+ * usable HIP device kzg_ctx_create fails with KZG_ERR_NO_DEVICE.
+ */
+#ifndef KZG_BN254_MI355X_H
+#define KZG_BN254_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kzg_ctx kzg_ctx;
+typedef struct kzg_srs kzg_srs;
+
+typedef enum {
+    KZG_OK = 0,
+    KZG_ERR_INVALID_ARG = -1,            /* null pointer / bad size */
+    KZG_ERR_NO_DEVICE = -2,              /* no HIP device: the product never falls back to the CPU */
+    KZG_ERR_DEVICE = -3,                 /* HIP runtime error, text in kzg_ctx_last_error */
+    KZG_ERR_MSM_LENGTH_MISMATCH = -4,    /* arkworks msm Err(min_len) -> KzgError::MsmError / CommitError (helpers.rs:332, kzg.rs:102,123) */
+    KZG_ERR_SRS_CAPACITY_EXCEEDED = -5,  /* KzgError::SrsCapacityExceeded (kzg.rs:89-94) */
+    KZG_ERR_POLY_LENGTH = -6,            /* SerializationError("polynomial length is not correct") (kzg.rs:112-116) */
+    KZG_ERR_NOT_POWER_OF_TWO = -7,       /* FFTError("length provided is not a power of 2") (kzg.rs:265-269) */
+    KZG_ERR_DOMAIN = -8,                 /* domain construction failed: n > 2^28 (polynomial.rs:132-134, kzg.rs:276-278) */
+    KZG_ERR_ROOTS_LENGTH = -9,           /* GenericError("inconsistent length between blob and root of unities") (kzg.rs:135-139,222-226) */
+    KZG_ERR_INVALID_INPUT_LENGTH = -10,  /* KzgError::InvalidInputLength (helpers.rs:485-487) */
+    KZG_ERR_TOO_LARGE = -11,             /* GenericError("Input size exceeds maximum polynomial size") (polynomial.rs:42-46) */
+    KZG_ERR_ROOT_NOT_FOUND = -12,        /* GenericError("Root of unity not found") (kzg.rs:199-201) */
+    KZG_ERR_ZERO_LENGTH = -13,           /* GenericError("Length of data after padding is 0") (helpers.rs:554-558) */
+    KZG_ERR_SRS_LENGTH = -14             /* GenericError("the length of data after padding is not valid with respect to the SRS") (helpers.rs:560-566) */
+} kzg_status;
+
+/* The reference's error string for a status (Appendix B of SURVEY.md). */
+const char* kzg_status_message(int32_t status);
+
+/* ---- context -------------------------------------------------------------------------------- */
+int32_t kzg_device_count(void);
+int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out);
+void    kzg_ctx_destroy(kzg_ctx* ctx);
+const char* kzg_ctx_last_error(const kzg_ctx* ctx);
+/* Tunables (0 = automatic): MSM window bits c in [2,16]; accumulate segment length. */
+int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len);
+
+/* ---- SRS: device-resident monomial G1 powers -------------------------------------------------- */
+/* Replaces holding `SRS.g1: Cow<[G1Affine]>` (prover/src/srs.rs:11-21) on the host and copying
+ * `srs.g1[..n].to_vec()` on every commit (kzg.rs:119).  n points, 8 u64 each.  Uploaded once. */
+int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);
+/* Test / bench utility (no counterpart in the reference, which loads ceremony files): synthetic SRS with a
+ * KNOWN tau, P_i = tau^i * G1, generated on the device; and read-back of a resident SRS in wire format. */
+int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], size_t n_points, kzg_srs** out);
+int32_t kzg_srs_download(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, size_t n, uint64_t* out_xy_mont);
+void    kzg_srs_free(kzg_srs* srs);
+size_t  kzg_srs_len(const kzg_srs* srs);
+
+/* ---- arkworks boundary 1: <G1Projective as VariableBaseMSM>::msm(bases, scalars).into_affine() -- */
+/* Call sites: prover/src/kzg.rs:100, :121; primitives/src/helpers.rs:332 (g1_lincomb).
+ * n_bases != n_scalars -> KZG_ERR_MSM_LENGTH_MISMATCH (arkworks returns Err(min_len)). */
+int32_t kzg_msm_g1(kzg_ctx* ctx, const uint64_t* bases_xy_mont, size_t n_bases,
+                   const uint64_t* scalars_mont, size_t n_scalars,
+                   uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* Same with bases = srs[offset .. offset + n) already resident (commit path). */
+int32_t kzg_msm_g1_srs(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
+                       const uint64_t* scalars_mont, size_t n,
+                       uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* Scalars already in device memory (d_scalars_mont: device pointer to n x 4 u64). */
+int32_t kzg_msm_g1_srs_device(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
+                              const void* d_scalars_mont, size_t n,
+                              uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* Multi-GPU sharding: partial sum of one shard, not converted to affine (16 u64 XYZZ). */
+int32_t kzg_msm_g1_srs_partial_device(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
+                                      const void* d_scalars_mont, size_t n, uint64_t out_xyzz_mont[16]);
+int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
+                               const uint64_t* scalars_mont, size_t n, uint64_t out_xyzz_mont[16]);
+/* Fold `count` gathered partial sums (count x 16 u64) and convert to affine.  Host-only, O(count). */
+int32_t kzg_g1_fold_partials(const uint64_t* partials_xyzz_mont, size_t count,
+                             uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+
+/* ---- arkworks boundary 2: GeneralEvaluationDomain::<Fr>::new(n).{fft,ifft}(&[Fr]) --------------- */
+/* Call sites: primitives/src/polynomial.rs:131-135 (ifft), :242-246 (fft).  Natural order in and out,
+ * omega = 5^((r-1)/n); the inverse transform includes the n^-1 scaling.  In place.
+ * n not a power of two -> KZG_ERR_NOT_POWER_OF_TWO; n > 2^28 -> KZG_ERR_DOMAIN. */
+int32_t kzg_fr_ntt(kzg_ctx* ctx, uint64_t* data_mont, size_t n, int32_t inverse);
+int32_t kzg_fr_ntt_device(kzg_ctx* ctx, void* d_data_mont, size_t n, int32_t inverse);
+
+/* ---- KZG surface (prover/src/kzg.rs) ----------------------------------------------------------- */
+/* KZG::commit_coeff_form (kzg.rs:107-125): n > srs len -> KZG_ERR_POLY_LENGTH. */
+int32_t kzg_commit_coeff_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* coeffs_mont, size_t n,
+                              uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* KZG::commit_eval_form (kzg.rs:84-104): n > srs len -> KZG_ERR_SRS_CAPACITY_EXCEEDED; n not a power of
+ * two -> KZG_ERR_NOT_POWER_OF_TWO.  Computed as MSM(srs, IFFT(evals)), identical to the reference's
+ * MSM(g1_ifft(srs), evals) (prover/src/lib.rs:43-47; prover/tests/kzg_test.rs:57-89). */
+int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
+                             uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* KZG::compute_proof / compute_proof_impl (kzg.rs:128-178, :215-234, on-domain branch :237-260).
+ * roots = KZG::expanded_roots_of_unity (n_roots entries); n != n_roots -> KZG_ERR_ROOTS_LENGTH.
+ * out_y (optional, 4 u64) receives y = p(z) (helpers.rs:475-535). */
+int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
+                          const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4],
+                          uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont);
+/* helpers::evaluate_polynomial_in_evaluation_form (helpers.rs:475-535) on the domain of size n. */
+int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t* evals_mont, size_t n,
+                                                   const uint64_t z_mont[4], uint64_t out_y_mont[4]);
+/* helpers::calculate_roots_of_unity (helpers.rs:553-589): out receives next_pow2(ceil(len/32)) elements
+ * (capacity `cap` elements); *n_out = count. */
+int32_t kzg_calculate_roots_of_unity(kzg_ctx* ctx, uint64_t length_of_data_after_padding,
+                                     uint64_t* out_mont, size_t cap, size_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

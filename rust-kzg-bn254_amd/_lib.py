@@ -1,0 +1,148 @@
+"""ctypes binding of libkzg_bn254_mi355x.so — the C-ABI declared in include/kzg_bn254_mi355x.h.
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).  If it is
+missing, or no HIP device is usable, every operation FAILS LOUDLY (DeviceError): there is no CPU
+fallback and nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .errors import DeviceError
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkzg_bn254_mi355x.so")
+
+# status codes (include/kzg_bn254_mi355x.h)
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_NO_DEVICE = -2
+ERR_DEVICE = -3
+ERR_MSM_LENGTH_MISMATCH = -4
+ERR_SRS_CAPACITY_EXCEEDED = -5
+ERR_POLY_LENGTH = -6
+ERR_NOT_POWER_OF_TWO = -7
+ERR_DOMAIN = -8
+ERR_ROOTS_LENGTH = -9
+ERR_INVALID_INPUT_LENGTH = -10
+ERR_TOO_LARGE = -11
+ERR_ROOT_NOT_FOUND = -12
+ERR_ZERO_LENGTH = -13
+ERR_SRS_LENGTH = -14
+
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+sz = C.c_size_t
+i32 = C.c_int32
+
+# name -> (restype, argtypes); every symbol include/kzg_bn254_mi355x.h declares
+PROTOTYPES = {
+    "kzg_status_message": (C.c_char_p, [i32]),
+    "kzg_device_count": (i32, []),
+    "kzg_ctx_create": (i32, [i32, C.POINTER(vp)]),
+    "kzg_ctx_destroy": (None, [vp]),
+    "kzg_ctx_last_error": (C.c_char_p, [vp]),
+    "kzg_ctx_set_msm_window": (i32, [vp, i32, i32]),
+    "kzg_srs_upload": (i32, [vp, u64p, sz, C.POINTER(vp)]),
+    "kzg_srs_generate": (i32, [vp, u64p, sz, C.POINTER(vp)]),
+    "kzg_srs_download": (i32, [vp, vp, sz, sz, u64p]),
+    "kzg_srs_free": (None, [vp]),
+    "kzg_srs_len": (sz, [vp]),
+    "kzg_msm_g1": (i32, [vp, u64p, sz, u64p, sz, u64p, u8p]),
+    "kzg_msm_g1_srs": (i32, [vp, vp, sz, u64p, sz, u64p, u8p]),
+    "kzg_msm_g1_srs_device": (i32, [vp, vp, sz, vp, sz, u64p, u8p]),
+    "kzg_msm_g1_srs_partial_device": (i32, [vp, vp, sz, vp, sz, u64p]),
+    "kzg_msm_g1_srs_partial": (i32, [vp, vp, sz, u64p, sz, u64p]),
+    "kzg_g1_fold_partials": (i32, [u64p, sz, u64p, u8p]),
+    "kzg_fr_ntt": (i32, [vp, u64p, sz, i32]),
+    "kzg_fr_ntt_device": (i32, [vp, vp, sz, i32]),
+    "kzg_commit_coeff_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
+    "kzg_commit_eval_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
+    "kzg_compute_proof": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, u64p, u8p, u64p]),
+    "kzg_evaluate_polynomial_in_evaluation_form": (i32, [vp, u64p, sz, u64p, u64p]),
+    "kzg_calculate_roots_of_unity": (i32, [vp, C.c_uint64, u64p, sz, C.POINTER(sz)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DeviceError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950). No CPU fallback exists.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def status_message(status: int) -> str:
+    return load().kzg_status_message(status).decode()
+
+
+def as_u64(a, cols):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1 and cols and a.size % cols == 0:
+        a = a.reshape(-1, cols)
+    return a
+
+
+def ptr(a):
+    return a.ctypes.data_as(u64p)
+
+
+class Context:
+    """One GPU.  `kzg_ctx` of the C-ABI."""
+
+    def __init__(self, device_id=0):
+        lib = load()
+        h = vp()
+        rc = lib.kzg_ctx_create(device_id, C.byref(h))
+        if rc != OK:
+            raise DeviceError(f"kzg_ctx_create(device {device_id}) failed: {status_message(rc)}")
+        self.handle = h
+        self.device_id = device_id
+
+    def last_error(self):
+        return load().kzg_ctx_last_error(self.handle).decode()
+
+    def check_device(self, rc):
+        if rc in (ERR_DEVICE, ERR_NO_DEVICE):
+            raise DeviceError(f"{status_message(rc)}: {self.last_error()}")
+        if rc == ERR_INVALID_ARG:
+            raise ValueError("invalid argument passed to the C-ABI")
+
+    def set_msm_window(self, c_bits=0, segment_len=0):
+        rc = load().kzg_ctx_set_msm_window(self.handle, c_bits, segment_len)
+        if rc != OK:
+            raise ValueError("window bits must be 0 (auto) or in [2,16]")
+
+    def close(self):
+        if self.handle:
+            load().kzg_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=None):
+    """Process-wide context for `device_id` (default: LOCAL_RANK or 0)."""
+    if device_id is None:
+        device_id = int(os.environ.get("KZG_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device_id not in _default_ctx:
+        _default_ctx[device_id] = Context(device_id)
+    return _default_ctx[device_id]

@@ -1,0 +1,327 @@
+// capi.hip — the C-ABI of include/kzg_bn254_mi355x.h.  Plain pointers and sizes only.
+#include "engine.h"
+#include "host_curve.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace kzg {
+
+int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where) {
+    if (ctx) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s: %s", where, hipGetErrorString(e));
+        ctx->last_error = buf;
+    }
+    (void)hipGetLastError();
+    return KZG_ERR_DEVICE;
+}
+
+// polynomial pipeline (poly.hip)
+int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
+                  uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof);
+int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
+
+}  // namespace kzg
+
+using namespace kzg;
+
+extern "C" {
+
+const char* kzg_status_message(int32_t status) {
+    switch (status) {
+        case KZG_OK: return "ok";
+        case KZG_ERR_INVALID_ARG: return "invalid argument";
+        case KZG_ERR_NO_DEVICE: return "no HIP device available (this library has no CPU fallback)";
+        case KZG_ERR_DEVICE: return "HIP runtime error";
+        case KZG_ERR_MSM_LENGTH_MISMATCH: return "MSM Error: bases and scalars have different lengths";
+        case KZG_ERR_SRS_CAPACITY_EXCEEDED: return "SRS capacity exceeded";
+        case KZG_ERR_POLY_LENGTH: return "polynomial length is not correct";
+        case KZG_ERR_NOT_POWER_OF_TWO: return "length provided is not a power of 2";
+        case KZG_ERR_DOMAIN: return "Could not perform IFFT due to domain consturction error";
+        case KZG_ERR_ROOTS_LENGTH: return "inconsistent length between blob and root of unities";
+        case KZG_ERR_INVALID_INPUT_LENGTH: return "Invalid input length";
+        case KZG_ERR_TOO_LARGE: return "Input size exceeds maximum polynomial size";
+        case KZG_ERR_ROOT_NOT_FOUND: return "Root of unity not found";
+        case KZG_ERR_ZERO_LENGTH: return "Length of data after padding is 0";
+        case KZG_ERR_SRS_LENGTH: return "the length of data after padding is not valid with respect to the SRS";
+        default: return "unknown status";
+    }
+}
+
+int32_t kzg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out) {
+    if (!out) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = kzg_device_count();
+    if (n <= 0 || device_id < 0 || device_id >= n) return KZG_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) { (void)hipGetLastError(); return KZG_ERR_NO_DEVICE; }
+    kzg_ctx* ctx = new (std::nothrow) kzg_ctx();
+    if (!ctx) return KZG_ERR_INVALID_ARG;
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete ctx; return KZG_ERR_DEVICE; }
+    *out = ctx;
+    return KZG_OK;
+}
+
+void kzg_ctx_destroy(kzg_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->msm.release();
+    ctx->ntt.release();
+    ctx->poly_a.release(); ctx->poly_b.release(); ctx->poly_c.release(); ctx->poly_small.release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* kzg_ctx_last_error(const kzg_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len) {
+    if (!ctx || c_bits < 0 || c_bits > 16 || c_bits == 1 || segment_len < 0) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->msm_c_override = c_bits;
+    ctx->msm_seg_override = segment_len;
+    return KZG_OK;
+}
+
+// ---- SRS ------------------------------------------------------------------------------------------
+static int32_t upload_points(kzg_ctx* ctx, const uint64_t* xy, size_t n, uint4* d_out, DeviceBuffer& staging) {
+    KZG_HIP_TRY(ctx, staging.reserve(n * 64));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(staging.p, xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = points_wire_to_device(ctx, staging.as<uint4>(), d_out, n);
+    if (rc != KZG_OK) return rc;
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out) {
+    if (!ctx || !out || (!g1_xy_mont && n_points)) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_points > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    kzg_srs* s = new (std::nothrow) kzg_srs();
+    if (!s) return KZG_ERR_INVALID_ARG;
+    s->ctx = ctx;
+    s->n = n_points;
+    if (n_points) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
+        if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
+        int32_t rc = upload_points(ctx, g1_xy_mont, n_points, s->d_points, ctx->msm.bases_wire);
+        if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
+    }
+    *out = s;
+    return KZG_OK;
+}
+
+int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], size_t n_points, kzg_srs** out) {
+    if (!ctx || !out || !tau_mont) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_points > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    kzg_srs* s = new (std::nothrow) kzg_srs();
+    if (!s) return KZG_ERR_INVALID_ARG;
+    s->ctx = ctx;
+    s->n = n_points;
+    if (n_points) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
+        if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
+        int32_t rc = srs_generate(ctx, tau_mont, n_points, s->d_points);
+        if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
+    }
+    *out = s;
+    return KZG_OK;
+}
+
+int32_t kzg_srs_download(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, size_t n, uint64_t* out_xy_mont) {
+    if (!ctx || !srs || srs->ctx != ctx || (n && !out_xy_mont)) return KZG_ERR_INVALID_ARG;
+    if (offset > srs->n || n > srs->n - offset) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return srs_download(ctx, srs->d_points + 4 * offset, n, out_xy_mont);
+}
+
+void kzg_srs_free(kzg_srs* srs) {
+    if (!srs) return;
+    if (srs->d_points) { (void)hipSetDevice(srs->ctx->device); (void)hipFree(srs->d_points); }
+    delete srs;
+}
+
+size_t kzg_srs_len(const kzg_srs* srs) { return srs ? srs->n : 0; }
+
+// ---- MSM ------------------------------------------------------------------------------------------
+static int32_t stage_scalars(kzg_ctx* ctx, const uint64_t* scalars, size_t n, const void** d_out) {
+    KZG_HIP_TRY(ctx, ctx->msm.scalars.reserve(n * 32 + 32));
+    if (n) KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    *d_out = ctx->msm.scalars.p;
+    return KZG_OK;
+}
+static void write_identity(uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
+    if (out_xy) memset(out_xy, 0, 64);
+    if (out_inf) *out_inf = 1;
+    if (out_xyzz) memset(out_xyzz, 0, 128);
+}
+
+int32_t kzg_msm_g1(kzg_ctx* ctx, const uint64_t* bases_xy_mont, size_t n_bases, const uint64_t* scalars_mont, size_t n_scalars,
+                   uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!ctx || !out_xy_mont) return KZG_ERR_INVALID_ARG;
+    if (n_bases != n_scalars) return KZG_ERR_MSM_LENGTH_MISMATCH;
+    if (n_bases && (!bases_xy_mont || !scalars_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n_bases == 0) { write_identity(out_xy_mont, out_is_infinity, nullptr); return KZG_OK; }
+    KZG_HIP_TRY(ctx, ctx->msm.bases.reserve(n_bases * 64));
+    int32_t rc = upload_points(ctx, bases_xy_mont, n_bases, ctx->msm.bases.as<uint4>(), ctx->msm.bases_wire);
+    if (rc != KZG_OK) return rc;
+    const void* d_scalars;
+    rc = stage_scalars(ctx, scalars_mont, n_scalars, &d_scalars);
+    if (rc != KZG_OK) return rc;
+    return msm_run(ctx, ctx->msm.bases.as<uint4>(), d_scalars, n_bases, out_xy_mont, out_is_infinity, nullptr);
+}
+
+static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
+                              uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
+    if (!ctx || !srs || srs->ctx != ctx || (!out_xy && !out_xyzz)) return KZG_ERR_INVALID_ARG;
+    if (n && !scalars) return KZG_ERR_INVALID_ARG;
+    if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) { write_identity(out_xy, out_inf, out_xyzz); return KZG_OK; }
+    const void* d_scalars = scalars;
+    if (!on_device) {
+        int32_t rc = stage_scalars(ctx, static_cast<const uint64_t*>(scalars), n, &d_scalars);
+        if (rc != KZG_OK) return rc;
+    }
+    return msm_run(ctx, srs->d_points + 4 * offset, d_scalars, n, out_xy, out_inf, out_xyzz);
+}
+
+int32_t kzg_msm_g1_srs(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const uint64_t* scalars_mont, size_t n,
+                       uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!out_xy_mont) return KZG_ERR_INVALID_ARG;
+    return msm_srs_common(ctx, srs, offset, scalars_mont, false, n, out_xy_mont, out_is_infinity, nullptr);
+}
+int32_t kzg_msm_g1_srs_device(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* d_scalars_mont, size_t n,
+                              uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!out_xy_mont) return KZG_ERR_INVALID_ARG;
+    return msm_srs_common(ctx, srs, offset, d_scalars_mont, true, n, out_xy_mont, out_is_infinity, nullptr);
+}
+int32_t kzg_msm_g1_srs_partial_device(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* d_scalars_mont, size_t n,
+                                      uint64_t out_xyzz_mont[16]) {
+    if (!out_xyzz_mont) return KZG_ERR_INVALID_ARG;
+    return msm_srs_common(ctx, srs, offset, d_scalars_mont, true, n, nullptr, nullptr, out_xyzz_mont);
+}
+int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const uint64_t* scalars_mont, size_t n,
+                               uint64_t out_xyzz_mont[16]) {
+    if (!out_xyzz_mont) return KZG_ERR_INVALID_ARG;
+    return msm_srs_common(ctx, srs, offset, scalars_mont, false, n, nullptr, nullptr, out_xyzz_mont);
+}
+
+int32_t kzg_g1_fold_partials(const uint64_t* partials_xyzz_mont, size_t count, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!out_xy_mont || (count && !partials_xyzz_mont)) return KZG_ERR_INVALID_ARG;
+    kzg_host::Xyzz acc = kzg_host::xyzz_inf();
+    for (size_t i = 0; i < count; ++i) {
+        kzg_host::Xyzz p;
+        memcpy(&p, partials_xyzz_mont + 16 * i, 128);
+        acc = kzg_host::xyzz_add(acc, p);
+    }
+    kzg_host::xyzz_to_affine(acc, out_xy_mont, out_is_infinity);
+    return KZG_OK;
+}
+
+// ---- NTT ------------------------------------------------------------------------------------------
+int32_t kzg_fr_ntt_device(kzg_ctx* ctx, void* d_data_mont, size_t n, int32_t inverse) {
+    if (!ctx || (!d_data_mont && n)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t rc = ntt_run(ctx, d_data_mont, n, inverse != 0);
+    if (rc != KZG_OK) return rc;
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+int32_t kzg_fr_ntt(kzg_ctx* ctx, uint64_t* data_mont, size_t n, int32_t inverse) {
+    if (!ctx || (!data_mont && n)) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
+    if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_a.p, data_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = ntt_run(ctx, ctx->poly_a.p, n, inverse != 0);
+    if (rc != KZG_OK) return rc;
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(data_mont, ctx->poly_a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+// ---- KZG surface ------------------------------------------------------------------------------------
+int32_t kzg_commit_coeff_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* coeffs_mont, size_t n,
+                              uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!ctx || !srs || !out_xy_mont) return KZG_ERR_INVALID_ARG;
+    if (n > srs->n) return KZG_ERR_POLY_LENGTH;                       // kzg.rs:112-116
+    return msm_srs_common(ctx, srs, 0, coeffs_mont, false, n, out_xy_mont, out_is_infinity, nullptr);
+}
+
+int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
+                             uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!ctx || !srs || srs->ctx != ctx || !out_xy_mont || (n && !evals_mont)) return KZG_ERR_INVALID_ARG;
+    if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;             // kzg.rs:89-94
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO; // kzg.rs:265-269 (g1_ifft)
+    if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = ntt_run(ctx, ctx->poly_a.p, n, true);               // coefficients = IFFT(evaluations)
+    if (rc != KZG_OK) return rc;
+    return msm_run(ctx, srs->d_points, ctx->poly_a.p, n, out_xy_mont, out_is_infinity, nullptr);
+}
+
+int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
+                          const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4],
+                          uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont) {
+    (void)roots_mont;   // KZG::expanded_roots_of_unity can only hold the canonical domain (kzg.rs:65-72): its length is what is checked
+    if (!ctx || !srs || srs->ctx != ctx || !out_xy_mont || !z_mont || (n && !evals_mont)) return KZG_ERR_INVALID_ARG;
+    if (n != n_roots) return KZG_ERR_ROOTS_LENGTH;                    // kzg.rs:135-139, :222-226
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;
+    if (n > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return proof_run(ctx, srs, evals_mont, n, z_mont, out_xy_mont, out_is_infinity, out_y_mont, true);
+}
+
+int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t* evals_mont, size_t n,
+                                                   const uint64_t z_mont[4], uint64_t out_y_mont[4]) {
+    if (!ctx || !z_mont || !out_y_mont || (n && !evals_mont)) return KZG_ERR_INVALID_ARG;
+    if (n == 0) return KZG_ERR_ZERO_LENGTH;
+    if ((n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;      // helpers.rs:485-487
+    if (n > ((size_t)1 << 28)) return KZG_ERR_SRS_LENGTH;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return proof_run(ctx, nullptr, evals_mont, n, z_mont, nullptr, nullptr, out_y_mont, false);
+}
+
+int32_t kzg_calculate_roots_of_unity(kzg_ctx* ctx, uint64_t length_of_data_after_padding, uint64_t* out_mont, size_t cap, size_t* n_out) {
+    if (!ctx || !n_out) return KZG_ERR_INVALID_ARG;
+    if (length_of_data_after_padding == 0) return KZG_ERR_ZERO_LENGTH;                  // helpers.rs:554-558
+    uint64_t elems = (length_of_data_after_padding + 31) / 32;
+    if (elems > ((uint64_t)1 << 28)) return KZG_ERR_SRS_LENGTH;                          // helpers.rs:560-566
+    size_t n = 1;
+    while (n < elems) n <<= 1;
+    *n_out = n;
+    if (!out_mont || cap < n) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return roots_run(ctx, out_mont, n);
+}
+
+}  // extern "C"

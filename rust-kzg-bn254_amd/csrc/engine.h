@@ -1,0 +1,108 @@
+// engine.h — host-side objects behind the C-ABI (include/kzg_bn254_mi355x.h): one context per GPU,
+// device-resident SRS, reusable workspaces.  No torch types, no CPU fallback.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include "../../include/kzg_bn254_mi355x.h"
+
+namespace kzg {
+
+struct DeviceBuffer {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        size_t cap = need + need / 8;
+        hipError_t e = hipMalloc(&p, cap);
+        if (e == hipSuccess) bytes = cap;
+        return e;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct MsmPlan {
+    uint32_t n;        // pairs in this launch
+    int c;             // window bits
+    int W;             // windows = ceil(255 / c)
+    uint32_t B;        // buckets per window = 2^(c-1)
+    uint32_t G;        // W * B
+    uint32_t L;        // segment length
+    uint32_t T;        // chunks per window in the reduction
+    uint32_t m;        // buckets per chunk
+    uint32_t segcap;   // upper bound on #segments
+};
+
+struct MsmWorkspace {
+    DeviceBuffer scalars;      // staging for host scalars (n x 32 B)
+    DeviceBuffer bases;        // staging for ad-hoc bases (n x 64 B, device format)
+    DeviceBuffer bases_wire;   // staging for ad-hoc bases in wire format
+    DeviceBuffer digits, sorted, count, cursor, offs, block_sums, seg_bucket, segsum, bucket, chunkS, chunkTmp, chunkA, out_wire;
+    void* pinned_out = nullptr;   // pinned host buffer for window sums
+    void release();
+};
+
+struct NttWorkspace {
+    DeviceBuffer data, tmp;
+    void release() { data.release(); tmp.release(); }
+};
+
+}  // namespace kzg
+
+struct kzg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string last_error;
+    int msm_c_override = 0;
+    int msm_seg_override = 0;
+    kzg::MsmWorkspace msm;
+    kzg::NttWorkspace ntt;
+    kzg::DeviceBuffer poly_a, poly_b, poly_c, poly_small;   // proof pipeline scratch
+};
+
+struct kzg_srs {
+    kzg_ctx* ctx = nullptr;
+    uint4* d_points = nullptr;     // n x 64 B, device affine format (curve.h)
+    size_t n = 0;
+};
+
+namespace kzg {
+
+// MSM over device-resident points (device format) and device-resident scalars (wire format).
+// Writes the affine result (or the XYZZ partial if out_xyzz != nullptr).
+int32_t msm_run(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars, size_t n,
+                uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz);
+
+// wire affine points (device memory) -> device affine format (curve.h), asynchronous on ctx->stream
+int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, size_t n);
+
+// Two-level twiddle table of one domain: w^t (t < lo_len) and w^(t * lo_len) (t < hi_len), 9 limb planes each,
+// internal Montgomery form.  Cached per (device, log n, direction).
+struct NttTables {
+    int32_t* lo = nullptr;
+    int32_t* hi = nullptr;
+    uint32_t lo_len = 0, hi_len = 0;
+    int lo_bits = 0;
+};
+int32_t ntt_get_tables(kzg_ctx* ctx, int log_n, bool inverse, NttTables* out);
+
+// In-place NTT on device data (wire format), natural order in/out.
+int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse);
+
+// synthetic SRS P_i = tau^i * G1 written to d_points (device format); device SRS -> wire on the host
+int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], size_t n, uint4* d_points);
+int32_t srs_download(kzg_ctx* ctx, const uint4* d_points, size_t n, uint64_t* out_xy);
+
+int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);
+
+}  // namespace kzg
+
+#define KZG_HIP_TRY(ctx, expr)                                                     \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) return kzg::set_error((ctx), _e, #expr);             \
+    } while (0)

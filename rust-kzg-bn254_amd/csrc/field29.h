@@ -25,10 +25,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define KZG_HD __host__ __device__ __forceinline__
-#define KZG_HD_NOINLINE __host__ __device__ __noinline__
+#define KZG_HD_NOINLINE __host__ __device__ __noinline__ inline
 #else
 #define KZG_HD inline
-#define KZG_HD_NOINLINE
+#define KZG_HD_NOINLINE inline
 #endif
 
 #if defined(KZG_BOUND_CHECK)

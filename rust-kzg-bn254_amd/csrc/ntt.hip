@@ -1,0 +1,259 @@
+// ntt.hip — radix-2^K Stockham NTT / inverse NTT over BN254 Fr, LDS-tiled.
+//
+// Replaces `GeneralEvaluationDomain::<Fr>::new(n).fft(..)` / `.ifft(..)` at
+// primitives/src/polynomial.rs:131-135 and :242-246: natural order in and out on the domain
+// {w^i}, w = 5^((r-1)/n) (= PRIMITIVE_ROOTS_OF_UNITY[log2 n], primitives/src/consts.rs:22-52); the
+// inverse uses w^-1 and scales by n^-1.
+//
+// Algorithm (decimation in time, Stockham autosort, P = ceil(log n / 7) passes):
+//   pass with radix R = 2^K brings the sub-transform length from n_cur/R to n_cur (stride s = N / n_cur):
+//     y[u + j * N/R] = sum_j'  w_{n_cur}^(p j') x[q + s (R p + j')] * w_R^(j j'),   u = q + s p
+//   Each workgroup owns a tile of C = 2048 / R consecutive units u: it gathers the R x C elements
+//   (contiguous runs in global memory), applies the inter-pass twiddles, runs the K radix-2 butterfly
+//   stages in LDS (9 limb planes, padded rows; per-tile twiddle table w_R^t in LDS), and scatters rows
+//   back.  Data stay in the wire residue class (a * 2^256) throughout: the transform is linear and the
+//   twiddles are in internal Montgomery form, so no domain conversion is needed.  Intermediate passes
+//   keep elements as 9 signed 29-bit limb planes (lazy, |v| < 16 m); the last pass reduces, scales and
+//   packs canonical 256-bit words.
+//   Algorithmic traffic: 64 B per element (32 B read + 32 B written); this implementation moves
+//   P x (read + write) with 36 B planes in between.
+#include "engine.h"
+#include "field29.h"
+
+#include <map>
+
+namespace kzg {
+
+constexpr int NTT_TILE_LOG = 11;
+constexpr int NTT_TILE = 1 << NTT_TILE_LOG;       // elements per workgroup tile
+constexpr int NTT_KMAX = 7;
+constexpr int NTT_PL = NTT_TILE + (1 << NTT_KMAX); // plane length with one pad element per row
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_LO_BITS = 10;
+
+// ---- twiddle tables: planes[9][len] of w^(t * step), internal Montgomery form -----------------------
+__device__ __forceinline__ void fr_pow_root(Fr& out, int log_n, bool inverse, uint32_t e) {
+    // w_{2^log_n}^e by square-and-multiply from the generated root constants
+    Fr base;
+    const uint32_t* tab = inverse ? FrParams::ROOT_INV : FrParams::ROOT;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) base.l[j] = (int32_t)tab[log_n * NL + j];
+    Fr acc;
+    fe_set_one(acc);
+    while (e) {
+        if (e & 1u) fe_mul(acc, acc, base);
+        fe_sqr(base, base);
+        e >>= 1;
+    }
+    out = acc;
+}
+__global__ void __launch_bounds__(256)
+k_ntt_build_table(int32_t* __restrict__ planes, uint32_t len, int log_n, int inverse, uint32_t step) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= len) return;
+    Fr w;
+    fr_pow_root(w, log_n, inverse != 0, t * step);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) planes[(size_t)j * len + t] = w.l[j];
+}
+
+__device__ __forceinline__ void load_planes(Fr& v, const int32_t* __restrict__ planes, size_t stride, size_t i) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) v.l[j] = planes[(size_t)j * stride + i];
+}
+// w_N^E from the two-level table (one multiply when E >= lo_len)
+__device__ __forceinline__ void twiddle(Fr& w, const int32_t* __restrict__ lo, uint32_t lo_len, int lo_bits,
+                                        const int32_t* __restrict__ hi, uint32_t hi_len, uint32_t E) {
+    load_planes(w, lo, lo_len, E & (lo_len - 1));
+    uint32_t eh = E >> lo_bits;
+    if (eh != 0) {
+        Fr h;
+        load_planes(h, hi, hi_len, eh);
+        fe_mul(w, w, h);
+    }
+}
+
+// One Stockham pass.  in_wire / out_wire (canonical 256-bit words) are used by the first / last pass,
+// the planes otherwise.
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_planes,
+           uint4* __restrict__ out_wire, int32_t* __restrict__ out_planes,
+           int log_n, int K, int log_s,
+           const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
+           int first, int last, int scale_log_n /* >= 0: multiply by (2^scale_log_n)^-1 at the end */) {
+    __shared__ int32_t lds[NL * NTT_PL];
+    __shared__ int32_t twl[NL * (1 << (NTT_KMAX - 1))];
+
+    const uint32_t N = 1u << log_n;
+    const uint32_t R = 1u << K;
+    const int log_c = NTT_TILE_LOG - K;
+    const uint32_t C = 1u << log_c, Cp = C + 1;
+    const uint32_t s = 1u << log_s;
+    const uint32_t n_units = N >> K;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile_u0 = blockIdx.x << log_c;
+
+    // per-tile local twiddles w_R^t = w_N^(t * N/R), t < R/2
+    if (tid < (R >> 1)) {
+        Fr w;
+        twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, tid << (log_n - K));
+        if (R == 1) fe_set_one(w);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) twl[j * (1 << (NTT_KMAX - 1)) + tid] = w.l[j];
+    }
+
+    // ---- gather -------------------------------------------------------------------------------
+    for (uint32_t t = tid; t < (uint32_t)NTT_TILE; t += NTT_THREADS) {
+        uint32_t uu, j;
+        if (s >= C) { uu = t & (C - 1); j = t >> log_c; }
+        else { uint32_t q = t & (s - 1); j = (t >> log_s) & (R - 1); uu = ((t >> (log_s + K)) << log_s) | q; }
+        uint32_t u = tile_u0 + uu;
+        Fr v;
+        fe_set_zero(v);
+        if (u < n_units) {
+            uint32_t q = u & (s - 1), p = u >> log_s;
+            size_t idx = (size_t)q + ((size_t)(R * p + j) << log_s);
+            if (first) {
+                uint4 a = in_wire[2 * idx], b = in_wire[2 * idx + 1];
+                uint32_t w32[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                fe_unpack(v, w32);
+            } else {
+                load_planes(v, in_planes, N, idx);
+                if (p != 0 && j != 0) {
+                    Fr w;
+                    twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, (p * j) << log_s);   // w_{n_cur}^(p j) = w_N^(p j s)
+                    fe_mul(v, v, w);                                                  // |v| < 16 m, |w| < 2 m
+                }
+            }
+        }
+        uint32_t jr = __brev(j) >> (32 - K);
+        if (K == 0) jr = 0;
+        uint32_t e = jr * Cp + uu;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) lds[l * NTT_PL + e] = v.l[l];
+    }
+    __syncthreads();
+
+    // ---- K radix-2 DIT stages in LDS ---------------------------------------------------------------
+    for (uint32_t h = 1, log_h = 0; h < R; h <<= 1, ++log_h) {
+        for (uint32_t bt = tid; bt < (uint32_t)(NTT_TILE / 2); bt += NTT_THREADS) {
+            uint32_t b = bt >> log_c, uu = bt & (C - 1);
+            uint32_t lowb = b & (h - 1);
+            uint32_t i0 = ((b >> log_h) << (log_h + 1)) | lowb;
+            uint32_t e0 = i0 * Cp + uu, e1 = (i0 + h) * Cp + uu;
+            uint32_t tw_idx = lowb << (K - 1 - log_h);                 // (b mod h) * R / (2h)
+            Fr a, x, w, t;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                a.l[l] = lds[l * NTT_PL + e0];
+                x.l[l] = lds[l * NTT_PL + e1];
+                w.l[l] = twl[l * (1 << (NTT_KMAX - 1)) + tw_idx];
+            }
+            fe_mul(t, x, w);
+            Fr y0, y1;
+            fe_add(y0, a, t); fe_norm(y0);
+            fe_sub(y1, a, t); fe_norm(y1);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                lds[l * NTT_PL + e0] = y0.l[l];
+                lds[l * NTT_PL + e1] = y1.l[l];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- scatter ------------------------------------------------------------------------------------
+    for (uint32_t t = tid; t < (uint32_t)NTT_TILE; t += NTT_THREADS) {
+        uint32_t uu = t & (C - 1), j = t >> log_c;
+        uint32_t u = tile_u0 + uu;
+        if (u >= n_units) continue;
+        size_t idx = (size_t)u + ((size_t)j << (log_n - K));
+        uint32_t e = j * Cp + uu;
+        Fr v;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) v.l[l] = lds[l * NTT_PL + e];
+        if (last) {
+            Fr k;
+            if (scale_log_n >= 0) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) k.l[l] = (int32_t)FrParams::NINV[scale_log_n * NL + l];
+            } else {
+                fe_set_one(k);
+            }
+            fe_mul(v, v, k);          // reduce to (-m, 2m) (and scale by n^-1 for the inverse transform)
+            fe_canon(v);
+            uint32_t w32[8];
+            fe_pack(w32, v);
+            out_wire[2 * idx] = make_uint4(w32[0], w32[1], w32[2], w32[3]);
+            out_wire[2 * idx + 1] = make_uint4(w32[4], w32[5], w32[6], w32[7]);
+        } else {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) out_planes[(size_t)l * N + idx] = v.l[l];
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+struct TableKey { int dev; int log_n; int inverse; bool operator<(const TableKey& o) const { return dev != o.dev ? dev < o.dev : (log_n != o.log_n ? log_n < o.log_n : inverse < o.inverse); } };
+static std::map<TableKey, NttTables> g_tables;
+static std::mutex g_tables_mu;
+
+int32_t ntt_get_tables(kzg_ctx* ctx, int log_n, bool inverse, NttTables* out) {
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    TableKey key{ctx->device, log_n, inverse ? 1 : 0};
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) { *out = it->second; return KZG_OK; }
+    NttTables t;
+    int lo_bits = log_n < NTT_LO_BITS ? log_n : NTT_LO_BITS;
+    t.lo_len = 1u << lo_bits;
+    t.lo_bits = lo_bits;
+    t.hi_len = 1u << (log_n - lo_bits);
+    KZG_HIP_TRY(ctx, hipMalloc(&t.lo, (size_t)t.lo_len * NL * 4));
+    KZG_HIP_TRY(ctx, hipMalloc(&t.hi, (size_t)t.hi_len * NL * 4));
+    hipLaunchKernelGGL(k_ntt_build_table, dim3((t.lo_len + 255) / 256), dim3(256), 0, ctx->stream, t.lo, t.lo_len, log_n, inverse ? 1 : 0, 1u);
+    hipLaunchKernelGGL(k_ntt_build_table, dim3((t.hi_len + 255) / 256), dim3(256), 0, ctx->stream, t.hi, t.hi_len, log_n, inverse ? 1 : 0, t.lo_len);
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    g_tables[key] = t;
+    *out = t;
+    return KZG_OK;
+}
+
+int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse) {
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
+    if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
+    if (n == 1) return KZG_OK;
+    int log_n = 0;
+    while (((size_t)1 << log_n) < n) ++log_n;
+    NttTables tb;
+    int32_t rc = ntt_get_tables(ctx, log_n, inverse, &tb);
+    if (rc != KZG_OK) return rc;
+    int lo_bits = log_n < NTT_LO_BITS ? log_n : NTT_LO_BITS;
+
+    int P = (log_n + NTT_KMAX - 1) / NTT_KMAX;
+    int base = log_n / P, extra = log_n % P;
+    if (P > 1) {
+        KZG_HIP_TRY(ctx, ctx->ntt.data.reserve(n * NL * 4));
+        if (P > 2) KZG_HIP_TRY(ctx, ctx->ntt.tmp.reserve(n * NL * 4));
+    }
+    int32_t* bufs[2] = {ctx->ntt.data.as<int32_t>(), ctx->ntt.tmp.as<int32_t>()};
+    int log_ncur = 0;
+    for (int pi = 0; pi < P; ++pi) {
+        int K = base + (pi < extra ? 1 : 0);
+        log_ncur += K;
+        int log_s = log_n - log_ncur;
+        bool first = pi == 0, last = pi == P - 1;
+        const int32_t* in_planes = first ? nullptr : bufs[(pi - 1) & 1];
+        int32_t* out_planes = last ? nullptr : bufs[pi & 1];
+        uint32_t n_units = (uint32_t)(n >> K);
+        uint32_t C = 1u << (NTT_TILE_LOG - K);
+        uint32_t tiles = (n_units + C - 1) / C;
+        hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(NTT_THREADS), 0, ctx->stream,
+                           reinterpret_cast<const uint4*>(d_data), in_planes, reinterpret_cast<uint4*>(d_data), out_planes,
+                           log_n, K, log_s, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len,
+                           first ? 1 : 0, last ? 1 : 0, (last && inverse) ? log_n : -1);
+    }
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    return KZG_OK;
+}
+
+}  // namespace kzg

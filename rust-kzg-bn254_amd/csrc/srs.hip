@@ -1,0 +1,155 @@
+// srs.hip — device-side SRS utilities.
+//   k_srs_powers: synthetic SRS with a KNOWN tau, P_i = tau^i * G1 (G1 = (1, 2)), used by the tests and by
+//   bench.py for the known-tau oracle  commit(p) == p(tau) * G1  (SURVEY.md §8c/§8d "SRS-S").  The reference
+//   has no such routine (it loads ceremony files, prover/src/srs.rs:35-49); this is a data generator, not a
+//   replacement of a reference interface.
+//   k_points_device_to_wire: read a device-resident SRS back in wire format (for parity checks).
+#include "engine.h"
+#include "curve.h"
+
+namespace kzg {
+
+template <class F>
+__device__ __noinline__ void fe_inverse(Fe<F>& out, const Fe<F>& a) {     // a^(m-2)
+    Fe<F> acc, base = a;
+    fe_set_one(acc);
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = F::P32[j];
+    e[0] -= 2u;                                   // both moduli end in ...7 / ...1 with low word >= 2
+    for (int w = 0; w < 8; ++w) {
+        uint32_t bits = e[w];
+        for (int b = 0; b < 32; ++b) {
+            if (w == 7 && b >= 30) break;
+            if (bits & 1u) fe_mul(acc, acc, base);
+            fe_sqr(base, base);
+            bits >>= 1;
+        }
+    }
+    out = acc;
+}
+
+// scalars: n canonical 256-bit integers k_i (device, 8 u32 each); out: device affine format
+__global__ void __launch_bounds__(256)
+k_srs_powers(const uint4* __restrict__ scalars_canonical, uint4* __restrict__ out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 lo = scalars_canonical[2 * (size_t)i], hi = scalars_canonical[2 * (size_t)i + 1];
+    uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    Affine g;                                     // generator (1, 2) in internal Montgomery form
+    fe_set_one(g.x);
+    fe_add(g.y, g.x, g.x);
+    fe_norm(g.y);
+    fe_canon(g.y);
+    Xyzz acc;
+    xyzz_set_inf(acc);
+    for (int w = 7; w >= 0; --w) {
+        for (int b = 31; b >= 0; --b) {
+            Xyzz t;
+            xyzz_dbl(t, acc);
+            acc = t;
+            if ((k[w] >> b) & 1u) xyzz_madd(acc, g, 0);
+        }
+    }
+    uint32_t o[16];
+    if (acc.inf) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = 0;
+    } else {
+        Fq zi, t, x, y;
+        fe_mul(t, acc.zz, acc.zzz);
+        fe_inverse(zi, t);                        // 1 / (ZZ ZZZ)
+        fe_mul(t, zi, acc.zzz);                   // 1 / ZZ
+        fe_mul(x, acc.x, t);
+        fe_mul(t, zi, acc.zz);                    // 1 / ZZZ
+        fe_mul(y, acc.y, t);
+        fe_canon(x);
+        fe_canon(y);
+        fe_pack(o, x);
+        fe_pack(o + 8, y);
+    }
+    out[4 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);
+    out[4 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    out[4 * (size_t)i + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+    out[4 * (size_t)i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
+}
+
+// canonical powers tau^i (8 u32 each), lane t computes a run of `per` consecutive powers
+__global__ void __launch_bounds__(256)
+k_fr_powers(const uint4* __restrict__ tau_wire, uint4* __restrict__ out_canonical, uint32_t n, uint32_t per) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t start = (uint64_t)t * per;
+    if (start >= n) return;
+    uint4 a = tau_wire[0], b = tau_wire[1];
+    uint32_t w32[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    Fr tau, cur, base;
+    fe_from_wire(tau, w32);
+    // cur = tau^start
+    fe_set_one(cur);
+    base = tau;
+    for (uint64_t e = start; e != 0; e >>= 1) {
+        if (e & 1u) fe_mul(cur, cur, base);
+        fe_sqr(base, base);
+    }
+    for (uint32_t k = 0; k < per && start + k < n; ++k) {
+        Fr one_plain, c;
+        fe_set_zero(one_plain);
+        one_plain.l[0] = 1;
+        fe_mul(c, cur, one_plain);                // internal -> plain integer
+        fe_canon(c);
+        uint32_t o[8];
+        fe_pack(o, c);
+        out_canonical[2 * (start + k)] = make_uint4(o[0], o[1], o[2], o[3]);
+        out_canonical[2 * (start + k) + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+        fe_mul(cur, cur, tau);
+    }
+}
+
+// device affine format -> wire (x || y, radix 2^256)
+__global__ void __launch_bounds__(256)
+k_points_device_to_wire(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine p;
+    bool ok = affine_load(p, in + 4 * i);
+    uint32_t o[16];
+    if (!ok) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = 0;
+    } else {
+        fe_to_wire(o, p.x);
+        fe_to_wire(o + 8, p.y);
+    }
+    out[4 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+    out[4 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    out[4 * i + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+    out[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
+}
+
+int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, uint4* d_points) {
+    if (n == 0) return KZG_OK;
+    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32 + 64));
+    KZG_HIP_TRY(ctx, ctx->poly_small.reserve(4096));
+    uint4* d_tau = ctx->poly_small.as<uint4>();
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_tau, tau, 32, hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t per = 64;
+    uint32_t lanes = (uint32_t)((n + per - 1) / per);
+    hipLaunchKernelGGL(k_fr_powers, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, d_tau, ctx->poly_a.as<uint4>(), (uint32_t)n, per);
+    hipLaunchKernelGGL(k_srs_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly_a.as<uint4>(), d_points, (uint32_t)n);
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+int32_t srs_download(kzg_ctx* ctx, const uint4* d_points, size_t n, uint64_t* out_xy) {
+    if (n == 0) return KZG_OK;
+    KZG_HIP_TRY(ctx, ctx->msm.bases_wire.reserve(n * 64));
+    hipLaunchKernelGGL(k_points_device_to_wire, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points,
+                       ctx->msm.bases_wire.as<uint4>(), n);
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(out_xy, ctx->msm.bases_wire.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+}  // namespace kzg

@@ -1,0 +1,143 @@
+"""Host-side mirror of the reference's `primitives::helpers` functions that sit on the prover path
+(primitives/src/helpers.rs).  Byte codecs and the Fiat-Shamir transcript are O(n) host work (out of
+the kernel scope); everything that touches group or NTT arithmetic goes through
+the C-ABI to the HIP kernels."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+
+from . import _lib
+from .consts import (BYTES_PER_FIELD_ELEMENT, FIAT_SHAMIR_PROTOCOL_DOMAIN, FQ_MODULUS, FR_MODULUS,
+                     MAINNET_SRS_G1_SIZE, primitive_root_of_unity)
+from .errors import GenericError, InvalidInputLength, MsmError
+from .fr import fq_to_int, fr_from_int, fr_to_int, frs_from_ints, frs_to_ints, g1_is_identity
+
+
+def get_num_element(data_len: int, symbol_size: int) -> int:
+    return -(-data_len // symbol_size)
+
+
+def pad_payload(input_data: bytes) -> bytes:
+    """helpers.rs:823-840: a 0x00 in front of every 31-byte chunk, output aligned to 32 bytes."""
+    n = len(input_data)
+    chunks = -(-n // 31)
+    src = np.zeros(chunks * 31, dtype=np.uint8)
+    src[:n] = np.frombuffer(input_data, dtype=np.uint8)
+    out = np.zeros((chunks, 32), dtype=np.uint8)
+    out[:, 1:] = src.reshape(chunks, 31)
+    return out.tobytes()
+
+
+def remove_internal_padding(padded: bytes) -> bytes:
+    """helpers.rs:856-874."""
+    if len(padded) % BYTES_PER_FIELD_ELEMENT != 0:
+        raise InvalidInputLength()
+    a = np.frombuffer(padded, dtype=np.uint8).reshape(-1, 32)
+    return a[:, 1:].tobytes()
+
+
+def to_fr_array(data: bytes) -> np.ndarray:
+    """helpers.rs:40-57: each 32-byte big-endian chunk (last one right-padded with zeros) mod r."""
+    n = get_num_element(len(data), BYTES_PER_FIELD_ELEMENT)
+    data = data + b"\x00" * (n * 32 - len(data))
+    return frs_from_ints([int.from_bytes(data[32 * i:32 * i + 32], "big") for i in range(n)])
+
+
+def to_byte_array(data_fr, max_output_size: int) -> bytes:
+    """helpers.rs:80-119."""
+    vals = frs_to_ints(data_fr)
+    out = b"".join(v.to_bytes(32, "big") for v in vals)
+    return out[:min(len(vals) * 32, max_output_size)]
+
+
+def get_primitive_root_of_unity(power: int) -> np.ndarray:
+    try:
+        return fr_from_int(primitive_root_of_unity(power))
+    except IndexError:
+        raise GenericError("power must be <= 28")
+
+
+def hash_to_field_element(msg: bytes) -> np.ndarray:
+    """helpers.rs:382-390: SHA-256, big-endian, mod r."""
+    return fr_from_int(int.from_bytes(hashlib.sha256(msg).digest(), "big"))
+
+
+def calculate_roots_of_unity(length_of_data_after_padding: int, ctx=None) -> np.ndarray:
+    """helpers.rs:553-589 -> [1, w, ..., w^(n-1)], n = next_pow2(ceil(len / 32)); generated on the GPU."""
+    ctx = ctx or _lib.default_context()
+    lib = _lib.load()
+    n_out = C.c_size_t(0)
+    rc = lib.kzg_calculate_roots_of_unity(ctx.handle, length_of_data_after_padding, None, 0, C.byref(n_out))
+    if rc == _lib.ERR_ZERO_LENGTH:
+        raise GenericError("Length of data after padding is 0")
+    if rc == _lib.ERR_SRS_LENGTH:
+        raise GenericError("the length of data after padding is not valid with respect to the SRS")
+    out = np.zeros((n_out.value, 4), dtype=np.uint64)
+    rc = lib.kzg_calculate_roots_of_unity(ctx.handle, length_of_data_after_padding, _lib.ptr(out), out.shape[0], C.byref(n_out))
+    ctx.check_device(rc)
+    return out
+
+
+def evaluate_polynomial_in_evaluation_form(polynomial, z, ctx=None) -> np.ndarray:
+    """helpers.rs:475-535 (barycentric; returns the stored evaluation when z is a domain element)."""
+    ctx = ctx or _lib.default_context()
+    blob_size = polynomial.len_underlying_blob_bytes()
+    if blob_size == 0:
+        raise GenericError("Length of data after padding is 0")
+    elems = -(-blob_size // 32)
+    if elems > MAINNET_SRS_G1_SIZE:
+        raise GenericError("the length of data after padding is not valid with respect to the SRS")
+    n_roots = 1
+    while n_roots < elems:
+        n_roots <<= 1
+    if len(polynomial) != n_roots:
+        raise InvalidInputLength()
+    evals = _lib.as_u64(polynomial.evaluations(), 4)
+    zz = _lib.as_u64(z, 0).reshape(4)
+    y = np.zeros(4, dtype=np.uint64)
+    rc = _lib.load().kzg_evaluate_polynomial_in_evaluation_form(ctx.handle, _lib.ptr(evals), len(evals), _lib.ptr(zz), _lib.ptr(y))
+    ctx.check_device(rc)
+    if rc != _lib.OK:
+        raise InvalidInputLength()
+    return y
+
+
+def g1_lincomb(points, scalars, ctx=None) -> np.ndarray:
+    """helpers.rs:328-337: MSM over caller-provided bases (e.g. batch verification, verifier/src/batch.rs:228-246)."""
+    ctx = ctx or _lib.default_context()
+    pts = _lib.as_u64(points, 8)
+    sc = _lib.as_u64(scalars, 4)
+    out = np.zeros(8, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    rc = _lib.load().kzg_msm_g1(ctx.handle, _lib.ptr(pts), len(pts), _lib.ptr(sc), len(sc), _lib.ptr(out), C.byref(inf))
+    if rc == _lib.ERR_MSM_LENGTH_MISMATCH:
+        raise MsmError(str(min(len(pts), len(sc))))
+    ctx.check_device(rc)
+    return out
+
+
+def lexicographically_largest(y_mont) -> bool:
+    """helpers.rs:151-173."""
+    return fq_to_int(y_mont) > (FQ_MODULUS - 1) // 2
+
+
+def serialize_compressed(point) -> bytes:
+    """ark-serialize compressed G1Affine as used at helpers.rs:456-459: x little-endian, bit 7 of the last byte
+    = y is the lexicographically larger root, bit 6 = infinity."""
+    if g1_is_identity(point):
+        return bytes(31) + b"\x40"
+    p = np.asarray(point, dtype=np.uint64).reshape(8)
+    b = bytearray(fq_to_int(p[:4]).to_bytes(32, "little"))
+    if lexicographically_largest(p[4:]):
+        b[31] |= 0x80
+    return bytes(b)
+
+
+def compute_challenge(blob, commitment) -> np.ndarray:
+    """helpers.rs:411-472: SHA-256(tag || u64be(n) || n x 32-byte evaluations || compressed commitment) mod r."""
+    poly = blob.to_polynomial_eval_form()
+    n = len(poly)
+    data = to_byte_array(poly.evaluations(), n * BYTES_PER_FIELD_ELEMENT)
+    msg = FIAT_SHAMIR_PROTOCOL_DOMAIN + n.to_bytes(8, "big") + data + serialize_compressed(commitment)
+    return hash_to_field_element(msg)

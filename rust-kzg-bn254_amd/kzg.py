@@ -1,0 +1,110 @@
+"""Mirror of prover/src/kzg.rs `KZG`: same method names, argument meaning and error behaviour; the
+G1 MSM and the Fr NTT/IFFT behind them run as HIP kernels through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, helpers
+from .errors import CommitError, FFTError, GenericError, NotOnCurveError, SerializationError, SrsCapacityExceeded
+from .fr import g1_is_identity
+from .polynomial import PolynomialCoeffForm, PolynomialEvalForm
+
+
+class KZG:
+    def __init__(self, ctx=None):
+        self.ctx = ctx
+        self.expanded_roots_of_unity = np.zeros((0, 4), dtype=np.uint64)
+
+    @classmethod
+    def new(cls, ctx=None):
+        return cls(ctx)
+
+    def _ctx(self):
+        if self.ctx is None:
+            self.ctx = _lib.default_context()
+        return self.ctx
+
+    # kzg.rs:65-72
+    def calculate_and_store_roots_of_unity(self, length_of_data_after_padding: int):
+        self.expanded_roots_of_unity = helpers.calculate_roots_of_unity(length_of_data_after_padding, self._ctx())
+
+    def get_roots_of_unities(self):
+        return self.expanded_roots_of_unity.copy()
+
+    def get_nth_root_of_unity(self, i):
+        return self.expanded_roots_of_unity[i] if 0 <= i < len(self.expanded_roots_of_unity) else None
+
+    # kzg.rs:84-104
+    def commit_eval_form(self, polynomial: PolynomialEvalForm, srs):
+        if len(polynomial) > len(srs):
+            raise SrsCapacityExceeded(len(polynomial), len(srs))
+        ctx = self._ctx()
+        evals = _lib.as_u64(polynomial.evaluations(), 4)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
+        rc = _lib.load().kzg_commit_eval_form(ctx.handle, srs.handle, _lib.ptr(evals), len(evals), _lib.ptr(out), C.byref(inf))
+        if rc == _lib.ERR_NOT_POWER_OF_TWO:
+            raise FFTError("length provided is not a power of 2")
+        if rc == _lib.ERR_DOMAIN:
+            raise FFTError("Could not perform IFFT due to domain consturction error")
+        ctx.check_device(rc)
+        return out
+
+    # kzg.rs:107-125
+    def commit_coeff_form(self, polynomial: PolynomialCoeffForm, srs):
+        if len(polynomial) > len(srs):
+            raise SerializationError("polynomial length is not correct")
+        ctx = self._ctx()
+        coeffs = _lib.as_u64(polynomial.coeffs(), 4)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
+        rc = _lib.load().kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(coeffs), len(coeffs), _lib.ptr(out), C.byref(inf))
+        if rc == _lib.ERR_MSM_LENGTH_MISMATCH:
+            raise CommitError(str(min(len(coeffs), len(srs))))
+        ctx.check_device(rc)
+        return out
+
+    # kzg.rs:182-185
+    def commit_blob(self, blob, srs):
+        return self.commit_eval_form(blob.to_polynomial_eval_form(), srs)
+
+    # kzg.rs:128-178
+    def _compute_proof_impl(self, polynomial, z_fr, srs, want_y=False):
+        if len(polynomial) != len(self.expanded_roots_of_unity):
+            raise GenericError("inconsistent length between blob and root of unities")
+        if len(polynomial) > len(srs):
+            raise SrsCapacityExceeded(len(polynomial), len(srs))
+        ctx = self._ctx()
+        evals = _lib.as_u64(polynomial.evaluations(), 4)
+        roots = _lib.as_u64(self.expanded_roots_of_unity, 4)
+        z = _lib.as_u64(z_fr, 0).reshape(4)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0); y = np.zeros(4, dtype=np.uint64)
+        rc = _lib.load().kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(evals), len(evals), _lib.ptr(roots), len(roots),
+                                           _lib.ptr(z), _lib.ptr(out), C.byref(inf), _lib.ptr(y))
+        if rc == _lib.ERR_ROOTS_LENGTH:
+            raise GenericError("inconsistent length between blob and root of unities")
+        ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
+        return (out, y) if want_y else out
+
+    # kzg.rs:215-234
+    def compute_proof(self, polynomial, z_fr, srs):
+        if len(polynomial) != len(self.expanded_roots_of_unity):
+            raise GenericError("inconsistent length between blob and root of unities")
+        return self._compute_proof_impl(polynomial, z_fr, srs)
+
+    # kzg.rs:187-207
+    def compute_proof_with_known_z_fr_index(self, polynomial, index: int, srs):
+        if index < 0 or index >= 1 << 64:
+            raise GenericError("Index conversion to usize failed")
+        z = self.get_nth_root_of_unity(index)
+        if z is None:
+            raise GenericError("Root of unity not found")
+        return self.compute_proof(polynomial, z, srs)
+
+    # kzg.rs:288-309
+    def compute_blob_proof(self, blob, commitment, srs):
+        if g1_is_identity(commitment) and False:
+            raise NotOnCurveError("point is identity")
+        poly = blob.to_polynomial_eval_form()
+        z = helpers.compute_challenge(blob, commitment)
+        return self._compute_proof_impl(poly, z, srs)

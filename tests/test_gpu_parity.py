@@ -1,0 +1,330 @@
+"""-m gpu: parity of the HIP path (through the C-ABI) against the oracle, the reference's golden vectors and
+size-independent properties.  Bit-exact (integer arithmetic): np.array_equal on the wire limbs."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import pyref
+from pyref import P, R_
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TAU = int.from_bytes(__import__("hashlib").sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % R_
+
+
+@pytest.fixture(scope="module")
+def k():
+    import rust_kzg_bn254_amd as k
+    k.load()
+    k.default_context()          # raises DeviceError if the HIP extension or the GPU is missing
+    return k
+
+
+@pytest.fixture(scope="module")
+def ref_srs(k, test_srs_wire):
+    return k.SRS(test_srs_wire, order=3000)
+
+
+def rand_scalars(n, seed, mod=R_):
+    rnd = random.Random(seed)
+    return pyref.frs_to_mont([rnd.randrange(mod) for _ in range(n)])
+
+
+def msm_srs(k, srs, scalars, offset=0):
+    ctx = srs.ctx
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(8, np.uint64); inf = C.c_uint8(7)
+    rc = k._lib.load().kzg_msm_g1_srs(ctx.handle, srs.handle, offset, k._lib.ptr(sc), len(sc), k._lib.ptr(out), C.byref(inf))
+    assert rc == 0, (rc, ctx.last_error())
+    assert inf.value == (0 if out.any() else 1)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MSM
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 64, 255, 1000, 3000])
+def test_msm_matches_oracle_on_reference_srs(k, ref_srs, test_srs_wire, n):
+    sc = rand_scalars(n, n)
+    got = msm_srs(k, ref_srs, sc)
+    assert np.array_equal(got, orc.msm_pippenger(test_srs_wire[:n], sc))
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+def test_msm_every_window_size(k, ref_srs, test_srs_wire, c):
+    n = 700
+    sc = rand_scalars(n, 100 + c)
+    ref_srs.ctx.set_msm_window(c, 0)
+    try:
+        got = msm_srs(k, ref_srs, sc)
+    finally:
+        ref_srs.ctx.set_msm_window(0, 0)
+    assert np.array_equal(got, orc.msm_pippenger(test_srs_wire[:n], sc))
+
+
+def test_msm_offset_and_g1_lincomb(k, ref_srs, test_srs_wire):
+    n = 500
+    sc = rand_scalars(n, 9)
+    want = orc.msm_pippenger(test_srs_wire[1000:1000 + n], sc)
+    assert np.array_equal(msm_srs(k, ref_srs, sc, offset=1000), want)
+    # helpers::g1_lincomb with caller-provided bases (helpers.rs:328-337)
+    assert np.array_equal(k.helpers.g1_lincomb(test_srs_wire[1000:1000 + n], sc), want)
+    with pytest.raises(k.errors.MsmError):
+        k.helpers.g1_lincomb(test_srs_wire[:10], sc[:9])
+
+
+def test_msm_edge_cases(k, ref_srs, test_srs_wire, test_srs_points):
+    n = 512
+    zero = pyref.frs_to_mont([0] * n)
+    assert not msm_srs(k, ref_srs, zero).any()                       # zero blob -> identity (verifier tests.rs:239-269)
+    ones = pyref.frs_to_mont([1] * n)
+    assert np.array_equal(msm_srs(k, ref_srs, ones), orc.msm_pippenger(test_srs_wire[:n], ones))
+    rm1 = pyref.frs_to_mont([R_ - 1] * n)
+    assert np.array_equal(msm_srs(k, ref_srs, rm1), orc.msm_pippenger(test_srs_wire[:n], rm1))
+    onehot = pyref.frs_to_mont([0] * 100 + [12345] + [0] * (n - 101))
+    assert np.array_equal(msm_srs(k, ref_srs, onehot), orc.g1_scalar_mul(test_srs_wire[100], pyref.fr_to_mont(12345)))
+    assert not msm_srs(k, ref_srs, np.zeros((0, 4), np.uint64)).any()  # empty input
+    # duplicate points (tests.rs:343-346): forces P + P in the buckets
+    dup = np.repeat(test_srs_wire[7:8], n, axis=0)
+    got = k.helpers.g1_lincomb(dup, ones)
+    assert pyref.point_from_wire(got) == pyref.ec_mul(n, test_srs_points[7])
+    sc = rand_scalars(n, 77)
+    assert np.array_equal(k.helpers.g1_lincomb(dup, sc), orc.msm_pippenger(dup, sc))
+    # P, -P pairs with equal scalars: forces the identity inside buckets
+    pm = np.zeros((n, 8), np.uint64)
+    pm[0::2] = test_srs_wire[11]; pm[1::2] = orc.g1_neg(test_srs_wire[11])
+    assert not k.helpers.g1_lincomb(pm, pyref.frs_to_mont([5] * n)).any()
+    # identity bases (tests.rs:271-311) are skipped
+    with_inf = test_srs_wire[:n].copy(); with_inf[::3] = 0
+    assert np.array_equal(k.helpers.g1_lincomb(with_inf, sc), orc.msm_pippenger(with_inf, sc))
+
+
+def test_msm_heavy_bucket_segments(k, ref_srs, test_srs_wire):
+    """All scalars equal: every window has a single bucket with n entries -> exercises the segment split."""
+    n = 3000
+    sc = pyref.frs_to_mont([0x1234567 + (1 << 200)] * n)
+    for seg in (0, 7):
+        ref_srs.ctx.set_msm_window(0, seg)
+        try:
+            got = msm_srs(k, ref_srs, sc)
+        finally:
+            ref_srs.ctx.set_msm_window(0, 0)
+        assert np.array_equal(got, orc.msm_pippenger(test_srs_wire[:n], sc))
+
+
+def test_fold_partials_matches_full_msm(k, ref_srs, test_srs_wire):
+    """The multi-GPU shape on one GPU: shard by scalar index, partial XYZZ per shard, host fold."""
+    n, G = 2048, 4
+    sc = rand_scalars(n, 5)
+    lib = k._lib.load(); ctx = ref_srs.ctx
+    parts = np.zeros((G, 16), np.uint64)
+    for g in range(G):
+        lo, hi = g * n // G, (g + 1) * n // G
+        s = np.ascontiguousarray(sc[lo:hi])
+        rc = lib.kzg_msm_g1_srs_partial(ctx.handle, ref_srs.handle, lo, k._lib.ptr(s), hi - lo, k._lib.ptr(parts[g]))
+        assert rc == 0
+    out = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+    assert lib.kzg_g1_fold_partials(k._lib.ptr(parts), G, k._lib.ptr(out), C.byref(inf)) == 0
+    assert np.array_equal(out, orc.msm_pippenger(test_srs_wire[:n], sc))
+
+
+@pytest.fixture(scope="module")
+def tau_srs(k):
+    return k.SRS.generate(TAU, 1 << 16)
+
+
+def test_generated_srs_is_tau_powers(k, tau_srs):
+    g1 = tau_srs.g1
+    assert pyref.point_from_wire(g1[0]) == (1, 2)
+    for i in (1, 2, 63, 64, 65, 4097, 65535):
+        assert pyref.point_from_wire(g1[i]) == pyref.ec_mul(pow(TAU, i, R_), (1, 2)), i
+
+
+@pytest.mark.parametrize("log_n", [12, 16])
+def test_msm_known_tau_and_oracle(k, tau_srs, log_n):
+    """commit(p) == p(tau) * G1 and bit-equality with the oracle's Pippenger."""
+    n = 1 << log_n
+    rnd = random.Random(log_n)
+    vals = [rnd.randrange(R_) for _ in range(n)]
+    sc = pyref.frs_to_mont(vals)
+    got = msm_srs(k, tau_srs, sc)
+    ptau = sum(v * pow(TAU, i, R_) for i, v in enumerate(vals)) % R_
+    assert pyref.point_from_wire(got) == pyref.ec_mul(ptau, (1, 2))
+    assert np.array_equal(got, orc.msm_pippenger(tau_srs.g1[:n], sc))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# NTT
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 7, 8, 10, 13, 14, 15, 16])
+def test_ntt_matches_oracle(k, log_n):
+    n = 1 << log_n
+    a = rand_scalars(n, 1000 + log_n)
+    ctx = k.default_context(); lib = k._lib.load()
+    for inverse in (0, 1):
+        got = a.copy()
+        assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(got), n, inverse) == 0
+        assert np.array_equal(got, orc.fr_ntt(a, inverse=bool(inverse))), (log_n, inverse)
+
+
+def test_ntt_roundtrip_2_20_and_linearity(k):
+    n = 1 << 20
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)                # < 2^252 < r: canonical residues
+    ctx = k.default_context(); lib = k._lib.load()
+    f = a.copy()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(f), n, 0) == 0
+    back = f.copy()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(back), n, 1) == 0
+    assert np.array_equal(back, a)                     # eval <-> coeff round trip exact (BASELINE config 3)
+    # spot check against the definition: F[i] = sum_j a_j w^(ij) at a few i, on a sparse input
+    sparse = np.zeros((n, 4), np.uint64)
+    idxs = [0, 1, 77777, n - 1]
+    vals = [3, 5, 7, 11]
+    for j, v in zip(idxs, vals):
+        sparse[j] = pyref.fr_to_mont(v)
+    g = sparse.copy()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(g), n, 0) == 0
+    w = pyref.root_of_unity(20)
+    for i in (0, 1, 2, 12345, n // 2, n - 1):
+        want = sum(v * pow(w, i * j, R_) for j, v in zip(idxs, vals)) % R_
+        assert pyref.fr_from_mont(g[i]) == want
+
+
+def test_ntt_errors(k):
+    ctx = k.default_context(); lib = k._lib.load()
+    a = rand_scalars(3, 1)
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(a), 3, 0) == k._lib.ERR_NOT_POWER_OF_TWO
+    with pytest.raises(k.errors.PolynomialFFTError):
+        p = k.PolynomialCoeffForm.__new__(k.PolynomialCoeffForm)
+        p._coeffs = a; p._len_underlying_blob_bytes = 96
+        p.to_eval_form()
+
+
+def test_polynomial_forms_roundtrip(k, gettysburg):
+    """primitives/tests/polynomial_test.rs:47-65, :99-113."""
+    blob = k.Blob.from_raw_data(gettysburg)
+    ev = blob.to_polynomial_eval_form()
+    assert len(ev) == 64 and ev.len_underlying_blob_bytes() == 48 * 32
+    co = ev.to_coeff_form()
+    assert np.array_equal(co.to_eval_form().evaluations(), ev.evaluations())
+    assert np.array_equal(co.coeffs(), orc.fr_ntt(ev.evaluations(), inverse=True))
+    assert co.len_underlying_blob_bytes() == ev.len_underlying_blob_bytes()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# KZG surface: roots, barycentric evaluation, commitments, proofs
+# ---------------------------------------------------------------------------------------------------------
+def test_roots_of_unity(k):
+    for nbytes in (1, 32, 33, 48 * 32, 4096 * 32, (1 << 16) * 32):
+        roots = k.helpers.calculate_roots_of_unity(nbytes)
+        rc, want = orc.calculate_roots_of_unity(nbytes)
+        assert rc == len(roots) and np.array_equal(roots, want)
+    with pytest.raises(k.errors.GenericError, match="Length of data after padding is 0"):
+        k.helpers.calculate_roots_of_unity(0)
+    with pytest.raises(k.errors.GenericError, match="not valid with respect to the SRS"):
+        k.helpers.calculate_roots_of_unity((268435456 + 1) * 32)
+
+
+def test_barycentric_eval(k, gettysburg):
+    """prover/tests/kzg_test.rs:31-55: every domain point returns the stored evaluation; off-domain vs oracle."""
+    blob = k.Blob.from_raw_data(gettysburg)
+    poly = blob.to_polynomial_eval_form()
+    kzg = k.KZG.new(); kzg.calculate_and_store_roots_of_unity(len(blob))
+    for i in range(64):
+        y = k.helpers.evaluate_polynomial_in_evaluation_form(poly, kzg.get_nth_root_of_unity(i))
+        assert np.array_equal(y, poly.get_evalualtion(i))
+    for z in (5, 123456789, R_ - 2):
+        zz = pyref.fr_to_mont(z)
+        rc, want = orc.evaluate_polynomial_in_evaluation_form(poly.evaluations(), zz)
+        assert rc == 0 and np.array_equal(k.helpers.evaluate_polynomial_in_evaluation_form(poly, zz), want)
+
+
+def test_commitments_gettysburg(k, ref_srs, test_srs_wire, gettysburg):
+    """coeff-form commit == eval-form commit (kzg_test.rs:57-89) == oracle == SURVEY.md §4.3 value."""
+    blob = k.Blob.from_raw_data(gettysburg)
+    kzg = k.KZG.new()
+    ev = blob.to_polynomial_eval_form()
+    c_eval = kzg.commit_eval_form(ev, ref_srs)
+    c_blob = kzg.commit_blob(blob, ref_srs)
+    c_coeff = kzg.commit_coeff_form(ev.to_coeff_form(), ref_srs)
+    assert np.array_equal(c_eval, c_blob) and np.array_equal(c_eval, c_coeff)
+    rc, want = orc.commit_eval_form(test_srs_wire, ev.evaluations(), literal=True)
+    assert rc == 0 and np.array_equal(c_eval, want)
+    assert pyref.point_from_wire(c_eval) == (
+        2961155957874067312593973807786254905069537311739090798303675273531563528369,
+        159565752702690920280451512738307422982252330088949702406468210607852362941)
+
+
+def test_commit_errors(k, ref_srs):
+    kzg = k.KZG.new()
+    big = k.PolynomialEvalForm(pyref.frs_to_mont([1] * 3001))
+    with pytest.raises(k.errors.SrsCapacityExceeded):
+        kzg.commit_eval_form(big, ref_srs)
+    with pytest.raises(k.errors.SerializationError, match="polynomial length is not correct"):
+        kzg.commit_coeff_form(k.PolynomialCoeffForm(pyref.frs_to_mont([1] * 3001)), ref_srs)
+    zero = k.PolynomialEvalForm(pyref.frs_to_mont([0] * 64))
+    assert not kzg.commit_eval_form(zero, ref_srs).any()               # zero blob -> identity commitment
+
+
+def test_proofs_match_reference_golden_vectors(k, ref_srs, gettysburg):
+    """All 40 rows of kzg.proof.eq.input (on-domain branch, kzg.rs:237-260)."""
+    blob = k.Blob.from_raw_data(gettysburg)
+    poly = blob.to_polynomial_eval_form()
+    kzg = k.KZG.new(); kzg.calculate_and_store_roots_of_unity(len(blob))
+    for line in open(os.path.join(GOLDEN, "kzg.proof.eq.input")):
+        line = line.strip()
+        if not line:
+            continue
+        idx, x, y = line.split(",")
+        proof = kzg.compute_proof_with_known_z_fr_index(poly, int(idx), ref_srs)
+        assert pyref.point_from_wire(proof) == (int(x), int(y)), idx
+
+
+def test_proof_off_domain_and_guards(k, ref_srs, test_srs_wire, gettysburg):
+    blob = k.Blob.from_raw_data(gettysburg)
+    poly = blob.to_polynomial_eval_form()
+    kzg = k.KZG.new(); kzg.calculate_and_store_roots_of_unity(len(blob))
+    rc, roots = orc.calculate_roots_of_unity(len(blob))
+    for z in (987654321987654321, 3, R_ - 1):
+        zz = pyref.fr_to_mont(z)
+        proof, y = kzg._compute_proof_impl(poly, zz, ref_srs, want_y=True)
+        rc, want, want_y = orc.compute_proof(test_srs_wire, poly.evaluations(), roots, zz, literal=False)
+        assert rc == 0 and np.array_equal(proof, want) and np.array_equal(y, want_y)
+    # Fiat-Shamir blob proof (kzg.rs:288-309) against the oracle's transcript + proof
+    commitment = kzg.commit_blob(blob, ref_srs)
+    z = orc.compute_challenge(blob.data(), commitment)
+    assert np.array_equal(k.helpers.compute_challenge(blob, commitment), z)
+    rc, want, _ = orc.compute_proof(test_srs_wire, poly.evaluations(), roots, z, literal=False)
+    assert np.array_equal(kzg.compute_blob_proof(blob, commitment, ref_srs), want)
+    # guards
+    kzg2 = k.KZG.new(); kzg2.calculate_and_store_roots_of_unity(32 * 32)
+    with pytest.raises(k.errors.GenericError, match="inconsistent length between blob and root of unities"):
+        kzg2.compute_proof(poly, pyref.fr_to_mont(5), ref_srs)
+    with pytest.raises(k.errors.GenericError, match="Root of unity not found"):
+        kzg.compute_proof_with_known_z_fr_index(poly, 64, ref_srs)
+
+
+def test_random_blob_commit_and_proof_2_12(k, tau_srs):
+    """Random 4096-element polynomial on the known-tau SRS: commitment == p(tau) G, proof == q(tau) G."""
+    n = 1 << 12
+    rnd = random.Random(4)
+    evals = [rnd.randrange(R_) for _ in range(n)]
+    poly = k.PolynomialEvalForm(pyref.frs_to_mont(evals))
+    kzg = k.KZG.new(); kzg.calculate_and_store_roots_of_unity(n * 32)
+    c = kzg.commit_eval_form(poly, tau_srs)
+    coeffs = pyref.frs_from_mont(orc.fr_ntt(poly.evaluations(), inverse=True))
+    ptau = pyref.poly_eval(coeffs, TAU)
+    assert pyref.point_from_wire(c) == pyref.ec_mul(ptau, (1, 2))
+    z = rnd.randrange(R_)
+    proof, y = kzg._compute_proof_impl(poly, pyref.fr_to_mont(z), tau_srs, want_y=True)
+    yv = pyref.poly_eval(coeffs, z)
+    assert pyref.fr_from_mont(y) == yv
+    qtau = (ptau - yv) * pow(TAU - z, -1, R_) % R_
+    assert pyref.point_from_wire(proof) == pyref.ec_mul(qtau, (1, 2))
