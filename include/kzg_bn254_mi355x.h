@@ -60,14 +60,21 @@ void    kzg_ctx_destroy(kzg_ctx* ctx);
 const char* kzg_ctx_last_error(const kzg_ctx* ctx);
 /* Tunables (0 = automatic): MSM window bits c in [2,16]; accumulate segment length. */
 int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len);
+/* Measurement aid: when enabled, every MSM launch is bracketed phase by phase with HIP events on the
+ * context's launch stream.  phase_ms_out[0..7] = accumulated milliseconds of: digits, bucket scan, scatter,
+ * segment map, bucket ACCUMULATE (the dominant kernel), bucket finalise, window reduction, whole device span;
+ * *launches / *pairs = launches and (scalar, point) pairs covered.  Enabling resets the counters. */
+int32_t kzg_ctx_set_profiling(kzg_ctx* ctx, int32_t enable);
+int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* launches, uint64_t* pairs);
 
 /* ---- SRS: device-resident monomial G1 powers -------------------------------------------------- */
 /* Replaces holding `SRS.g1: Cow<[G1Affine]>` (prover/src/srs.rs:11-21) on the host and copying
  * `srs.g1[..n].to_vec()` on every commit (kzg.rs:119).  n points, 8 u64 each.  Uploaded once. */
 int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);
 /* Test / bench utility (no counterpart in the reference, which loads ceremony files): synthetic SRS with a
- * KNOWN tau, P_i = tau^i * G1, generated on the device; and read-back of a resident SRS in wire format. */
-int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], size_t n_points, kzg_srs** out);
+ * KNOWN tau, P_i = tau^(first_power + i) * G1, generated on the device (a shard of the powers when
+ * first_power > 0); and read-back of a resident SRS in wire format. */
+int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_power, size_t n_points, kzg_srs** out);
 int32_t kzg_srs_download(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, size_t n, uint64_t* out_xy_mont);
 void    kzg_srs_free(kzg_srs* srs);
 size_t  kzg_srs_len(const kzg_srs* srs);

@@ -46,7 +46,9 @@ PROTOTYPES = {
     "kzg_ctx_last_error": (C.c_char_p, [vp]),
     "kzg_ctx_set_msm_window": (i32, [vp, i32, i32]),
     "kzg_srs_upload": (i32, [vp, u64p, sz, C.POINTER(vp)]),
-    "kzg_srs_generate": (i32, [vp, u64p, sz, C.POINTER(vp)]),
+    "kzg_srs_generate": (i32, [vp, u64p, C.c_uint64, sz, C.POINTER(vp)]),
+    "kzg_ctx_set_profiling": (i32, [vp, i32]),
+    "kzg_ctx_get_msm_profile": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kzg_srs_download": (i32, [vp, vp, sz, sz, u64p]),
     "kzg_srs_free": (None, [vp]),
     "kzg_srs_len": (sz, [vp]),

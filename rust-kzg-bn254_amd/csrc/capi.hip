@@ -91,6 +91,25 @@ int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len
     return KZG_OK;
 }
 
+int32_t kzg_ctx_set_profiling(kzg_ctx* ctx, int32_t enable) {
+    if (!ctx) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->profiling = enable != 0;
+    for (auto& v : ctx->msm.phase_ms) v = 0;
+    ctx->msm.profiled_launches = 0;
+    ctx->msm.profiled_pairs = 0;
+    return KZG_OK;
+}
+
+int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* launches, uint64_t* pairs) {
+    if (!ctx || !phase_ms_out) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 0; i < 8; ++i) phase_ms_out[i] = ctx->msm.phase_ms[i];
+    if (launches) *launches = ctx->msm.profiled_launches;
+    if (pairs) *pairs = ctx->msm.profiled_pairs;
+    return KZG_OK;
+}
+
 // ---- SRS ------------------------------------------------------------------------------------------
 static int32_t upload_points(kzg_ctx* ctx, const uint64_t* xy, size_t n, uint4* d_out, DeviceBuffer& staging) {
     KZG_HIP_TRY(ctx, staging.reserve(n * 64));
@@ -121,7 +140,7 @@ int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points
     return KZG_OK;
 }
 
-int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], size_t n_points, kzg_srs** out) {
+int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_power, size_t n_points, kzg_srs** out) {
     if (!ctx || !out || !tau_mont) return KZG_ERR_INVALID_ARG;
     *out = nullptr;
     if (n_points > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
@@ -134,7 +153,7 @@ int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], size_t n_poin
     if (n_points) {
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
         if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
-        int32_t rc = srs_generate(ctx, tau_mont, n_points, s->d_points);
+        int32_t rc = srs_generate(ctx, tau_mont, first_power, n_points, s->d_points);
         if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
     }
     *out = s;

@@ -42,6 +42,13 @@ struct MsmWorkspace {
     DeviceBuffer bases_wire;   // staging for ad-hoc bases in wire format
     DeviceBuffer digits, sorted, count, cursor, offs, block_sums, seg_bucket, segsum, bucket, chunkS, chunkTmp, chunkA, out_wire;
     void* pinned_out = nullptr;   // pinned host buffer for window sums
+    // optional per-phase timing with HIP events on the launch stream (kzg_ctx_set_profiling)
+    static constexpr int N_PHASES = 8;   // digits, scan, scatter, segments, accumulate, bucket_fin, reduce, whole launch
+    hipEvent_t ev[N_PHASES] = {};
+    bool ev_ready = false;
+    double phase_ms[N_PHASES] = {};
+    uint64_t profiled_launches = 0;
+    uint64_t profiled_pairs = 0;
     void release();
 };
 
@@ -59,6 +66,7 @@ struct kzg_ctx {
     std::string last_error;
     int msm_c_override = 0;
     int msm_seg_override = 0;
+    bool profiling = false;
     kzg::MsmWorkspace msm;
     kzg::NttWorkspace ntt;
     kzg::DeviceBuffer poly_a, poly_b, poly_c, poly_small;   // proof pipeline scratch
@@ -94,7 +102,7 @@ int32_t ntt_get_tables(kzg_ctx* ctx, int log_n, bool inverse, NttTables* out);
 int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse);
 
 // synthetic SRS P_i = tau^i * G1 written to d_points (device format); device SRS -> wire on the host
-int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], size_t n, uint4* d_points);
+int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_power, size_t n, uint4* d_points);
 int32_t srs_download(kzg_ctx* ctx, const uint4* d_points, size_t n, uint64_t* out_xy);
 
 int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);

@@ -16,6 +16,7 @@ void MsmWorkspace::release() {
                            &seg_bucket, &segsum, &bucket, &chunkS, &chunkTmp, &chunkA, &out_wire};
     for (auto* b : all) b->release();
     if (pinned_out) { (void)hipHostFree(pinned_out); pinned_out = nullptr; }
+    if (ev_ready) { for (auto& e : ev) (void)hipEventDestroy(e); ev_ready = false; }
 }
 
 static int ilog2_floor(size_t n) { int k = 0; while ((n >> (k + 1)) != 0) ++k; return k; }
@@ -75,29 +76,43 @@ static int32_t msm_launch(kzg_ctx* ctx, const uint4* d_points, const uint4* d_sc
     KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)p.W * 32 * 4));
     if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, 64 * 32 * 4 * 4, hipHostMallocDefault));
 
+    const bool prof = ctx->profiling;
+    if (prof && !ws.ev_ready) {
+        for (auto& e : ws.ev) KZG_HIP_TRY(ctx, hipEventCreate(&e));
+        ws.ev_ready = true;
+    }
+#define KZG_MARK(i) do { if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[i], st)); } while (0)
+
+    KZG_MARK(0);
     KZG_HIP_TRY(ctx, hipMemsetAsync(ws.count.p, 0, (size_t)p.G * 4, st));
     KZG_HIP_TRY(ctx, hipMemsetAsync(ws.cursor.p, 0, (size_t)p.G * 4, st));
 
     const uint32_t gn = (uint32_t)((n + 255) / 256);
     hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, p.B,
                        ws.digits.as<uint32_t>(), ws.count.as<uint32_t>());
+    KZG_MARK(1);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
                        ws.block_sums.as<unsigned long long>());
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
                        ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
+    KZG_MARK(2);
     hipLaunchKernelGGL(k_msm_scatter, dim3(gn), dim3(256), 0, st, ws.digits.as<uint32_t>(), p.n, p.W, p.B,
                        ws.offs.as<unsigned long long>(), ws.cursor.as<uint32_t>(), ws.sorted.as<uint32_t>());
     const uint32_t gg = (p.G + 255) / 256;
+    KZG_MARK(3);
     hipLaunchKernelGGL(k_msm_segments, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,
                        ws.seg_bucket.as<uint32_t>());
     const uint32_t gs = (p.segcap + 255) / 256;
+    KZG_MARK(4);
     hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, d_points, ws.sorted.as<uint32_t>(),
                        ws.seg_bucket.as<uint32_t>(), ws.offs.as<unsigned long long>(), p.G, p.L,
                        ws.segsum.as<int32_t>(), (size_t)p.segcap);
+    KZG_MARK(5);
     hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, p.m, n_chunks,
                        ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G);
     const uint32_t gc = (n_chunks + 255) / 256;
+    KZG_MARK(6);
     hipLaunchKernelGGL(k_red_chunk_sums, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, n_chunks, p.m,
                        ws.chunkS.as<int32_t>(), (size_t)n_chunks);
     hipLaunchKernelGGL(k_red_suffix_scan, dim3(p.W), dim3(p.T), 0, st, ws.chunkS.as<int32_t>(), ws.chunkTmp.as<int32_t>(),
@@ -106,9 +121,23 @@ static int32_t msm_launch(kzg_ctx* ctx, const uint4* d_points, const uint4* d_sc
                        ws.chunkS.as<int32_t>(), (size_t)n_chunks, n_chunks, p.T, p.m, ws.chunkA.as<int32_t>());
     hipLaunchKernelGGL(k_red_window_sum, dim3(p.W), dim3(p.T), 0, st, ws.chunkA.as<int32_t>(), (size_t)n_chunks, p.T,
                        ws.out_wire.as<uint32_t>());
+    KZG_MARK(7);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.pinned_out, ws.out_wire.p, (size_t)p.W * 128, hipMemcpyDeviceToHost, st));
     KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (prof) {
+        for (int i = 0; i < 7; ++i) {
+            float ms = 0;
+            KZG_HIP_TRY(ctx, hipEventElapsedTime(&ms, ws.ev[i], ws.ev[i + 1]));
+            ws.phase_ms[i] += ms;
+        }
+        float ms = 0;
+        KZG_HIP_TRY(ctx, hipEventElapsedTime(&ms, ws.ev[0], ws.ev[7]));
+        ws.phase_ms[7] += ms;
+        ws.profiled_launches += 1;
+        ws.profiled_pairs += n;
+    }
+#undef KZG_MARK
 
     // Horner over the window sums: at most 255 doublings on the host, beside the D2H copy
     kzg_host::Xyzz sums[128];

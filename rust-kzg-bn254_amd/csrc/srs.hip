@@ -76,7 +76,7 @@ k_srs_powers(const uint4* __restrict__ scalars_canonical, uint4* __restrict__ ou
 
 // canonical powers tau^i (8 u32 each), lane t computes a run of `per` consecutive powers
 __global__ void __launch_bounds__(256)
-k_fr_powers(const uint4* __restrict__ tau_wire, uint4* __restrict__ out_canonical, uint32_t n, uint32_t per) {
+k_fr_powers(const uint4* __restrict__ tau_wire, uint4* __restrict__ out_canonical, uint64_t first_power, uint32_t n, uint32_t per) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t start = (uint64_t)t * per;
     if (start >= n) return;
@@ -84,10 +84,10 @@ k_fr_powers(const uint4* __restrict__ tau_wire, uint4* __restrict__ out_canonica
     uint32_t w32[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     Fr tau, cur, base;
     fe_from_wire(tau, w32);
-    // cur = tau^start
+    // cur = tau^(first_power + start)
     fe_set_one(cur);
     base = tau;
-    for (uint64_t e = start; e != 0; e >>= 1) {
+    for (uint64_t e = first_power + start; e != 0; e >>= 1) {
         if (e & 1u) fe_mul(cur, cur, base);
         fe_sqr(base, base);
     }
@@ -126,7 +126,7 @@ k_points_device_to_wire(const uint4* __restrict__ in, uint4* __restrict__ out, s
     out[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
 }
 
-int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, uint4* d_points) {
+int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau[4], uint64_t first_power, size_t n, uint4* d_points) {
     if (n == 0) return KZG_OK;
     KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32 + 64));
     KZG_HIP_TRY(ctx, ctx->poly_small.reserve(4096));
@@ -134,7 +134,7 @@ int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, uint4* d_poi
     KZG_HIP_TRY(ctx, hipMemcpyAsync(d_tau, tau, 32, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t per = 64;
     uint32_t lanes = (uint32_t)((n + per - 1) / per);
-    hipLaunchKernelGGL(k_fr_powers, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, d_tau, ctx->poly_a.as<uint4>(), (uint32_t)n, per);
+    hipLaunchKernelGGL(k_fr_powers, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, d_tau, ctx->poly_a.as<uint4>(), first_power, (uint32_t)n, per);
     hipLaunchKernelGGL(k_srs_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly_a.as<uint4>(), d_points, (uint32_t)n);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -32,14 +32,14 @@ class SRS:
         raise NotImplementedError("SRS file loading is a 'next' row (DESIGN.md §9); build the SRS from decoded points")
 
     @classmethod
-    def generate(cls, tau: int, n: int, ctx=None):
-        """Synthetic SRS with known tau: P_i = tau^i * G1, generated on the device (tests / bench)."""
+    def generate(cls, tau: int, n: int, ctx=None, first_power: int = 0):
+        """Synthetic SRS with known tau: P_i = tau^(first_power + i) * G1, generated on the device (tests / bench)."""
         self = cls.__new__(cls)
         self.ctx = ctx or _lib.default_context()
         self.order = n
         h = C.c_void_p()
         t = fr_from_int(tau)
-        rc = _lib.load().kzg_srs_generate(self.ctx.handle, _lib.ptr(t), n, C.byref(h))
+        rc = _lib.load().kzg_srs_generate(self.ctx.handle, _lib.ptr(t), first_power, n, C.byref(h))
         self.ctx.check_device(rc)
         self.handle = h
         self._n = n
