@@ -1,0 +1,74 @@
+"""Multi-GPU sharding of the G1 MSM: one process per GPU, rank g owns the contiguous slice
+[g n / G, (g+1) n / G) of the SRS (resident on its GPU) and of the scalars; each rank runs a full Pippenger on
+its slice and emits ONE extended-Jacobian partial (16 x u64).  The only exchange is an all-gather of the G
+partials (G x 128 B over RCCL / xGMI; RCCL has no EC-add reduction op, so "all-reduce" = all-gather + fold);
+every rank then folds them on the host (G - 1 point additions + one inversion, kzg_g1_fold_partials).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    return rank * n // world, (rank + 1) * n // world
+
+
+def gather_partials(partial, world: int, device=None):
+    """all-gather of one 16 x u64 partial per rank -> (world, 16) uint64.  Uses torch.distributed when world > 1
+    (backend nccl = RCCL with CUDA tensors, gloo with CPU tensors)."""
+    partial = np.ascontiguousarray(partial, dtype=np.uint64).reshape(16)
+    if world == 1:
+        return partial.reshape(1, 16).copy()
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(partial.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    outs = [torch.empty(16, dtype=torch.int64, device=t.device) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return torch.stack(outs).cpu().numpy().view(np.uint64)
+
+
+def fold_partials(parts):
+    """(count, 16) XYZZ partials -> affine wire point (8 u64); host epilogue of the C-ABI."""
+    parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, 16)
+    out = np.zeros(8, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    rc = _lib.load().kzg_g1_fold_partials(_lib.ptr(parts), parts.shape[0], _lib.ptr(out), C.byref(inf))
+    if rc != _lib.OK:
+        raise ValueError(_lib.status_message(rc))
+    return out
+
+
+class ShardedMsm:
+    """MSM of n (scalar, point) pairs sharded over `world` ranks."""
+
+    def __init__(self, ctx, n: int, rank: int = 0, world: int = 1, gather_device="cuda"):
+        self.ctx, self.n, self.rank, self.world = ctx, n, rank, world
+        self.lo, self.hi = shard_bounds(n, rank, world)
+        self.len = self.hi - self.lo
+        self.gather_device = gather_device
+
+    def partial_device(self, srs_shard, d_scalars_ptr: int):
+        """Partial sum of this rank's slice; `srs_shard` holds points [lo, hi), scalars are in device memory."""
+        out = np.zeros(16, dtype=np.uint64)
+        rc = _lib.load().kzg_msm_g1_srs_partial_device(self.ctx.handle, srs_shard.handle, 0, C.c_void_p(d_scalars_ptr), self.len,
+                                                       _lib.ptr(out))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+        return out
+
+    def commit_device(self, srs_shard, d_scalars_ptr: int):
+        if self.world == 1:
+            out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
+            rc = _lib.load().kzg_msm_g1_srs_device(self.ctx.handle, srs_shard.handle, 0, C.c_void_p(d_scalars_ptr), self.len,
+                                                   _lib.ptr(out), C.byref(inf))
+            self.ctx.check_device(rc)
+            if rc != _lib.OK:
+                raise ValueError(_lib.status_message(rc))
+            return out
+        part = self.partial_device(srs_shard, d_scalars_ptr)
+        return fold_partials(gather_partials(part, self.world, self.gather_device))

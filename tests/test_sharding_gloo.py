@@ -1,0 +1,86 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU path's host logic: shard bounds, the all-gather of XYZZ
+partials over torch.distributed, and the product's host fold (kzg_g1_fold_partials).  There is no GPU here, so
+the per-rank partial sum is produced by the oracle *inside this test* as a stand-in for the HIP MSM; what is under
+test is everything around it (the same code bench.py runs at N > 1)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle as orc
+    import pyref
+    from rust_kzg_bn254_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pts = []
+    for i, line in enumerate(open(os.path.join(HERE, "golden", "srs.g1.points.string"))):
+        if i >= n:
+            break
+        x, y = line.strip().split(",")
+        pts.append((int(x), int(y)))
+    srs = pyref.points_to_wire(pts)
+    rng = np.random.default_rng(7)
+    vals = [int.from_bytes(rng.bytes(31), "big") for _ in range(n)]
+    if n > 6:
+        vals[3] = 0
+        vals[5] = pyref.R_ - 1
+    sc = pyref.frs_to_mont(vals)
+    lo, hi = sharding.shard_bounds(n, rank, world)
+    aff = orc.msm_pippenger(srs[lo:hi], sc[lo:hi], threads=1)          # stand-in for kzg_msm_g1_srs_partial_device
+    part = np.zeros(16, np.uint64)
+    if aff.any():
+        part[:8] = aff
+        part[8:12] = pyref.fq_to_mont(1)
+        part[12:16] = pyref.fq_to_mont(1)
+    gathered = sharding.gather_partials(part, world, device=None)
+    got = sharding.fold_partials(gathered)
+    want = orc.msm_pippenger(srs, sc, threads=1)
+    q.put((rank, bool(np.array_equal(got, want)), gathered.shape))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 5, 1])
+def test_sharded_msm_allgather_and_fold_world2(n):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    for _, ok, shape in res:
+        assert ok and tuple(shape) == (2, 16)
+
+
+def test_shard_bounds_cover_everything():
+    from rust_kzg_bn254_amd import sharding
+    for n in (0, 1, 7, 1 << 20):
+        for world in (1, 2, 3, 8):
+            b = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
