@@ -58,7 +58,8 @@ int32_t kzg_device_count(void);
 int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out);
 void    kzg_ctx_destroy(kzg_ctx* ctx);
 const char* kzg_ctx_last_error(const kzg_ctx* ctx);
-/* Tunables (0 = automatic): MSM window bits c in [2,16]; accumulate segment length. */
+/* Tunables (0 = automatic): MSM window bits c in [2,16]; accumulate segment length.  A non-zero c also forces the
+ * generic (no precomputed tables) mode for SRS-based calls. */
 int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len);
 /* Measurement aid: when enabled, every MSM launch is bracketed phase by phase with HIP events on the
  * context's launch stream.  phase_ms_out[0..7] = accumulated milliseconds of: digits, bucket scan, scatter,
@@ -69,7 +70,9 @@ int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* 
 
 /* ---- SRS: device-resident monomial G1 powers -------------------------------------------------- */
 /* Replaces holding `SRS.g1: Cow<[G1Affine]>` (prover/src/srs.rs:11-21) on the host and copying
- * `srs.g1[..n].to_vec()` on every commit (kzg.rs:119).  n points, 8 u64 each.  Uploaded once. */
+ * `srs.g1[..n].to_vec()` on every commit (kzg.rs:119).  n points, 8 u64 each.  Uploaded once; for
+ * 128 <= n (and table size <= 48 GiB) the upload also precomputes the window tables 2^(c w) * P_i
+ * (ceil(255 / c) x 64 B per point, c = clamp(floor(log2 n) - 4, 7, 16); KZG_NO_PRECOMPUTE=1 disables). */
 int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);
 /* Test / bench utility (no counterpart in the reference, which loads ceremony files): synthetic SRS with a
  * KNOWN tau, P_i = tau^(first_power + i) * G1, generated on the device (a shard of the powers when

@@ -134,6 +134,7 @@ int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
         if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
         int32_t rc = upload_points(ctx, g1_xy_mont, n_points, s->d_points, ctx->msm.bases_wire);
+        if (rc == KZG_OK) rc = srs_precompute(ctx, s);
         if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
     }
     *out = s;
@@ -154,6 +155,7 @@ int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t firs
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
         if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
         int32_t rc = srs_generate(ctx, tau_mont, first_power, n_points, s->d_points);
+        if (rc == KZG_OK) rc = srs_precompute(ctx, s);
         if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
     }
     *out = s;
@@ -203,7 +205,9 @@ int32_t kzg_msm_g1(kzg_ctx* ctx, const uint64_t* bases_xy_mont, size_t n_bases, 
     const void* d_scalars;
     rc = stage_scalars(ctx, scalars_mont, n_scalars, &d_scalars);
     if (rc != KZG_OK) return rc;
-    return msm_run(ctx, ctx->msm.bases.as<uint4>(), d_scalars, n_bases, out_xy_mont, out_is_infinity, nullptr);
+    MsmBases b;
+    b.points = ctx->msm.bases.as<uint4>();
+    return msm_run(ctx, b, d_scalars, n_bases, out_xy_mont, out_is_infinity, nullptr);
 }
 
 static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
@@ -219,7 +223,7 @@ static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, c
         int32_t rc = stage_scalars(ctx, static_cast<const uint64_t*>(scalars), n, &d_scalars);
         if (rc != KZG_OK) return rc;
     }
-    return msm_run(ctx, srs->d_points + 4 * offset, d_scalars, n, out_xy, out_inf, out_xyzz);
+    return msm_run(ctx, srs_bases(srs, offset, ctx->msm_c_override == 0), d_scalars, n, out_xy, out_inf, out_xyzz);
 }
 
 int32_t kzg_msm_g1_srs(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const uint64_t* scalars_mont, size_t n,
@@ -301,7 +305,7 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
     int32_t rc = ntt_run(ctx, ctx->poly_a.p, n, true);               // coefficients = IFFT(evaluations)
     if (rc != KZG_OK) return rc;
-    return msm_run(ctx, srs->d_points, ctx->poly_a.p, n, out_xy_mont, out_is_infinity, nullptr);
+    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_a.p, n, out_xy_mont, out_is_infinity, nullptr);
 }
 
 int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,

@@ -44,7 +44,7 @@ KZG_HD void xyzz_from_affine(Xyzz& r, const Affine& p, uint32_t neg) {
 }
 
 // Doubling of an affine point (mdbl-2008-s-1 with ZZ = ZZZ = 1).  y2 already carries the sign.
-KZG_HD_NOINLINE void xyzz_dbl_affine(Xyzz& r, const Fq& x2, const Fq& y2) {
+KZG_HD void xyzz_dbl_affine_impl(Xyzz& r, const Fq& x2, const Fq& y2) {
     Fq u, v, w, s, m, t, xx;
     fe_dbl(u, y2); fe_norm(u);                 // |u| < 2m
     fe_sqr(v, u);                              // V = U^2
@@ -63,8 +63,10 @@ KZG_HD_NOINLINE void xyzz_dbl_affine(Xyzz& r, const Fq& x2, const Fq& y2) {
     r.inf = false;
 }
 
+KZG_HD_NOINLINE void xyzz_dbl_affine(Xyzz& r, const Fq& x2, const Fq& y2) { xyzz_dbl_affine_impl(r, x2, y2); }
+
 // Doubling of a stored XYZZ value (dbl-2008-s-1).
-KZG_HD_NOINLINE void xyzz_dbl(Xyzz& r, const Xyzz& p) {
+KZG_HD void xyzz_dbl_impl(Xyzz& r, const Xyzz& p) {
     if (p.inf) { r = p; return; }
     Fq u, v, w, s, m, t, xx;
     fe_dbl(u, p.y); fe_norm(u);                // |u| < 6m
@@ -85,13 +87,23 @@ KZG_HD_NOINLINE void xyzz_dbl(Xyzz& r, const Xyzz& p) {
     r.x = x3; r.y = y3; r.inf = false;
 }
 
+KZG_HD_NOINLINE void xyzz_dbl(Xyzz& r, const Xyzz& p) { xyzz_dbl_impl(r, p); }
+
 // Slow path of the mixed add when X1 == x2 (P == +-Q): double or cancel.
-KZG_HD_NOINLINE void xyzz_madd_exceptional(Xyzz& acc, const Fq& x2, const Fq& y2s, const Fq& rr) {
-    if (fe_is_zero_mod(rr)) xyzz_dbl_affine(acc, x2, y2s);     // same point
-    else xyzz_set_inf(acc);                                     // opposite points
+// INLINE_SLOW = true keeps the slow path inside the caller (no call: the kernel's register budget then also binds
+// the slow path, which simply spills there); false calls an out-of-line copy (smaller code, callee picks its budget).
+template <bool INLINE_SLOW>
+KZG_HD void xyzz_madd_exceptional(Xyzz& acc, const Fq& x2, const Fq& y2s, const Fq& rr) {
+    if (fe_is_zero_mod(rr)) {                                   // same point
+        if (INLINE_SLOW) xyzz_dbl_affine_impl(acc, x2, y2s);
+        else xyzz_dbl_affine(acc, x2, y2s);
+    } else {
+        xyzz_set_inf(acc);                                      // opposite points
+    }
 }
 
 // acc += (neg ? -p : p), p affine and NOT the identity (callers skip identity bases).   madd-2008-s
+template <bool INLINE_SLOW = false>
 KZG_HD void xyzz_madd(Xyzz& acc, const Affine& p, uint32_t neg) {
     if (acc.inf) { xyzz_from_affine(acc, p, neg); return; }
     Fq y2s, u2, s2, pp_, rr_, P, R, ppp, q, t, v;
@@ -102,7 +114,7 @@ KZG_HD void xyzz_madd(Xyzz& acc, const Affine& p, uint32_t neg) {
     fe_sub(R, s2, acc.y);                      // R in (-4m, 5m)
     fe_sqr(pp_, P);                            // 81 m^2 < 169 m^2
     fe_sqr(rr_, R);
-    if (__builtin_expect(fe_is_zero_mod(pp_), 0)) { xyzz_madd_exceptional(acc, p.x, y2s, rr_); return; }
+    if (__builtin_expect(fe_is_zero_mod(pp_), 0)) { xyzz_madd_exceptional<INLINE_SLOW>(acc, p.x, y2s, rr_); return; }
     fe_mul(ppp, P, pp_);                       // 9m * 2m
     fe_mul(q, acc.x, pp_);                     // 7m * 2m
     fe_sub(v, rr_, ppp); fe_sub(v, v, q); fe_sub(v, v, q); fe_norm(v);   // X3 = RR - PPP - 2Q in (-7m, 5m)
@@ -115,12 +127,18 @@ KZG_HD void xyzz_madd(Xyzz& acc, const Affine& p, uint32_t neg) {
     fe_mul(acc.zzz, acc.zzz, ppp);
 }
 
-KZG_HD_NOINLINE void xyzz_add_exceptional(Xyzz& r, const Xyzz& a, const Fq& rr) {
-    if (fe_is_zero_mod(rr)) xyzz_dbl(r, a);
-    else xyzz_set_inf(r);
+template <bool INLINE_SLOW>
+KZG_HD void xyzz_add_exceptional(Xyzz& r, const Xyzz& a, const Fq& rr) {
+    if (fe_is_zero_mod(rr)) {
+        if (INLINE_SLOW) xyzz_dbl_impl(r, a);
+        else xyzz_dbl(r, a);
+    } else {
+        xyzz_set_inf(r);
+    }
 }
 
 // r = a + b, both stored-form XYZZ.   add-2008-s
+template <bool INLINE_SLOW = false>
 KZG_HD void xyzz_add(Xyzz& r, const Xyzz& a, const Xyzz& b) {
     if (a.inf) { r = b; return; }
     if (b.inf) { r = a; return; }
@@ -133,7 +151,7 @@ KZG_HD void xyzz_add(Xyzz& r, const Xyzz& a, const Xyzz& b) {
     fe_sub(R, s2, s1);
     fe_sqr(pp_, P);
     fe_sqr(rr_, R);
-    if (__builtin_expect(fe_is_zero_mod(pp_), 0)) { xyzz_add_exceptional(r, a, rr_); return; }
+    if (__builtin_expect(fe_is_zero_mod(pp_), 0)) { xyzz_add_exceptional<INLINE_SLOW>(r, a, rr_); return; }
     fe_mul(ppp, P, pp_);
     fe_mul(q, u1, pp_);
     fe_sub(v, rr_, ppp); fe_sub(v, v, q); fe_sub(v, v, q); fe_norm(v);   // (-6m, 5m)

@@ -40,7 +40,7 @@ struct MsmWorkspace {
     DeviceBuffer scalars;      // staging for host scalars (n x 32 B)
     DeviceBuffer bases;        // staging for ad-hoc bases (n x 64 B, device format)
     DeviceBuffer bases_wire;   // staging for ad-hoc bases in wire format
-    DeviceBuffer digits, sorted, count, cursor, offs, block_sums, seg_bucket, segsum, bucket, chunkS, chunkTmp, chunkA, out_wire;
+    DeviceBuffer digits, sorted, count, cursor, blockbase, offs, block_sums, seg_bucket, segsum, bucket, chunkS, chunkTmp, chunkA, out_wire;
     void* pinned_out = nullptr;   // pinned host buffer for window sums
     // optional per-phase timing with HIP events on the launch stream (kzg_ctx_set_profiling)
     static constexpr int N_PHASES = 8;   // digits, scan, scatter, segments, accumulate, bucket_fin, reduce, whole launch
@@ -67,6 +67,7 @@ struct kzg_ctx {
     int msm_c_override = 0;
     int msm_seg_override = 0;
     bool profiling = false;
+    bool lds_attr_set = false;
     kzg::MsmWorkspace msm;
     kzg::NttWorkspace ntt;
     kzg::DeviceBuffer poly_a, poly_b, poly_c, poly_small;   // proof pipeline scratch
@@ -74,16 +75,38 @@ struct kzg_ctx {
 
 struct kzg_srs {
     kzg_ctx* ctx = nullptr;
-    uint4* d_points = nullptr;     // n x 64 B, device affine format (curve.h)
+    // device affine format (curve.h), 64 B per point.  Without precomputation: n points.  With precomputed
+    // window tables (pre_W > 0): pre_W x n points, table w holds T_w[i] = 2^(pre_c * w) * P_i (table 0 = the SRS).
+    uint4* d_points = nullptr;
     size_t n = 0;
+    int pre_c = 0;
+    int pre_W = 0;
 };
 
 namespace kzg {
 
+// Bases of one MSM: `points` = first base of the slice; table_stride > 0 selects the precomputed-table mode
+// (tables `table_stride` points apart, window bits c, W tables).
+struct MsmBases {
+    const uint4* points = nullptr;
+    uint32_t table_stride = 0;
+    int c = 0;
+    int W = 0;
+};
+inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, bool allow_tables) {
+    MsmBases b;
+    b.points = srs->d_points + 4 * offset;
+    if (allow_tables && srs->pre_W > 0) { b.table_stride = (uint32_t)srs->n; b.c = srs->pre_c; b.W = srs->pre_W; }
+    return b;
+}
+
 // MSM over device-resident points (device format) and device-resident scalars (wire format).
 // Writes the affine result (or the XYZZ partial if out_xyzz != nullptr).
-int32_t msm_run(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars, size_t n,
+int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n,
                 uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz);
+
+// Precompute the window tables of an SRS in place (reallocates srs->d_points); no-op for small / huge SRS.
+int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs);
 
 // wire affine points (device memory) -> device affine format (curve.h), asynchronous on ctx->stream
 int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, size_t n);

@@ -1,6 +1,13 @@
 // msm.hip — host orchestration of the G1 MSM kernels (msm_kernels.h).
 // Replaces `G1Projective::msm(..)` + `.into_affine()` at prover/src/kzg.rs:100-101, :121-122 and
 // primitives/src/helpers.rs:332-336.
+//
+// Two modes share the digit / sort / accumulate kernels:
+//   table mode   (SRS with precomputed window tables T_w[i] = 2^(c w) P_i, built once at upload — HBM capacity is
+//                 spent to remove work): every (scalar, window) entry adds +-T_w[i] into ONE set of 2^(c-1) buckets;
+//                 W n mixed adds, one shuffle-based bucket reduction, no Horner.
+//   generic mode (caller-provided bases, e.g. g1_lincomb; tiny or huge SRS): W bucket sets, per-window reduction,
+//                 Horner over the W window sums on the host.
 #include "engine.h"
 #include "msm_kernels.h"
 #include "host_curve.h"
@@ -12,7 +19,7 @@
 namespace kzg {
 
 void MsmWorkspace::release() {
-    DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &cursor, &offs, &block_sums,
+    DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &cursor, &blockbase, &offs, &block_sums,
                            &seg_bucket, &segsum, &bucket, &chunkS, &chunkTmp, &chunkA, &out_wire};
     for (auto* b : all) b->release();
     if (pinned_out) { (void)hipHostFree(pinned_out); pinned_out = nullptr; }
@@ -21,30 +28,54 @@ void MsmWorkspace::release() {
 
 static int ilog2_floor(size_t n) { int k = 0; while ((n >> (k + 1)) != 0) ++k; return k; }
 
-static MsmPlan make_plan(const kzg_ctx* ctx, size_t n) {
-    MsmPlan p;
+struct Plan {
+    uint32_t n;          // pairs in this launch
+    bool tables;         // table mode
+    int c, W;
+    uint32_t B;          // buckets per set
+    uint32_t sets;       // bucket sets (1 in table mode, W otherwise)
+    uint32_t G;          // sets * B
+    uint32_t L;          // segment length
+    uint32_t set_len;    // digit entries per set
+    uint32_t tile_len, tiles_per_set, tiles;
+    uint32_t T, m;       // generic-mode reduction: chunks per window, buckets per chunk
+    uint32_t segcap;
+};
+
+static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases) {
+    Plan p;
     p.n = (uint32_t)n;
-    int c = ctx->msm_c_override;
-    if (c == 0) {
-        const char* env = getenv("KZG_MSM_C");
-        if (env) c = atoi(env);
+    p.tables = bases.table_stride != 0;
+    int c;
+    if (p.tables) {
+        c = bases.c;
+    } else {
+        c = ctx->msm_c_override;
+        if (c == 0) { const char* env = getenv("KZG_MSM_C"); if (env) c = atoi(env); }
+        if (c == 0) c = std::min(14, std::max(4, ilog2_floor(n) - 6));
+        c = std::min(16, std::max(2, c));
     }
-    if (c == 0) c = std::min(14, std::max(4, ilog2_floor(n) - 6));
-    c = std::min(16, std::max(2, c));
     p.c = c;
     p.W = (255 + c - 1) / c;
     p.B = 1u << (c - 1);
-    p.G = (uint32_t)p.W * p.B;
+    p.sets = p.tables ? 1u : (uint32_t)p.W;
+    p.G = p.sets * p.B;
     int L = ctx->msm_seg_override;
-    if (L == 0) {
-        const char* env = getenv("KZG_MSM_SEG");
-        if (env) L = atoi(env);
-    }
-    if (L <= 0) L = 64;
+    if (L == 0) { const char* env = getenv("KZG_MSM_SEG"); if (env) L = atoi(env); }
+    if (L <= 0) L = 96;
     p.L = (uint32_t)L;
+    const size_t entries = (size_t)p.W * n;
+    p.set_len = (uint32_t)(p.tables ? entries : n);
+    // sort tiles: large against the bucket count (one contiguous flush of B counters per tile), and not too many
+    size_t mult = 2;
+    { const char* env = getenv("KZG_SORT_TILE_MULT"); if (env && atoi(env) > 0) mult = (size_t)atoi(env); }
+    size_t tile = std::max<size_t>(4096, mult * p.B);
+    while (((size_t)p.set_len + tile - 1) / tile * p.sets > 1024) tile *= 2;
+    p.tile_len = (uint32_t)tile;
+    p.tiles_per_set = (uint32_t)(((size_t)p.set_len + tile - 1) / tile);
+    p.tiles = p.tiles_per_set * p.sets;
     p.T = std::min<uint32_t>(p.B, RED_T);
     p.m = p.B / p.T;
-    size_t entries = (size_t)p.W * n;
     p.segcap = (uint32_t)(entries / p.L + std::min<size_t>(p.G, entries) + 1);
     return p;
 }
@@ -52,29 +83,41 @@ static MsmPlan make_plan(const kzg_ctx* ctx, size_t n) {
 // Largest number of pairs one launch takes: W * n must fit the 32-bit positions of the sort.
 static const size_t MSM_MAX_LAUNCH = (size_t)1 << 24;
 
-static int32_t msm_launch(kzg_ctx* ctx, const uint4* d_points, const uint4* d_scalars, size_t n, kzg_host::Xyzz* result) {
-    MsmPlan p = make_plan(ctx, n);
+static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_scalars, size_t n, kzg_host::Xyzz* result) {
+    const Plan p = make_plan(ctx, n, bases);
     MsmWorkspace& ws = ctx->msm;
     hipStream_t st = ctx->stream;
     const size_t entries = (size_t)p.W * n;
     const uint32_t n_chunks = (uint32_t)p.W * p.T;
     const uint32_t nb = (p.G + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > SCAN_TILE) return KZG_ERR_INVALID_ARG;
+    const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
 
     KZG_HIP_TRY(ctx, ws.digits.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.sorted.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.count.reserve((size_t)p.G * 4));
-    KZG_HIP_TRY(ctx, ws.cursor.reserve((size_t)p.G * 4));
+    KZG_HIP_TRY(ctx, ws.blockbase.reserve((size_t)p.tiles * p.B * 4));
+    KZG_HIP_TRY(ctx, ws.cursor.reserve(((size_t)p.G + 1) * 4));          // queue of heavy buckets
     KZG_HIP_TRY(ctx, ws.offs.reserve(((size_t)p.G + 1) * 8));
     KZG_HIP_TRY(ctx, ws.block_sums.reserve((size_t)SCAN_TILE * 8));
     KZG_HIP_TRY(ctx, ws.seg_bucket.reserve((size_t)p.segcap * 4));
     KZG_HIP_TRY(ctx, ws.segsum.reserve((size_t)p.segcap * 36 * 4));
     KZG_HIP_TRY(ctx, ws.bucket.reserve((size_t)p.G * 36 * 4));
-    KZG_HIP_TRY(ctx, ws.chunkS.reserve((size_t)n_chunks * 36 * 4));
-    KZG_HIP_TRY(ctx, ws.chunkTmp.reserve((size_t)n_chunks * 36 * 4));
-    KZG_HIP_TRY(ctx, ws.chunkA.reserve((size_t)n_chunks * 36 * 4));
-    KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)p.W * 32 * 4));
-    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, 64 * 32 * 4 * 4, hipHostMallocDefault));
+    if (p.tables) {
+        KZG_HIP_TRY(ctx, ws.chunkS.reserve((size_t)7 * G1 * 36 * 4));          // X1
+        KZG_HIP_TRY(ctx, ws.chunkA.reserve((size_t)13 * G1p * 36 * 4));        // Y | X2
+    } else {
+        KZG_HIP_TRY(ctx, ws.chunkS.reserve((size_t)n_chunks * 36 * 4));
+        KZG_HIP_TRY(ctx, ws.chunkTmp.reserve((size_t)n_chunks * 36 * 4));
+        KZG_HIP_TRY(ctx, ws.chunkA.reserve((size_t)n_chunks * 36 * 4));
+    }
+    KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)128 * 32 * 4));
+    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, 128 * 32 * 4, hipHostMallocDefault));
+    if (!ctx->lds_attr_set) {
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        ctx->lds_attr_set = true;
+    }
 
     const bool prof = ctx->profiling;
     if (prof && !ws.ev_ready) {
@@ -85,45 +128,73 @@ static int32_t msm_launch(kzg_ctx* ctx, const uint4* d_points, const uint4* d_sc
 
     KZG_MARK(0);
     KZG_HIP_TRY(ctx, hipMemsetAsync(ws.count.p, 0, (size_t)p.G * 4, st));
-    KZG_HIP_TRY(ctx, hipMemsetAsync(ws.cursor.p, 0, (size_t)p.G * 4, st));
-
+    KZG_HIP_TRY(ctx, hipMemsetAsync(ws.cursor.p, 0, 4, st));
     const uint32_t gn = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, p.B,
-                       ws.digits.as<uint32_t>(), ws.count.as<uint32_t>());
+    hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, ws.digits.as<uint32_t>());
     KZG_MARK(1);
+    const size_t lds_bytes = (size_t)p.B * 4;
+    hipLaunchKernelGGL(k_sort_hist, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.set_len, p.tile_len,
+                       p.tiles_per_set, p.B, ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
                        ws.block_sums.as<unsigned long long>());
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
                        ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
     KZG_MARK(2);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(gn), dim3(256), 0, st, ws.digits.as<uint32_t>(), p.n, p.W, p.B,
-                       ws.offs.as<unsigned long long>(), ws.cursor.as<uint32_t>(), ws.sorted.as<uint32_t>());
+    hipLaunchKernelGGL(k_sort_scatter, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.n, p.set_len, p.tile_len,
+                       p.tiles_per_set, p.B, ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), bases.table_stride,
+                       ws.sorted.as<uint32_t>());
     const uint32_t gg = (p.G + 255) / 256;
     KZG_MARK(3);
     hipLaunchKernelGGL(k_msm_segments, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,
                        ws.seg_bucket.as<uint32_t>());
     const uint32_t gs = (p.segcap + 255) / 256;
     KZG_MARK(4);
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, d_points, ws.sorted.as<uint32_t>(),
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(),
                        ws.seg_bucket.as<uint32_t>(), ws.offs.as<unsigned long long>(), p.G, p.L,
                        ws.segsum.as<int32_t>(), (size_t)p.segcap);
     KZG_MARK(5);
-    hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, p.m, n_chunks,
-                       ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G);
-    const uint32_t gc = (n_chunks + 255) / 256;
-    KZG_MARK(6);
-    hipLaunchKernelGGL(k_red_chunk_sums, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, n_chunks, p.m,
-                       ws.chunkS.as<int32_t>(), (size_t)n_chunks);
-    hipLaunchKernelGGL(k_red_suffix_scan, dim3(p.W), dim3(p.T), 0, st, ws.chunkS.as<int32_t>(), ws.chunkTmp.as<int32_t>(),
-                       (size_t)n_chunks, p.T);
-    hipLaunchKernelGGL(k_red_chunk_running, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G,
-                       ws.chunkS.as<int32_t>(), (size_t)n_chunks, n_chunks, p.T, p.m, ws.chunkA.as<int32_t>());
-    hipLaunchKernelGGL(k_red_window_sum, dim3(p.W), dim3(p.T), 0, st, ws.chunkA.as<int32_t>(), (size_t)n_chunks, p.T,
-                       ws.out_wire.as<uint32_t>());
+    uint32_t n_out;                       // wire XYZZ values copied to the host
+    if (p.tables) {
+        hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, 0u, 0u,
+                           ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_bucket_fin_heavy, dim3(256), dim3(256), 0, st, ws.offs.as<unsigned long long>(), 0u, 0u,
+                           ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
+        KZG_MARK(6);
+        const uint32_t waves1 = G1 * 7;
+        hipLaunchKernelGGL(k_red_bits1, dim3((waves1 * 64 + 255) / 256), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, p.B, G1,
+                           ws.chunkS.as<int32_t>(), (size_t)7 * G1);
+        if (G1 == 1) {
+            n_out = 7;
+            hipLaunchKernelGGL(k_xyzz_to_wire, dim3(1), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, n_out, ws.out_wire.as<uint32_t>());
+        } else {
+            const uint32_t waves2 = 13 * G1p;
+            int32_t* y = ws.chunkA.as<int32_t>();
+            hipLaunchKernelGGL(k_red_bits2, dim3((waves2 * 64 + 255) / 256), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p,
+                               y, y + (size_t)6 * G1p, (size_t)13 * G1p);
+            n_out = 13 * G1p;
+            hipLaunchKernelGGL(k_xyzz_to_wire, dim3(1), dim3(256), 0, st, y, (size_t)13 * G1p, n_out, ws.out_wire.as<uint32_t>());
+        }
+    } else {
+        hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, p.m, n_chunks,
+                           ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_bucket_fin_heavy, dim3(256), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.m, n_chunks,
+                           ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
+        const uint32_t gc = (n_chunks + 255) / 256;
+        KZG_MARK(6);
+        hipLaunchKernelGGL(k_red_chunk_sums, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, n_chunks, p.m,
+                           ws.chunkS.as<int32_t>(), (size_t)n_chunks);
+        hipLaunchKernelGGL(k_red_suffix_scan, dim3(p.W), dim3(p.T), 0, st, ws.chunkS.as<int32_t>(), ws.chunkTmp.as<int32_t>(),
+                           (size_t)n_chunks, p.T);
+        hipLaunchKernelGGL(k_red_chunk_running, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G,
+                           ws.chunkS.as<int32_t>(), (size_t)n_chunks, n_chunks, p.T, p.m, ws.chunkA.as<int32_t>());
+        hipLaunchKernelGGL(k_red_window_sum, dim3(p.W), dim3(p.T), 0, st, ws.chunkA.as<int32_t>(), (size_t)n_chunks, p.T,
+                           ws.out_wire.as<uint32_t>());
+        n_out = (uint32_t)p.W;
+    }
     KZG_MARK(7);
     KZG_HIP_TRY(ctx, hipGetLastError());
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.pinned_out, ws.out_wire.p, (size_t)p.W * 128, hipMemcpyDeviceToHost, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.pinned_out, ws.out_wire.p, (size_t)n_out * 128, hipMemcpyDeviceToHost, st));
     KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
     if (prof) {
         for (int i = 0; i < 7; ++i) {
@@ -139,11 +210,44 @@ static int32_t msm_launch(kzg_ctx* ctx, const uint4* d_points, const uint4* d_sc
     }
 #undef KZG_MARK
 
-    // Horner over the window sums: at most 255 doublings on the host, beside the D2H copy
-    kzg_host::Xyzz sums[128];
+    // host epilogue on O(100) points
+    using kzg_host::Xyzz;
+    Xyzz vals[128];
     const uint64_t* w = reinterpret_cast<const uint64_t*>(ws.pinned_out);
-    for (int i = 0; i < p.W; ++i) memcpy(&sums[i], w + 16 * i, 128);
-    *result = kzg_host::horner_windows(sums, p.W, p.c);
+    for (uint32_t i = 0; i < n_out; ++i) memcpy(&vals[i], w + 16 * i, 128);
+    if (!p.tables) {
+        *result = kzg_host::horner_windows(vals, p.W, p.c);        // sum_w 2^(c w) S_w: <= 255 doublings
+        return KZG_OK;
+    }
+    // sum_b (b+1) V_b = T + sum_j 2^j S_j over the bits j of the 0-based bucket index
+    Xyzz S[32];
+    int nbits = 0;
+    Xyzz total;
+    if (G1 == 1) {
+        for (int j = 0; j < 6; ++j) S[j] = vals[j];
+        nbits = 6;
+        total = vals[6];
+    } else {
+        const Xyzz* Y = vals;
+        const Xyzz* X2 = vals + 6 * G1p;
+        for (int j = 0; j < 6; ++j) {
+            Xyzz a = kzg_host::xyzz_inf(), b = kzg_host::xyzz_inf();
+            for (uint32_t g = 0; g < G1p; ++g) { a = kzg_host::xyzz_add(a, Y[j * G1p + g]); b = kzg_host::xyzz_add(b, X2[j * G1p + g]); }
+            S[j] = a;
+            S[6 + j] = b;
+        }
+        nbits = 12;
+        total = kzg_host::xyzz_inf();
+        for (uint32_t g = 0; g < G1p; ++g) total = kzg_host::xyzz_add(total, X2[6 * G1p + g]);
+        for (int i = 0; (1u << i) < G1p; ++i) {
+            Xyzz a = kzg_host::xyzz_inf();
+            for (uint32_t g = 0; g < G1p; ++g) if ((g >> i) & 1u) a = kzg_host::xyzz_add(a, X2[6 * G1p + g]);
+            S[nbits++] = a;
+        }
+    }
+    Xyzz acc = kzg_host::xyzz_inf();
+    for (int j = nbits - 1; j >= 0; --j) { acc = kzg_host::xyzz_dbl(acc); acc = kzg_host::xyzz_add(acc, S[j]); }
+    *result = kzg_host::xyzz_add(acc, total);
     return KZG_OK;
 }
 
@@ -154,13 +258,15 @@ int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, s
     return KZG_OK;
 }
 
-int32_t msm_run(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars, size_t n,
+int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n,
                 uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
     kzg_host::Xyzz total = kzg_host::xyzz_inf();
     for (size_t off = 0; off < n; off += MSM_MAX_LAUNCH) {
         size_t len = std::min(MSM_MAX_LAUNCH, n - off);
         kzg_host::Xyzz part;
-        int32_t rc = msm_launch(ctx, d_points + 4 * off, reinterpret_cast<const uint4*>(d_scalars) + 2 * off, len, &part);
+        MsmBases b = bases;
+        b.points = bases.points + 4 * off;
+        int32_t rc = msm_launch(ctx, b, reinterpret_cast<const uint4*>(d_scalars) + 2 * off, len, &part);
         if (rc != KZG_OK) return rc;
         total = kzg_host::xyzz_add(total, part);
     }

@@ -28,8 +28,7 @@ constexpr int RED_T = 512;          // chunks (= threads of the per-window scan 
 // -------------------------------------------------------------------------------------------------
 // digits[w * n + i] = (|d| - 1) | (d < 0) << 31, or DIGIT_NONE for d == 0.
 __global__ void __launch_bounds__(256)
-k_msm_digits(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32_t B,
-             uint32_t* __restrict__ digits, uint32_t* __restrict__ count) {
+k_msm_digits(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32_t* __restrict__ digits) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint4 lo = scalars[2 * (size_t)i], hi = scalars[2 * (size_t)i + 1];
@@ -47,10 +46,7 @@ k_msm_digits(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32
         uint32_t mag = neg ? (1u << c) - raw : raw;          // |digit| in [0, 2^(c-1)]
         carry = neg;
         uint32_t v = DIGIT_NONE;
-        if (mag != 0) {
-            v = (mag - 1) | (neg << 31);
-            atomicAdd(&count[(size_t)w * B + (mag - 1)], 1u);
-        }
+        if (mag != 0) v = (mag - 1) | (neg << 31);
         digits[(size_t)w * n + i] = v;
     }
 }
@@ -122,19 +118,56 @@ k_scan_final(const uint32_t* __restrict__ count, uint32_t G, uint32_t L, const u
 }
 
 // -------------------------------------------------------------------------------------------------
-// 3. scatter entries into bucket order
+// 3. counting sort of the digit array by bucket, histograms and cursors privatised in LDS
 // -------------------------------------------------------------------------------------------------
+// The digit array is cut into `sets` independent key spaces of `set_len` entries each (sets = W windows of n
+// entries, or ONE set of W*n entries when the SRS carries precomputed window tables); every workgroup owns one
+// tile of one set.  Random global atomics ran at ~19 G/s (v0: 2.5 ms for 2^20 x 19 entries); LDS atomics plus one
+// contiguous flush per tile remove that cost.
 __global__ void __launch_bounds__(256)
-k_msm_scatter(const uint32_t* __restrict__ digits, uint32_t n, int W, uint32_t B,
-              const unsigned long long* __restrict__ offs, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (int w = 0; w < W; ++w) {
-        uint32_t v = digits[(size_t)w * n + i];
+k_sort_hist(const uint32_t* __restrict__ digits, uint32_t set_len, uint32_t tile_len, uint32_t tiles_per_set, uint32_t B,
+            uint32_t* __restrict__ count, uint32_t* __restrict__ blockbase) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t set = blockIdx.x / tiles_per_set, tile = blockIdx.x % tiles_per_set;
+    const uint32_t lo = tile * tile_len;
+    const uint32_t hi = (set_len - lo < tile_len) ? set_len : lo + tile_len;
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lds_u32[b] = 0;
+    __syncthreads();
+    const uint32_t* d = digits + (size_t)set * set_len;
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        uint32_t v = d[e];
+        if (v != DIGIT_NONE) atomicAdd(&lds_u32[v & 0x7FFFFFFFu], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+        uint32_t h = lds_u32[b];
+        uint32_t base = h ? atomicAdd(&count[(size_t)set * B + b], h) : 0u;     // contiguous addresses across lanes
+        blockbase[(size_t)blockIdx.x * B + b] = base;
+    }
+}
+// entry written for digit e of a set: point index | sign << 31.
+//   table_stride == 0 : index = i                       (bases used as given, one bucket set per window)
+//   table_stride  > 0 : index = w * table_stride + i    (precomputed tables T_w[i] = 2^(c w) P_i, one bucket set)
+__global__ void __launch_bounds__(256)
+k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len, uint32_t tile_len, uint32_t tiles_per_set, uint32_t B,
+               const unsigned long long* __restrict__ offs, const uint32_t* __restrict__ blockbase, uint32_t table_stride,
+               uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t set = blockIdx.x / tiles_per_set, tile = blockIdx.x % tiles_per_set;
+    const uint32_t lo = tile * tile_len;
+    const uint32_t hi = (set_len - lo < tile_len) ? set_len : lo + tile_len;
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x)
+        lds_u32[b] = (uint32_t)offs[(size_t)set * B + b] + blockbase[(size_t)blockIdx.x * B + b];
+    __syncthreads();
+    const uint32_t* d = digits + (size_t)set * set_len;
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        uint32_t v = d[e];
         if (v == DIGIT_NONE) continue;
-        size_t g = (size_t)w * B + (v & 0x7FFFFFFFu);
-        uint32_t pos = (uint32_t)offs[g] + atomicAdd(&cursor[g], 1u);
-        sorted[pos] = i | (v & 0x80000000u);
+        uint32_t pos = atomicAdd(&lds_u32[v & 0x7FFFFFFFu], 1u);
+        uint32_t idx;
+        if (table_stride) { uint32_t w = e / n; idx = w * table_stride + (e - w * n); }
+        else idx = e;
+        sorted[pos] = idx | (v & 0x80000000u);
     }
 }
 
@@ -152,27 +185,79 @@ k_msm_segments(const unsigned long long* __restrict__ offs, uint32_t G, uint32_t
 // -------------------------------------------------------------------------------------------------
 // 5. bucket accumulation: one lane per segment
 // -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+
+__device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
+    const Fq* s[4] = {&v.x, &v.y, &v.zz, &v.zzz};
+    Fq* t[4] = {&r.x, &r.y, &r.zz, &r.zzz};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < NL; ++j) t[q]->l[j] = __shfl_down(s[q]->l[j], d, 64);
+    r.inf = __shfl_down((int)v.inf, d, 64) != 0;
+}
+
+// One lane per segment (<= L entries of one bucket).  Segments of a bucket are consecutive, so after the serial part
+// the lanes of a wave that share a bucket fold their partials with a SEGMENTED suffix scan over ds_bpermute
+// shuffles (all lanes busy; ~log2(segments per bucket) extra adds).  Only the first lane of each run stores:
+// the surviving partials of bucket g sit at segment ids  s0(g)  and the multiples of 64 inside (s0, s1).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))        // 4 waves/SIMD (<= 128 VGPRs): 3 waves/SIMD issues ~20 % slower per instruction
 k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted,
                  const uint32_t* __restrict__ seg_bucket, const unsigned long long* __restrict__ offs, uint32_t G, uint32_t L,
                  int32_t* __restrict__ segsum, size_t seg_stride) {
-    uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nseg = (uint32_t)(offs[G] >> 32);
-    if (sid >= nseg) return;
-    uint32_t g = seg_bucket[sid];
-    unsigned long long o0 = offs[g], o1 = offs[g + 1];
-    uint32_t s = sid - (uint32_t)(o0 >> 32);
-    uint32_t begin = (uint32_t)o0 + s * L, end = (uint32_t)o1;
-    if (end - begin > L) end = begin + L;
+    const uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t nseg = (uint32_t)(offs[G] >> 32);
+    const bool active = sid < nseg;
+    uint32_t g = 0xFFFFFFFFu, begin = 0, end = 0;
+    if (active) {
+        g = seg_bucket[sid];
+        unsigned long long o0 = offs[g], o1 = offs[g + 1];
+        uint32_t s = sid - (uint32_t)(o0 >> 32);
+        begin = (uint32_t)o0 + s * L;
+        end = (uint32_t)o1;
+        if (end - begin > L) end = begin + L;
+    }
     Xyzz acc;
     xyzz_set_inf(acc);
-    for (uint32_t e = begin; e < end; ++e) {
-        uint32_t v = sorted[e];
-        Affine p;
-        if (!affine_load(p, points + 4 * (size_t)(v & 0x7FFFFFFFu))) continue;      // identity base
-        xyzz_madd(acc, p, v >> 31);
+    if (begin < end) {
+        // software pipeline: the 64-byte point of entry e+1 is requested before the ~2 700-instruction mixed add of
+        // entry e, so the random gather (HBM-resident tables) is hidden behind arithmetic
+        uint32_t v = sorted[begin];
+        const uint4* src = points + 4 * (size_t)(v & 0x7FFFFFFFu);
+        uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        for (uint32_t e = begin; e < end; ++e) {
+            const uint32_t neg = v >> 31;
+            uint32_t wx[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            uint32_t wy[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const uint32_t any = q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x | q2.y | q2.z | q2.w | q3.x | q3.y | q3.z | q3.w;
+            if (e + 1 < end) {
+                v = sorted[e + 1];
+                src = points + 4 * (size_t)(v & 0x7FFFFFFFu);
+                q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+            }
+            if (any == 0) continue;                                                       // identity base
+            Affine p;
+            fe_unpack(p.x, wx);
+            fe_unpack(p.y, wy);
+            xyzz_madd<true>(acc, p, neg);
+        }
     }
-    xyzz_store(segsum, seg_stride, sid, acc);
+    // segmented suffix scan: acc_lane = sum of the partials of lanes lane .. end of its bucket run in this wave
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t gd = __shfl_down(g, d, 64);
+        const bool join = active && (lane + d < 64) && gd == g;
+        if (!__any(join)) continue;                      // wave-uniform: nobody has a partner at this distance
+        Xyzz u;
+        xyzz_shfl_down(u, acc, d);
+        if (join) {
+            Xyzz r;
+            xyzz_add<true>(r, acc, u);
+            acc = r;
+        }
+    }
+    const uint32_t gprev = __shfl_up(g, 1, 64);
+    if (active && (lane == 0 || gprev != g)) xyzz_store(segsum, seg_stride, sid, acc);
 }
 
 // Bucket g of the G = W * B buckets is stored at a transposed position so that the reduction kernels,
@@ -180,21 +265,67 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
 __device__ __forceinline__ size_t bucket_pos(uint32_t g, uint32_t m, uint32_t n_chunks) {
     return (size_t)(g % m) * n_chunks + (g / m);
 }
+// surviving partial k of a bucket whose segments are [s0, s1): k = 0 -> s0, k >= 1 -> the k-th multiple of 64 above s0
+__device__ __forceinline__ uint32_t partial_count(uint32_t s0, uint32_t s1) {
+    if (s1 == s0) return 0;
+    return 1 + ((s1 - 1) / 64 - s0 / 64);
+}
+__device__ __forceinline__ uint32_t partial_sid(uint32_t s0, uint32_t k) { return k == 0 ? s0 : (s0 / 64 + k) * 64; }
+
+constexpr uint32_t FIN_SERIAL_MAX = 4;
+// thread per bucket: buckets with <= 4 surviving partials (the normal case: 1-2) are summed serially; heavier ones
+// (skewed scalars: few distinct digits) are queued for k_msm_bucket_fin_heavy.
 __global__ void __launch_bounds__(256)
 k_msm_bucket_fin(const unsigned long long* __restrict__ offs, uint32_t G, uint32_t m, uint32_t n_chunks,
-                 const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ bucket, size_t bucket_stride) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+                 const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ bucket, size_t bucket_stride,
+                 uint32_t* __restrict__ heavy /* [0] = count, [1..] = bucket ids */) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
-    uint32_t s0 = (uint32_t)(offs[g] >> 32), s1 = (uint32_t)(offs[g + 1] >> 32);
+    const uint32_t s0 = (uint32_t)(offs[g] >> 32), s1 = (uint32_t)(offs[g + 1] >> 32);
+    const uint32_t np = partial_count(s0, s1);
+    if (np > FIN_SERIAL_MAX) {
+        heavy[1 + atomicAdd(&heavy[0], 1u)] = g;
+        return;
+    }
     Xyzz acc;
     xyzz_set_inf(acc);
-    for (uint32_t s = s0; s < s1; ++s) {
+    for (uint32_t k = 0; k < np; ++k) {
         Xyzz v, t;
-        xyzz_load(v, segsum, seg_stride, s);
+        xyzz_load(v, segsum, seg_stride, partial_sid(s0, k));
         xyzz_add(t, acc, v);
         acc = t;
     }
-    xyzz_store(bucket, bucket_stride, bucket_pos(g, m, n_chunks), acc);
+    xyzz_store(bucket, bucket_stride, m ? bucket_pos(g, m, n_chunks) : (size_t)g, acc);
+}
+// one wave per queued bucket (grid-stride over the queue): lanes take partials round-robin, then a shuffle tree
+__global__ void __launch_bounds__(256)
+k_msm_bucket_fin_heavy(const unsigned long long* __restrict__ offs, uint32_t m, uint32_t n_chunks,
+                       const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ bucket, size_t bucket_stride,
+                       const uint32_t* __restrict__ heavy) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t count = heavy[0];
+    for (uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; h < count; h += n_waves) {
+        const uint32_t g = heavy[1 + h];
+        const uint32_t s0 = (uint32_t)(offs[g] >> 32), s1 = (uint32_t)(offs[g + 1] >> 32);
+        const uint32_t np = partial_count(s0, s1);
+        Xyzz acc;
+        xyzz_set_inf(acc);
+        for (uint32_t k = lane; k < np; k += 64) {
+            Xyzz v, t;
+            xyzz_load(v, segsum, seg_stride, partial_sid(s0, k));
+            xyzz_add(t, acc, v);
+            acc = t;
+        }
+#pragma unroll 1
+        for (int d = 32; d >= 1; d >>= 1) {
+            Xyzz u, r;
+            xyzz_shfl_down(u, acc, d);
+            xyzz_add(r, acc, u);
+            acc = r;
+        }
+        if (lane == 0) xyzz_store(bucket, bucket_stride, m ? bucket_pos(g, m, n_chunks) : (size_t)g, acc);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -287,6 +418,74 @@ k_red_window_sum(int32_t* __restrict__ a, size_t stride, uint32_t T, uint32_t* _
         xyzz_to_wire(w, v);
         for (int j = 0; j < 32; ++j) out_wire[(size_t)blockIdx.x * 32 + j] = w[j];
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 6b. low-latency bucket reduction for ONE bucket set (precomputed-table mode), B a multiple of 64
+// -------------------------------------------------------------------------------------------------
+// sum_b (b+1) V_b = T + sum_j 2^j S_j,  T = sum_b V_b,  S_j = sum_{b : bit j of b} V_b.
+// A dependent EC addition costs ~13 us on a lone wave, so the classic running sum (2 serial adds per bucket of
+// a chunk) is latency bound; here every partial sum is a 6-step wave tree over ds_bpermute shuffles:
+// one wave per (group of 64 values, role); role j < 6 sums the lanes whose index has bit j set, role 6 sums all.
+// Applied again to the group totals it yields bits 6..11, and so on; the few remaining values go to the host.
+// role sum over one group of <= 64 stored values in[first .. first + count): role j < 6 takes the lanes whose
+// index has bit j set, role 6 takes all.  Result valid in lane 0.
+__device__ __forceinline__ void wave_role_sum(Xyzz& v, const int32_t* __restrict__ in, size_t in_stride, size_t first,
+                                              uint32_t count, uint32_t lane, uint32_t role) {
+    const bool take = lane < count && (role == 6 || ((lane >> role) & 1u));
+    if (take) xyzz_load(v, in, in_stride, first + lane);
+    else xyzz_set_inf(v);
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz u, r;
+        xyzz_shfl_down(u, v, d);
+        xyzz_add(r, v, u);
+        v = r;
+    }
+}
+// level 1: X1[role * G1 + g] = role sum of bucket group g (64 buckets), roles 0..6, G1 = B / 64
+__global__ void __launch_bounds__(256)
+k_red_bits1(const int32_t* __restrict__ bucket, size_t bucket_stride, uint32_t B, uint32_t G1,
+            int32_t* __restrict__ x1, size_t x_stride) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= G1 * 7u) return;
+    const uint32_t g = wave / 7u, role = wave % 7u;
+    Xyzz v;
+    wave_role_sum(v, bucket, bucket_stride, (size_t)g * 64, B - g * 64 < 64 ? B - g * 64 : 64, lane, role);
+    if (lane == 0) xyzz_store(x1, x_stride, (size_t)role * G1 + g, v);
+}
+// level 2 (one launch, two kinds of job): with G1p = ceil(G1 / 64)
+//   job <  6 G1p : Y[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                 (a < 6: finishes bits 0..5)
+//   job >= 6 G1p : X2[role * G1p + g2] = role sum of the totals X1[6][g2 * 64 .. +64) (bits 6..11 and totals)
+__global__ void __launch_bounds__(256)
+k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p,
+            int32_t* __restrict__ y, int32_t* __restrict__ x2, size_t out_stride) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= 13u * G1p) return;
+    Xyzz v;
+    if (wave < 6u * G1p) {
+        const uint32_t a = wave / G1p, g = wave % G1p;
+        const uint32_t cnt = G1 - g * 64 < 64 ? G1 - g * 64 : 64;
+        wave_role_sum(v, x1, x_stride, (size_t)a * G1 + (size_t)g * 64, cnt, lane, 6);
+        if (lane == 0) xyzz_store(y, out_stride, wave, v);
+    } else {
+        const uint32_t j = wave - 6u * G1p, g2 = j / 7u, role = j % 7u;
+        const uint32_t cnt = G1 - g2 * 64 < 64 ? G1 - g2 * 64 : 64;
+        wave_role_sum(v, x1, x_stride, (size_t)6 * G1 + (size_t)g2 * 64, cnt, lane, role);
+        if (lane == 0) xyzz_store(x2, out_stride, (size_t)role * G1p + g2, v);
+    }
+}
+// stored-form XYZZ planes -> wire words (32 u32 per element)
+__global__ void __launch_bounds__(256)
+k_xyzz_to_wire(const int32_t* __restrict__ in, size_t stride, uint32_t n, uint32_t* __restrict__ out_wire) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xyzz v;
+    xyzz_load(v, in, stride, i);
+    uint32_t w[32];
+    xyzz_to_wire(w, v);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) out_wire[(size_t)i * 32 + j] = w[j];
 }
 
 // -------------------------------------------------------------------------------------------------

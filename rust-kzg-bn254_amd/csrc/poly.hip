@@ -326,7 +326,7 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
     // commit_eval_form(quotient): coefficients = IFFT(q), then MSM over the monomial SRS (kzg.rs:176-177)
     rc = ntt_run(ctx, ctx->poly_c.p, n, true);
     if (rc != KZG_OK) return rc;
-    return msm_run(ctx, srs->d_points, ctx->poly_c.p, n, out_xy, out_inf, nullptr);
+    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_c.p, n, out_xy, out_inf, nullptr);
 }
 
 }  // namespace kzg

@@ -7,6 +7,8 @@
 #include "engine.h"
 #include "curve.h"
 
+#include <cstdlib>
+
 namespace kzg {
 
 template <class F>
@@ -105,6 +107,43 @@ k_fr_powers(const uint4* __restrict__ tau_wire, uint4* __restrict__ out_canonica
     }
 }
 
+// One step of the window-table precomputation: next[i] = 2^c * prev[i] (affine in, affine out).
+// c doublings in XYZZ, then one Fermat inversion per point.  One-time cost at SRS upload.
+__global__ void __launch_bounds__(256)
+k_srs_window_step(const uint4* __restrict__ prev, uint4* __restrict__ next, size_t n, int c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine p;
+    uint32_t o[16];
+    if (!affine_load(p, prev + 4 * i)) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = 0;
+    } else {
+        Xyzz acc;
+        xyzz_dbl_affine(acc, p.x, p.y);
+        for (int k = 1; k < c; ++k) {
+            Xyzz t;
+            xyzz_dbl(t, acc);
+            acc = t;
+        }
+        Fq zi, t, x, y;
+        fe_mul(t, acc.zz, acc.zzz);
+        fe_inverse(zi, t);
+        fe_mul(t, zi, acc.zzz);
+        fe_mul(x, acc.x, t);
+        fe_mul(t, zi, acc.zz);
+        fe_mul(y, acc.y, t);
+        fe_canon(x);
+        fe_canon(y);
+        fe_pack(o, x);
+        fe_pack(o + 8, y);
+    }
+    next[4 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+    next[4 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    next[4 * i + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+    next[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
+}
+
 // device affine format -> wire (x || y, radix 2^256)
 __global__ void __launch_bounds__(256)
 k_points_device_to_wire(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
@@ -138,6 +177,40 @@ int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau[4], uint64_t first_power, 
     hipLaunchKernelGGL(k_srs_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly_a.as<uint4>(), d_points, (uint32_t)n);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+// Window tables T_w = 2^(c w) * SRS for w < W, contiguous after the SRS itself.  Spends HBM capacity (W x 64 B per
+// point: 1 GiB for 2^20 points at c = 16) to turn the MSM into W n mixed adds into a single bucket set.
+int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
+    const char* env = getenv("KZG_NO_PRECOMPUTE");
+    if (env && atoi(env) != 0) return KZG_OK;
+    const size_t n = srs->n;
+    if (n < 128) return KZG_OK;
+    int lg = 0;
+    while ((n >> (lg + 1)) != 0) ++lg;
+    int c = lg - 4;
+    if (c < 7) c = 7;
+    if (c > 16) c = 16;
+    const char* envc = getenv("KZG_TABLE_C");
+    if (envc && atoi(envc) >= 7 && atoi(envc) <= 16) c = atoi(envc);
+    const int W = (255 + c - 1) / c;
+    const size_t bytes = (size_t)W * n * 64;
+    if (bytes > ((size_t)48 << 30) || (size_t)W * n >= ((size_t)1 << 31)) return KZG_OK;
+    uint4* table = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&table), bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return KZG_OK; }      // not enough memory: stay in generic mode
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(table, srs->d_points, n * 64, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int w = 1; w < W; ++w) {
+        hipLaunchKernelGGL(k_srs_window_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           table + 4 * (size_t)(w - 1) * n, table + 4 * (size_t)w * n, n, c);
+    }
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    KZG_HIP_TRY(ctx, hipFree(srs->d_points));
+    srs->d_points = table;
+    srs->pre_c = c;
+    srs->pre_W = W;
     return KZG_OK;
 }
 

@@ -158,6 +158,44 @@ def test_msm_known_tau_and_oracle(k, tau_srs, log_n):
     assert np.array_equal(got, orc.msm_pippenger(tau_srs.g1[:n], sc))
 
 
+def test_table_mode_and_generic_mode_agree(k, tau_srs):
+    """SRS calls use the precomputed window tables; a forced window size switches to the generic path."""
+    n = 1 << 14
+    sc = rand_scalars(n, 4242)
+    a = msm_srs(k, tau_srs, sc)
+    tau_srs.ctx.set_msm_window(13, 0)
+    try:
+        b = msm_srs(k, tau_srs, sc)
+    finally:
+        tau_srs.ctx.set_msm_window(0, 0)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, k.helpers.g1_lincomb(tau_srs.g1[:n], sc))
+    # sub-range of the tables
+    assert np.array_equal(msm_srs(k, tau_srs, sc[:5000], offset=777), k.helpers.g1_lincomb(tau_srs.g1[777:5777], sc[:5000]))
+
+
+def test_msm_2_20_known_tau(k):
+    """BASELINE config 2 at full size: 2^20 blob-like scalars; property check commit == p(tau) * G1."""
+    n = 1 << 20
+    srs = k.SRS.generate(TAU, n)
+    rng = np.random.default_rng(11)
+    raw = rng.integers(32, 127, size=(n, 31), dtype=np.uint8)
+    vals = [int.from_bytes(raw[i].tobytes(), "big") for i in range(n)]
+    sc = pyref.frs_to_mont(vals)
+    got = msm_srs(k, srs, sc)
+    ptau, cur = 0, 1
+    for v in vals:
+        ptau = (ptau + v * cur) % R_
+        cur = cur * TAU % R_
+    assert pyref.point_from_wire(got) == pyref.ec_mul(ptau, (1, 2))
+    # degenerate: all scalars equal to one -> sum of all SRS points = (tau^n - 1)/(tau - 1) * G1
+    ones = pyref.frs_to_mont([1]) * np.ones((n, 1), dtype=np.uint64)
+    ones = np.ascontiguousarray(np.broadcast_to(pyref.fr_to_mont(1), (n, 4)))
+    geo = (pow(TAU, n, R_) - 1) * pow(TAU - 1, -1, R_) % R_
+    assert pyref.point_from_wire(msm_srs(k, srs, ones)) == pyref.ec_mul(geo, (1, 2))
+    srs.close()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # NTT
 # ---------------------------------------------------------------------------------------------------------

@@ -93,6 +93,43 @@ KERNELF64(k_fma_f64,       "v_fma_f64 %0, %1, %2, %0")
 KERNELF64(k_add_f64,       "v_add_f64 %0, %1, %0")
 KERNELF64(k_mul_f64,       "v_mul_f64 %0, %1, %0")
 
+// single DEPENDENT chain (what a product-scanning column accumulator looks like)
+#define KERNEL64DEP(NAME, ASM, ...)                                                       \
+__global__ void NAME(uint32_t* out, uint32_t seed) {                                      \
+  uint64_t a0 = seed + threadIdx.x;                                                       \
+  uint32_t b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x9e3779b9u;                  \
+  for (int i = 0; i < ITERS; ++i) {                                                       \
+    _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                  \
+      asm volatile(ASM : "+v"(a0) : "v"(b), "v"(c) : __VA_ARGS__);                        \
+    }                                                                                     \
+  }                                                                                       \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a0 ^ (uint32_t)(a0 >> 32);       \
+}
+KERNEL64DEP(k_mad_u64_dep,  "v_mad_u64_u32 %0, s[20:21], %1, %2, %0", "s20", "s21")
+KERNEL64DEP(k_mad_i64_dep,  "v_mad_i64_i32 %0, s[20:21], %1, %2, %0", "s20", "s21")
+KERNEL64(k_mad_i64_i32,     "v_mad_i64_i32 %0, s[20:21], %1, %2, %0", "s20", "s21")
+KERNEL64(k_ashr_i64,        "v_ashrrev_i64 %0, 29, %0", "memory")
+KERNEL32(k_and_b32,         "v_and_b32 %0, %1, %0", "memory")
+KERNEL32(k_sub_u32,         "v_sub_u32 %0, %1, %0", "memory")
+KERNEL32(k_ashr_i32,        "v_ashrrev_i32 %0, 29, %0", "memory")
+KERNEL32(k_mov_b32,         "v_mov_b32 %0, %1", "memory")
+KERNEL32(k_cndmask,         "v_cndmask_b32 %0, %1, %0, vcc", "memory")
+
+// two interleaved dependent chains
+__global__ void k_mad_2chains(uint32_t* out, uint32_t seed) {
+  uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1;
+  uint32_t b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x9e3779b9u;
+  for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+    for (int u = 0; u < UNROLL / 2; ++u) {
+      asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(a0) : "v"(b), "v"(c) : "s20", "s21");
+      asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(a1) : "v"(b), "v"(c) : "s20", "s21");
+    }
+  }
+  uint64_t x = a0 ^ a1;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)x ^ (uint32_t)(x >> 32);
+}
+
 // mixed: one mad_u64_u32 followed by two full-rate adds (the CIOS inner step shape)
 __global__ void k_mix_mad_2add(uint32_t* out, uint32_t seed) {
   uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;
@@ -128,9 +165,13 @@ int main() {
     {"v_lshl_add_u64", k_lshl_add_u64, 1},
     {"v_fma_f64", k_fma_f64, 1}, {"v_add_f64", k_add_f64, 1}, {"v_mul_f64", k_mul_f64, 1},
     {"mad_u64+add_co+addc", k_mix_mad_2add, 3},
+    {"v_mad_u64_u32 1 dep chain", k_mad_u64_dep, 1}, {"v_mad_i64_i32 1 dep chain", k_mad_i64_dep, 1},
+    {"v_mad_u64_u32 2 dep chains", k_mad_2chains, 1}, {"v_mad_i64_i32 (8 chains)", k_mad_i64_i32, 1},
+    {"v_ashrrev_i64", k_ashr_i64, 1}, {"v_and_b32", k_and_b32, 1}, {"v_sub_u32", k_sub_u32, 1},
+    {"v_ashrrev_i32", k_ashr_i32, 1}, {"v_mov_b32", k_mov_b32, 1}, {"v_cndmask_b32", k_cndmask, 1},
   };
   uint32_t* d; 
-  for (int wavesPerSimd : {1, 2, 4, 8}) {
+  for (int wavesPerSimd : {1, 2, 3, 4, 8}) {
     int threads = 256;                       // 4 waves = 1 per SIMD
     int blocks = cus * wavesPerSimd;         // wavesPerSimd blocks per CU
     CHECK(hipMalloc(&d, (size_t)blocks * threads * 4));
