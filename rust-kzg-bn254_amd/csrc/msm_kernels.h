@@ -292,7 +292,7 @@ k_msm_bucket_fin(const unsigned long long* __restrict__ offs, uint32_t G, uint32
     for (uint32_t k = 0; k < np; ++k) {
         Xyzz v, t;
         xyzz_load(v, segsum, seg_stride, partial_sid(s0, k));
-        xyzz_add(t, acc, v);
+        xyzz_add<true>(t, acc, v);
         acc = t;
     }
     xyzz_store(bucket, bucket_stride, m ? bucket_pos(g, m, n_chunks) : (size_t)g, acc);
@@ -314,14 +314,14 @@ k_msm_bucket_fin_heavy(const unsigned long long* __restrict__ offs, uint32_t m, 
         for (uint32_t k = lane; k < np; k += 64) {
             Xyzz v, t;
             xyzz_load(v, segsum, seg_stride, partial_sid(s0, k));
-            xyzz_add(t, acc, v);
+            xyzz_add<true>(t, acc, v);
             acc = t;
         }
 #pragma unroll 1
         for (int d = 32; d >= 1; d >>= 1) {
             Xyzz u, r;
             xyzz_shfl_down(u, acc, d);
-            xyzz_add(r, acc, u);
+            xyzz_add<true>(r, acc, u);
             acc = r;
         }
         if (lane == 0) xyzz_store(bucket, bucket_stride, m ? bucket_pos(g, m, n_chunks) : (size_t)g, acc);
@@ -439,7 +439,7 @@ __device__ __forceinline__ void wave_role_sum(Xyzz& v, const int32_t* __restrict
     for (int d = 32; d >= 1; d >>= 1) {
         Xyzz u, r;
         xyzz_shfl_down(u, v, d);
-        xyzz_add(r, v, u);
+        xyzz_add<true>(r, v, u);
         v = r;
     }
 }

@@ -12,7 +12,7 @@
 namespace kzg {
 
 template <class F>
-__device__ __noinline__ void fe_inverse(Fe<F>& out, const Fe<F>& a) {     // a^(m-2)
+__device__ __forceinline__ void fe_inverse(Fe<F>& out, const Fe<F>& a) {     // a^(m-2)
     Fe<F> acc, base = a;
     fe_set_one(acc);
     uint32_t e[8];
@@ -48,9 +48,9 @@ k_srs_powers(const uint4* __restrict__ scalars_canonical, uint4* __restrict__ ou
     for (int w = 7; w >= 0; --w) {
         for (int b = 31; b >= 0; --b) {
             Xyzz t;
-            xyzz_dbl(t, acc);
+            xyzz_dbl_impl(t, acc);
             acc = t;
-            if ((k[w] >> b) & 1u) xyzz_madd(acc, g, 0);
+            if ((k[w] >> b) & 1u) xyzz_madd<true>(acc, g, 0);
         }
     }
     uint32_t o[16];
@@ -120,10 +120,10 @@ k_srs_window_step(const uint4* __restrict__ prev, uint4* __restrict__ next, size
         for (int j = 0; j < 16; ++j) o[j] = 0;
     } else {
         Xyzz acc;
-        xyzz_dbl_affine(acc, p.x, p.y);
+        xyzz_dbl_affine_impl(acc, p.x, p.y);
         for (int k = 1; k < c; ++k) {
             Xyzz t;
-            xyzz_dbl(t, acc);
+            xyzz_dbl_impl(t, acc);
             acc = t;
         }
         Fq zi, t, x, y;

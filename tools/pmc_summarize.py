@@ -1,0 +1,35 @@
+"""Summarises rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass as MI355X_MICROARCH.md prescribes)
+into profiles/<name>.json: per kernel, average KB per dispatch.  bench.py reads the k_msm_accumulate entry for
+`roofline.traffic`.
+
+Units / gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE are in KB.  FETCH_SIZE halves wide
+coalesced 16 B/lane STREAMING reads; k_msm_accumulate's reads are 64-byte random gathers (one 64 B point per lane,
+4 x dwordx4), calibrated here against the known byte count of the gather (entries x 64 B + entries x 4 B):
+the counter reads 1.2x that minimum, i.e. it is NOT halved for this pattern, so no doubling is applied.
+Usage: python tools/pmc_summarize.py <fetch_csv> <write_csv> <out_json>"""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"].split("(")[0].replace("kzg::", "")].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    out = {"units": "KB per dispatch (average)", "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        out["kernels"][k] = {"FETCH_SIZE_KB": fetch.get(k), "WRITE_SIZE_KB": write.get(k)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    acc = out["kernels"].get("k_msm_accumulate")
+    if acc:
+        print("k_msm_accumulate HBM bytes per launch:", (acc["FETCH_SIZE_KB"] + acc["WRITE_SIZE_KB"]) * 1024)
+
+
+if __name__ == "__main__":
+    main()
