@@ -121,6 +121,10 @@ int32_t kzg_commit_coeff_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* 
  * MSM(g1_ifft(srs), evals) (prover/src/lib.rs:43-47; prover/tests/kzg_test.rs:57-89). */
 int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
                              uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* KZG::g1_ifft (kzg.rs:263-285): Lagrange-basis SRS L_i = n^-1 sum_j w^(-ij) P_j of the first n SRS points, natural
+ * order, n x 8 u64 written to out.  n not a power of two -> KZG_ERR_NOT_POWER_OF_TWO ("length provided is not a
+ * power of 2"); n > 2^28 -> KZG_ERR_DOMAIN.  Not used by the commit / proof path of this library. */
+int32_t kzg_g1_ifft(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy_mont);
 /* KZG::compute_proof / compute_proof_impl (kzg.rs:128-178, :215-234, on-domain branch :237-260).
  * roots = KZG::expanded_roots_of_unity (n_roots entries); n != n_roots -> KZG_ERR_ROOTS_LENGTH.
  * out_y (optional, 4 u64) receives y = p(z) (helpers.rs:475-535). */

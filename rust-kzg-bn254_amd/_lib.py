@@ -62,6 +62,7 @@ PROTOTYPES = {
     "kzg_fr_ntt_device": (i32, [vp, vp, sz, i32]),
     "kzg_commit_coeff_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
     "kzg_commit_eval_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
+    "kzg_g1_ifft": (i32, [vp, vp, sz, u64p]),
     "kzg_compute_proof": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, u64p, u8p, u64p]),
     "kzg_evaluate_polynomial_in_evaluation_form": (i32, [vp, u64p, sz, u64p, u64p]),
     "kzg_calculate_roots_of_unity": (i32, [vp, C.c_uint64, u64p, sz, C.POINTER(sz)]),

@@ -308,6 +308,17 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_a.p, n, out_xy_mont, out_is_infinity, nullptr);
 }
 
+int32_t kzg_g1_ifft(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy_mont) {
+    if (!ctx || !srs || srs->ctx != ctx) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;             // kzg.rs:265-269
+    if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;                               // kzg.rs:275-278
+    if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
+    if (!out_xy_mont) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return g1_ifft_run(ctx, srs, n, out_xy_mont);
+}
+
 int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
                           const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4],
                           uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont) {

@@ -101,6 +101,23 @@ class KZG:
             raise GenericError("Root of unity not found")
         return self.compute_proof(polynomial, z, srs)
 
+    # kzg.rs:263-285
+    def g1_ifft(self, length: int, srs):
+        """Lagrange-basis SRS of size `length` (natural order), (length, 8) uint64 wire points."""
+        if length <= 0 or (length & (length - 1)) != 0:
+            raise FFTError("length provided is not a power of 2")
+        ctx = self._ctx()
+        out = np.zeros((length, 8), dtype=np.uint64)
+        rc = _lib.load().kzg_g1_ifft(ctx.handle, srs.handle, length, _lib.ptr(out))
+        if rc == _lib.ERR_NOT_POWER_OF_TWO:
+            raise FFTError("length provided is not a power of 2")
+        if rc == _lib.ERR_DOMAIN:
+            raise FFTError("Could not perform IFFT due to domain consturction error")
+        if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
+            raise SrsCapacityExceeded(length, len(srs))
+        ctx.check_device(rc)
+        return out
+
     # kzg.rs:288-309
     def compute_blob_proof(self, blob, commitment, srs):
         if g1_is_identity(commitment) and False:

@@ -366,3 +366,29 @@ def test_random_blob_commit_and_proof_2_12(k, tau_srs):
     assert pyref.fr_from_mont(y) == yv
     qtau = (ptau - yv) * pow(TAU - z, -1, R_) % R_
     assert pyref.point_from_wire(proof) == pyref.ec_mul(qtau, (1, 2))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# g1_ifft (kzg.rs:263-285)
+# ---------------------------------------------------------------------------------------------------------
+def test_g1_ifft_matches_lagrange_fixture_and_oracle(k, ref_srs, test_srs_wire, gettysburg):
+    kzg = k.KZG.new()
+    want = []
+    for line in open(os.path.join(GOLDEN, "lagrangeG1SRS.txt")):
+        line = line.strip()
+        if line:
+            x, y = line.split(",")[-2:]
+            want.append((int(x), int(y)))
+    got = kzg.g1_ifft(64, ref_srs)
+    assert [pyref.point_from_wire(g) for g in got] == want            # all 64 points of the reference's fixture
+    for n in (1, 2, 8, 256):
+        rc, o = orc.g1_ifft(test_srs_wire, n)
+        assert rc == 0 and np.array_equal(kzg.g1_ifft(n, ref_srs), o), n
+    with pytest.raises(k.errors.FFTError, match="length provided is not a power of 2"):   # kzg_test.rs:131-161
+        kzg.g1_ifft(15, ref_srs)
+    with pytest.raises(k.errors.SrsCapacityExceeded):
+        kzg.g1_ifft(4096, ref_srs)
+    # the reference's literal eval-form commitment: MSM over the Lagrange bases == this library's IFFT + MSM
+    blob = k.Blob.from_raw_data(gettysburg)
+    ev = blob.to_polynomial_eval_form()
+    assert np.array_equal(k.helpers.g1_lincomb(got, ev.evaluations()), kzg.commit_eval_form(ev, ref_srs))

@@ -47,3 +47,9 @@ t_cc = timeit(lambda: lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr
 t_pr = timeit(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(uni), n, None, n, _lib.ptr(z), _lib.ptr(out), C.byref(inf), _lib.ptr(y)), reps=5)
 t_ev = timeit(lambda: lib.kzg_evaluate_polynomial_in_evaluation_form(ctx.handle, _lib.ptr(uni), n, _lib.ptr(z), _lib.ptr(y)), reps=5)
 print(f"host-buffer paths 2^{log_n}: commit_coeff {t_cc:.3f} ms  commit_eval {t_ce:.3f} ms  compute_proof {t_pr:.3f} ms  evaluate {t_ev:.3f} ms", flush=True)
+
+kz = k.KZG.new(ctx)
+for m in (64, 2048):
+    t0 = time.perf_counter(); kz.g1_ifft(m, srs); t = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); kz.g1_ifft(m, srs); t2 = (time.perf_counter() - t0) * 1e3
+    print(f"g1_ifft({m}): {t2:.2f} ms (first call {t:.2f} ms)", flush=True)
