@@ -62,9 +62,14 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases) {
     p.G = p.sets * p.B;
     int L = ctx->msm_seg_override;
     if (L == 0) { const char* env = getenv("KZG_MSM_SEG"); if (env) L = atoi(env); }
-    if (L <= 0) L = 96;
-    p.L = (uint32_t)L;
     const size_t entries = (size_t)p.W * n;
+    if (L <= 0) {
+        // one lane per segment: aim at ~2 700 waves (one round at 4 waves/SIMD); short segments keep small MSMs
+        // from serialising ~100 dependent mixed adds (10 us each) in a handful of waves
+        size_t want = (entries + (size_t)64 * 2730 - 1) / ((size_t)64 * 2730);
+        L = (int)std::min<size_t>(96, std::max<size_t>(4, want));
+    }
+    p.L = (uint32_t)L;
     p.set_len = (uint32_t)(p.tables ? entries : n);
     // sort tiles: large against the bucket count (one contiguous flush of B counters per tile), and not too many
     size_t mult = 2;

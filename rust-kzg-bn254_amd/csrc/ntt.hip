@@ -28,8 +28,12 @@ constexpr int NTT_TILE_LOG = 11;
 constexpr int NTT_TILE = 1 << NTT_TILE_LOG;       // elements per workgroup tile
 constexpr int NTT_KMAX = 7;
 constexpr int NTT_PL = NTT_TILE + (1 << NTT_KMAX); // plane length with one pad element per row
-constexpr int NTT_THREADS = 256;
+#ifndef KZG_NTT_THREADS
+#define KZG_NTT_THREADS 512
+#endif
+constexpr int NTT_THREADS = KZG_NTT_THREADS;
 constexpr int NTT_LO_BITS = 10;
+constexpr int NTT_TW = 96;                         // LDS twiddle entries: R/2 local + R row entries must fit (2 tiles per CU)
 
 // ---- twiddle tables: planes[9][len] of w^(t * step), internal Montgomery form -----------------------
 __device__ __forceinline__ void fr_pow_root(Fr& out, int log_n, bool inverse, uint32_t e) {
@@ -82,7 +86,8 @@ k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_pla
            const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
            int first, int last, int scale_log_n /* >= 0: multiply by (2^scale_log_n)^-1 at the end */) {
     __shared__ int32_t lds[NL * NTT_PL];
-    __shared__ int32_t twl[NL * (1 << (NTT_KMAX - 1))];
+    // twiddle scratch: entries [0, R/2) = per-tile w_R^t; entries [64, 64 + R) = inter-pass row (only when R <= 32...64 fits)
+    __shared__ int32_t twl[NL * NTT_TW];
 
     const uint32_t N = 1u << log_n;
     const uint32_t R = 1u << K;
@@ -99,8 +104,19 @@ k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_pla
         twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, tid << (log_n - K));
         if (R == 1) fe_set_one(w);
 #pragma unroll
-        for (int j = 0; j < NL; ++j) twl[j * (1 << (NTT_KMAX - 1)) + tid] = w.l[j];
+        for (int j = 0; j < NL; ++j) twl[j * NTT_TW + tid] = w.l[j];
     }
+
+    // every unit of the tile has the same p = tile_u0 >> log_s, and the row fits behind the local twiddles
+    const bool row_tw = !first && s >= C && (R >> 1) + R <= (uint32_t)NTT_TW;
+    if (row_tw && tid < R) {
+        const uint32_t p = tile_u0 >> log_s;
+        Fr w;
+        twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, (p * tid) << log_s);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) twl[j * NTT_TW + (R >> 1) + tid] = w.l[j];
+    }
+    if (row_tw) __syncthreads();
 
     // ---- gather -------------------------------------------------------------------------------
     for (uint32_t t = tid; t < (uint32_t)NTT_TILE; t += NTT_THREADS) {
@@ -121,7 +137,12 @@ k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_pla
                 load_planes(v, in_planes, N, idx);
                 if (p != 0 && j != 0) {
                     Fr w;
-                    twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, (p * j) << log_s);   // w_{n_cur}^(p j) = w_N^(p j s)
+                    if (row_tw) {
+#pragma unroll
+                        for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + (R >> 1) + j];
+                    } else {
+                        twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, (p * j) << log_s);   // w_{n_cur}^(p j) = w_N^(p j s)
+                    }
                     fe_mul(v, v, w);                                                  // |v| < 16 m, |w| < 2 m
                 }
             }
@@ -147,9 +168,10 @@ k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_pla
             for (int l = 0; l < NL; ++l) {
                 a.l[l] = lds[l * NTT_PL + e0];
                 x.l[l] = lds[l * NTT_PL + e1];
-                w.l[l] = twl[l * (1 << (NTT_KMAX - 1)) + tw_idx];
+                w.l[l] = twl[l * NTT_TW + tw_idx];
             }
-            fe_mul(t, x, w);
+            if (h == 1) t = x;                         // stage 1: every twiddle is w_R^0 = 1
+            else fe_mul(t, x, w);
             Fr y0, y1;
             fe_add(y0, a, t); fe_norm(y0);
             fe_sub(y1, a, t); fe_norm(y1);
@@ -236,9 +258,18 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse) {
         if (P > 2) KZG_HIP_TRY(ctx, ctx->ntt.tmp.reserve(n * NL * 4));
     }
     int32_t* bufs[2] = {ctx->ntt.data.as<int32_t>(), ctx->ntt.tmp.as<int32_t>()};
+    int Ks[8];
+    for (int pi = 0; pi < P; ++pi) Ks[pi] = base;
+    {
+        int order[8], no = 0;
+        order[no++] = 0;
+        if (P > 1) order[no++] = P - 1;
+        for (int pi = 1; pi + 1 < P; ++pi) order[no++] = pi;
+        for (int e = 0; e < extra; ++e) Ks[order[e]] += 1;
+    }
     int log_ncur = 0;
     for (int pi = 0; pi < P; ++pi) {
-        int K = base + (pi < extra ? 1 : 0);
+        int K = Ks[pi];
         log_ncur += K;
         int log_s = log_n - log_ncur;
         bool first = pi == 0, last = pi == P - 1;
