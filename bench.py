@@ -158,6 +158,31 @@ def main():
             "phases_ms_per_launch": {name: phase[i] / max(1, launches.value) for i, name in enumerate(
                 ["digits", "scan", "scatter", "segments", "accumulate", "bucket_fin", "reduce", "device_total"])},
         }
+        if world == 1:
+            # secondary figures of the same run (outside the timed region; BASELINE configs 3 and 4 on one GPU)
+            def avg_ms(fn, reps=10, warm=2):
+                for _ in range(warm):
+                    fn()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / reps * 1e3
+            d_ntt = d_scalars.clone()
+            ntt_ms = avg_ms(lambda: lib.kzg_fr_ntt_device(ctx.handle, C.c_void_p(d_ntt.data_ptr()), n, 0))
+            intt_ms = avg_ms(lambda: lib.kzg_fr_ntt_device(ctx.handle, C.c_void_p(d_ntt.data_ptr()), n, 1))
+            o8 = np.zeros(8, np.uint64); o4 = np.zeros(4, np.uint64); oi = C.c_uint8(0)
+            zq = np.ascontiguousarray(scalars[12345 % n])
+            ce_ms = avg_ms(lambda: lib.kzg_commit_eval_form(ctx.handle, srs.handle, _lib.ptr(scalars), n, _lib.ptr(o8), C.byref(oi)), reps=5)
+            pr_ms = avg_ms(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(scalars), n, None, n, _lib.ptr(zq), _lib.ptr(o8),
+                                                         C.byref(oi), _lib.ptr(o4)), reps=5)
+            cc_ms = avg_ms(lambda: lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(scalars), n, _lib.ptr(o8), C.byref(oi)), reps=5)
+            out["secondary"] = {
+                "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,
+                "fr_ntt_algorithmic_GBps": 64.0 * n / (ntt_ms * 1e-3) / 1e9, "fr_ntt_frac_of_hbm_peak": 64.0 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "host_buffers_commit_coeff_ms": cc_ms, "host_buffers_commit_eval_ms": ce_ms, "host_buffers_compute_proof_ms": pr_ms,
+                "note": "NTT on device-resident data (64 B per element algorithmic); host_buffers_* include the 32 MiB H2D copy of the scalars (PCIe)"}
         if world == 1 and not args.no_cpu_baseline:
             import oracle as orc                                   # checker + reported CPU baseline only
             cores = os.cpu_count() or 1

@@ -212,7 +212,7 @@ int32_t kzg_msm_g1(kzg_ctx* ctx, const uint64_t* bases_xy_mont, size_t n_bases, 
 
 static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
                               uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
-    if (!ctx || !srs || srs->ctx != ctx || (!out_xy && !out_xyzz)) return KZG_ERR_INVALID_ARG;
+    if (!ctx || !srs || srs->ctx->device != ctx->device || (!out_xy && !out_xyzz)) return KZG_ERR_INVALID_ARG;   // an SRS may be shared by the contexts of its GPU
     if (n && !scalars) return KZG_ERR_INVALID_ARG;
     if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
     std::lock_guard<std::mutex> lk(ctx->mu);

@@ -118,10 +118,8 @@ KZG_HD void xyzz_madd(Xyzz& acc, const Affine& p, uint32_t neg) {
     fe_mul(ppp, P, pp_);                       // 9m * 2m
     fe_mul(q, acc.x, pp_);                     // 7m * 2m
     fe_sub(v, rr_, ppp); fe_sub(v, v, q); fe_sub(v, v, q); fe_norm(v);   // X3 = RR - PPP - 2Q in (-7m, 5m)
-    fe_sub(t, q, v);                           // (-6m, 9m)
-    fe_mul(t, R, t);                           // 5m * 9m = 45 m^2
-    fe_mul(u2, acc.y, ppp);                    // 3m * 2m
-    fe_sub(acc.y, t, u2); fe_norm(acc.y);      // Y3 in (-3m, 3m)
+    fe_sub(t, q, v);                           // (-6m, 9m), limbs within +-2^29
+    fe_mulsub(acc.y, R, t, acc.y, ppp);        // Y3 = R (Q - X3) - Y1 PPP: 45 m^2 + 6 m^2, one reduction -> (-m, 2m)
     acc.x = v;
     fe_mul(acc.zz, acc.zz, pp_);
     fe_mul(acc.zzz, acc.zzz, ppp);
@@ -156,10 +154,8 @@ KZG_HD void xyzz_add(Xyzz& r, const Xyzz& a, const Xyzz& b) {
     fe_mul(q, u1, pp_);
     fe_sub(v, rr_, ppp); fe_sub(v, v, q); fe_sub(v, v, q); fe_norm(v);   // (-6m, 5m)
     fe_sub(t, q, v);                           // (-6m, 8m)
-    fe_mul(t, R, t);                           // 3m * 8m
-    fe_mul(u2, s1, ppp);
     Fq y3;
-    fe_sub(y3, t, u2); fe_norm(y3);            // (-3m, 3m)
+    fe_mulsub(y3, R, t, s1, ppp);              // Y3 = R (Q - X3) - S1 PPP, one reduction -> (-m, 2m)
     fe_mul(t, a.zz, b.zz);
     fe_mul(r.zz, t, pp_);
     fe_mul(t, a.zzz, b.zzz);

@@ -113,6 +113,63 @@ KZG_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
     for (int j = 0; j < NL; ++j) r.l[j] = out[j];
 }
 
+// Fused (a*b - c*d) * 2^-261 mod m with ONE Montgomery reduction (saves 81 mads + 9 mul_lo against two fe_mul and a
+// subtraction).  Needs all four operands' limbs within +-2^29 (27 * 2^58 < 2^63 per column) and |a*b| + |c*d| < 2^261 m.
+// Result normalised, in (-m, 2m).
+template <class F>
+KZG_HD void fe_mulsub(Fe<F>& r, const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, const Fe<F>& d) {
+#if defined(KZG_BOUND_CHECK)
+    {
+        long double mx = 0;
+        for (int j = 0; j < NL; ++j) {
+            mx = fmaxl(mx, fmaxl(fabsl((long double)a.l[j]) * fabsl((long double)b.l[j]), 0.0L));
+        }
+        long double ma = 0, mb = 0, mc = 0, md = 0;
+        for (int j = 0; j < NL; ++j) {
+            ma = fmaxl(ma, fabsl((long double)a.l[j])); mb = fmaxl(mb, fabsl((long double)b.l[j]));
+            mc = fmaxl(mc, fabsl((long double)c.l[j])); md = fmaxl(md, fabsl((long double)d.l[j]));
+        }
+        if (9.0L * (ma * mb + mc * md) + 9.0L * 288230376151711744.0L >= 9223372036854775807.0L) {
+            fprintf(stderr, "KZG_BOUND_CHECK: fe_mulsub limb bound violated: %Lg %Lg %Lg %Lg\n", ma, mb, mc, md); abort();
+        }
+        long double m = fe_modulus_approx<F>();
+        long double prod = fabsl(fe_approx(a)) * fabsl(fe_approx(b)) + fabsl(fe_approx(c)) * fabsl(fe_approx(d));
+        if (prod >= ldexpl(1.0L, 261) * m) { fprintf(stderr, "KZG_BOUND_CHECK: fe_mulsub value bound violated\n"); abort(); }
+    }
+#endif
+    int64_t acc = 0;
+    int32_t m[NL];
+    int32_t out[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+#pragma unroll
+        for (int j = 0; j <= k; ++j) {
+            acc += (int64_t)a.l[j] * (int64_t)b.l[k - j];
+            acc -= (int64_t)c.l[j] * (int64_t)d.l[k - j];
+        }
+#pragma unroll
+        for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
+        acc += (int64_t)m[k] * (int64_t)(int32_t)F::P[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) {
+            acc += (int64_t)a.l[j] * (int64_t)b.l[k - j];
+            acc -= (int64_t)c.l[j] * (int64_t)d.l[k - j];
+        }
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        acc >>= LB;
+    }
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = out[j];
+}
+
 // Montgomery square: the symmetric products are taken once against the doubled limb.
 template <class F>
 KZG_HD void fe_sqr(Fe<F>& r, const Fe<F>& a) {

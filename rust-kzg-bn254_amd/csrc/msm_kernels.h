@@ -222,7 +222,10 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
     if (begin < end) {
         // software pipeline: the 64-byte point of entry e+1 is requested before the ~2 700-instruction mixed add of
         // entry e, so the random gather (HBM-resident tables) is hidden behind arithmetic
+        // two-deep pipeline: index e+2 and point e+1 are in flight while entry e is added, so neither the index
+        // load (dependent address) nor the 64-byte gather is waited for inside an iteration
         uint32_t v = sorted[begin];
+        uint32_t v1 = (begin + 1 < end) ? sorted[begin + 1] : 0u;
         const uint4* src = points + 4 * (size_t)(v & 0x7FFFFFFFu);
         uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
         for (uint32_t e = begin; e < end; ++e) {
@@ -231,9 +234,10 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
             uint32_t wy[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
             const uint32_t any = q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x | q2.y | q2.z | q2.w | q3.x | q3.y | q3.z | q3.w;
             if (e + 1 < end) {
-                v = sorted[e + 1];
+                v = v1;
                 src = points + 4 * (size_t)(v & 0x7FFFFFFFu);
                 q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+                if (e + 2 < end) v1 = sorted[e + 2];
             }
             if (any == 0) continue;                                                       // identity base
             Affine p;
