@@ -19,7 +19,7 @@
 namespace kzg {
 
 void MsmWorkspace::release() {
-    DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &cursor, &blockbase, &offs, &block_sums,
+    DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &cursor, &blockbase, &sort_tmp, &sort_small, &offs, &block_sums,
                            &seg_bucket, &segsum, &bucket, &chunkS, &chunkTmp, &chunkA, &out_wire};
     for (auto* b : all) b->release();
     if (pinned_out) { (void)hipHostFree(pinned_out); pinned_out = nullptr; }
@@ -38,6 +38,8 @@ struct Plan {
     uint32_t L;          // segment length
     uint32_t set_len;    // digit entries per set
     uint32_t tile_len, tiles_per_set, tiles;
+    bool sort2;          // two-level sort (table mode, index fits 25 bits)
+    uint32_t Hb, tile1, tiles1, tiles2cap;
     uint32_t T, m;       // generic-mode reduction: chunks per window, buckets per chunk
     uint32_t segcap;
 };
@@ -79,6 +81,16 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases) {
     p.tile_len = (uint32_t)tile;
     p.tiles_per_set = (uint32_t)(((size_t)p.set_len + tile - 1) / tile);
     p.tiles = p.tiles_per_set * p.sets;
+    {
+        const char* env = getenv("KZG_SORT2");
+        const bool want = !(env && atoi(env) == 0);
+        p.sort2 = want && p.tables && p.c - 1 > SORT2_LO_BITS + 1 && p.c - 1 - SORT2_LO_BITS <= 9 &&
+                  (size_t)p.W * bases.table_stride <= ((size_t)1 << 25) && entries >= ((size_t)1 << 16);
+        p.Hb = p.sort2 ? (p.B >> SORT2_LO_BITS) : 0;
+        p.tile1 = 32768;
+        p.tiles1 = (uint32_t)((entries + p.tile1 - 1) / p.tile1);
+        p.tiles2cap = (uint32_t)(entries / SORT2_CHUNK + p.Hb + 1);
+    }
     p.T = std::min<uint32_t>(p.B, RED_T);
     p.m = p.B / p.T;
     p.segcap = (uint32_t)(entries / p.L + std::min<size_t>(p.G, entries) + 1);
@@ -103,6 +115,11 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
     KZG_HIP_TRY(ctx, ws.count.reserve((size_t)p.G * 4));
     KZG_HIP_TRY(ctx, ws.blockbase.reserve((size_t)p.tiles * p.B * 4));
     KZG_HIP_TRY(ctx, ws.cursor.reserve(((size_t)p.G + 1) * 4));          // queue of heavy buckets
+    if (p.sort2) {
+        KZG_HIP_TRY(ctx, ws.sort_tmp.reserve(entries * 4));
+        KZG_HIP_TRY(ctx, ws.sort_small.reserve(((size_t)3 * (p.Hb + 1) + p.tiles2cap) * 4 + 64));
+        KZG_HIP_TRY(ctx, ws.blockbase.reserve(std::max((size_t)p.tiles1 * p.Hb, (size_t)p.tiles2cap * SORT2_LO) * 4));
+    }
     KZG_HIP_TRY(ctx, ws.offs.reserve(((size_t)p.G + 1) * 8));
     KZG_HIP_TRY(ctx, ws.block_sums.reserve((size_t)SCAN_TILE * 8));
     KZG_HIP_TRY(ctx, ws.seg_bucket.reserve((size_t)p.segcap * 4));
@@ -138,17 +155,42 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
     hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, ws.digits.as<uint32_t>());
     KZG_MARK(1);
     const size_t lds_bytes = (size_t)p.B * 4;
-    hipLaunchKernelGGL(k_sort_hist, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.set_len, p.tile_len,
-                       p.tiles_per_set, p.B, ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
-                       ws.block_sums.as<unsigned long long>());
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
-                       ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
-    KZG_MARK(2);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.n, p.set_len, p.tile_len,
-                       p.tiles_per_set, p.B, ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), bases.table_stride,
-                       ws.sorted.as<uint32_t>());
+    if (p.sort2) {
+        uint32_t* small = ws.sort_small.as<uint32_t>();
+        uint32_t* ccount = small;                       // Hb
+        uint32_t* cstart = small + (p.Hb + 1);          // Hb + 1
+        uint32_t* tstart = small + 2 * (p.Hb + 1);      // Hb + 1
+        uint32_t* tile_bin = small + 3 * (p.Hb + 1);    // tiles2cap
+        KZG_HIP_TRY(ctx, hipMemsetAsync(ccount, 0, (size_t)p.Hb * 4, st));
+        hipLaunchKernelGGL(k_sort2_hist1, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.tile1, p.Hb,
+                           ccount, ws.blockbase.as<uint32_t>());
+        hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart);
+        hipLaunchKernelGGL(k_sort2_scatter1, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, ws.digits.as<uint32_t>(), p.n, (uint32_t)entries, p.tile1,
+                           p.Hb, cstart, ws.blockbase.as<uint32_t>(), bases.table_stride, ws.sort_tmp.as<uint32_t>());
+        hipLaunchKernelGGL(k_sort2_tiles, dim3((p.Hb + 255) / 256), dim3(256), 0, st, tstart, p.Hb, tile_bin);
+        hipLaunchKernelGGL(k_sort2_hist2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
+                           ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
+                           ws.block_sums.as<unsigned long long>());
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
+        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
+                           ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
+        KZG_MARK(2);
+        hipLaunchKernelGGL(k_sort2_scatter2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
+                           ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), ws.sorted.as<uint32_t>());
+    } else {
+        hipLaunchKernelGGL(k_sort_hist, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.set_len, p.tile_len,
+                           p.tiles_per_set, p.B, ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
+                           ws.block_sums.as<unsigned long long>());
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
+        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
+                           ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
+        KZG_MARK(2);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.n, p.set_len, p.tile_len,
+                           p.tiles_per_set, p.B, ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), bases.table_stride,
+                           ws.sorted.as<uint32_t>());
+    }
     const uint32_t gg = (p.G + 255) / 256;
     KZG_MARK(3);
     hipLaunchKernelGGL(k_msm_segments, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,

@@ -172,6 +172,118 @@ k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len
 }
 
 // -------------------------------------------------------------------------------------------------
+// 3b. two-level counting sort (table mode): coarse bins first, then the low key bits inside every bin
+// -------------------------------------------------------------------------------------------------
+// The single-pass scatter above writes 4-byte entries to ~2^15 different bucket regions: rocprofv3 counted 486 MiB
+// written for 64 MiB of payload (partial-line writes).  Here pass 1 groups entries by the high key bits (<= 512
+// bins: every tile writes runs of >= 256 B per bin), pass 2 sorts each bin's entries by the low 6 key bits (runs of
+// ~512 B per bucket).  Between the passes an entry is one u32: sign << 31 | low key << 25 | point index (< 2^25).
+constexpr int SORT2_LO_BITS = 6;
+constexpr uint32_t SORT2_LO = 1u << SORT2_LO_BITS;
+constexpr uint32_t SORT2_IDX_MASK = (1u << 25) - 1u;
+constexpr uint32_t SORT2_CHUNK = 16384;         // entries per pass-2 tile
+
+__global__ void __launch_bounds__(256)
+k_sort2_hist1(const uint32_t* __restrict__ digits, uint32_t E, uint32_t tile_len, uint32_t Hb,
+              uint32_t* __restrict__ ccount, uint32_t* __restrict__ blockbase1) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t lo = blockIdx.x * tile_len;
+    const uint32_t hi = (E - lo < tile_len) ? E : lo + tile_len;
+    for (uint32_t b = threadIdx.x; b < Hb; b += blockDim.x) lds_u32[b] = 0;
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        uint32_t v = digits[e];
+        if (v != DIGIT_NONE) atomicAdd(&lds_u32[(v & 0x7FFFFFFFu) >> SORT2_LO_BITS], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < Hb; b += blockDim.x) {
+        uint32_t h = lds_u32[b];
+        blockbase1[(size_t)blockIdx.x * Hb + b] = h ? atomicAdd(&ccount[b], h) : 0u;
+    }
+}
+// single block: cstart[h] = exclusive scan of the coarse counts, tstart[h] = exclusive scan of ceil(count / CHUNK)
+__global__ void __launch_bounds__(512)
+k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restrict__ cstart, uint32_t* __restrict__ tstart) {
+    __shared__ uint32_t a[512], b[512];
+    const uint32_t t = threadIdx.x;
+    uint32_t c = t < Hb ? ccount[t] : 0u;
+    uint32_t k = (c + SORT2_CHUNK - 1) / SORT2_CHUNK;
+    a[t] = c; b[t] = k;
+    __syncthreads();
+    for (uint32_t d = 1; d < 512; d <<= 1) {
+        uint32_t x = t >= d ? a[t - d] : 0u, y = t >= d ? b[t - d] : 0u;
+        __syncthreads();
+        a[t] += x; b[t] += y;
+        __syncthreads();
+    }
+    if (t < Hb) { cstart[t] = a[t] - c; tstart[t] = b[t] - k; }
+    if (t == Hb - 1) { cstart[Hb] = a[t]; tstart[Hb] = b[t]; }
+}
+__global__ void __launch_bounds__(256)
+k_sort2_scatter1(const uint32_t* __restrict__ digits, uint32_t n, uint32_t E, uint32_t tile_len, uint32_t Hb,
+                 const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ blockbase1, uint32_t table_stride,
+                 uint32_t* __restrict__ tmp1) {
+    extern __shared__ uint32_t lds_u32[];
+    const uint32_t lo = blockIdx.x * tile_len;
+    const uint32_t hi = (E - lo < tile_len) ? E : lo + tile_len;
+    for (uint32_t b = threadIdx.x; b < Hb; b += blockDim.x) lds_u32[b] = cstart[b] + blockbase1[(size_t)blockIdx.x * Hb + b];
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        uint32_t v = digits[e];
+        if (v == DIGIT_NONE) continue;
+        uint32_t key = v & 0x7FFFFFFFu;
+        uint32_t pos = atomicAdd(&lds_u32[key >> SORT2_LO_BITS], 1u);
+        uint32_t w = e / n;
+        uint32_t idx = w * table_stride + (e - w * n);
+        tmp1[pos] = (v & 0x80000000u) | ((key & (SORT2_LO - 1)) << 25) | idx;
+    }
+}
+// pass-2 tile -> coarse bin
+__global__ void __launch_bounds__(256)
+k_sort2_tiles(const uint32_t* __restrict__ tstart, uint32_t Hb, uint32_t* __restrict__ tile_bin) {
+    uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= Hb) return;
+    for (uint32_t t = tstart[h]; t < tstart[h + 1]; ++t) tile_bin[t] = h;
+}
+__global__ void __launch_bounds__(256)
+k_sort2_hist2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
+              const uint32_t* __restrict__ tile_bin, uint32_t Hb, uint32_t* __restrict__ count, uint32_t* __restrict__ blockbase2) {
+    __shared__ uint32_t hist[SORT2_LO];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= tstart[Hb]) return;
+    const uint32_t h = tile_bin[tile];
+    const uint32_t lo = cstart[h] + (tile - tstart[h]) * SORT2_CHUNK;
+    const uint32_t hi = (cstart[h + 1] - lo < SORT2_CHUNK) ? cstart[h + 1] : lo + SORT2_CHUNK;
+    if (threadIdx.x < SORT2_LO) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&hist[(tmp1[e] >> 25) & (SORT2_LO - 1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < SORT2_LO) {
+        uint32_t c = hist[threadIdx.x];
+        blockbase2[(size_t)tile * SORT2_LO + threadIdx.x] = c ? atomicAdd(&count[(size_t)h * SORT2_LO + threadIdx.x], c) : 0u;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
+                 const uint32_t* __restrict__ tile_bin, uint32_t Hb, const unsigned long long* __restrict__ offs,
+                 const uint32_t* __restrict__ blockbase2, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cur[SORT2_LO];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= tstart[Hb]) return;
+    const uint32_t h = tile_bin[tile];
+    const uint32_t lo = cstart[h] + (tile - tstart[h]) * SORT2_CHUNK;
+    const uint32_t hi = (cstart[h + 1] - lo < SORT2_CHUNK) ? cstart[h + 1] : lo + SORT2_CHUNK;
+    if (threadIdx.x < SORT2_LO)
+        cur[threadIdx.x] = (uint32_t)offs[(size_t)h * SORT2_LO + threadIdx.x] + blockbase2[(size_t)tile * SORT2_LO + threadIdx.x];
+    __syncthreads();
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        uint32_t v = tmp1[e];
+        uint32_t pos = atomicAdd(&cur[(v >> 25) & (SORT2_LO - 1)], 1u);
+        sorted[pos] = v & (0x80000000u | SORT2_IDX_MASK);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // 4. segment -> bucket map
 // -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
