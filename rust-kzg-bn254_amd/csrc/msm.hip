@@ -85,7 +85,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases) {
         const char* env = getenv("KZG_SORT2");
         const bool want = !(env && atoi(env) == 0);
         p.sort2 = want && p.tables && p.c - 1 > SORT2_LO_BITS + 1 && p.c - 1 - SORT2_LO_BITS <= 9 &&
-                  (size_t)p.W * bases.table_stride <= ((size_t)1 << 25) && entries >= ((size_t)1 << 16);
+                  (size_t)p.W * bases.table_stride <= ((size_t)1 << 25) && entries >= ((size_t)1 << 23);   // ~0.1 ms of extra launches: only pays on large sorts
         p.Hb = p.sort2 ? (p.B >> SORT2_LO_BITS) : 0;
         p.tile1 = 32768;
         p.tiles1 = (uint32_t)((entries + p.tile1 - 1) / p.tile1);
@@ -208,14 +208,14 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
         hipLaunchKernelGGL(k_msm_bucket_fin_heavy, dim3(256), dim3(256), 0, st, ws.offs.as<unsigned long long>(), 0u, 0u,
                            ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
         KZG_MARK(6);
-        const uint32_t waves1 = G1 * 7;
+        const uint32_t waves1 = G1;
         hipLaunchKernelGGL(k_red_bits1, dim3((waves1 * 64 + 255) / 256), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, p.B, G1,
                            ws.chunkS.as<int32_t>(), (size_t)7 * G1);
         if (G1 == 1) {
             n_out = 7;
             hipLaunchKernelGGL(k_xyzz_to_wire, dim3(1), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, n_out, ws.out_wire.as<uint32_t>());
         } else {
-            const uint32_t waves2 = 13 * G1p;
+            const uint32_t waves2 = 7 * G1p;
             int32_t* y = ws.chunkA.as<int32_t>();
             hipLaunchKernelGGL(k_red_bits2, dim3((waves2 * 64 + 255) / 256), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p,
                                y, y + (size_t)6 * G1p, (size_t)13 * G1p);

@@ -544,51 +544,60 @@ k_red_window_sum(int32_t* __restrict__ a, size_t stride, uint32_t T, uint32_t* _
 // a chunk) is latency bound; here every partial sum is a 6-step wave tree over ds_bpermute shuffles:
 // one wave per (group of 64 values, role); role j < 6 sums the lanes whose index has bit j set, role 6 sums all.
 // Applied again to the group totals it yields bits 6..11, and so on; the few remaining values go to the host.
-// role sum over one group of <= 64 stored values in[first .. first + count): role j < 6 takes the lanes whose
-// index has bit j set, role 6 takes all.  Result valid in lane 0.
-__device__ __forceinline__ void wave_role_sum(Xyzz& v, const int32_t* __restrict__ in, size_t in_stride, size_t first,
-                                              uint32_t count, uint32_t lane, uint32_t role) {
-    const bool take = lane < count && (role == 6 || ((lane >> role) & 1u));
-    if (take) xyzz_load(v, in, in_stride, first + lane);
-    else xyzz_set_inf(v);
+// Superset-sum ("zeta") transform over the 64 lanes of a wave: after the 6 steps lane x holds the sum of the values
+// of all lanes l with (l & x) == x.  Lane 0 = total T; lane 2^k = S_k (sum over the lanes whose index has bit k set):
+// all seven sums the bucket reduction needs from a group of 64 buckets come out of 6 wave-wide additions.
+__device__ __forceinline__ void wave_zeta(Xyzz& v, uint32_t lane) {
 #pragma unroll 1
-    for (int d = 32; d >= 1; d >>= 1) {
-        Xyzz u, r;
-        xyzz_shfl_down(u, v, d);
-        xyzz_add<true>(r, v, u);
-        v = r;
+    for (int k = 0; k < 6; ++k) {
+        Xyzz u;
+        xyzz_shfl_down(u, v, 1 << k);
+        if (((lane >> k) & 1u) == 0) {
+            Xyzz r;
+            xyzz_add<true>(r, v, u);
+            v = r;
+        }
     }
 }
-// level 1: X1[role * G1 + g] = role sum of bucket group g (64 buckets), roles 0..6, G1 = B / 64
+__device__ __forceinline__ int zeta_role(uint32_t lane) {       // lane 0 -> role 6 (total), lane 2^k -> role k, else -1
+    if (lane == 0) return 6;
+    if ((lane & (lane - 1)) != 0) return -1;
+    return __ffs((int)lane) - 1;
+}
+// level 1: X1[role * G1 + g] for the bucket group g (64 buckets): role k < 6 = S_k, role 6 = T.   One wave per group.
 __global__ void __launch_bounds__(256)
 k_red_bits1(const int32_t* __restrict__ bucket, size_t bucket_stride, uint32_t B, uint32_t G1,
             int32_t* __restrict__ x1, size_t x_stride) {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= G1 * 7u) return;
-    const uint32_t g = wave / 7u, role = wave % 7u;
+    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (g >= G1) return;
     Xyzz v;
-    wave_role_sum(v, bucket, bucket_stride, (size_t)g * 64, B - g * 64 < 64 ? B - g * 64 : 64, lane, role);
-    if (lane == 0) xyzz_store(x1, x_stride, (size_t)role * G1 + g, v);
+    if (g * 64 + lane < B) xyzz_load(v, bucket, bucket_stride, (size_t)g * 64 + lane);
+    else xyzz_set_inf(v);
+    wave_zeta(v, lane);
+    const int role = zeta_role(lane);
+    if (role >= 0) xyzz_store(x1, x_stride, (size_t)role * G1 + g, v);
 }
 // level 2 (one launch, two kinds of job): with G1p = ceil(G1 / 64)
-//   job <  6 G1p : Y[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                 (a < 6: finishes bits 0..5)
-//   job >= 6 G1p : X2[role * G1p + g2] = role sum of the totals X1[6][g2 * 64 .. +64) (bits 6..11 and totals)
+//   wave <  6 G1p : Y[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                      (a < 6: finishes bits 0..5)
+//   wave >= 6 G1p : X2[role * G1p + g2], role 0..6, zeta transform of the totals X1[6][g2 * 64 .. +64)  (bits 6..11, totals)
 __global__ void __launch_bounds__(256)
 k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p,
             int32_t* __restrict__ y, int32_t* __restrict__ x2, size_t out_stride) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= 13u * G1p) return;
+    if (wave >= 7u * G1p) return;
+    const bool sum_job = wave < 6u * G1p;
+    const uint32_t a = sum_job ? wave / G1p : 6u;
+    const uint32_t g = sum_job ? wave % G1p : wave - 6u * G1p;
+    const uint32_t cnt = G1 - g * 64 < 64 ? G1 - g * 64 : 64;
     Xyzz v;
-    if (wave < 6u * G1p) {
-        const uint32_t a = wave / G1p, g = wave % G1p;
-        const uint32_t cnt = G1 - g * 64 < 64 ? G1 - g * 64 : 64;
-        wave_role_sum(v, x1, x_stride, (size_t)a * G1 + (size_t)g * 64, cnt, lane, 6);
+    if (lane < cnt) xyzz_load(v, x1, x_stride, (size_t)a * G1 + (size_t)g * 64 + lane);
+    else xyzz_set_inf(v);
+    wave_zeta(v, lane);
+    if (sum_job) {
         if (lane == 0) xyzz_store(y, out_stride, wave, v);
     } else {
-        const uint32_t j = wave - 6u * G1p, g2 = j / 7u, role = j % 7u;
-        const uint32_t cnt = G1 - g2 * 64 < 64 ? G1 - g2 * 64 : 64;
-        wave_role_sum(v, x1, x_stride, (size_t)6 * G1 + (size_t)g2 * 64, cnt, lane, role);
-        if (lane == 0) xyzz_store(x2, out_stride, (size_t)role * G1p + g2, v);
+        const int role = zeta_role(lane);
+        if (role >= 0) xyzz_store(x2, out_stride, (size_t)role * G1p + g, v);
     }
 }
 // stored-form XYZZ planes -> wire words (32 u32 per element)
