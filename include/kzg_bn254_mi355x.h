@@ -121,6 +121,13 @@ int32_t kzg_commit_coeff_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* 
  * MSM(g1_ifft(srs), evals) (prover/src/lib.rs:43-47; prover/tests/kzg_test.rs:57-89). */
 int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
                              uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* helpers::to_fr_array + PolynomialEvalForm::new padding (helpers.rs:40-57, polynomial.rs:41-57): each 32-byte big-endian
+ * chunk of the (already padded) blob mod r, last chunk right-padded with zeros, zero-extended to the next power of two;
+ * *n_out = that length; out needs cap >= *n_out elements (call with out = NULL to query). */
+int32_t kzg_blob_to_fr(kzg_ctx* ctx, const uint8_t* blob_bytes, size_t len, uint64_t* out_mont, size_t cap, size_t* n_out);
+/* KZG::commit_blob (kzg.rs:182-185) = Blob::to_polynomial_eval_form + commit_eval_form, bytes in, point out. */
+int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len,
+                        uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
 /* KZG::g1_ifft (kzg.rs:263-285): Lagrange-basis SRS L_i = n^-1 sum_j w^(-ij) P_j of the first n SRS points, natural
  * order, n x 8 u64 written to out.  n not a power of two -> KZG_ERR_NOT_POWER_OF_TWO ("length provided is not a
  * power of 2"); n > 2^28 -> KZG_ERR_DOMAIN.  Not used by the commit / proof path of this library. */

@@ -22,6 +22,7 @@ int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where) {
 int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
                   uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
+int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out);
 
 }  // namespace kzg
 
@@ -306,6 +307,42 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     int32_t rc = ntt_run(ctx, ctx->poly_a.p, n, true);               // coefficients = IFFT(evaluations)
     if (rc != KZG_OK) return rc;
     return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_a.p, n, out_xy_mont, out_is_infinity, nullptr);
+}
+
+static size_t next_pow2_sz(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
+
+int32_t kzg_blob_to_fr(kzg_ctx* ctx, const uint8_t* blob_bytes, size_t len, uint64_t* out_mont, size_t cap, size_t* n_out) {
+    if (!ctx || !n_out) return KZG_ERR_INVALID_ARG;
+    const size_t n_elems = (len + 31) / 32;
+    if (n_elems > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;                       // polynomial.rs:42-46
+    const size_t n_padded = next_pow2_sz(n_elems);                                   // next_power_of_two(0) == 1
+    *n_out = n_padded;                                                               // size query: out == NULL
+    if (!out_mont || cap < n_padded || (len && !blob_bytes)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* d = nullptr;
+    int32_t rc = blob_to_fr_run(ctx, blob_bytes, len, n_padded, &d);
+    if (rc != KZG_OK) return rc;
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(out_mont, d, n_padded * 32, hipMemcpyDeviceToHost, ctx->stream));
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len,
+                        uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!ctx || !srs || srs->ctx->device != ctx->device || !out_xy_mont || (len && !blob_bytes)) return KZG_ERR_INVALID_ARG;
+    const size_t n_elems = (len + 31) / 32;
+    if (n_elems > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    const size_t n = next_pow2_sz(n_elems);
+    if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;                            // kzg.rs:89-94
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* d = nullptr;
+    int32_t rc = blob_to_fr_run(ctx, blob_bytes, len, n, &d);                        // Blob::to_polynomial_eval_form
+    if (rc != KZG_OK) return rc;
+    rc = ntt_run(ctx, d, n, true);                                                   // commit_eval_form: IFFT ...
+    if (rc != KZG_OK) return rc;
+    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), d, n, out_xy_mont, out_is_infinity, nullptr);   // ... + MSM
 }
 
 int32_t kzg_g1_ifft(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy_mont) {

@@ -247,6 +247,41 @@ k_poly_quotient_on_domain(uint32_t n, NttTables tb, const int32_t* __restrict__ 
     wire_store(q_out, m, q);
 }
 
+// ---- blob bytes -> Fr (helpers::to_fr_array, primitives/src/helpers.rs:40-57) ---------------------------------------
+// element i = the 32 big-endian bytes [32 i, 32 i + 32) (the last chunk right-padded with zeros) mod r, emitted in wire
+// (Montgomery, radix 2^256) form; elements i >= n_elems (power-of-two padding of PolynomialEvalForm::new,
+// polynomial.rs:49-51) are zero.  One multiply: x * (2^(256+261) mod r) * 2^-261 = x * 2^256 mod r, x < 2^256 < 5.3 r.
+__global__ void __launch_bounds__(POLY_THREADS)
+k_blob_to_fr(const uint8_t* __restrict__ bytes, size_t len, uint32_t n_elems, uint32_t n_padded, uint4* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_padded) return;
+    uint32_t w32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < n_elems) {
+        const size_t base = (size_t)i * 32;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {              // word k (little-endian) = bytes 28-4k .. 31-4k of the big-endian chunk
+            uint32_t w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                size_t pos = base + (size_t)(28 - 4 * k + b);
+                uint32_t byte = pos < len ? bytes[pos] : 0u;
+                w = (w << 8) | byte;
+            }
+            w32[k] = w;
+        }
+    }
+    Fr x, kk, r;
+    fe_unpack(x, w32);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) kk.l[j] = (int32_t)FrParams::K_RAW[j];       // 2^(256+261) mod r
+    fe_mul(r, x, kk);                                                          // x * 2^256 mod r, in (-m, 2m)
+    fe_canon(r);
+    uint32_t o[8];
+    fe_pack(o, r);
+    out[2 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);
+    out[2 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 // ---- roots of unity -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(POLY_THREADS)
 k_poly_roots(uint4* __restrict__ out, uint32_t n, NttTables tb) {
@@ -271,6 +306,19 @@ int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n) {
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->poly_a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+// bytes (host) -> n_padded wire elements in ctx->poly_a (device); returns the device pointer
+int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out) {
+    const size_t n_elems = (len + 31) / 32;
+    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n_padded * 32 + 32));
+    KZG_HIP_TRY(ctx, ctx->poly_c.reserve(len + 32));
+    if (len) KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_c.p, bytes, len, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_blob_to_fr, dim3((unsigned)((n_padded + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, ctx->stream,
+                       ctx->poly_c.as<uint8_t>(), len, (uint32_t)n_elems, (uint32_t)n_padded, ctx->poly_a.as<uint4>());
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    *d_out = ctx->poly_a.p;
     return KZG_OK;
 }
 

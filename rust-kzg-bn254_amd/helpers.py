@@ -37,9 +37,20 @@ def remove_internal_padding(padded: bytes) -> bytes:
     return a[:, 1:].tobytes()
 
 
-def to_fr_array(data: bytes) -> np.ndarray:
-    """helpers.rs:40-57: each 32-byte big-endian chunk (last one right-padded with zeros) mod r."""
+def to_fr_array(data: bytes, ctx=None) -> np.ndarray:
+    """helpers.rs:40-57: each 32-byte big-endian chunk (last one right-padded with zeros) mod r.
+    Small inputs are converted on the host (pure byte arithmetic, no GPU needed); large ones by `kzg_blob_to_fr`."""
     n = get_num_element(len(data), BYTES_PER_FIELD_ELEMENT)
+    if n >= 4096:
+        ctx = ctx or _lib.default_context()
+        buf = np.frombuffer(data, dtype=np.uint8)
+        n_out = C.c_size_t(0)
+        lib = _lib.load()
+        lib.kzg_blob_to_fr(ctx.handle, None, len(data), None, 0, C.byref(n_out))
+        out = np.zeros((n_out.value, 4), dtype=np.uint64)
+        rc = lib.kzg_blob_to_fr(ctx.handle, buf.ctypes.data_as(_lib.u8p), len(data), _lib.ptr(out), out.shape[0], C.byref(n_out))
+        ctx.check_device(rc)
+        return out[:n]
     data = data + b"\x00" * (n * 32 - len(data))
     return frs_from_ints([int.from_bytes(data[32 * i:32 * i + 32], "big") for i in range(n)])
 

@@ -64,7 +64,24 @@ class KZG:
 
     # kzg.rs:182-185
     def commit_blob(self, blob, srs):
-        return self.commit_eval_form(blob.to_polynomial_eval_form(), srs)
+        """Bytes in, point out: bytes -> Fr, IFFT and MSM all on the device (`kzg_commit_blob`)."""
+        ctx = self._ctx()
+        data = blob.data()
+        n_elems = -(-len(data) // 32)
+        n = 1
+        while n < n_elems:
+            n <<= 1
+        if n > len(srs):
+            raise SrsCapacityExceeded(n, len(srs))
+        buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
+        rc = _lib.load().kzg_commit_blob(ctx.handle, srs.handle, buf.ctypes.data_as(_lib.u8p), len(data), _lib.ptr(out), C.byref(inf))
+        if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
+            raise SrsCapacityExceeded(n, len(srs))
+        if rc == _lib.ERR_TOO_LARGE:
+            raise GenericError("Input size exceeds maximum polynomial size")
+        ctx.check_device(rc)
+        return out
 
     # kzg.rs:128-178
     def _compute_proof_impl(self, polynomial, z_fr, srs, want_y=False):

@@ -392,3 +392,39 @@ def test_g1_ifft_matches_lagrange_fixture_and_oracle(k, ref_srs, test_srs_wire, 
     blob = k.Blob.from_raw_data(gettysburg)
     ev = blob.to_polynomial_eval_form()
     assert np.array_equal(k.helpers.g1_lincomb(got, ev.evaluations()), kzg.commit_eval_form(ev, ref_srs))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# blob codec + commit_blob on the device (helpers.rs:40-57, kzg.rs:182-185)
+# ---------------------------------------------------------------------------------------------------------
+def test_blob_to_fr_and_commit_blob(k, tau_srs, ref_srs, gettysburg):
+    lib = k._lib.load(); ctx = k.default_context()
+    data = open(os.path.join(GOLDEN, "blobs.txt"), "rb").read()               # 4096 gnark-generated elements
+    for cut in (len(data), len(data) - 7, 33, 32, 1):                         # ragged tails are right-padded with zeros
+        d = data[:cut]
+        buf = np.frombuffer(d, dtype=np.uint8)
+        n_out = C.c_size_t(0)
+        lib.kzg_blob_to_fr(ctx.handle, None, len(d), None, 0, C.byref(n_out))
+        out = np.zeros((n_out.value, 4), np.uint64)
+        assert lib.kzg_blob_to_fr(ctx.handle, buf.ctypes.data_as(k._lib.u8p), len(d), k._lib.ptr(out), len(out), C.byref(n_out)) == 0
+        want = orc.to_fr_array(d)
+        assert n_out.value == pyref.next_pow2(len(want)) and np.array_equal(out[:len(want)], want) and not out[len(want):].any()
+    # non-canonical chunks are reduced mod r (From<Vec<u8>> for Blob does not validate)
+    raw = bytes([0xFF] * 64)
+    buf = np.frombuffer(raw, dtype=np.uint8); out = np.zeros((2, 4), np.uint64); n_out = C.c_size_t(0)
+    assert lib.kzg_blob_to_fr(ctx.handle, buf.ctypes.data_as(k._lib.u8p), 64, k._lib.ptr(out), 2, C.byref(n_out)) == 0
+    assert pyref.frs_from_mont(out) == [(2 ** 256 - 1) % R_] * 2
+    # python mirror picks the device path for >= 4096 elements
+    assert np.array_equal(k.helpers.to_fr_array(data), orc.to_fr_array(data))
+    # commit_blob: bytes in, point out
+    kzg = k.KZG.new()
+    blob = k.Blob.from_raw_data(gettysburg)
+    assert np.array_equal(kzg.commit_blob(blob, ref_srs), kzg.commit_eval_form(blob.to_polynomial_eval_form(), ref_srs))
+    big = k.Blob.from_padded_unchecked(data)                                  # 4096 elements on the 2^16 known-tau SRS
+    c = kzg.commit_blob(big, tau_srs)
+    rc, want = orc.commit_eval_form(tau_srs.g1[:4096], orc.to_fr_array(data), literal=False)
+    assert rc == 0 and np.array_equal(c, want)
+    with pytest.raises(k.errors.SrsCapacityExceeded):
+        kzg.commit_blob(k.Blob.from_padded_unchecked(bytes(32 * 3001)), ref_srs)
+    zero = k.Blob.from_padded_unchecked(bytes(32 * 64))
+    assert not kzg.commit_blob(zero, ref_srs).any()                           # zero blob -> identity (tests.rs:239-269)
