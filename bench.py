@@ -77,10 +77,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Rehearsal switch (one-GPU box): KZG_BENCH_BACKEND=gloo runs every rank on GPU 0 and gathers through host memory.
+    backend = os.environ.get("KZG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import rust_kzg_bn254_amd as k
     from rust_kzg_bn254_amd import _lib
@@ -92,7 +99,7 @@ def main():
     tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % FR
 
     # ---- inputs: this rank's shard of the SRS (resident) and of the scalars (resident) ---------------------------
-    sh = ShardedMsm(ctx, n, rank, world)
+    sh = ShardedMsm(ctx, n, rank, world, gather_device="cuda" if backend == "nccl" else None)
     srs = k.SRS.generate(tau, sh.len, ctx=ctx, first_power=sh.lo)
     scalars = blob_like_scalars(n, 0x4B5A472D424E3235 & 0x7FFFFFFF)      # identical on every rank (seeded)
     d_scalars = torch.from_numpy(scalars[sh.lo:sh.hi].view(np.int64)).cuda()
@@ -117,9 +124,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank must hold the same folded commitment
+        chk = torch.from_numpy(result.view(np.int64).copy())
+        if backend == "nccl":
+            chk = chk.cuda()
+        ref = chk.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, chk), "ranks disagree on the folded commitment"
 
     phase = (C.c_double * 8)()
     launches, pairs = C.c_uint64(0), C.c_uint64(0)

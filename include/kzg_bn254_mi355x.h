@@ -88,6 +88,11 @@ size_t  kzg_srs_len(const kzg_srs* srs);
 int32_t kzg_msm_g1(kzg_ctx* ctx, const uint64_t* bases_xy_mont, size_t n_bases,
                    const uint64_t* scalars_mont, size_t n_scalars,
                    uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* `batch` independent MSMs of n pairs each in one kernel sequence: bases = batch x n points, scalars = batch x n
+ * elements (MSM b uses the b-th block of each), out = batch x 8 u64 (+ batch infinity flags).  This is the shape of
+ * verifier/src/batch.rs:228,245,246 (three g1_lincomb calls of equal length); results equal `batch` kzg_msm_g1 calls. */
+int32_t kzg_msm_g1_batch(kzg_ctx* ctx, const uint64_t* bases_xy_mont, const uint64_t* scalars_mont, size_t n, size_t batch,
+                         uint64_t* out_xy_mont, uint8_t* out_is_infinity);
 /* Same with bases = srs[offset .. offset + n) already resident (commit path). */
 int32_t kzg_msm_g1_srs(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
                        const uint64_t* scalars_mont, size_t n,

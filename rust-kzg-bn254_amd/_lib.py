@@ -53,6 +53,7 @@ PROTOTYPES = {
     "kzg_srs_free": (None, [vp]),
     "kzg_srs_len": (sz, [vp]),
     "kzg_msm_g1": (i32, [vp, u64p, sz, u64p, sz, u64p, u8p]),
+    "kzg_msm_g1_batch": (i32, [vp, u64p, u64p, sz, sz, u64p, u8p]),
     "kzg_msm_g1_srs": (i32, [vp, vp, sz, u64p, sz, u64p, u8p]),
     "kzg_msm_g1_srs_device": (i32, [vp, vp, sz, vp, sz, u64p, u8p]),
     "kzg_msm_g1_srs_partial_device": (i32, [vp, vp, sz, vp, sz, u64p]),

@@ -211,6 +211,26 @@ int32_t kzg_msm_g1(kzg_ctx* ctx, const uint64_t* bases_xy_mont, size_t n_bases, 
     return msm_run(ctx, b, d_scalars, n_bases, out_xy_mont, out_is_infinity, nullptr);
 }
 
+int32_t kzg_msm_g1_batch(kzg_ctx* ctx, const uint64_t* bases_xy_mont, const uint64_t* scalars_mont, size_t n, size_t batch,
+                         uint64_t* out_xy_mont, uint8_t* out_is_infinity) {
+    if (!ctx || !out_xy_mont || batch == 0 || batch > 64) return KZG_ERR_INVALID_ARG;
+    if (n && (!bases_xy_mont || !scalars_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) {
+        for (size_t i = 0; i < batch; ++i) write_identity(out_xy_mont + 8 * i, out_is_infinity ? out_is_infinity + i : nullptr, nullptr);
+        return KZG_OK;
+    }
+    const size_t total = n * batch;
+    KZG_HIP_TRY(ctx, ctx->msm.bases.reserve(total * 64));
+    int32_t rc = upload_points(ctx, bases_xy_mont, total, ctx->msm.bases.as<uint4>(), ctx->msm.bases_wire);
+    if (rc != KZG_OK) return rc;
+    const void* d_scalars;
+    rc = stage_scalars(ctx, scalars_mont, total, &d_scalars);
+    if (rc != KZG_OK) return rc;
+    return msm_run_batch(ctx, ctx->msm.bases.as<uint4>(), d_scalars, n, (uint32_t)batch, out_xy_mont, out_is_infinity);
+}
+
 static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
                               uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
     if (!ctx || !srs || srs->ctx->device != ctx->device || (!out_xy && !out_xyzz)) return KZG_ERR_INVALID_ARG;   // an SRS may be shared by the contexts of its GPU

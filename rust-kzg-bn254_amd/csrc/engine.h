@@ -105,6 +105,9 @@ inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, bool allow_tables) 
 int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n,
                 uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz);
 
+int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars, size_t n, uint32_t batch,
+                      uint64_t* out_xy, uint8_t* out_inf);
+
 // Precompute the window tables of an SRS in place (reallocates srs->d_points); no-op for small / huge SRS.
 int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs);
 

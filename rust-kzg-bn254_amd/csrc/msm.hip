@@ -29,7 +29,8 @@ void MsmWorkspace::release() {
 static int ilog2_floor(size_t n) { int k = 0; while ((n >> (k + 1)) != 0) ++k; return k; }
 
 struct Plan {
-    uint32_t n;          // pairs in this launch
+    uint32_t n;          // pairs per MSM in this launch
+    uint32_t batch;      // independent MSMs of n pairs each (generic mode only; 1 otherwise)
     bool tables;         // table mode
     int c, W;
     uint32_t B;          // buckets per set
@@ -44,9 +45,10 @@ struct Plan {
     uint32_t segcap;
 };
 
-static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases) {
+static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint32_t batch) {
     Plan p;
     p.n = (uint32_t)n;
+    p.batch = batch;
     p.tables = bases.table_stride != 0;
     int c;
     if (p.tables) {
@@ -60,11 +62,11 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases) {
     p.c = c;
     p.W = (255 + c - 1) / c;
     p.B = 1u << (c - 1);
-    p.sets = p.tables ? 1u : (uint32_t)p.W;
+    p.sets = p.tables ? 1u : (uint32_t)p.W * batch;
     p.G = p.sets * p.B;
     int L = ctx->msm_seg_override;
     if (L == 0) { const char* env = getenv("KZG_MSM_SEG"); if (env) L = atoi(env); }
-    const size_t entries = (size_t)p.W * n;
+    const size_t entries = (size_t)p.W * n * batch;
     if (L <= 0) {
         // one lane per segment: aim at ~2 700 waves (one round at 4 waves/SIMD); short segments keep small MSMs
         // from serialising ~100 dependent mixed adds (10 us each) in a handful of waves
@@ -100,12 +102,15 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases) {
 // Largest number of pairs one launch takes: W * n must fit the 32-bit positions of the sort.
 static const size_t MSM_MAX_LAUNCH = (size_t)1 << 24;
 
-static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_scalars, size_t n, kzg_host::Xyzz* result) {
-    const Plan p = make_plan(ctx, n, bases);
+static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_scalars, size_t n, uint32_t batch, kzg_host::Xyzz* result) {
+    if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
+    const Plan p = make_plan(ctx, n, bases, batch);
     MsmWorkspace& ws = ctx->msm;
     hipStream_t st = ctx->stream;
-    const size_t entries = (size_t)p.W * n;
-    const uint32_t n_chunks = (uint32_t)p.W * p.T;
+    const size_t entries = (size_t)p.W * n * batch;
+    const uint32_t n_windows = (uint32_t)p.W * batch;          // window sums produced in generic mode
+    if (!p.tables && n_windows > 1024) return KZG_ERR_INVALID_ARG;
+    const uint32_t n_chunks = n_windows * p.T;
     const uint32_t nb = (p.G + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > SCAN_TILE) return KZG_ERR_INVALID_ARG;
     const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
@@ -133,8 +138,8 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
         KZG_HIP_TRY(ctx, ws.chunkTmp.reserve((size_t)n_chunks * 36 * 4));
         KZG_HIP_TRY(ctx, ws.chunkA.reserve((size_t)n_chunks * 36 * 4));
     }
-    KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)128 * 32 * 4));
-    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, 128 * 32 * 4, hipHostMallocDefault));
+    KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)1024 * 32 * 4));
+    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, 1024 * 32 * 4, hipHostMallocDefault));
     if (!ctx->lds_attr_set) {
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -151,8 +156,9 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
     KZG_MARK(0);
     KZG_HIP_TRY(ctx, hipMemsetAsync(ws.count.p, 0, (size_t)p.G * 4, st));
     KZG_HIP_TRY(ctx, hipMemsetAsync(ws.cursor.p, 0, 4, st));
-    const uint32_t gn = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, ws.digits.as<uint32_t>());
+    const uint32_t n_total = p.n * batch;
+    const uint32_t gn = (n_total + 255) / 256;
+    hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, n_total, p.n, p.c, p.W, ws.digits.as<uint32_t>());
     KZG_MARK(1);
     const size_t lds_bytes = (size_t)p.B * 4;
     if (p.sort2) {
@@ -189,7 +195,7 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
         KZG_MARK(2);
         hipLaunchKernelGGL(k_sort_scatter, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.n, p.set_len, p.tile_len,
                            p.tiles_per_set, p.B, ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), bases.table_stride,
-                           ws.sorted.as<uint32_t>());
+                           (uint32_t)p.W, ws.sorted.as<uint32_t>());
     }
     const uint32_t gg = (p.G + 255) / 256;
     KZG_MARK(3);
@@ -231,13 +237,13 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
         KZG_MARK(6);
         hipLaunchKernelGGL(k_red_chunk_sums, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, n_chunks, p.m,
                            ws.chunkS.as<int32_t>(), (size_t)n_chunks);
-        hipLaunchKernelGGL(k_red_suffix_scan, dim3(p.W), dim3(p.T), 0, st, ws.chunkS.as<int32_t>(), ws.chunkTmp.as<int32_t>(),
+        hipLaunchKernelGGL(k_red_suffix_scan, dim3(n_windows), dim3(p.T), 0, st, ws.chunkS.as<int32_t>(), ws.chunkTmp.as<int32_t>(),
                            (size_t)n_chunks, p.T);
         hipLaunchKernelGGL(k_red_chunk_running, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G,
                            ws.chunkS.as<int32_t>(), (size_t)n_chunks, n_chunks, p.T, p.m, ws.chunkA.as<int32_t>());
-        hipLaunchKernelGGL(k_red_window_sum, dim3(p.W), dim3(p.T), 0, st, ws.chunkA.as<int32_t>(), (size_t)n_chunks, p.T,
+        hipLaunchKernelGGL(k_red_window_sum, dim3(n_windows), dim3(p.T), 0, st, ws.chunkA.as<int32_t>(), (size_t)n_chunks, p.T,
                            ws.out_wire.as<uint32_t>());
-        n_out = (uint32_t)p.W;
+        n_out = n_windows;
     }
     KZG_MARK(7);
     KZG_HIP_TRY(ctx, hipGetLastError());
@@ -259,11 +265,12 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
 
     // host epilogue on O(100) points
     using kzg_host::Xyzz;
-    Xyzz vals[128];
+    static thread_local Xyzz vals[1024];
     const uint64_t* w = reinterpret_cast<const uint64_t*>(ws.pinned_out);
     for (uint32_t i = 0; i < n_out; ++i) memcpy(&vals[i], w + 16 * i, 128);
     if (!p.tables) {
-        *result = kzg_host::horner_windows(vals, p.W, p.c);        // sum_w 2^(c w) S_w: <= 255 doublings
+        for (uint32_t b = 0; b < batch; ++b)
+            result[b] = kzg_host::horner_windows(vals + (size_t)b * p.W, p.W, p.c);   // sum_w 2^(c w) S_w: <= 255 doublings
         return KZG_OK;
     }
     // sum_b (b+1) V_b = T + sum_j 2^j S_j over the bits j of the 0-based bucket index
@@ -313,12 +320,26 @@ int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size
         kzg_host::Xyzz part;
         MsmBases b = bases;
         b.points = bases.points + 4 * off;
-        int32_t rc = msm_launch(ctx, b, reinterpret_cast<const uint4*>(d_scalars) + 2 * off, len, &part);
+        int32_t rc = msm_launch(ctx, b, reinterpret_cast<const uint4*>(d_scalars) + 2 * off, len, 1, &part);
         if (rc != KZG_OK) return rc;
         total = kzg_host::xyzz_add(total, part);
     }
     if (out_xyzz) memcpy(out_xyzz, &total, 128);
     if (out_xy) kzg_host::xyzz_to_affine(total, out_xy, out_inf);
+    return KZG_OK;
+}
+
+// `batch` independent MSMs of n pairs each over concatenated caller bases (generic mode): one kernel sequence.
+int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars, size_t n, uint32_t batch,
+                      uint64_t* out_xy /* batch x 8 */, uint8_t* out_inf /* batch */) {
+    if (n > MSM_MAX_LAUNCH / batch) return KZG_ERR_TOO_LARGE;
+    MsmBases b;
+    b.points = d_points;
+    kzg_host::Xyzz res[64];
+    if (batch > 64) return KZG_ERR_INVALID_ARG;
+    int32_t rc = msm_launch(ctx, b, reinterpret_cast<const uint4*>(d_scalars), n, batch, res);
+    if (rc != KZG_OK) return rc;
+    for (uint32_t i = 0; i < batch; ++i) kzg_host::xyzz_to_affine(res[i], out_xy + 8 * i, out_inf ? out_inf + i : nullptr);
     return KZG_OK;
 }
 

@@ -27,11 +27,13 @@ constexpr int RED_T = 512;          // chunks (= threads of the per-window scan 
 // 1. scalars -> signed digits + histogram
 // -------------------------------------------------------------------------------------------------
 // digits[w * n + i] = (|d| - 1) | (d < 0) << 31, or DIGIT_NONE for d == 0.
+// `n_total` scalars = batch * n; scalar j belongs to MSM j / n, whose digit rows are (j / n) * W + w.
 __global__ void __launch_bounds__(256)
-k_msm_digits(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32_t* __restrict__ digits) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint4 lo = scalars[2 * (size_t)i], hi = scalars[2 * (size_t)i + 1];
+k_msm_digits(const uint4* __restrict__ scalars, uint32_t n_total, uint32_t n, int c, int W, uint32_t* __restrict__ digits) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_total) return;
+    const uint32_t msm = j / n, i = j - msm * n;
+    uint4 lo = scalars[2 * (size_t)j], hi = scalars[2 * (size_t)j + 1];
     uint32_t w32[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint32_t k[8];
     fe_wire_to_canonical_words<FrParams>(k, w32);           // `into_bigint()`
@@ -47,7 +49,7 @@ k_msm_digits(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32
         carry = neg;
         uint32_t v = DIGIT_NONE;
         if (mag != 0) v = (mag - 1) | (neg << 31);
-        digits[(size_t)w * n + i] = v;
+        digits[((size_t)msm * W + w) * n + i] = v;
     }
 }
 
@@ -151,9 +153,10 @@ k_sort_hist(const uint32_t* __restrict__ digits, uint32_t set_len, uint32_t tile
 __global__ void __launch_bounds__(256)
 k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len, uint32_t tile_len, uint32_t tiles_per_set, uint32_t B,
                const unsigned long long* __restrict__ offs, const uint32_t* __restrict__ blockbase, uint32_t table_stride,
-               uint32_t* __restrict__ sorted) {
+               uint32_t windows_per_msm, uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lds_u32[];
     const uint32_t set = blockIdx.x / tiles_per_set, tile = blockIdx.x % tiles_per_set;
+    const uint32_t base_idx = table_stride ? 0u : (set / windows_per_msm) * n;      // batched MSMs: bases are concatenated
     const uint32_t lo = tile * tile_len;
     const uint32_t hi = (set_len - lo < tile_len) ? set_len : lo + tile_len;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x)
@@ -166,7 +169,7 @@ k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len
         uint32_t pos = atomicAdd(&lds_u32[v & 0x7FFFFFFFu], 1u);
         uint32_t idx;
         if (table_stride) { uint32_t w = e / n; idx = w * table_stride + (e - w * n); }
-        else idx = e;
+        else idx = base_idx + e;
         sorted[pos] = idx | (v & 0x80000000u);
     }
 }

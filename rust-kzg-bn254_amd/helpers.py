@@ -128,6 +128,29 @@ def g1_lincomb(points, scalars, ctx=None) -> np.ndarray:
     return out
 
 
+def g1_lincomb_batch(points_list, scalars_list, ctx=None):
+    """Several `g1_lincomb` calls of equal length in one kernel sequence (`kzg_msm_g1_batch`), e.g. the three MSMs of
+    verifier/src/batch.rs:228,245,246.  Returns a list of affine wire points."""
+    ctx = ctx or _lib.default_context()
+    k = len(points_list)
+    pts = [_lib.as_u64(p, 8).reshape(-1, 8) for p in points_list]
+    scs = [_lib.as_u64(s_, 4).reshape(-1, 4) for s_ in scalars_list]
+    n = pts[0].shape[0]
+    for p_, s_ in zip(pts, scs):
+        if p_.shape[0] != n or s_.shape[0] != n:
+            raise MsmError(str(min(p_.shape[0], s_.shape[0])))
+    allp = np.ascontiguousarray(np.concatenate(pts)) if n else np.zeros((0, 8), np.uint64)
+    alls = np.ascontiguousarray(np.concatenate(scs)) if n else np.zeros((0, 4), np.uint64)
+    out = np.zeros((k, 8), dtype=np.uint64)
+    inf = np.zeros(k, dtype=np.uint8)
+    rc = _lib.load().kzg_msm_g1_batch(ctx.handle, _lib.ptr(allp) if n else None, _lib.ptr(alls) if n else None, n, k, _lib.ptr(out),
+                                      inf.ctypes.data_as(_lib.u8p))
+    ctx.check_device(rc)
+    if rc != _lib.OK:
+        raise GenericError(_lib.status_message(rc))
+    return [out[i] for i in range(k)]
+
+
 def lexicographically_largest(y_mont) -> bool:
     """helpers.rs:151-173."""
     return fq_to_int(y_mont) > (FQ_MODULUS - 1) // 2

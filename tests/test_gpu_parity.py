@@ -428,3 +428,21 @@ def test_blob_to_fr_and_commit_blob(k, tau_srs, ref_srs, gettysburg):
         kzg.commit_blob(k.Blob.from_padded_unchecked(bytes(32 * 3001)), ref_srs)
     zero = k.Blob.from_padded_unchecked(bytes(32 * 64))
     assert not kzg.commit_blob(zero, ref_srs).any()                           # zero blob -> identity (tests.rs:239-269)
+
+
+def test_batched_lincomb_like_batch_verification(k, test_srs_wire):
+    """The three equal-length MSMs of verifier/src/batch.rs:228,245,246 in one launch sequence (BASELINE config 5 shape),
+    with duplicated and identity points (verifier/tests/tests.rs:343-346, :271-311)."""
+    n = 1000
+    proofs = test_srs_wire[:n].copy(); proofs[5] = proofs[6]; proofs[17] = 0
+    c_minus_y = test_srs_wire[1000:1000 + n].copy(); c_minus_y[3] = c_minus_y[4]
+    r_powers = rand_scalars(n, 31); r_times_z = rand_scalars(n, 32)
+    got = k.helpers.g1_lincomb_batch([proofs, proofs, c_minus_y], [r_powers, r_times_z, r_powers])
+    want = [orc.msm_pippenger(proofs, r_powers), orc.msm_pippenger(proofs, r_times_z), orc.msm_pippenger(c_minus_y, r_powers)]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert np.array_equal(got[0], k.helpers.g1_lincomb(proofs, r_powers))
+    one = k.helpers.g1_lincomb_batch([proofs], [r_powers])
+    assert np.array_equal(one[0], want[0])
+    with pytest.raises(k.errors.MsmError):
+        k.helpers.g1_lincomb_batch([proofs, proofs[:10]], [r_powers, r_powers])

@@ -28,3 +28,19 @@ for log_n in (10, 12, 14, 16, 18):
         lib.kzg_ctx_set_profiling(ctx.handle, 0)
         print(f"n=2^{log_n} {label} wall={wall:7.3f} ms | " + " ".join(f"{nm}={ph[i]/10:.3f}" for i, nm in enumerate(names)), flush=True)
     srs.close()
+
+# BASELINE config 5 shape: three 4096-point MSMs, separately and batched
+n = 4096
+uni = rng.integers(0, 1 << 62, size=(3 * n, 4), dtype=np.uint64); uni[:, 3] &= np.uint64((1 << 60) - 1)
+srs = k.SRS.generate(tau, 3 * n, ctx=ctx); pts = srs.g1
+out = np.zeros((3, 8), np.uint64); inf = np.zeros(3, np.uint8)
+def sep():
+    for b in range(3):
+        lib.kzg_msm_g1(ctx.handle, _lib.ptr(pts[b * n:(b + 1) * n]), n, _lib.ptr(uni[b * n:(b + 1) * n]), n, _lib.ptr(out[b]), None)
+def bat():
+    lib.kzg_msm_g1_batch(ctx.handle, _lib.ptr(pts), _lib.ptr(uni), n, 3, _lib.ptr(out), inf.ctypes.data_as(_lib.u8p))
+for name, fn in (("3 x kzg_msm_g1(4096)", sep), ("kzg_msm_g1_batch(4096 x 3)", bat)):
+    for _ in range(3): fn()
+    t0 = time.perf_counter()
+    for _ in range(10): fn()
+    print(f"{name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms", flush=True)
