@@ -68,9 +68,9 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     if (L == 0) { const char* env = getenv("KZG_MSM_SEG"); if (env) L = atoi(env); }
     const size_t entries = (size_t)p.W * n * batch;
     if (L <= 0) {
-        // one lane per segment: aim at ~2 700 waves (one round at 4 waves/SIMD); short segments keep small MSMs
+        // one lane per segment: aim at ~2 700 waves; short segments keep small MSMs
         // from serialising ~100 dependent mixed adds (10 us each) in a handful of waves
-        size_t want = (entries + (size_t)64 * 2730 - 1) / ((size_t)64 * 2730);
+        size_t want = (entries + (size_t)64 * 2730 - 1) / ((size_t)64 * 2730);      // measured best at 2^20 (L = 96); the kernel is issue bound, so the split matters little
         L = (int)std::min<size_t>(96, std::max<size_t>(4, want));
     }
     p.L = (uint32_t)L;
@@ -95,7 +95,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     }
     p.T = std::min<uint32_t>(p.B, RED_T);
     p.m = p.B / p.T;
-    p.segcap = (uint32_t)(entries / p.L + std::min<size_t>(p.G, entries) + 1);
+    p.segcap = (uint32_t)(entries / p.L + entries / (2 * (size_t)p.L) + std::min<size_t>(p.G, entries) + 1);   // round(cnt / L) <= 1.5 cnt / L + 1
     return p;
 }
 

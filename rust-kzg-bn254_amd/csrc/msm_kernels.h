@@ -60,8 +60,16 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
+// segments of a bucket with cnt entries: round(cnt / L) (>= 1 if cnt > 0); the accumulate kernel cuts the bucket into
+// that many EQUAL parts, so every lane of a wave runs nearly the same trip count (<= 1.5 L) and the segment total
+// stays ~ entries / L (a ceil() here made 6 % extra, tiny segments and a ragged second round of waves)
+__device__ __forceinline__ uint32_t seg_count(uint32_t cnt, uint32_t L) {
+    if (cnt == 0) return 0;
+    uint32_t s = (cnt + L / 2) / L;
+    return s ? s : 1u;
+}
 __device__ __forceinline__ unsigned long long scan_pack(uint32_t cnt, uint32_t L) {
-    return (unsigned long long)cnt | ((unsigned long long)((cnt + L - 1) / L) << 32);
+    return (unsigned long long)cnt | ((unsigned long long)seg_count(cnt, L) << 32);
 }
 // block-wide exclusive scan of one u64 per thread; returns the exclusive prefix, *total = block sum
 __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long* total,
@@ -327,10 +335,10 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
     if (active) {
         g = seg_bucket[sid];
         unsigned long long o0 = offs[g], o1 = offs[g + 1];
-        uint32_t s = sid - (uint32_t)(o0 >> 32);
-        begin = (uint32_t)o0 + s * L;
-        end = (uint32_t)o1;
-        if (end - begin > L) end = begin + L;
+        const uint32_t s = sid - (uint32_t)(o0 >> 32), ns = (uint32_t)(o1 >> 32) - (uint32_t)(o0 >> 32);
+        const uint32_t cnt = (uint32_t)o1 - (uint32_t)o0;
+        begin = (uint32_t)o0 + (uint32_t)(((unsigned long long)s * cnt) / ns);
+        end = (uint32_t)o0 + (uint32_t)(((unsigned long long)(s + 1) * cnt) / ns);
     }
     Xyzz acc;
     xyzz_set_inf(acc);
