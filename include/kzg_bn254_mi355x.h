@@ -47,7 +47,9 @@ typedef enum {
     KZG_ERR_TOO_LARGE = -11,             /* GenericError("Input size exceeds maximum polynomial size") (polynomial.rs:42-46) */
     KZG_ERR_ROOT_NOT_FOUND = -12,        /* GenericError("Root of unity not found") (kzg.rs:199-201) */
     KZG_ERR_ZERO_LENGTH = -13,           /* GenericError("Length of data after padding is 0") (helpers.rs:554-558) */
-    KZG_ERR_SRS_LENGTH = -14             /* GenericError("the length of data after padding is not valid with respect to the SRS") (helpers.rs:560-566) */
+    KZG_ERR_SRS_LENGTH = -14,            /* GenericError("the length of data after padding is not valid with respect to the SRS") (helpers.rs:560-566) */
+    KZG_ERR_DESERIALIZE = -15,           /* DeserializationError("point at infinity not coded properly for g1") (helpers.rs:191-195) */
+    KZG_ERR_NOT_ON_CURVE = -16           /* NotOnCurveError("compressed g1 point not on curve: ..") (helpers.rs:203-208) */
 } kzg_status;
 
 /* The reference's error string for a status (Appendix B of SURVEY.md). */
@@ -74,6 +76,12 @@ int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* 
  * 128 <= n (and table size <= 48 GiB) the upload also precomputes the window tables 2^(c w) * P_i
  * (ceil(255 / c) x 64 B per point, c = clamp(floor(log2 n) - 4, 7, 16); KZG_NO_PRECOMPUTE=1 disables). */
 int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);
+/* SRS::new's point decoding on the GPU (prover/src/srs.rs:35-49, :51-68 -> helpers.rs:175-226 read_g1_point_from_bytes_be):
+ * `bytes` = the first n_points x 32 bytes of a gnark-format compressed G1 file (big-endian x, flags in the top two bits of
+ * byte 0).  All points are decompressed in one kernel (one 254-bit exponentiation per point) and the SRS is made resident
+ * like kzg_srs_upload.  A malformed point -> KZG_ERR_DESERIALIZE / KZG_ERR_NOT_ON_CURVE with *bad_index = its position
+ * (the reference's loader panics there, srs.rs:60-63). */
+int32_t kzg_srs_load_compressed_be(kzg_ctx* ctx, const uint8_t* bytes, size_t n_points, kzg_srs** out, uint64_t* bad_index);
 /* Test / bench utility (no counterpart in the reference, which loads ceremony files): synthetic SRS with a
  * KNOWN tau, P_i = tau^(first_power + i) * G1, generated on the device (a shard of the powers when
  * first_power > 0); and read-back of a resident SRS in wire format. */

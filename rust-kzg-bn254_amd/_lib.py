@@ -30,6 +30,8 @@ ERR_TOO_LARGE = -11
 ERR_ROOT_NOT_FOUND = -12
 ERR_ZERO_LENGTH = -13
 ERR_SRS_LENGTH = -14
+ERR_DESERIALIZE = -15
+ERR_NOT_ON_CURVE = -16
 
 u64p = C.POINTER(C.c_uint64)
 u8p = C.POINTER(C.c_uint8)
@@ -46,6 +48,7 @@ PROTOTYPES = {
     "kzg_ctx_last_error": (C.c_char_p, [vp]),
     "kzg_ctx_set_msm_window": (i32, [vp, i32, i32]),
     "kzg_srs_upload": (i32, [vp, u64p, sz, C.POINTER(vp)]),
+    "kzg_srs_load_compressed_be": (i32, [vp, u8p, sz, C.POINTER(vp), C.POINTER(C.c_uint64)]),
     "kzg_srs_generate": (i32, [vp, u64p, C.c_uint64, sz, C.POINTER(vp)]),
     "kzg_ctx_set_profiling": (i32, [vp, i32]),
     "kzg_ctx_get_msm_profile": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

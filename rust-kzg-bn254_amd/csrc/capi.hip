@@ -47,6 +47,8 @@ const char* kzg_status_message(int32_t status) {
         case KZG_ERR_ROOT_NOT_FOUND: return "Root of unity not found";
         case KZG_ERR_ZERO_LENGTH: return "Length of data after padding is 0";
         case KZG_ERR_SRS_LENGTH: return "the length of data after padding is not valid with respect to the SRS";
+        case KZG_ERR_DESERIALIZE: return "point at infinity not coded properly for g1";
+        case KZG_ERR_NOT_ON_CURVE: return "compressed g1 point not on curve";
         default: return "unknown status";
     }
 }
@@ -156,6 +158,32 @@ int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t firs
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
         if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
         int32_t rc = srs_generate(ctx, tau_mont, first_power, n_points, s->d_points);
+        if (rc == KZG_OK) rc = srs_precompute(ctx, s);
+        if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
+    }
+    *out = s;
+    return KZG_OK;
+}
+
+int32_t kzg_srs_load_compressed_be(kzg_ctx* ctx, const uint8_t* bytes, size_t n_points, kzg_srs** out, uint64_t* bad_index) {
+    if (!ctx || !out || (n_points && !bytes)) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_points > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    kzg_srs* s = new (std::nothrow) kzg_srs();
+    if (!s) return KZG_ERR_INVALID_ARG;
+    s->ctx = ctx;
+    s->n = n_points;
+    if (n_points) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
+        if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
+        uint32_t kind = 0, idx = 0;
+        int32_t rc = srs_decompress(ctx, bytes, n_points, s->d_points, &kind, &idx);
+        if (rc == KZG_OK && kind != 0) {
+            if (bad_index) *bad_index = idx;
+            rc = kind == 1 ? KZG_ERR_DESERIALIZE : KZG_ERR_NOT_ON_CURVE;
+        }
         if (rc == KZG_OK) rc = srs_precompute(ctx, s);
         if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
     }

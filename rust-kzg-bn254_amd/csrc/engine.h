@@ -130,6 +130,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse);
 // synthetic SRS P_i = tau^i * G1 written to d_points (device format); device SRS -> wire on the host
 int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_power, size_t n, uint4* d_points);
 int32_t srs_download(kzg_ctx* ctx, const uint4* d_points, size_t n, uint64_t* out_xy);
+int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_points, uint32_t* err_kind, uint32_t* err_index);
 
 // KZG::g1_ifft: Lagrange-basis SRS of size n (n a power of two <= srs->n), affine wire points to the host
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy);

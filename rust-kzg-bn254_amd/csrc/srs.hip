@@ -144,6 +144,101 @@ k_srs_window_step(const uint4* __restrict__ prev, uint4* __restrict__ next, size
     next[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
 }
 
+// Batch decompression of gnark-format compressed G1 points (prover/src/srs.rs:51-68 -> primitives/src/helpers.rs:175-226):
+// 32 big-endian bytes per point, top two bits of byte 0: 01 = infinity (rest must be zero), 10 = smaller y, 11 = larger y;
+// x = remaining 254 bits mod p; y = sqrt(x^3 + 3) = (x^3 + 3)^((p+1)/4) (p = 3 mod 4), sign chosen by
+// lexicographically_largest (helpers.rs:151-173: y > (p-1)/2 on the canonical integer).  The subgroup check of the
+// reference is vacuous on BN254 G1 (cofactor 1).  One lane per point; status[0] = first error (0 ok, 1 bad infinity
+// encoding, 2 not on curve), status[1] = its index.
+__global__ void __launch_bounds__(256)
+k_srs_decompress_be(const uint8_t* __restrict__ bytes, uint4* __restrict__ out, uint32_t n, uint32_t* __restrict__ status) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* b = bytes + (size_t)i * 32;
+    const uint32_t flag = b[0] & 0xC0u;
+    uint32_t o[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = 0;
+    uint32_t err = 0;
+    if (flag == 0x40u) {
+        uint32_t rest = b[0] & 0x3Fu;
+        for (int k = 1; k < 32; ++k) rest |= b[k];
+        if (rest) err = 1;                               // "point at infinity not coded properly for g1"
+    } else {
+        uint32_t w32[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                    // little-endian word k = big-endian bytes 28-4k .. 31-4k
+            uint32_t w = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint32_t byte = b[28 - 4 * k + t];
+                if (k == 7 && t == 0) byte &= 0x3Fu;
+                w = (w << 8) | byte;
+            }
+            w32[k] = w;
+        }
+        Fq x, y2, y, t, kin, b3;
+        fe_unpack(x, w32);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { kin.l[j] = (int32_t)FqParams::K_PLAIN_IN[j]; b3.l[j] = (int32_t)FqParams::B3[j]; }
+        fe_mul(x, x, kin);                               // Fq::from_be_bytes_mod_order -> internal form, (-m, 2m)
+        fe_sqr(t, x);
+        fe_mul(y2, t, x);
+        fe_add(y2, y2, b3);
+        fe_norm(y2);                                     // x^3 + 3, |.| < 4m
+        // y = y2^((p+1)/4), square-and-multiply from the least significant bit
+        {
+            Fq acc, base = y2;
+            fe_set_one(acc);
+            for (int w = 0; w < 8; ++w) {
+                uint32_t bits = FqParams::SQRT_EXP32[w];
+                for (int bb = 0; bb < 32; ++bb) {
+                    if (w == 7 && bb >= 28) break;       // (p+1)/4 < 2^252
+                    if (bits & 1u) fe_mul(acc, acc, base);
+                    fe_sqr(base, base);
+                    bits >>= 1;
+                }
+            }
+            y = acc;
+        }
+        fe_sqr(t, y);
+        fe_sub(t, t, y2);
+        fe_reduce(t);
+        if (!fe_is_zero_mod(t)) {
+            err = 2;                                     // "compressed g1 point not on curve"
+        } else {
+            // canonical integers of x (internal form) and of y (plain) for the sign rule
+            Fq one_plain, yc;
+            fe_set_zero(one_plain);
+            one_plain.l[0] = 1;
+            fe_mul(yc, y, one_plain);
+            fe_canon(yc);
+            uint32_t yw[8];
+            fe_pack(yw, yc);
+            bool ge = true;                              // yc >= (p+1)/2 ?
+            for (int k = 7; k >= 0; --k) {
+                if (yw[k] != FqParams::HALF_UP32[k]) { ge = yw[k] > FqParams::HALF_UP32[k]; break; }
+            }
+            const bool negate = ge ? (flag == 0x80u) : (flag == 0xC0u);
+            Fq ys;
+            fe_canon(y);                                 // [0, m) before the sign flip so that -y stays inside (-m, 2m)
+            fe_cneg(ys, y, negate ? 1u : 0u);
+            fe_norm(ys);
+            fe_canon(x);
+            fe_canon(ys);
+            fe_pack(o, x);
+            fe_pack(o + 8, ys);
+        }
+    }
+    if (err) {
+        if (atomicCAS(&status[0], 0u, err) == 0u) status[1] = i;
+    }
+    out[4 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);
+    out[4 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    out[4 * (size_t)i + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+    out[4 * (size_t)i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
+}
+
 // device affine format -> wire (x || y, radix 2^256)
 __global__ void __launch_bounds__(256)
 k_points_device_to_wire(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
@@ -211,6 +306,27 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
     srs->d_points = table;
     srs->pre_c = c;
     srs->pre_W = W;
+    return KZG_OK;
+}
+
+// compressed big-endian points (host bytes) -> d_points (device format); *err_kind / *err_index describe the first bad point
+int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_points, uint32_t* err_kind, uint32_t* err_index) {
+    *err_kind = 0;
+    *err_index = 0;
+    if (n == 0) return KZG_OK;
+    KZG_HIP_TRY(ctx, ctx->poly_c.reserve(n * 32));
+    KZG_HIP_TRY(ctx, ctx->poly_small.reserve(4096));
+    uint32_t* d_status = ctx->poly_small.as<uint32_t>();
+    KZG_HIP_TRY(ctx, hipMemsetAsync(d_status, 0, 8, ctx->stream));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_c.p, bytes, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_srs_decompress_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly_c.as<uint8_t>(), d_points,
+                       (uint32_t)n, d_status);
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    uint32_t st[2] = {0, 0};
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(st, d_status, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *err_kind = st[0];
+    *err_index = st[1];
     return KZG_OK;
 }
 

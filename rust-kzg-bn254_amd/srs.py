@@ -1,13 +1,13 @@
 """Mirror of prover/src/srs.rs `SRS { g1, order }`, with the monomial G1 powers RESIDENT ON THE GPU
 (uploaded once through `kzg_srs_upload`) instead of being copied on every commit (kzg.rs:119).
-File loading / point decompression (srs.rs:81-251) stays a host-side concern and is listed as a
-"next" row in DESIGN.md; construct from already-decoded points."""
+`SRS.new(path, order, points_to_load)` reads the gnark-format file and decompresses all points in one GPU kernel
+(`kzg_srs_load_compressed_be`); `SRS(points)` takes already-decoded wire-format points."""
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
-from .errors import GenericError
+from .errors import DeserializationError, GenericError, NotOnCurveError
 from .fr import fr_from_int
 
 
@@ -27,9 +27,30 @@ class SRS:
 
     @classmethod
     def new(cls, path_to_g1_points, order, points_to_load, ctx=None):
+        """SRS::new (srs.rs:35-49): read `points_to_load` compressed points (32 bytes each, gnark big-endian flags) and
+        decompress them on the GPU (`kzg_srs_load_compressed_be`)."""
         if points_to_load > order:
-            raise GenericError("Number of points to load exceeds SRS order.")
-        raise NotImplementedError("SRS file loading is a 'next' row (DESIGN.md §9); build the SRS from decoded points")
+            raise GenericError("Number of points to load exceeds SRS order.")               # srs.rs:36-40
+        with open(path_to_g1_points, "rb") as f:
+            data = f.read(32 * points_to_load)
+        if len(data) != 32 * points_to_load:                                                  # srs.rs:128-134
+            raise GenericError(f"Expected {points_to_load} points, only read {len(data) // 32}")
+        self = cls.__new__(cls)
+        self.ctx = ctx or _lib.default_context()
+        self.order = int(order)
+        h = C.c_void_p()
+        bad = C.c_uint64(0)
+        buf = np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, np.uint8)
+        rc = _lib.load().kzg_srs_load_compressed_be(self.ctx.handle, buf.ctypes.data_as(_lib.u8p), points_to_load, C.byref(h), C.byref(bad))
+        if rc == _lib.ERR_DESERIALIZE:
+            raise DeserializationError("point at infinity not coded properly for g1")
+        if rc == _lib.ERR_NOT_ON_CURVE:
+            chunk = list(data[32 * bad.value:32 * bad.value + 32])
+            raise NotOnCurveError(f"compressed g1 point not on curve: {chunk}")
+        self.ctx.check_device(rc)
+        self.handle = h
+        self._n = points_to_load
+        return self
 
     @classmethod
     def generate(cls, tau: int, n: int, ctx=None, first_power: int = 0):

@@ -446,3 +446,46 @@ def test_batched_lincomb_like_batch_verification(k, test_srs_wire):
     assert np.array_equal(one[0], want[0])
     with pytest.raises(k.errors.MsmError):
         k.helpers.g1_lincomb_batch([proofs, proofs[:10]], [r_powers, r_powers])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SRS::new: GPU decompression of gnark-format files (srs.rs:35-49, helpers.rs:175-226)
+# ---------------------------------------------------------------------------------------------------------
+def test_srs_new_decompresses_reference_file(k, test_srs_wire, gettysburg, tmp_path):
+    path = os.path.join(GOLDEN, "g1.point")
+    srs = k.SRS.new(path, 3000, 3000)
+    assert len(srs) == 3000 and srs.order == 3000
+    assert np.array_equal(srs.g1, test_srs_wire)                      # all 3000 points == srs.g1.points.string
+    part = k.SRS.new(path, 3000, 64)
+    assert np.array_equal(part.g1, test_srs_wire[:64])
+    # a commitment over the file-loaded SRS equals the one over the uploaded SRS
+    blob = k.Blob.from_raw_data(gettysburg)
+    kzg = k.KZG.new()
+    assert pyref.point_from_wire(kzg.commit_blob(blob, srs)) == (
+        2961155957874067312593973807786254905069537311739090798303675273531563528369,
+        159565752702690920280451512738307422982252330088949702406468210607852362941)
+    with pytest.raises(k.errors.GenericError, match="Number of points to load exceeds SRS order."):   # kzg_test.rs:19-28
+        k.SRS.new(path, 3000, 3001)
+    raw = bytearray(open(path, "rb").read()[:32 * 8])
+    # infinity encodings and flipped sign flags
+    good = bytes(raw)
+    raw[32:64] = bytes([0x40]) + bytes(31)                             # point 1 := infinity
+    raw[64] ^= 0x40                                                    # point 2: smaller <-> larger y
+    f = tmp_path / "mod.point"; f.write_bytes(bytes(raw))
+    mod = k.SRS.new(str(f), 8, 8).g1
+    assert not mod[1].any()
+    assert np.array_equal(mod[2], orc.g1_neg(test_srs_wire[2])) and np.array_equal(mod[3], test_srs_wire[3])
+    for i in range(8):
+        rc, want = orc.g1_decompress_be(bytes(raw[32 * i:32 * i + 32]))
+        assert rc == 0 and np.array_equal(mod[i], want)
+    bad = bytearray(good); bad[32] = 0x41; bad[33:64] = bytes(31)      # infinity flag with stray bits
+    f.write_bytes(bytes(bad))
+    with pytest.raises(k.errors.DeserializationError, match="point at infinity not coded properly for g1"):
+        k.SRS.new(str(f), 8, 8)
+    x = 1
+    while pow((x ** 3 + 3) % P, (P - 1) // 2, P) == 1:
+        x += 1
+    bad = bytearray(good); bad[96:128] = bytes([0x80]) + x.to_bytes(31, "big")          # x with x^3 + 3 a non-residue
+    f.write_bytes(bytes(bad))
+    with pytest.raises(k.errors.NotOnCurveError, match="compressed g1 point not on curve"):
+        k.SRS.new(str(f), 8, 8)

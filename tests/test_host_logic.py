@@ -135,3 +135,5 @@ def test_srs_order_guard(k):
     """prover/tests/kzg_test.rs:19-28."""
     with pytest.raises(k.errors.GenericError, match="Number of points to load exceeds SRS order."):
         k.SRS.new("tests/test-files/g1.point", 3000, 3001)
+    with pytest.raises(k.errors.GenericError, match="Expected 3001 points"):
+        k.SRS.new(os.path.join(ROOT, "tests", "golden", "g1.point"), 4000, 3001)
