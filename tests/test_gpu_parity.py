@@ -489,3 +489,47 @@ def test_srs_new_decompresses_reference_file(k, test_srs_wire, gettysburg, tmp_p
     f.write_bytes(bytes(bad))
     with pytest.raises(k.errors.NotOnCurveError, match="compressed g1 point not on curve"):
         k.SRS.new(str(f), 8, 8)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# randomized differential test: sizes, scalar patterns, window / segment settings
+# ---------------------------------------------------------------------------------------------------------
+def _patterned_scalars(rnd, n):
+    kind = rnd.randrange(7)
+    if kind == 0:
+        vals = [rnd.randrange(R_) for _ in range(n)]                         # uniform
+    elif kind == 1:
+        vals = [rnd.randrange(1 << rnd.choice([1, 8, 31, 64, 128, 200])) for _ in range(n)]   # short scalars
+    elif kind == 2:
+        pool = [rnd.randrange(R_) for _ in range(3)]
+        vals = [rnd.choice(pool) for _ in range(n)]                          # few distinct values -> heavy buckets
+    elif kind == 3:
+        vals = [R_ - 1 - rnd.randrange(1 << 16) for _ in range(n)]           # near r: carries through every window
+    elif kind == 4:
+        vals = [int.from_bytes(bytes(rnd.randrange(32, 127) for _ in range(31)), "big") for _ in range(n)]   # blob-like
+    elif kind == 5:
+        vals = [(1 << rnd.randrange(254)) % R_ for _ in range(n)]           # one-hot bits
+    else:
+        vals = [0 if rnd.random() < 0.7 else rnd.randrange(R_) for _ in range(n)]   # mostly zero (padded polynomials)
+    return pyref.frs_to_mont(vals)
+
+
+def test_msm_randomized_differential(k, ref_srs, tau_srs, test_srs_wire):
+    rnd = random.Random(20261003)
+    tau_pts = tau_srs.g1[:6000]
+    for case in range(36):
+        use_tau = case % 3 == 0
+        srs, pts = (tau_srs, tau_pts) if use_tau else (ref_srs, test_srs_wire)
+        nmax = 6000 if use_tau else 3000
+        n = rnd.choice([1, 2, 63, 64, 65, 127, 128, 129, rnd.randrange(1, nmax), rnd.randrange(1, nmax), nmax])
+        off = rnd.randrange(0, nmax - n + 1)
+        sc = _patterned_scalars(rnd, n)
+        c = rnd.choice([0, 0, 0, 4, 7, 9, 12, 15, 16])                       # 0 = table mode (SRS tables), else generic
+        seg = rnd.choice([0, 0, 1, 3, 8, 33, 200])
+        srs.ctx.set_msm_window(c, seg)
+        try:
+            got = msm_srs(k, srs, sc, offset=off)
+        finally:
+            srs.ctx.set_msm_window(0, 0)
+        want = orc.msm_pippenger(pts[off:off + n], sc)
+        assert np.array_equal(got, want), (case, n, off, c, seg)
