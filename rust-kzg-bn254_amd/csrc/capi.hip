@@ -78,6 +78,8 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->msm.release();
+    ctx->msm2.release();
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_inputs); (void)hipEventDestroy(ctx->ev_acc); }
     ctx->ntt.release();
     ctx->poly_a.release(); ctx->poly_b.release(); ctx->poly_c.release(); ctx->poly_small.release();
     (void)hipStreamDestroy(ctx->stream);
@@ -98,18 +100,20 @@ int32_t kzg_ctx_set_profiling(kzg_ctx* ctx, int32_t enable) {
     if (!ctx) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->profiling = enable != 0;
-    for (auto& v : ctx->msm.phase_ms) v = 0;
-    ctx->msm.profiled_launches = 0;
-    ctx->msm.profiled_pairs = 0;
+    for (auto* w : {&ctx->msm, &ctx->msm2}) {
+        for (auto& v : w->phase_ms) v = 0;
+        w->profiled_launches = 0;
+        w->profiled_pairs = 0;
+    }
     return KZG_OK;
 }
 
 int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* launches, uint64_t* pairs) {
     if (!ctx || !phase_ms_out) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    for (int i = 0; i < 8; ++i) phase_ms_out[i] = ctx->msm.phase_ms[i];
-    if (launches) *launches = ctx->msm.profiled_launches;
-    if (pairs) *pairs = ctx->msm.profiled_pairs;
+    for (int i = 0; i < 8; ++i) phase_ms_out[i] = ctx->msm.phase_ms[i] + ctx->msm2.phase_ms[i];
+    if (launches) *launches = ctx->msm.profiled_launches + ctx->msm2.profiled_launches;
+    if (pairs) *pairs = ctx->msm.profiled_pairs + ctx->msm2.profiled_pairs;
     return KZG_OK;
 }
 

@@ -69,6 +69,9 @@ struct kzg_ctx {
     bool profiling = false;
     bool lds_attr_set = false;
     kzg::MsmWorkspace msm;
+    kzg::MsmWorkspace msm2;             // second half of a split MSM (own stream)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_inputs = nullptr, ev_acc = nullptr;
     kzg::NttWorkspace ntt;
     kzg::DeviceBuffer poly_a, poly_b, poly_c, poly_small;   // proof pipeline scratch
 };

@@ -102,11 +102,20 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
 // Largest number of pairs one launch takes: W * n must fit the 32-bit positions of the sort.
 static const size_t MSM_MAX_LAUNCH = (size_t)1 << 24;
 
-static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_scalars, size_t n, uint32_t batch, kzg_host::Xyzz* result) {
+// What msm_enqueue leaves in flight on its stream; msm_finish waits for it and runs the host epilogue.
+struct Pending {
+    Plan p;
+    uint32_t n_out = 0;
+    uint32_t batch = 1;
+    size_t n = 0;
+};
+
+// Enqueue every kernel of one MSM (or batch) plus the D2H copy of its O(100) result points on `st`, using `ws`.
+// wait_acc / signal_acc (optional) order this launch's accumulate kernel after / before another stream's.
+static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
+                           uint32_t batch, hipEvent_t wait_acc, hipEvent_t signal_acc, Pending* pend) {
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
     const Plan p = make_plan(ctx, n, bases, batch);
-    MsmWorkspace& ws = ctx->msm;
-    hipStream_t st = ctx->stream;
     const size_t entries = (size_t)p.W * n * batch;
     const uint32_t n_windows = (uint32_t)p.W * batch;          // window sums produced in generic mode
     if (!p.tables && n_windows > 1024) return KZG_ERR_INVALID_ARG;
@@ -202,11 +211,13 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
     hipLaunchKernelGGL(k_msm_segments, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,
                        ws.seg_bucket.as<uint32_t>());
     const uint32_t gs = (p.segcap + 255) / 256;
+    if (wait_acc) KZG_HIP_TRY(ctx, hipStreamWaitEvent(st, wait_acc, 0));
     KZG_MARK(4);
     hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(),
                        ws.seg_bucket.as<uint32_t>(), ws.offs.as<unsigned long long>(), p.G, p.L,
                        ws.segsum.as<int32_t>(), (size_t)p.segcap);
     KZG_MARK(5);
+    if (signal_acc) KZG_HIP_TRY(ctx, hipEventRecord(signal_acc, st));
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
         hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, 0u, 0u,
@@ -248,8 +259,20 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
     KZG_MARK(7);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.pinned_out, ws.out_wire.p, (size_t)n_out * 128, hipMemcpyDeviceToHost, st));
+#undef KZG_MARK
+    pend->p = p;
+    pend->n_out = n_out;
+    pend->batch = batch;
+    pend->n = n;
+    return KZG_OK;
+}
+
+static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const Pending& pend, kzg_host::Xyzz* result) {
+    const Plan& p = pend.p;
+    const uint32_t n_out = pend.n_out, batch = pend.batch;
+    const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
     KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (prof) {
+    if (ctx->profiling && ws.ev_ready) {
         for (int i = 0; i < 7; ++i) {
             float ms = 0;
             KZG_HIP_TRY(ctx, hipEventElapsedTime(&ms, ws.ev[i], ws.ev[i + 1]));
@@ -259,9 +282,8 @@ static int32_t msm_launch(kzg_ctx* ctx, const MsmBases& bases, const uint4* d_sc
         KZG_HIP_TRY(ctx, hipEventElapsedTime(&ms, ws.ev[0], ws.ev[7]));
         ws.phase_ms[7] += ms;
         ws.profiled_launches += 1;
-        ws.profiled_pairs += n;
+        ws.profiled_pairs += pend.n * batch;
     }
-#undef KZG_MARK
 
     // host epilogue on O(100) points
     using kzg_host::Xyzz;
@@ -312,17 +334,54 @@ int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, s
     return KZG_OK;
 }
 
+// EXPERIMENT, off by default (KZG_MSM_SPLIT=1 enables): cut a large table-mode MSM in two halves by scalar index and
+// enqueue them on two streams with their own workspaces, so that the latency-bound sort / bucket reduction of one half
+// run beside the issue-bound accumulate of the other (accumulates ordered by an event).  Measured on MI355X at 2^20:
+// 2.36 ms against 2.09 ms unsplit -- the small kernels stretch 3-4x when they share SIMDs with accumulate waves
+// (reduce 0.12 -> 0.43 ms) and slow the accumulate (0.78 -> 0.91 ms per half), so nothing is hidden for free.
+static const size_t MSM_SPLIT_MIN = (size_t)1 << 19;
+
 int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n,
                 uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
     kzg_host::Xyzz total = kzg_host::xyzz_inf();
-    for (size_t off = 0; off < n; off += MSM_MAX_LAUNCH) {
-        size_t len = std::min(MSM_MAX_LAUNCH, n - off);
-        kzg_host::Xyzz part;
-        MsmBases b = bases;
-        b.points = bases.points + 4 * off;
-        int32_t rc = msm_launch(ctx, b, reinterpret_cast<const uint4*>(d_scalars) + 2 * off, len, 1, &part);
+    const uint4* sc = reinterpret_cast<const uint4*>(d_scalars);
+    bool split = false;
+    { const char* env = getenv("KZG_MSM_SPLIT"); if (env && atoi(env) != 0) split = bases.table_stride != 0 && n >= MSM_SPLIT_MIN && n <= MSM_MAX_LAUNCH; }
+    if (split) {
+        if (!ctx->stream2) {
+            KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inputs, hipEventDisableTiming));
+            KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming));
+        }
+        const size_t na = n / 2, nb_ = n - na;
+        // stream 2 must see whatever produced the scalars on the main stream (e.g. a staged H2D copy)
+        KZG_HIP_TRY(ctx, hipEventRecord(ctx->ev_inputs, ctx->stream));
+        KZG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_inputs, 0));
+        Pending pa, pb;
+        MsmBases ba = bases, bb = bases;
+        bb.points = bases.points + 4 * na;
+        int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, ba, sc, na, 1, nullptr, ctx->ev_acc, &pa);
         if (rc != KZG_OK) return rc;
-        total = kzg_host::xyzz_add(total, part);
+        rc = msm_enqueue(ctx, ctx->msm2, ctx->stream2, bb, sc + 2 * na, nb_, 1, ctx->ev_acc, nullptr, &pb);
+        if (rc != KZG_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+        kzg_host::Xyzz ra, rb;
+        rc = msm_finish(ctx, ctx->msm, ctx->stream, pa, &ra);
+        int32_t rc2 = msm_finish(ctx, ctx->msm2, ctx->stream2, pb, &rb);
+        if (rc != KZG_OK) return rc;
+        if (rc2 != KZG_OK) return rc2;
+        total = kzg_host::xyzz_add(ra, rb);
+    } else {
+        for (size_t off = 0; off < n; off += MSM_MAX_LAUNCH) {
+            size_t len = std::min(MSM_MAX_LAUNCH, n - off);
+            kzg_host::Xyzz part;
+            MsmBases b = bases;
+            b.points = bases.points + 4 * off;
+            Pending pend;
+            int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, b, sc + 2 * off, len, 1, nullptr, nullptr, &pend);
+            if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, &part);
+            if (rc != KZG_OK) return rc;
+            total = kzg_host::xyzz_add(total, part);
+        }
     }
     if (out_xyzz) memcpy(out_xyzz, &total, 128);
     if (out_xy) kzg_host::xyzz_to_affine(total, out_xy, out_inf);
@@ -337,7 +396,9 @@ int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars
     b.points = d_points;
     kzg_host::Xyzz res[64];
     if (batch > 64) return KZG_ERR_INVALID_ARG;
-    int32_t rc = msm_launch(ctx, b, reinterpret_cast<const uint4*>(d_scalars), n, batch, res);
+    Pending pend;
+    int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, b, reinterpret_cast<const uint4*>(d_scalars), n, batch, nullptr, nullptr, &pend);
+    if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, res);
     if (rc != KZG_OK) return rc;
     for (uint32_t i = 0; i < batch; ++i) kzg_host::xyzz_to_affine(res[i], out_xy + 8 * i, out_inf ? out_inf + i : nullptr);
     return KZG_OK;
