@@ -49,7 +49,10 @@ typedef enum {
     KZG_ERR_ZERO_LENGTH = -13,           /* GenericError("Length of data after padding is 0") (helpers.rs:554-558) */
     KZG_ERR_SRS_LENGTH = -14,            /* GenericError("the length of data after padding is not valid with respect to the SRS") (helpers.rs:560-566) */
     KZG_ERR_DESERIALIZE = -15,           /* DeserializationError("point at infinity not coded properly for g1") (helpers.rs:191-195) */
-    KZG_ERR_NOT_ON_CURVE = -16           /* NotOnCurveError("compressed g1 point not on curve: ..") (helpers.rs:203-208) */
+    KZG_ERR_NOT_ON_CURVE = -16,          /* NotOnCurveError("compressed g1 point not on curve: ..") (helpers.rs:203-208) */
+    KZG_ERR_G1_NOT_ON_CURVE = -17,       /* NotOnCurveError("G1 point not on curve") (helpers.rs:694-699, validate_g1_point) */
+    KZG_ERR_G2_TAU_NOT_ON_CURVE = -18,   /* NotOnCurveError("Invalid trusted setup: G2_TAU not on curve") (verify.rs:29-33, batch.rs:214-216) */
+    KZG_ERR_TAU_EQUALS_Z = -19           /* GenericError("Evaluation point equals trusted setup secret") (verify.rs:56-60) */
 } kzg_status;
 
 /* The reference's error string for a status (Appendix B of SURVEY.md). */
@@ -158,6 +161,30 @@ int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t*
  * (capacity `cap` elements); *n_out = count. */
 int32_t kzg_calculate_roots_of_unity(kzg_ctx* ctx, uint64_t length_of_data_after_padding,
                                      uint64_t* out_mont, size_t cap, size_t* n_out);
+
+/* ---- verifier surface ------------------------------------------------------------
+ * G2 wire format: 16 u64 = x.c0 | x.c1 | y.c0 | y.c1, each a 4 x u64 Montgomery Fq (arkworks' Fq2{c0,c1} in memory);
+ * identity = all zeros.  The pairing itself is O(1) per verification and runs on the host (reduced Tate pairing:
+ * it decides `multi_pairing(..).is_zero()` exactly as arkworks' optimal ate does); the n-point linear combinations of
+ * batch verification run on the GPU.  g2_tau_mont = NULL selects consts::G2_TAU (primitives/src/consts.rs:55-64). */
+int32_t kzg_g2_generator(uint64_t out_g2_mont[16]);                  /* G2Affine::generator() */
+int32_t kzg_g2_tau_mainnet(uint64_t out_g2_mont[16]);                /* consts::G2_TAU */
+int32_t kzg_g2_mul_generator(const uint64_t scalar_mont[4], uint64_t out_g2_mont[16]);   /* [s]G2 (tests / custom setups) */
+/* helpers::pairings_verify(a1, a2, b1, b2) (helpers.rs:392-398): *out_ok = (e(a1,a2) == e(b1,b2)).  Host-only. */
+int32_t kzg_pairings_verify(const uint64_t a1_xy_mont[8], const uint64_t a2_g2_mont[16],
+                            const uint64_t b1_xy_mont[8], const uint64_t b2_g2_mont[16], int32_t* out_ok);
+/* verify::verify_proof (verifier/src/verify.rs:10-72).  Off-curve commitment/proof -> KZG_ERR_G1_NOT_ON_CURVE;
+ * [tau - z]G2 == identity -> KZG_ERR_TAU_EQUALS_Z.  Host-only. */
+int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t proof_xy_mont[8],
+                         const uint64_t value_mont[4], const uint64_t z_mont[4],
+                         const uint64_t* g2_tau_mont, int32_t* out_ok);
+/* batch::verify_kzg_proof_batch (verifier/src/batch.rs:185-256) after the caller has derived r_powers from its
+ * transcript (compute_r_powers, batch.rs:76-168): point validation, the three g1_lincomb calls as one batched GPU MSM,
+ * the final 2-pairing check. */
+int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_mont, const uint64_t* zs_mont,
+                                   const uint64_t* ys_mont, const uint64_t* proofs_xy_mont,
+                                   const uint64_t* r_powers_mont, size_t n,
+                                   const uint64_t* g2_tau_mont, int32_t* out_ok);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,9 @@ ERR_ZERO_LENGTH = -13
 ERR_SRS_LENGTH = -14
 ERR_DESERIALIZE = -15
 ERR_NOT_ON_CURVE = -16
+ERR_G1_NOT_ON_CURVE = -17
+ERR_G2_TAU_NOT_ON_CURVE = -18
+ERR_TAU_EQUALS_Z = -19
 
 u64p = C.POINTER(C.c_uint64)
 u8p = C.POINTER(C.c_uint8)
@@ -72,6 +75,12 @@ PROTOTYPES = {
     "kzg_compute_proof": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, u64p, u8p, u64p]),
     "kzg_evaluate_polynomial_in_evaluation_form": (i32, [vp, u64p, sz, u64p, u64p]),
     "kzg_calculate_roots_of_unity": (i32, [vp, C.c_uint64, u64p, sz, C.POINTER(sz)]),
+    "kzg_g2_generator": (i32, [u64p]),
+    "kzg_g2_tau_mainnet": (i32, [u64p]),
+    "kzg_g2_mul_generator": (i32, [u64p, u64p]),
+    "kzg_pairings_verify": (i32, [u64p, u64p, u64p, u64p, C.POINTER(i32)]),
+    "kzg_verify_proof": (i32, [u64p, u64p, u64p, u64p, u64p, C.POINTER(i32)]),
+    "kzg_verify_kzg_proof_batch": (i32, [vp, u64p, u64p, u64p, u64p, u64p, sz, u64p, C.POINTER(i32)]),
 }
 
 _lib = None

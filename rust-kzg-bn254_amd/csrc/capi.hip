@@ -1,10 +1,12 @@
 // capi.hip — the C-ABI of include/kzg_bn254_mi355x.h.  Plain pointers and sizes only.
 #include "engine.h"
 #include "host_curve.h"
+#include "host_pairing.h"
 
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 namespace kzg {
 
@@ -49,6 +51,9 @@ const char* kzg_status_message(int32_t status) {
         case KZG_ERR_SRS_LENGTH: return "the length of data after padding is not valid with respect to the SRS";
         case KZG_ERR_DESERIALIZE: return "point at infinity not coded properly for g1";
         case KZG_ERR_NOT_ON_CURVE: return "compressed g1 point not on curve";
+        case KZG_ERR_G1_NOT_ON_CURVE: return "G1 point not on curve";
+        case KZG_ERR_G2_TAU_NOT_ON_CURVE: return "Invalid trusted setup: G2_TAU not on curve";
+        case KZG_ERR_TAU_EQUALS_Z: return "Evaluation point equals trusted setup secret";
         default: return "unknown status";
     }
 }
@@ -309,6 +314,102 @@ int32_t kzg_g1_fold_partials(const uint64_t* partials_xyzz_mont, size_t count, u
         acc = kzg_host::xyzz_add(acc, p);
     }
     kzg_host::xyzz_to_affine(acc, out_xy_mont, out_is_infinity);
+    return KZG_OK;
+}
+
+// ---- verifier surface: O(1) host pairing, data-parallel part on the GPU ---------------------------------------------
+static bool load_g2_tau(const uint64_t* g2_tau_mont, kzg_host::G2* out) {
+    *out = g2_tau_mont ? kzg_host::g2_from_wire(g2_tau_mont) : kzg_host::g2_tau_mainnet();
+    return kzg_host::g2_on_curve(*out);
+}
+
+int32_t kzg_g2_generator(uint64_t out_g2_mont[16]) {
+    if (!out_g2_mont) return KZG_ERR_INVALID_ARG;
+    kzg_host::g2_to_wire(kzg_host::g2_generator(), out_g2_mont);
+    return KZG_OK;
+}
+int32_t kzg_g2_tau_mainnet(uint64_t out_g2_mont[16]) {
+    if (!out_g2_mont) return KZG_ERR_INVALID_ARG;
+    kzg_host::g2_to_wire(kzg_host::g2_tau_mainnet(), out_g2_mont);
+    return KZG_OK;
+}
+int32_t kzg_g2_mul_generator(const uint64_t scalar_mont[4], uint64_t out_g2_mont[16]) {
+    if (!scalar_mont || !out_g2_mont) return KZG_ERR_INVALID_ARG;
+    uint64_t k[4];
+    kzg_host::fr_wire_to_canonical(scalar_mont, k);
+    kzg_host::g2_to_wire(kzg_host::g2_mul(kzg_host::g2_generator(), k), out_g2_mont);
+    return KZG_OK;
+}
+
+int32_t kzg_pairings_verify(const uint64_t a1_xy_mont[8], const uint64_t a2_g2_mont[16], const uint64_t b1_xy_mont[8],
+                            const uint64_t b2_g2_mont[16], int32_t* out_ok) {
+    if (!a1_xy_mont || !a2_g2_mont || !b1_xy_mont || !b2_g2_mont || !out_ok) return KZG_ERR_INVALID_ARG;
+    using namespace kzg_host;
+    G1 a1 = g1_from_wire(a1_xy_mont), b1 = g1_from_wire(b1_xy_mont);
+    G2 a2 = g2_from_wire(a2_g2_mont), b2 = g2_from_wire(b2_g2_mont);
+    if (!g1_on_curve(a1) || !g1_on_curve(b1)) return KZG_ERR_G1_NOT_ON_CURVE;
+    if (!g2_on_curve(a2) || !g2_on_curve(b2)) return KZG_ERR_INVALID_ARG;
+    *out_ok = pairings_verify(a1, a2, b1, b2) ? 1 : 0;
+    return KZG_OK;
+}
+
+int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t proof_xy_mont[8], const uint64_t value_mont[4],
+                         const uint64_t z_mont[4], const uint64_t* g2_tau_mont, int32_t* out_ok) {
+    if (!commitment_xy_mont || !proof_xy_mont || !value_mont || !z_mont || !out_ok) return KZG_ERR_INVALID_ARG;
+    using namespace kzg_host;
+    G1 commitment = g1_from_wire(commitment_xy_mont), proof = g1_from_wire(proof_xy_mont);
+    if (!g1_on_curve(commitment) || !g1_on_curve(proof)) return KZG_ERR_G1_NOT_ON_CURVE;   // verify.rs:18,22 (G1 has cofactor 1)
+    G2 g2_tau;
+    if (!load_g2_tau(g2_tau_mont, &g2_tau)) return KZG_ERR_G2_TAU_NOT_ON_CURVE;            // verify.rs:29-33
+    uint64_t y[4], z[4];
+    fr_wire_to_canonical(value_mont, y);
+    fr_wire_to_canonical(z_mont, z);
+    G1 gen; gen.x = FQ_ONE; gen.y = FQ_TWO; gen.inf = false;
+    G1 commit_minus_value = g1_add(commitment, g1_neg(g1_mul(gen, y)));                    // verify.rs:37-42
+    G2 x_minus_z = g2_add(g2_tau, g2_neg(g2_mul(g2_generator(), z)));                      // verify.rs:46-51
+    if (x_minus_z.inf) return KZG_ERR_TAU_EQUALS_Z;                                        // verify.rs:56-60
+    *out_ok = pairings_verify(commit_minus_value, g2_generator(), proof, x_minus_z) ? 1 : 0;   // verify.rs:66-71
+    return KZG_OK;
+}
+
+int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_mont, const uint64_t* zs_mont, const uint64_t* ys_mont,
+                                   const uint64_t* proofs_xy_mont, const uint64_t* r_powers_mont, size_t n,
+                                   const uint64_t* g2_tau_mont, int32_t* out_ok) {
+    if (!ctx || !out_ok) return KZG_ERR_INVALID_ARG;
+    if (n && (!commitments_xy_mont || !zs_mont || !ys_mont || !proofs_xy_mont || !r_powers_mont)) return KZG_ERR_INVALID_ARG;
+    using namespace kzg_host;
+    for (size_t i = 0; i < n; ++i)                                                         // batch.rs:203-210
+        if (!g1_on_curve(g1_from_wire(commitments_xy_mont + 8 * i)) || !g1_on_curve(g1_from_wire(proofs_xy_mont + 8 * i)))
+            return KZG_ERR_G1_NOT_ON_CURVE;
+    G2 g2_tau;
+    if (!load_g2_tau(g2_tau_mont, &g2_tau)) return KZG_ERR_G2_TAU_NOT_ON_CURVE;            // batch.rs:214-216
+    // scalars of the three linear combinations (batch.rs:228, :245, :246).  sum_i r^i (C_i - [y_i]G) is evaluated as
+    // sum_i r^i C_i - [sum_i r^i y_i] G: the same group element with one fixed-base product instead of n.
+    std::vector<uint64_t> bases(3 * n * 8), scalars(3 * n * 4);
+    uint64_t s[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t t[4];
+        fr_mul(r_powers_mont + 4 * i, zs_mont + 4 * i, scalars.data() + (n + i) * 4);      // r^i z_i
+        fr_mul(r_powers_mont + 4 * i, ys_mont + 4 * i, t);
+        fr_add(s, t, s);
+    }
+    if (n) {
+        memcpy(bases.data(), proofs_xy_mont, n * 64);
+        memcpy(bases.data() + n * 8, proofs_xy_mont, n * 64);
+        memcpy(bases.data() + 2 * n * 8, commitments_xy_mont, n * 64);
+        memcpy(scalars.data(), r_powers_mont, n * 32);
+        memcpy(scalars.data() + 2 * n * 4, r_powers_mont, n * 32);
+    }
+    uint64_t sums[3 * 8];
+    uint8_t infs[3];
+    int32_t rc = kzg_msm_g1_batch(ctx, bases.data(), scalars.data(), n, 3, sums, infs);
+    if (rc != KZG_OK) return rc;
+    G1 proof_lincomb = g1_from_wire(sums), proof_z_lincomb = g1_from_wire(sums + 8), c_lincomb = g1_from_wire(sums + 16);
+    uint64_t s_int[4];
+    fr_wire_to_canonical(s, s_int);
+    G1 gen; gen.x = FQ_ONE; gen.y = FQ_TWO; gen.inf = false;
+    G1 rhs = g1_add(g1_add(c_lincomb, g1_neg(g1_mul(gen, s_int))), proof_z_lincomb);       // batch.rs:249
+    *out_ok = pairings_verify(proof_lincomb, g2_tau, rhs, g2_generator()) ? 1 : 0;         // batch.rs:253-254
     return KZG_OK;
 }
 

@@ -1,0 +1,255 @@
+// host_pairing.h — host-side BN254 pairing check for the verifier surface:
+// `helpers::pairings_verify` (primitives/src/helpers.rs:392-398), `verify_proof` (verifier/src/verify.rs:10-72) and the
+// final check of `verify_kzg_proof_batch` (verifier/src/batch.rs:253-254).  O(1) work per verification; the data-parallel
+// part of batch verification (three n-point MSMs) runs on the GPU (kzg_msm_g1_batch).
+//
+// The reference calls arkworks' optimal-ate `Bn254::multi_pairing` and only looks at `result.is_zero()` (is the product
+// the identity of GT).  Any bilinear non-degenerate pairing decides that predicate identically, so this file implements
+// the simplest one to verify: the reduced Tate pairing  t(P, Q) = f_{r,P}(psi(Q))^((p^12 - 1)/r)  with the G1 point as the
+// Miller-loop point (affine arithmetic in Fq), psi the untwist G2 -> E(Fq12), and Fq12 = Fq[w]/(w^12 - 18 w^6 + 82)
+// (w^6 = 9 + u).  Not performance tuned (~50 ms per check): it closes the API, the hot path is elsewhere.
+#pragma once
+#include "host_curve.h"
+#include "pairing_constants.h"
+
+namespace kzg_host {
+
+// ---- Fq helpers -------------------------------------------------------------------------------------------------
+inline Fq fq_zero() { Fq z; memset(&z, 0, sizeof z); return z; }
+inline Fq neg(const Fq& a) { return is_zero(a) ? a : sub(fq_zero(), a); }
+
+// ---- Fr (scalar field) in wire form: Montgomery product, sum, and conversion to canonical integer words --------------------------------
+static const uint64_t FR_INV = 0xc2e1f593efffffffULL;           // -r^-1 mod 2^64
+inline bool fr_geq_r(const uint64_t t[4]) {
+    for (int i = 3; i >= 0; --i) { if (t[i] != FR_MODULUS_WORDS[i]) return t[i] > FR_MODULUS_WORDS[i]; }
+    return true;
+}
+inline void fr_sub_r(uint64_t t[4]) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)t[i] - FR_MODULUS_WORDS[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+}
+inline void fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    uint64_t t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (u128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        u128 top = (u128)t[4] + (uint64_t)c;
+        uint64_t m = t[0] * FR_INV;
+        c = ((u128)m * FR_MODULUS_WORDS[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) { c += (u128)m * FR_MODULUS_WORDS[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        top += (uint64_t)c;
+        t[3] = (uint64_t)top; t[4] = (uint64_t)(top >> 64);
+    }
+    if (t[4] || fr_geq_r(t)) fr_sub_r(t);
+    memcpy(out, t, 32);
+}
+inline void fr_add(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    uint64_t t[4]; u128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (u128)a[i] + b[i]; t[i] = (uint64_t)c; c >>= 64; }
+    if (c || fr_geq_r(t)) fr_sub_r(t);
+    memcpy(out, t, 32);
+}
+inline void fr_wire_to_canonical(const uint64_t in[4], uint64_t out[4]) {    // x 2^-256: Montgomery product with the integer 1
+    const uint64_t one[4] = {1, 0, 0, 0};
+    fr_mul(in, one, out);
+}
+
+// ---- G1 affine (host) -----------------------------------------------------------------------------------------------------
+struct G1 { Fq x, y; bool inf; };
+inline G1 g1_from_wire(const uint64_t xy[8]) {
+    G1 p; memcpy(p.x.l, xy, 32); memcpy(p.y.l, xy + 4, 32); p.inf = is_zero(p.x) && is_zero(p.y); return p;
+}
+inline bool g1_on_curve(const G1& p) {
+    if (p.inf) return true;
+    return eq(sqr(p.y), add(mul(sqr(p.x), p.x), FQ_THREE));
+}
+inline G1 g1_neg(const G1& p) { G1 r = p; if (!p.inf) r.y = neg(p.y); return r; }
+inline G1 g1_add(const G1& a, const G1& b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    Fq lam;
+    if (eq(a.x, b.x)) {
+        if (!eq(a.y, b.y) || is_zero(a.y)) { G1 r; r.x = fq_zero(); r.y = fq_zero(); r.inf = true; return r; }
+        Fq xx = sqr(a.x);
+        lam = mul(add(dbl(xx), xx), inv(dbl(a.y)));
+    } else {
+        lam = mul(sub(b.y, a.y), inv(sub(b.x, a.x)));
+    }
+    G1 r; r.inf = false;
+    r.x = sub(sub(sqr(lam), a.x), b.x);
+    r.y = sub(mul(lam, sub(a.x, r.x)), a.y);
+    return r;
+}
+inline G1 g1_mul(const G1& p, const uint64_t k[4]) {
+    G1 acc; acc.x = fq_zero(); acc.y = fq_zero(); acc.inf = true;
+    for (int i = 255; i >= 0; --i) {
+        acc = g1_add(acc, acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) acc = g1_add(acc, p);
+    }
+    return acc;
+}
+inline void g1_to_wire(const G1& p, uint64_t xy[8]) {
+    if (p.inf) { memset(xy, 0, 64); return; }
+    memcpy(xy, p.x.l, 32); memcpy(xy + 4, p.y.l, 32);
+}
+
+// ---- Fq2 = Fq[u]/(u^2 + 1), G2 affine over Fq2 on y^2 = x^3 + 3/(9+u) --------------------------------------------------------
+struct Fq2 { Fq c0, c1; };
+inline Fq2 add(const Fq2& a, const Fq2& b) { return {add(a.c0, b.c0), add(a.c1, b.c1)}; }
+inline Fq2 sub(const Fq2& a, const Fq2& b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+inline Fq2 neg(const Fq2& a) { return {neg(a.c0), neg(a.c1)}; }
+inline Fq2 mul(const Fq2& a, const Fq2& b) {
+    Fq t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1);
+    return {sub(t0, t1), sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), t0), t1)};
+}
+inline Fq2 sqr(const Fq2& a) { return mul(a, a); }
+inline bool is_zero(const Fq2& a) { return is_zero(a.c0) && is_zero(a.c1); }
+inline bool eq(const Fq2& a, const Fq2& b) { return eq(a.c0, b.c0) && eq(a.c1, b.c1); }
+inline Fq2 inv(const Fq2& a) {                    // (c0 - c1 u) / (c0^2 + c1^2)
+    Fq n = inv(add(sqr(a.c0), sqr(a.c1)));
+    return {mul(a.c0, n), neg(mul(a.c1, n))};
+}
+struct G2 { Fq2 x, y; bool inf; };
+inline G2 g2_inf() { G2 r; memset(&r, 0, sizeof r); r.inf = true; return r; }
+inline G2 g2_from_wire(const uint64_t w[16]) {
+    G2 p; memcpy(p.x.c0.l, w, 32); memcpy(p.x.c1.l, w + 4, 32); memcpy(p.y.c0.l, w + 8, 32); memcpy(p.y.c1.l, w + 12, 32);
+    p.inf = is_zero(p.x) && is_zero(p.y);
+    return p;
+}
+inline void g2_to_wire(const G2& p, uint64_t w[16]) {
+    if (p.inf) { memset(w, 0, 128); return; }
+    memcpy(w, p.x.c0.l, 32); memcpy(w + 4, p.x.c1.l, 32); memcpy(w + 8, p.y.c0.l, 32); memcpy(w + 12, p.y.c1.l, 32);
+}
+inline G2 g2_generator() { G2 g; g.x = {G2_GEN_X0, G2_GEN_X1}; g.y = {G2_GEN_Y0, G2_GEN_Y1}; g.inf = false; return g; }
+inline G2 g2_tau_mainnet() { G2 g; g.x = {G2_TAU_X0, G2_TAU_X1}; g.y = {G2_TAU_Y0, G2_TAU_Y1}; g.inf = false; return g; }
+inline bool g2_on_curve(const G2& p) {             // helpers.rs:264-285 is_on_curve_g2
+    if (p.inf) return true;
+    Fq2 b = {TWIST_B0, TWIST_B1};
+    return eq(sqr(p.y), add(mul(sqr(p.x), p.x), b));
+}
+inline G2 g2_neg(const G2& p) { G2 r = p; if (!p.inf) r.y = neg(p.y); return r; }
+inline G2 g2_add(const G2& a, const G2& b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    Fq2 lam;
+    if (eq(a.x, b.x)) {
+        if (!eq(a.y, b.y) || is_zero(a.y)) return g2_inf();
+        Fq2 xx = sqr(a.x);
+        lam = mul(add(add(xx, xx), xx), inv(add(a.y, a.y)));
+    } else {
+        lam = mul(sub(b.y, a.y), inv(sub(b.x, a.x)));
+    }
+    G2 r; r.inf = false;
+    r.x = sub(sub(sqr(lam), a.x), b.x);
+    r.y = sub(mul(lam, sub(a.x, r.x)), a.y);
+    return r;
+}
+inline G2 g2_mul(const G2& p, const uint64_t k[4]) {
+    G2 acc = g2_inf();
+    for (int i = 255; i >= 0; --i) {
+        acc = g2_add(acc, acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) acc = g2_add(acc, p);
+    }
+    return acc;
+}
+
+// ---- Fq12 = Fq[w] / (w^12 - 18 w^6 + 82) ----------------------------------------------------------------------------------------
+struct Fq12 { Fq c[12]; };
+inline Fq12 fq12_one() { Fq12 r; memset(&r, 0, sizeof r); r.c[0] = FQ_ONE; return r; }
+inline bool fq12_is_one(const Fq12& a) {
+    if (!eq(a.c[0], FQ_ONE)) return false;
+    for (int i = 1; i < 12; ++i) if (!is_zero(a.c[i])) return false;
+    return true;
+}
+inline void fq12_reduce(Fq t[23], Fq12& r) {          // w^12 = 18 w^6 - 82
+    for (int k = 22; k >= 12; --k) {
+        if (is_zero(t[k])) continue;
+        t[k - 6] = add(t[k - 6], mul(t[k], FQ_EIGHTEEN));
+        t[k - 12] = sub(t[k - 12], mul(t[k], FQ_EIGHTYTWO));
+    }
+    for (int i = 0; i < 12; ++i) r.c[i] = t[i];
+}
+inline Fq12 mul(const Fq12& a, const Fq12& b) {
+    Fq t[23];
+    for (int i = 0; i < 23; ++i) t[i] = fq_zero();
+    for (int i = 0; i < 12; ++i) {
+        if (is_zero(a.c[i])) continue;
+        for (int j = 0; j < 12; ++j) {
+            if (is_zero(b.c[j])) continue;
+            t[i + j] = add(t[i + j], mul(a.c[i], b.c[j]));
+        }
+    }
+    Fq12 r; fq12_reduce(t, r); return r;
+}
+inline Fq12 fq12_pow(const Fq12& a, const uint64_t* e, int words) {
+    Fq12 acc = fq12_one();
+    bool started = false;
+    for (int i = words * 64 - 1; i >= 0; --i) {
+        if (started) acc = mul(acc, acc);
+        if ((e[i >> 6] >> (i & 63)) & 1) { acc = started ? mul(acc, a) : a; started = true; }
+    }
+    return acc;
+}
+
+// untwisted coordinates of a G2 point inside Fq12:  x' = x w^2, y' = y w^3, where a + b u = (a - 9 b) + b w^6
+struct UntwistedQ { Fq x2, x8, y3, y9; };             // x' = x2 w^2 + x8 w^8,  y' = y3 w^3 + y9 w^9
+inline UntwistedQ untwist(const G2& q) {
+    UntwistedQ r;
+    r.x2 = sub(q.x.c0, mul(q.x.c1, FQ_NINE)); r.x8 = q.x.c1;
+    r.y3 = sub(q.y.c0, mul(q.y.c1, FQ_NINE)); r.y9 = q.y.c1;
+    return r;
+}
+// line through T1, T2 in G1 (slope lam) evaluated at the untwisted Q:  lam (x' - x1) - (y' - y1)
+inline Fq12 line_eval(const Fq& lam, const G1& t1, const UntwistedQ& q) {
+    Fq12 l; memset(&l, 0, sizeof l);
+    l.c[0] = sub(t1.y, mul(lam, t1.x));
+    l.c[2] = mul(lam, q.x2);
+    l.c[8] = mul(lam, q.x8);
+    l.c[3] = neg(q.y3);
+    l.c[9] = neg(q.y9);
+    return l;
+}
+// Miller function f_{r,P}(psi(Q)) of the Tate pairing (vertical lines dropped: they lie in Fq6 and die in the final exponentiation)
+inline Fq12 miller_tate(const G1& p, const G2& q2) {
+    Fq12 f = fq12_one();
+    if (p.inf || q2.inf) return f;
+    const UntwistedQ q = untwist(q2);
+    G1 t = p;
+    int top = 255;
+    while (!((FR_MODULUS_WORDS[top >> 6] >> (top & 63)) & 1)) --top;
+    for (int i = top - 1; i >= 0; --i) {
+        // doubling step
+        {
+            Fq xx = sqr(t.x);
+            Fq lam = mul(add(dbl(xx), xx), inv(dbl(t.y)));
+            f = mul(mul(f, f), line_eval(lam, t, q));
+            G1 n; n.inf = false;
+            n.x = sub(sqr(lam), dbl(t.x));
+            n.y = sub(mul(lam, sub(t.x, n.x)), t.y);
+            t = n;
+        }
+        if ((FR_MODULUS_WORDS[i >> 6] >> (i & 63)) & 1) {
+            if (eq(t.x, p.x)) {                       // T = -P (last step): vertical line, result is the identity
+                t.inf = true;
+                continue;
+            }
+            Fq lam = mul(sub(p.y, t.y), inv(sub(p.x, t.x)));
+            f = mul(f, line_eval(lam, t, q));
+            G1 n; n.inf = false;
+            n.x = sub(sub(sqr(lam), t.x), p.x);
+            n.y = sub(mul(lam, sub(t.x, n.x)), t.y);
+            t = n;
+        }
+    }
+    return f;
+}
+inline Fq12 final_exponentiation(const Fq12& f) { return fq12_pow(f, FINAL_EXP, FINAL_EXP_WORDS); }
+inline Fq12 pairing(const G1& p, const G2& q) { return final_exponentiation(miller_tate(p, q)); }
+
+// helpers::pairings_verify(a1, a2, b1, b2): e(a1, a2) * e(-b1, b2) == 1   (helpers.rs:392-398)
+inline bool pairings_verify(const G1& a1, const G2& a2, const G1& b1, const G2& b2) {
+    Fq12 f = mul(miller_tate(a1, a2), miller_tate(g1_neg(b1), b2));
+    return fq12_is_one(final_exponentiation(f));
+}
+
+}  // namespace kzg_host

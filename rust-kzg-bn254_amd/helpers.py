@@ -10,7 +10,7 @@ import numpy as np
 from . import _lib
 from .consts import (BYTES_PER_FIELD_ELEMENT, FIAT_SHAMIR_PROTOCOL_DOMAIN, FQ_MODULUS, FR_MODULUS,
                      MAINNET_SRS_G1_SIZE, primitive_root_of_unity)
-from .errors import GenericError, InvalidInputLength, MsmError
+from .errors import GenericError, InvalidInputLength, MsmError, NotOnCurveError
 from .fr import fq_to_int, fr_from_int, fr_to_int, frs_from_ints, frs_to_ints, g1_is_identity
 
 
@@ -168,8 +168,84 @@ def serialize_compressed(point) -> bytes:
     return bytes(b)
 
 
+def is_on_curve_g1(point) -> bool:
+    """helpers.rs:239-261 (y^2 = x^3 + 3; the identity counts as on the curve)."""
+    if g1_is_identity(point):
+        return True
+    p = np.asarray(point, dtype=np.uint64).reshape(8)
+    x, y = fq_to_int(p[:4]), fq_to_int(p[4:])
+    return (y * y - x * x * x - 3) % FQ_MODULUS == 0
+
+
+def validate_g1_point(point) -> None:
+    """helpers.rs:694-708: on curve + correct subgroup (G1 of BN254 has cofactor 1, so the second check is implied)."""
+    if not is_on_curve_g1(point):
+        raise NotOnCurveError("G1 point not on curve")
+
+
+def compute_powers(base, count: int) -> np.ndarray:
+    """helpers.rs:298-315: [base^0 .. base^(count-1)]."""
+    b = fr_to_int(base)
+    out, cur = [], 1
+    for _ in range(count):
+        out.append(cur)
+        cur = cur * b % FR_MODULUS
+    return frs_from_ints(out)
+
+
+def usize_to_be_bytes(number: int) -> bytes:
+    """helpers.rs:769-771."""
+    return int(number).to_bytes(8, "big")
+
+
+def pairings_verify(a1, a2, b1, b2) -> bool:
+    """helpers.rs:392-398: e(a1, a2) == e(b1, b2).  a2, b2: G2 wire points (16 u64).  O(1) host pairing inside the library."""
+    ok = _lib.i32(0)
+    rc = _lib.load().kzg_pairings_verify(_lib.ptr(_lib.as_u64(a1, 0).reshape(8)), _lib.ptr(_lib.as_u64(a2, 0).reshape(16)),
+                                         _lib.ptr(_lib.as_u64(b1, 0).reshape(8)), _lib.ptr(_lib.as_u64(b2, 0).reshape(16)),
+                                         C.byref(ok))
+    if rc == _lib.ERR_G1_NOT_ON_CURVE:
+        raise NotOnCurveError("G1 point not on curve")
+    if rc != _lib.OK:
+        raise ValueError(_lib.status_message(rc))
+    return bool(ok.value)
+
+
+def g2_generator() -> np.ndarray:
+    out = np.zeros(16, dtype=np.uint64)
+    _lib.load().kzg_g2_generator(_lib.ptr(out))
+    return out
+
+
+def g2_tau() -> np.ndarray:
+    """consts::G2_TAU (primitives/src/consts.rs:55-64)."""
+    out = np.zeros(16, dtype=np.uint64)
+    _lib.load().kzg_g2_tau_mainnet(_lib.ptr(out))
+    return out
+
+
+def g2_mul_generator(scalar) -> np.ndarray:
+    out = np.zeros(16, dtype=np.uint64)
+    _lib.load().kzg_g2_mul_generator(_lib.ptr(_lib.as_u64(scalar, 0).reshape(4)), _lib.ptr(out))
+    return out
+
+
+def compute_challenges_and_evaluate_polynomial(blobs, commitments, ctx=None):
+    """helpers.rs:613-665."""
+    if len(blobs) != len(commitments) and len(blobs) != 0:
+        raise GenericError("length's of the input are not the same or is empty")
+    zs, ys = [], []
+    for blob, commitment in zip(blobs, commitments):
+        poly = blob.to_polynomial_eval_form()
+        z = compute_challenge(blob, commitment)
+        ys.append(evaluate_polynomial_in_evaluation_form(poly, z, ctx))
+        zs.append(z)
+    return zs, ys
+
+
 def compute_challenge(blob, commitment) -> np.ndarray:
     """helpers.rs:411-472: SHA-256(tag || u64be(n) || n x 32-byte evaluations || compressed commitment) mod r."""
+    validate_g1_point(commitment)
     poly = blob.to_polynomial_eval_form()
     n = len(poly)
     data = to_byte_array(poly.evaluations(), n * BYTES_PER_FIELD_ELEMENT)

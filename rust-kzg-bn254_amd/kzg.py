@@ -137,8 +137,7 @@ class KZG:
 
     # kzg.rs:288-309
     def compute_blob_proof(self, blob, commitment, srs):
-        if g1_is_identity(commitment) and False:
-            raise NotOnCurveError("point is identity")
+        helpers.validate_g1_point(commitment)
         poly = blob.to_polynomial_eval_form()
         z = helpers.compute_challenge(blob, commitment)
         return self._compute_proof_impl(poly, z, srs)

@@ -1,0 +1,35 @@
+// Host-only self-check of csrc/host_pairing.h (built by tests/test_pairing_host.py with g++; no GPU, no oracle).
+// Prints one line per property: "<name> 0|1".
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+#include "host_pairing.h"
+using namespace kzg_host;
+
+static bool fq12_eq(const Fq12& a, const Fq12& b) { for (int i = 0; i < 12; ++i) if (!eq(a.c[i], b.c[i])) return false; return true; }
+
+int main() {
+    G1 g; g.x = FQ_ONE; g.y = FQ_TWO; g.inf = false;
+    G2 h = g2_generator();
+    printf("g1_on_curve %d\n", (int)g1_on_curve(g));
+    printf("g2_gen_on_curve %d\n", (int)g2_on_curve(h));
+    printf("g2_tau_on_curve %d\n", (int)g2_on_curve(g2_tau_mainnet()));
+    uint64_t r[4]; memcpy(r, FR_MODULUS_WORDS, 32);
+    printf("g2_gen_order_r %d\n", (int)g2_mul(h, r).inf);
+    printf("g1_gen_order_r %d\n", (int)g1_mul(g, r).inf);
+    auto t0 = std::chrono::steady_clock::now();
+    Fq12 e = pairing(g, h);
+    auto t1 = std::chrono::steady_clock::now();
+    printf("nondegenerate %d\n", (int)!fq12_is_one(e));
+    printf("order_r %d\n", (int)fq12_is_one(fq12_pow(e, r, 4)));
+    uint64_t a[4] = {0x1234567890abcdefULL, 0x0fedcba987654321ULL, 0x1111, 0}, b[4] = {0xdeadbeefcafef00dULL, 77, 0, 0};
+    Fq12 eab = fq12_pow(fq12_pow(e, a, 4), b, 4);
+    printf("bilinear %d\n", (int)fq12_eq(pairing(g1_mul(g, a), g2_mul(h, b)), eab));
+    printf("bilinear_left %d\n", (int)fq12_eq(pairing(g1_mul(g, a), h), fq12_pow(e, a, 4)));
+    printf("bilinear_right %d\n", (int)fq12_eq(pairing(g, g2_mul(h, b)), fq12_pow(e, b, 4)));
+    printf("verify_true %d\n", (int)pairings_verify(g1_mul(g, a), g2_mul(h, b), g1_mul(g, b), g2_mul(h, a)));
+    printf("verify_false %d\n", (int)!pairings_verify(g1_mul(g, a), g2_mul(h, b), g1_mul(g, b), h));
+    printf("identity_pairs %d\n", (int)pairings_verify(g1_mul(g, r), h, g, g2_inf()));
+    fprintf(stderr, "one pairing: %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
+    return 0;
+}

@@ -1,0 +1,161 @@
+"""-m gpu: the verifier row end to end, mirroring verifier/tests/tests.rs.  Commitments and proofs come from the HIP
+prover path (MSM / NTT / proof pipeline on the GPU), verification = GPU barycentric evaluation + batched GPU MSMs + the
+library's O(1) host pairing.  The reference's tests use the mainnet SRS file and consts::G2_TAU; that file is not part of
+the reference tree available here, so the setup is SRS.generate(TAU) on the GPU with [TAU]G2 passed explicitly.
+Independent of the oracle: a pairing check is a cryptographic proof that commitment and proof are correct."""
+import random
+
+import numpy as np
+import pytest
+
+import pyref
+from pyref import R_
+
+pytestmark = pytest.mark.gpu
+
+TAU = int.from_bytes(__import__("hashlib").sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % R_
+
+
+@pytest.fixture(scope="module")
+def k():
+    import rust_kzg_bn254_amd as k
+    k.load()
+    k.default_context()
+    return k
+
+
+@pytest.fixture(scope="module")
+def srs(k):
+    return k.SRS.generate(TAU, 4096)
+
+
+@pytest.fixture(scope="module")
+def g2_tau(k):
+    return k.helpers.g2_mul_generator(k.fr.fr_from_int(TAU))
+
+
+def _prove(k, srs, raw):
+    kz = k.KZG.new()
+    blob = k.Blob.from_raw_data(raw)
+    kz.calculate_and_store_roots_of_unity(len(blob))
+    poly = blob.to_polynomial_eval_form()
+    commitment = kz.commit_eval_form(poly, srs)
+    proof = kz.compute_blob_proof(blob, commitment, srs)
+    return blob, commitment, proof
+
+
+def test_compute_kzg_proof_and_verify(k, srs, g2_tau, gettysburg):
+    """tests.rs:28-77: every 6th index of the Gettysburg polynomial (each verification costs two host pairings)."""
+    kz = k.KZG.new()
+    blob = k.Blob.from_raw_data(gettysburg)
+    poly = blob.to_polynomial_eval_form()
+    kz.calculate_and_store_roots_of_unity(len(blob))
+    commitment = kz.commit_eval_form(poly, srs)
+    m = poly.len_underlying_blob_field_elements()
+    for index in range(0, len(poly) - 1, 6):
+        proof = kz.compute_proof_with_known_z_fr_index(poly, index, srs)
+        value, z = poly.get_evalualtion(index), kz.get_nth_root_of_unity(index)
+        assert k.verify_proof(commitment, proof, value, z, g2_tau) is True
+        other = kz.get_nth_root_of_unity((index + 1) % m)
+        assert k.verify_proof(commitment, proof, value, other, g2_tau) is False
+    assert k.verify_proof(commitment, proof, value, z) is False        # mainnet G2_TAU is a different setup
+
+
+def test_random_blobs_single_and_batch(k, srs, g2_tau):
+    """tests.rs:80-132 and :135-192 (12 blobs instead of 100; lengths 35..50000 bytes)."""
+    rnd = random.Random(5)
+    blobs, commitments, proofs = [], [], []
+    for _ in range(12):
+        raw = bytes(rnd.randrange(32, 127) for _ in range(rnd.randrange(35, 50000)))
+        b, c, p = _prove(k, srs, raw)
+        blobs.append(b); commitments.append(c); proofs.append(p)
+    for b, c, p in list(zip(blobs, commitments, proofs))[:3]:
+        assert k.verify_blob_kzg_proof(b, c, p, g2_tau) is True
+    assert k.verify_blob_kzg_proof(blobs[0], commitments[0], proofs[1], g2_tau) is False
+    assert k.verify_blob_kzg_proof_batch(blobs, commitments, proofs, g2_tau) is True
+    bad_blobs = blobs[:-1] + [k.Blob.from_raw_data(b"random")]
+    assert k.verify_blob_kzg_proof_batch(bad_blobs, commitments, proofs, g2_tau) is False
+    rand_pt = lambda s: np.array(pyref.point_to_wire(pyref.ec_mul(s, (1, 2))), dtype=np.uint64)   # noqa: E731
+    bad_commitments = commitments[:-1] + [rand_pt(123457)]
+    assert k.verify_blob_kzg_proof_batch(blobs, bad_commitments, proofs, g2_tau) is False
+    bad_proofs = proofs[:-1] + [rand_pt(7654321)]
+    assert k.verify_blob_kzg_proof_batch(blobs, commitments, bad_proofs, g2_tau) is False
+    assert k.verify_blob_kzg_proof_batch(bad_blobs, bad_commitments, bad_proofs, g2_tau) is False
+    assert k.verify_blob_kzg_proof_batch(blobs, commitments, proofs) is False          # wrong setup
+
+
+def test_compute_multiple_kzg_proof(k, srs, g2_tau, gettysburg):
+    """tests.rs:195-237."""
+    b1, c1, p1 = _prove(k, srs, gettysburg)
+    b2, c2, p2 = _prove(k, srs, b"17704588942648532530972307366230787358793284390049200127770755029903181125533")
+    assert k.verify_blob_kzg_proof_batch([b1, b2], [c1, c2], [p1, p2], g2_tau) is True
+    assert k.verify_blob_kzg_proof_batch([b1, b2], [c2, c1], [p1, p2], g2_tau) is False
+    assert k.verify_blob_kzg_proof_batch([], [], [], g2_tau) is True
+
+
+def test_kzg_zero_blob(k, srs, g2_tau):
+    """tests.rs:240-269: the all-zero blob commits to the identity and verifies, singly and in a batch."""
+    blob, commitment, proof = _prove(k, srs, bytes(62))
+    assert blob.data() == bytes(64)
+    assert k.fr.g1_is_identity(commitment)
+    assert k.verify_blob_kzg_proof_batch([blob], [commitment], [proof], g2_tau) is True
+    assert k.verify_blob_kzg_proof(blob, commitment, proof, g2_tau) is True
+
+
+def test_kzg_batch_proof_with_infinity(k, srs, g2_tau, gettysburg):
+    """tests.rs:272-311: identity proofs are valid inputs (result is a bool, not an error)."""
+    b1, c1, p1 = _prove(k, srs, gettysburg)
+    ident = np.zeros(8, dtype=np.uint64)
+    assert k.verify_blob_kzg_proof_batch([b1], [c1], [ident], g2_tau) is False
+    b2, c2, _ = _prove(k, srs, b"second input")
+    assert k.verify_blob_kzg_proof_batch([b1, b2], [c1, c2], [p1, ident], g2_tau) in (True, False)
+
+
+def test_kzg_batch_proof_invalid_curve_points(k, srs, g2_tau, gettysburg):
+    """tests.rs:314-380: off-curve commitments / proofs are rejected with NotOnCurveError; length mismatch with GenericError."""
+    b, c, p = _prove(k, srs, gettysburg)
+    off = np.array(pyref.point_to_wire((1, 3)), dtype=np.uint64)
+    p_plus_1 = p.copy()
+    x, y = pyref.point_from_wire(p)
+    p_plus_1[4:] = np.array(pyref.point_to_wire((x, (y + 1) % pyref.P)), dtype=np.uint64)[4:]
+    cases = [([off, c], [p, p]), ([c, c], [off, p]), ([off, c], [off, p]), ([c, off], [p, off]), ([c, off], [p, p_plus_1]),
+             ([off, off], [off, p_plus_1]), ([c, c], [p, p_plus_1])]
+    for commitments, proofs in cases:
+        with pytest.raises(k.errors.NotOnCurveError):
+            k.verify_blob_kzg_proof_batch([b, b], commitments, proofs, g2_tau)
+    with pytest.raises(k.errors.NotOnCurveError):
+        k.verify_blob_kzg_proof(b, off, p, g2_tau)
+    with pytest.raises(k.errors.NotOnCurveError):
+        k.KZG.new().compute_blob_proof(b, off, srs)
+    with pytest.raises(k.errors.GenericError, match="length's of the input are not the same"):
+        k.verify_blob_kzg_proof_batch([b, b], [c], [p, p], g2_tau)
+    # the C entry point validates too (a binding that skips the host-side loop still gets the reference's error)
+    import ctypes as C
+    ok = C.c_int32(0)
+    one = k.fr.fr_from_int(1).reshape(1, 4)
+    rc = k._lib.load().kzg_verify_kzg_proof_batch(k.default_context().handle, k._lib.ptr(off.reshape(1, 8)), k._lib.ptr(one), k._lib.ptr(one),
+                                                  k._lib.ptr(p.reshape(1, 8).copy()), k._lib.ptr(one), 1, None, C.byref(ok))
+    assert rc == k._lib.ERR_G1_NOT_ON_CURVE
+
+
+def test_batch_4096_proofs_reuse(k, srs, g2_tau, gettysburg):
+    """verify_kzg_proof_batch at n = 4096 (batch.rs:185-256): the same valid (C, z, y, proof) row repeated — the three
+    4096-point linear combinations run as one batched GPU MSM; flipping one y makes it fail."""
+    kz = k.KZG.new()
+    blob = k.Blob.from_raw_data(gettysburg)
+    poly = blob.to_polynomial_eval_form()
+    kz.calculate_and_store_roots_of_unity(len(blob))
+    commitment = kz.commit_eval_form(poly, srs)
+    rows = []
+    for i in range(4):
+        z = k.fr.fr_from_int(1000003 + i)
+        proof = kz.compute_proof(poly, z, srs)
+        y = k.helpers.evaluate_polynomial_in_evaluation_form(poly, z)
+        rows.append((commitment, z, y, proof))
+    n = 4096
+    sel = [rows[i % 4] for i in range(n)]
+    cs, zs, ys, ps = ([r[j] for r in sel] for j in range(4))
+    lens = [64] * n
+    assert k.verifier.verify_kzg_proof_batch(cs, zs, ys, ps, lens, g2_tau) is True
+    ys[2077] = k.fr.fr_from_int(5)
+    assert k.verifier.verify_kzg_proof_batch(cs, zs, ys, ps, lens, g2_tau) is False

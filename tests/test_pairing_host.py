@@ -1,0 +1,154 @@
+"""CPU tests of the verifier row's host pairing (rust-kzg-bn254_amd/csrc/host_pairing.h) and of the host-only C-ABI
+entry points kzg_pairings_verify / kzg_verify_proof (no GPU needed: O(1) host arithmetic inside the library).
+
+Pins: (1) algebraic properties of the pairing (bilinearity, non-degeneracy, order r) from a g++ build of the header;
+(2) end-to-end KZG relations on a known-tau setup whose commitments and proofs come from the oracle (CPU), following
+verifier/tests/tests.rs:28-77.  `pairings_verify` only asks whether a product of pairings is the identity, a predicate
+that every non-degenerate bilinear pairing on (G1, G2) decides identically, so these properties pin it completely."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import pyref
+from pyref import R_
+
+import rust_kzg_bn254_amd as kzg
+from rust_kzg_bn254_amd import _lib, helpers, verifier
+from rust_kzg_bn254_amd.errors import GenericError, NotOnCurveError
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "rust-kzg-bn254_amd", "csrc")
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def test_pairing_properties_host_build(tmp_path):
+    exe = str(tmp_path / "pairingcheck")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + CSRC, os.path.join(HERE, "hostcheck", "pairingcheck.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split("\n")
+    rows = dict(line.split() for line in out if line.strip())
+    assert len(rows) == 13
+    assert all(v == "1" for v in rows.values()), rows
+
+
+def _g1(pt):
+    return np.array(pyref.point_to_wire(pt), dtype=np.uint64).reshape(8)
+
+
+TAU = 0x1F3A5C7E9B2D4F60718293A4B5C6D7E8F9
+
+
+@pytest.fixture(scope="module")
+def known_tau_srs():
+    """64 powers [tau^i]G built by the oracle's scalar multiplication, and [tau]G2 from the library's G2 arithmetic.
+    (The reference's verifier tests use the mainnet SRS file, which is not shipped in the reference tree here; the G1
+    test fixture g1.point belongs to a different setup than consts::G2_TAU, so pairing tests need a self-made setup.)"""
+    g = _g1((1, 2))
+    pts = [np.asarray(orc.g1_scalar_mul(g, pyref.fr_to_mont(pow(TAU, i, R_))), dtype=np.uint64).reshape(8) for i in range(64)]
+    return np.stack(pts), helpers.g2_mul_generator(kzg.fr.fr_from_int(TAU))
+
+
+def test_srs_points_pair_with_g2_tau(known_tau_srs, test_srs_wire):
+    """e(P_{i+1}, G2) == e(P_i, [tau]G2); and the mainnet G2_TAU does NOT pair with another setup's points."""
+    srs, tau = known_tau_srs
+    g2 = helpers.g2_generator()
+    assert helpers.pairings_verify(srs[1], g2, srs[0], tau)
+    assert helpers.pairings_verify(srs[7], g2, srs[6], tau)
+    assert not helpers.pairings_verify(srs[2], g2, srs[0], tau)
+    assert not helpers.pairings_verify(srs[1], tau, srs[0], g2)
+    assert not helpers.pairings_verify(srs[1], g2, srs[0], helpers.g2_tau())
+    other = np.asarray(test_srs_wire, dtype=np.uint64).reshape(-1, 8)
+    assert not helpers.pairings_verify(other[1], g2, other[0], tau)
+
+
+def _gettysburg_setup(srs, gettysburg):
+    padded = orc.pad_payload(gettysburg)
+    evals = orc.to_fr_array(padded)
+    n = 64
+    a = np.zeros((n, 4), dtype=np.uint64)
+    a[: len(evals)] = np.asarray(evals, dtype=np.uint64).reshape(-1, 4)
+    rc, roots = orc.calculate_roots_of_unity(len(padded))
+    assert rc == n
+    rc, commitment = orc.commit_eval_form(srs, a, literal=False)[:2]
+    assert rc == 0
+    return a, np.asarray(roots, dtype=np.uint64).reshape(-1, 4), np.asarray(commitment, dtype=np.uint64).reshape(8)
+
+
+def test_oracle_proofs_verify(known_tau_srs, gettysburg):
+    """verifier/tests/tests.rs:28-77 with CPU-side (oracle) commitment and proofs: verify_proof(commitment, proof_idx,
+    evals[idx], roots[idx]) is true, and false for the next root / a wrong value; an off-domain point too."""
+    srs, tau = known_tau_srs
+    a, roots, commitment = _gettysburg_setup(srs, gettysburg)
+    for idx in (0, 1, 17, 47):
+        rc, proof, y = orc.compute_proof(srs, a, roots, roots[idx], literal=False)
+        assert rc == 0
+        proof = np.asarray(proof, dtype=np.uint64).reshape(8)
+        assert verifier.verify_proof(commitment, proof, a[idx], roots[idx], tau) is True
+        assert verifier.verify_proof(commitment, proof, a[idx], roots[(idx + 1) % 48], tau) is False
+        assert verifier.verify_proof(commitment, proof, a[(idx + 1) % 48], roots[idx], tau) is False
+    z = kzg.fr.fr_from_int(0xDEADBEEF12345)
+    rc, proof, y = orc.compute_proof(srs, a, roots, z, literal=False)
+    assert rc == 0
+    assert verifier.verify_proof(commitment, np.asarray(proof, dtype=np.uint64).reshape(8), np.asarray(y, dtype=np.uint64).reshape(4), z, tau) is True
+    assert verifier.verify_proof(commitment, np.asarray(proof, dtype=np.uint64).reshape(8), np.asarray(y, dtype=np.uint64).reshape(4), z) is False
+
+
+def test_verify_proof_identity_points_and_invalid_points(test_srs_wire):
+    """verifier/tests/tests.rs:383-409 (identity points are accepted as inputs), :412-457 (off-curve points rejected)."""
+    srs = np.asarray(test_srs_wire, dtype=np.uint64).reshape(-1, 8)
+    ident = np.zeros(8, dtype=np.uint64)
+    one = kzg.fr.fr_from_int(1)
+    two = kzg.fr.fr_from_int(2)
+    assert verifier.verify_proof(ident, srs[3], one, two) in (True, False)
+    assert verifier.verify_proof(srs[3], ident, one, two) in (True, False)
+    # zero polynomial: C = identity, proof = identity, y = 0 holds at any z
+    assert verifier.verify_proof(ident, ident, kzg.fr.fr_from_int(0), two) is True
+    bad = srs[5].copy()
+    bad[4] ^= 1
+    with pytest.raises(NotOnCurveError, match="G1 point not on curve"):
+        verifier.verify_proof(bad, srs[3], one, two)
+    with pytest.raises(NotOnCurveError, match="G1 point not on curve"):
+        verifier.verify_proof(srs[3], bad, one, two)
+
+
+def test_verify_proof_custom_tau_and_tau_equals_z():
+    """Known-tau setup: commitment to p(X) = 3 + 5X + 7X^2 built by oracle scalar muls; proof for z; tau == z is rejected
+    (verify.rs:56-60)."""
+    tau, z = 123456789123456789, 987654321
+    coeffs = [3, 5, 7]
+    p_tau = sum(c * pow(tau, i, R_) for i, c in enumerate(coeffs)) % R_
+    y = sum(c * pow(z, i, R_) for i, c in enumerate(coeffs)) % R_
+    q_tau = (p_tau - y) * pow(tau - z, -1, R_) % R_
+    g = _g1((1, 2))
+    commitment = np.asarray(orc.g1_scalar_mul(g, pyref.fr_to_mont(p_tau)), dtype=np.uint64).reshape(8)
+    proof = np.asarray(orc.g1_scalar_mul(g, pyref.fr_to_mont(q_tau)), dtype=np.uint64).reshape(8)
+    g2_tau = helpers.g2_mul_generator(kzg.fr.fr_from_int(tau))
+    assert verifier.verify_proof(commitment, proof, kzg.fr.fr_from_int(y), kzg.fr.fr_from_int(z), g2_tau) is True
+    assert verifier.verify_proof(commitment, proof, kzg.fr.fr_from_int(y + 1), kzg.fr.fr_from_int(z), g2_tau) is False
+    assert verifier.verify_proof(commitment, proof, kzg.fr.fr_from_int(y), kzg.fr.fr_from_int(z), None) is False   # mainnet tau
+    with pytest.raises(GenericError, match="Evaluation point equals trusted setup secret"):
+        verifier.verify_proof(commitment, proof, kzg.fr.fr_from_int(y), kzg.fr.fr_from_int(tau), g2_tau)
+    bad_tau = g2_tau.copy()
+    bad_tau[0] ^= 1
+    with pytest.raises(NotOnCurveError, match="G2_TAU not on curve"):
+        verifier.verify_proof(commitment, proof, kzg.fr.fr_from_int(y), kzg.fr.fr_from_int(z), bad_tau)
+
+
+def test_compute_r_powers_transcript_layout(test_srs_wire):
+    """batch.rs:76-168: byte layout of the batch transcript, checked against an independent construction + the oracle's SHA-256."""
+    srs = np.asarray(test_srs_wire, dtype=np.uint64).reshape(-1, 8)
+    cs, ps = [srs[1], srs[2]], [srs[3], np.zeros(8, dtype=np.uint64)]
+    zs = [kzg.fr.fr_from_int(11), kzg.fr.fr_from_int(R_ - 1)]
+    ys = [kzg.fr.fr_from_int(5), kzg.fr.fr_from_int(0)]
+    lens = [64, 4]
+    got = verifier.compute_r_powers(cs, zs, ys, ps, lens)
+    data = b"EIGENDA_RCKZGBATCH___V1_" + bytes(8) + (2).to_bytes(8, "big") + (64).to_bytes(8, "big") + (4).to_bytes(8, "big")
+    for c, z, y, p in zip(cs, (11, R_ - 1), (5, 0), ps):
+        data += orc.g1_serialize_compressed_ark(c) + z.to_bytes(32, "big") + y.to_bytes(32, "big") + orc.g1_serialize_compressed_ark(p)
+    r = int.from_bytes(orc.sha256(data), "big") % R_
+    assert kzg.fr.frs_to_ints(got) == [1, r]
+    assert len(verifier.compute_r_powers([], [], [], [], [])) == 0
