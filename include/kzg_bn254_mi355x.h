@@ -117,6 +117,17 @@ int32_t kzg_msm_g1_srs_partial_device(kzg_ctx* ctx, const kzg_srs* srs, size_t o
                                       const void* d_scalars_mont, size_t n, uint64_t out_xyzz_mont[16]);
 int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
                                const uint64_t* scalars_mont, size_t n, uint64_t out_xyzz_mont[16]);
+/* Asynchronous form for streams of commitments (software pipelining): `begin` enqueues the whole kernel sequence of one
+ * MSM over srs[offset .. offset + n) on the stream of `slot` (0 or 1; each slot has its own stream and workspace) and
+ * returns without waiting; `end` waits for that slot, runs the O(1) host epilogue and writes the affine point
+ * (out_xy_mont / out_is_infinity) and/or the unconverted partial sum (out_xyzz_mont, 16 u64); either may be NULL.
+ * With begin(k+1) issued before end(k), the sort / bucket-reduction phases of one MSM run beside the accumulation of the
+ * other and the host epilogue leaves the critical path.  d_scalars_mont must be complete before `begin` and stay
+ * untouched until `end`.  1 <= n <= 2^24; a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG. */
+int32_t kzg_msm_g1_srs_device_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
+                                    const void* d_scalars_mont, size_t n, int32_t slot);
+int32_t kzg_msm_g1_srs_end(kzg_ctx* ctx, int32_t slot, uint64_t* out_xy_mont, uint8_t* out_is_infinity,
+                           uint64_t* out_xyzz_mont);
 /* Fold `count` gathered partial sums (count x 16 u64) and convert to affine.  Host-only, O(count). */
 int32_t kzg_g1_fold_partials(const uint64_t* partials_xyzz_mont, size_t count,
                              uint64_t out_xy_mont[8], uint8_t* out_is_infinity);

@@ -82,6 +82,8 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    msm_drop_slots(ctx);
     ctx->msm.release();
     ctx->msm2.release();
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_inputs); (void)hipEventDestroy(ctx->ev_acc); }
@@ -303,6 +305,20 @@ int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, 
                                uint64_t out_xyzz_mont[16]) {
     if (!out_xyzz_mont) return KZG_ERR_INVALID_ARG;
     return msm_srs_common(ctx, srs, offset, scalars_mont, false, n, nullptr, nullptr, out_xyzz_mont);
+}
+
+int32_t kzg_msm_g1_srs_device_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* d_scalars_mont, size_t n, int32_t slot) {
+    if (!ctx || !srs || srs->ctx->device != ctx->device || !d_scalars_mont) return KZG_ERR_INVALID_ARG;
+    if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return msm_begin(ctx, slot, srs_bases(srs, offset, ctx->msm_c_override == 0), d_scalars_mont, n);
+}
+int32_t kzg_msm_g1_srs_end(kzg_ctx* ctx, int32_t slot, uint64_t* out_xy_mont, uint8_t* out_is_infinity, uint64_t* out_xyzz_mont) {
+    if (!ctx || (!out_xy_mont && !out_xyzz_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return msm_end(ctx, slot, out_xy_mont, out_is_infinity, out_xyzz_mont);
 }
 
 int32_t kzg_g1_fold_partials(const uint64_t* partials_xyzz_mont, size_t count, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {

@@ -59,6 +59,8 @@ struct NttWorkspace {
 
 }  // namespace kzg
 
+namespace kzg { struct MsmPending; }
+
 struct kzg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -72,6 +74,7 @@ struct kzg_ctx {
     kzg::MsmWorkspace msm2;             // second half of a split MSM (own stream)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_inputs = nullptr, ev_acc = nullptr;
+    kzg::MsmPending* slot_pending[2] = {nullptr, nullptr};   // kzg_msm_g1_srs_device_begin / _end (slot 0: stream + msm, slot 1: stream2 + msm2)
     kzg::NttWorkspace ntt;
     kzg::DeviceBuffer poly_a, poly_b, poly_c, poly_small;   // proof pipeline scratch
 };
@@ -108,6 +111,9 @@ inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, bool allow_tables) 
 int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n,
                 uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz);
 
+int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_scalars, size_t n);
+int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz);
+void msm_drop_slots(kzg_ctx* ctx);
 int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars, size_t n, uint32_t batch,
                       uint64_t* out_xy, uint8_t* out_inf);
 

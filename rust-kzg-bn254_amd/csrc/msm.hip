@@ -9,6 +9,7 @@
 //   generic mode (caller-provided bases, e.g. g1_lincomb; tiny or huge SRS): W bucket sets, per-window reduction,
 //                 Horner over the W window sums on the host.
 #include "engine.h"
+#include <new>
 #include "msm_kernels.h"
 #include "host_curve.h"
 
@@ -327,6 +328,47 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     return KZG_OK;
 }
 
+// ---- two-slot asynchronous form: begin enqueues, end waits and runs the host epilogue ---------------------------------
+struct MsmPending : Pending {};
+
+static int32_t ensure_stream2(kzg_ctx* ctx) {
+    if (ctx->stream2) return KZG_OK;
+    KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inputs, hipEventDisableTiming));
+    KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming));
+    return KZG_OK;
+}
+
+int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_scalars, size_t n) {
+    if (slot < 0 || slot > 1 || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;     // slot still in flight
+    if (n == 0 || n > MSM_MAX_LAUNCH) return KZG_ERR_TOO_LARGE;
+    if (slot == 1) { int32_t rc = ensure_stream2(ctx); if (rc != KZG_OK) return rc; }
+    MsmPending* pend = new (std::nothrow) MsmPending();
+    if (!pend) return KZG_ERR_DEVICE;
+    int32_t rc = msm_enqueue(ctx, slot ? ctx->msm2 : ctx->msm, slot ? ctx->stream2 : ctx->stream, bases,
+                             reinterpret_cast<const uint4*>(d_scalars), n, 1, nullptr, nullptr, pend);
+    if (rc != KZG_OK) { delete pend; return rc; }
+    ctx->slot_pending[slot] = pend;
+    return KZG_OK;
+}
+
+int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
+    if (slot < 0 || slot > 1 || !ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;    // nothing in flight
+    MsmPending* pend = ctx->slot_pending[slot];
+    ctx->slot_pending[slot] = nullptr;
+    kzg_host::Xyzz total;
+    int32_t rc = msm_finish(ctx, slot ? ctx->msm2 : ctx->msm, slot ? ctx->stream2 : ctx->stream, *pend, &total);
+    delete pend;
+    if (rc != KZG_OK) return rc;
+    if (out_xyzz) memcpy(out_xyzz, &total, 128);
+    if (out_xy) kzg_host::xyzz_to_affine(total, out_xy, out_inf);
+    return KZG_OK;
+}
+
+void msm_drop_slots(kzg_ctx* ctx) {
+    for (int s = 0; s < 2; ++s) { delete ctx->slot_pending[s]; ctx->slot_pending[s] = nullptr; }
+}
+
 int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, size_t n) {
     if (n == 0) return KZG_OK;
     hipLaunchKernelGGL(k_points_wire_to_device, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_wire, d_out, n);
@@ -348,11 +390,7 @@ int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size
     bool split = false;
     { const char* env = getenv("KZG_MSM_SPLIT"); if (env && atoi(env) != 0) split = bases.table_stride != 0 && n >= MSM_SPLIT_MIN && n <= MSM_MAX_LAUNCH; }
     if (split) {
-        if (!ctx->stream2) {
-            KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-            KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inputs, hipEventDisableTiming));
-            KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming));
-        }
+        { int32_t rc0 = ensure_stream2(ctx); if (rc0 != KZG_OK) return rc0; }
         const size_t na = n / 2, nb_ = n - na;
         // stream 2 must see whatever produced the scalars on the main stream (e.g. a staged H2D copy)
         KZG_HIP_TRY(ctx, hipEventRecord(ctx->ev_inputs, ctx->stream));

@@ -72,3 +72,39 @@ class ShardedMsm:
             return out
         part = self.partial_device(srs_shard, d_scalars_ptr)
         return fold_partials(gather_partials(part, self.world, self.gather_device))
+
+    # ---- software-pipelined form (kzg_msm_g1_srs_device_begin / kzg_msm_g1_srs_end) -----------------------------------
+    def begin(self, srs_shard, d_scalars_ptr: int, slot: int):
+        """Enqueue this rank's partial MSM on `slot` (0 / 1) without waiting."""
+        rc = _lib.load().kzg_msm_g1_srs_device_begin(self.ctx.handle, srs_shard.handle, 0, C.c_void_p(d_scalars_ptr), self.len, slot)
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+
+    def end(self, slot: int):
+        """Wait for `slot`; returns the folded commitment (all-gather of the partials + host fold when world > 1)."""
+        if self.world == 1:
+            out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
+            rc = _lib.load().kzg_msm_g1_srs_end(self.ctx.handle, slot, _lib.ptr(out), C.byref(inf), None)
+        else:
+            part = np.zeros(16, dtype=np.uint64)
+            rc = _lib.load().kzg_msm_g1_srs_end(self.ctx.handle, slot, None, None, _lib.ptr(part))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+        if self.world == 1:
+            return out
+        return fold_partials(gather_partials(part, self.world, self.gather_device))
+
+    def commit_stream(self, srs_shard, d_scalars_ptrs):
+        """Commitments of a stream of scalar buffers (device pointers to this rank's slices), two MSMs in flight:
+        MSM k+1 is enqueued before MSM k is waited for, so its sort runs beside MSM k's accumulation and the exchange /
+        host fold of MSM k overlap MSM k+1.  Yields the commitments in order."""
+        prev = None
+        for k, ptr in enumerate(d_scalars_ptrs):
+            self.begin(srs_shard, ptr, k & 1)
+            if prev is not None:
+                yield self.end(prev)
+            prev = k & 1
+        if prev is not None:
+            yield self.end(prev)

@@ -1,0 +1,31 @@
+"""Shard-size MSM latency vs. number of MSMs in flight (one context = one stream + workspace each).
+Models what one rank of an N-GPU sharded commitment does: its slice of the SRS, n/N scalars resident in HBM."""
+import ctypes as C, hashlib, os, sys, time
+from concurrent.futures import ThreadPoolExecutor
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+import rust_kzg_bn254_amd as k
+from rust_kzg_bn254_amd import _lib
+lib = _lib.load()
+ctxs = [k.Context(0) for _ in range(3)]
+tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % bench.FR
+for log_n in (17, 18, 19, 20):
+    n = 1 << log_n
+    srs = k.SRS.generate(tau, n, ctx=ctxs[0])
+    sc = bench.blob_like_scalars(n, 123)
+    d = torch.from_numpy(sc.view(np.int64)).cuda(); torch.cuda.synchronize()
+    outs = [np.zeros(16, np.uint64) for _ in ctxs]
+    def one(i):
+        rc = lib.kzg_msm_g1_srs_partial_device(ctxs[i].handle, srs.handle, 0, C.c_void_p(d.data_ptr()), n, _lib.ptr(outs[i]))
+        assert rc == 0, rc
+    for inflight in (1, 2, 3):
+        with ThreadPoolExecutor(inflight) as ex:
+            list(ex.map(one, [j % inflight for j in range(6)]))
+            steps = 60
+            t0 = time.perf_counter()
+            list(ex.map(one, [j % inflight for j in range(steps)]))
+            dt = time.perf_counter() - t0
+        print(f"n=2^{log_n} in flight {inflight}: {dt/steps*1e3:.3f} ms/MSM", flush=True)
+    srs.close()
