@@ -79,6 +79,21 @@ inline void fe_check_mul_operands(const Fe<F>& a, const Fe<F>& b, const char* wh
 #define KZG_CHECK_MUL(a, b, what) ((void)0)
 #endif
 
+// The compiler tracks known-non-negative limbs (anything masked with LMASK) and, for a product of such a limb with a
+// signed one, gives up v_mad_i64_i32 for a v_mad_u64_u32 + sign-correction pair (2 mads + 2 moves per product: +7 % VALU
+// instructions in the mixed add).  Passing operand limbs through an empty asm hides the range without emitting code.
+KZG_HD int32_t fe_opaque(int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
+template <class F>
+KZG_HD void fe_opaque_limbs(int32_t (&o)[NL], const Fe<F>& a) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) o[j] = fe_opaque(a.l[j]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Montgomery product a * b * 2^-261 mod m.  Finely-integrated product scanning: column k sums
 // a_j b_(k-j) and m_j p_(k-j); its low 29 bits are cancelled by m_k p_0; the rest carries on.
@@ -89,10 +104,13 @@ KZG_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
     int64_t acc = 0;
     int32_t m[NL];
     int32_t out[NL];
+    int32_t al[NL], bl[NL];
+    fe_opaque_limbs(al, a);
+    fe_opaque_limbs(bl, b);
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
-        for (int j = 0; j <= k; ++j) acc += (int64_t)a.l[j] * (int64_t)b.l[k - j];
+        for (int j = 0; j <= k; ++j) acc += (int64_t)al[j] * (int64_t)bl[k - j];
 #pragma unroll
         for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
         m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
@@ -102,7 +120,7 @@ KZG_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
-        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)a.l[j] * (int64_t)b.l[k - j];
+        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)al[j] * (int64_t)bl[k - j];
 #pragma unroll
         for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
         out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
@@ -140,12 +158,18 @@ KZG_HD void fe_mulsub(Fe<F>& r, const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, 
     int64_t acc = 0;
     int32_t m[NL];
     int32_t out[NL];
+    int32_t al[NL], bl[NL], ncl[NL], dl[NL];
+    fe_opaque_limbs(al, a);
+    fe_opaque_limbs(bl, b);
+    fe_opaque_limbs(dl, d);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) ncl[j] = fe_opaque(-c.l[j]);
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
         for (int j = 0; j <= k; ++j) {
-            acc += (int64_t)a.l[j] * (int64_t)b.l[k - j];
-            acc -= (int64_t)c.l[j] * (int64_t)d.l[k - j];
+            acc += (int64_t)al[j] * (int64_t)bl[k - j];
+            acc += (int64_t)ncl[j] * (int64_t)dl[k - j];
         }
 #pragma unroll
         for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
@@ -157,8 +181,8 @@ KZG_HD void fe_mulsub(Fe<F>& r, const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, 
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
         for (int j = k - NL + 1; j < NL; ++j) {
-            acc += (int64_t)a.l[j] * (int64_t)b.l[k - j];
-            acc -= (int64_t)c.l[j] * (int64_t)d.l[k - j];
+            acc += (int64_t)al[j] * (int64_t)bl[k - j];
+            acc += (int64_t)ncl[j] * (int64_t)dl[k - j];
         }
 #pragma unroll
         for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
@@ -179,12 +203,14 @@ KZG_HD void fe_sqr(Fe<F>& r, const Fe<F>& a) {
     int32_t out[NL];
     int32_t a2[NL];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) a2[j] = a.l[j] * 2;
+    for (int j = 0; j < NL; ++j) a2[j] = fe_opaque(a.l[j] * 2);
+    int32_t al[NL];
+    fe_opaque_limbs(al, a);
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
-        for (int j = 0; 2 * j < k; ++j) acc += (int64_t)a2[j] * (int64_t)a.l[k - j];
-        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * (int64_t)a.l[k / 2];
+        for (int j = 0; 2 * j < k; ++j) acc += (int64_t)a2[j] * (int64_t)al[k - j];
+        if ((k & 1) == 0) acc += (int64_t)al[k / 2] * (int64_t)al[k / 2];
 #pragma unroll
         for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
         m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
@@ -194,8 +220,8 @@ KZG_HD void fe_sqr(Fe<F>& r, const Fe<F>& a) {
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
-        for (int j = k - NL + 1; 2 * j < k; ++j) acc += (int64_t)a2[j] * (int64_t)a.l[k - j];
-        if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * (int64_t)a.l[k / 2];
+        for (int j = k - NL + 1; 2 * j < k; ++j) acc += (int64_t)a2[j] * (int64_t)al[k - j];
+        if ((k & 1) == 0) acc += (int64_t)al[k / 2] * (int64_t)al[k / 2];
 #pragma unroll
         for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
         out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
