@@ -205,7 +205,47 @@ def main():
             pr_ms = avg_ms(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(scalars), n, None, n, _lib.ptr(zq), _lib.ptr(o8),
                                                          C.byref(oi), _lib.ptr(o4)), reps=5)
             cc_ms = avg_ms(lambda: lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(scalars), n, _lib.ptr(o8), C.byref(oi)), reps=5)
+            # stream of host-buffer commitments, two in flight (kzg_msm_g1_srs_begin / _end): H2D copies overlap kernels
+            def stream_host(reps=8):
+                prev = None
+                for i in range(reps):
+                    rc = lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, _lib.ptr(scalars), n, i & 1)
+                    assert rc == 0, rc
+                    if prev is not None:
+                        assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), None) == 0
+                    prev = i & 1
+                assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), None) == 0
+            stream_host(2)
+            t = time.perf_counter(); stream_host(8); cc_stream_ms = (time.perf_counter() - t) / 8 * 1e3
+            assert np.array_equal(o8, result), "streamed host-buffer commitment differs"
+            # config 4 front end: blob bytes (host) -> Fr -> INTT -> MSM (kzg_commit_blob), 2^20 elements = 32 MiB of padded bytes
+            blob_bytes = np.frombuffer(b"".join(b"\x00" + bytes(r) for r in np.random.default_rng(7).integers(32, 127, size=(n, 31), dtype=np.uint8)), dtype=np.uint8).copy()
+            u8p = C.POINTER(C.c_uint8)
+            cb_ms = avg_ms(lambda: lib.kzg_commit_blob(ctx.handle, srs.handle, blob_bytes.ctypes.data_as(u8p), blob_bytes.size, _lib.ptr(o8), C.byref(oi)), reps=5)
+            # config 5 shape: verify_kzg_proof_batch core at n = 4096 (three 4096-point MSMs batched on the GPU + host pairing check)
+            nb = 4096
+            g1w = np.zeros((nb, 8), dtype=np.uint64)
+            assert lib.kzg_srs_download(ctx.handle, srs.handle, 0, nb, _lib.ptr(g1w)) == 0
+            fr_sel = np.ascontiguousarray(scalars[:nb])
+            okf = C.c_int32(0)
+            tau_g2 = np.zeros(16, np.uint64)
+            lib.kzg_g2_mul_generator(_lib.ptr(k.fr.fr_from_int(tau)), _lib.ptr(tau_g2))
+            g1c = np.ascontiguousarray(g1w)
+            bv_ms = avg_ms(lambda: lib.kzg_verify_kzg_proof_batch(ctx.handle, _lib.ptr(g1c), _lib.ptr(fr_sel), _lib.ptr(fr_sel), _lib.ptr(g1c), _lib.ptr(fr_sel),
+                                                                 nb, _lib.ptr(tau_g2), C.byref(okf)), reps=3, warm=1)
+            o3 = np.zeros((3, 8), np.uint64); i3 = np.zeros(3, np.uint8)
+            b3 = np.ascontiguousarray(np.concatenate([g1c, g1c, g1c])); s3 = np.ascontiguousarray(np.concatenate([fr_sel, fr_sel, fr_sel]))
+            m3_ms = avg_ms(lambda: lib.kzg_msm_g1_batch(ctx.handle, _lib.ptr(b3), _lib.ptr(s3), nb, 3, _lib.ptr(o3), i3.ctypes.data_as(u8p)), reps=10)
+            # measured copy ceiling of this box (device-to-device, 1 GiB): read + write bytes per second
+            big = torch.empty(1 << 28, dtype=torch.int32, device="cuda"); big2 = torch.empty_like(big)
+            copy_ms = avg_ms(lambda: big2.copy_(big), reps=10)
+            copy_gbs = 2.0 * big.numel() * 4 / (copy_ms * 1e-3) / 1e9
+            del big, big2
             out["secondary"] = {
+                "host_buffers_commit_coeff_streamed_ms": cc_stream_ms,
+                "commit_blob_from_host_bytes_ms": cb_ms,
+                "batch_verify_4096_core_ms": bv_ms, "batch_verify_4096_three_msms_ms": m3_ms,
+                "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,
                 "fr_ntt_algorithmic_GBps": 64.0 * n / (ntt_ms * 1e-3) / 1e9, "fr_ntt_frac_of_hbm_peak": 64.0 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "host_buffers_commit_coeff_ms": cc_ms, "host_buffers_commit_eval_ms": ce_ms, "host_buffers_compute_proof_ms": pr_ms,
@@ -221,6 +261,12 @@ def main():
             out["cpu_baseline"] = {"value": n / cpu_s, "unit": "pairs/s", "cores": min(cores, 17), "kind": "port",
                                    "sample": "the same 2^%d-pair MSM once: oracle/ C restatement of arkworks' signed-window "
                                              "Pippenger (c=15, one thread per window, 17 windows), %.2f s wall" % (LOG_N, cpu_s)}
+            m1 = 1 << 16                                           # single-thread sample (SURVEY.md §8d asks for both)
+            t1 = time.perf_counter()
+            orc.msm_pippenger(g1[:m1], scalars[:m1], threads=1)
+            cpu1_s = time.perf_counter() - t1
+            out["cpu_baseline"]["single_thread"] = {"value": m1 / cpu1_s, "unit": "pairs/s", "cores": 1,
+                                                    "sample": "2^16-pair MSM, same port, 1 thread, %.2f s wall" % cpu1_s}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

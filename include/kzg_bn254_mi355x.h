@@ -126,6 +126,11 @@ int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
  * untouched until `end`.  1 <= n <= 2^24; a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG. */
 int32_t kzg_msm_g1_srs_device_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
                                     const void* d_scalars_mont, size_t n, int32_t slot);
+/* Same with the scalars in host memory (n x 4 u64): the H2D copy is issued on the slot's stream into the slot's staging
+ * buffer, so with two slots alternating it runs beside the other slot's kernels.  The host buffer may be reused as soon as
+ * `begin` returns only if it is pageable memory (the runtime stages it); a pinned buffer must stay valid until `end`. */
+int32_t kzg_msm_g1_srs_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
+                             const uint64_t* scalars_mont, size_t n, int32_t slot);
 int32_t kzg_msm_g1_srs_end(kzg_ctx* ctx, int32_t slot, uint64_t* out_xy_mont, uint8_t* out_is_infinity,
                            uint64_t* out_xyzz_mont);
 /* Fold `count` gathered partial sums (count x 16 u64) and convert to affine.  Host-only, O(count). */

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "kzg_msm_g1_srs_partial_device": (i32, [vp, vp, sz, vp, sz, u64p]),
     "kzg_msm_g1_srs_partial": (i32, [vp, vp, sz, u64p, sz, u64p]),
     "kzg_msm_g1_srs_device_begin": (i32, [vp, vp, sz, vp, sz, i32]),
+    "kzg_msm_g1_srs_begin": (i32, [vp, vp, sz, u64p, sz, i32]),
     "kzg_msm_g1_srs_end": (i32, [vp, i32, u64p, u8p, u64p]),
     "kzg_g1_fold_partials": (i32, [u64p, sz, u64p, u8p]),
     "kzg_fr_ntt": (i32, [vp, u64p, sz, i32]),

@@ -314,6 +314,20 @@ int32_t kzg_msm_g1_srs_device_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t off
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return msm_begin(ctx, slot, srs_bases(srs, offset, ctx->msm_c_override == 0), d_scalars_mont, n);
 }
+int32_t kzg_msm_g1_srs_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const uint64_t* scalars_mont, size_t n, int32_t slot) {
+    if (!ctx || !srs || srs->ctx->device != ctx->device || !scalars_mont || slot < 0 || slot > 1) return KZG_ERR_INVALID_ARG;
+    if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
+    // H2D copy on the slot's own stream into the slot's own staging buffer: it overlaps the other slot's kernels
+    hipStream_t st = ctx->stream;
+    if (slot == 1) { int32_t rc = msm_slot_stream(ctx, 1, &st); if (rc != KZG_OK) return rc; }
+    MsmWorkspace& ws = slot ? ctx->msm2 : ctx->msm;
+    KZG_HIP_TRY(ctx, ws.scalars.reserve(n * 32 + 32));
+    if (n) KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, st));
+    return msm_begin(ctx, slot, srs_bases(srs, offset, ctx->msm_c_override == 0), ws.scalars.p, n);
+}
 int32_t kzg_msm_g1_srs_end(kzg_ctx* ctx, int32_t slot, uint64_t* out_xy_mont, uint8_t* out_is_infinity, uint64_t* out_xyzz_mont) {
     if (!ctx || (!out_xy_mont && !out_xyzz_mont)) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);

@@ -111,6 +111,7 @@ inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, bool allow_tables) 
 int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n,
                 uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz);
 
+int32_t msm_slot_stream(kzg_ctx* ctx, int slot, hipStream_t* out);
 int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_scalars, size_t n);
 int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz);
 void msm_drop_slots(kzg_ctx* ctx);

@@ -345,9 +345,16 @@ static int32_t ensure_stream2(kzg_ctx* ctx) {
     return KZG_OK;
 }
 
+int32_t msm_slot_stream(kzg_ctx* ctx, int slot, hipStream_t* out) {
+    if (slot == 1) { int32_t rc = ensure_stream2(ctx); if (rc != KZG_OK) return rc; }
+    *out = slot ? ctx->stream2 : ctx->stream;
+    return KZG_OK;
+}
+
 int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_scalars, size_t n) {
     if (slot < 0 || slot > 1 || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;     // slot still in flight
-    if (n == 0 || n > MSM_MAX_LAUNCH) return KZG_ERR_TOO_LARGE;
+    if (n == 0) return KZG_ERR_INVALID_ARG;
+    if (n > MSM_MAX_LAUNCH) return KZG_ERR_TOO_LARGE;
     if (slot == 1) { int32_t rc = ensure_stream2(ctx); if (rc != KZG_OK) return rc; }
     MsmPending* pend = new (std::nothrow) MsmPending();
     if (!pend) return KZG_ERR_DEVICE;

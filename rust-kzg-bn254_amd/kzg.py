@@ -62,6 +62,44 @@ class KZG:
         ctx.check_device(rc)
         return out
 
+    def commit_coeff_form_stream(self, polynomials, srs):
+        """`commit_coeff_form` over a stream of polynomials, two in flight (`kzg_msm_g1_srs_begin` / `_end`): the H2D copy and
+        the sort of polynomial k+1 run beside the bucket accumulation of polynomial k.  Yields the commitments in order."""
+        ctx = self._ctx()
+        lib = _lib.load()
+
+        def end(slot):
+            out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
+            rc = lib.kzg_msm_g1_srs_end(ctx.handle, slot, _lib.ptr(out), C.byref(inf), None)
+            ctx.check_device(rc)
+            if rc != _lib.OK:
+                raise CommitError(_lib.status_message(rc))
+            return out
+
+        prev = None
+        k = 0
+        for polynomial in polynomials:
+            if len(polynomial) > len(srs):
+                raise SerializationError("polynomial length is not correct")
+            coeffs = _lib.as_u64(polynomial.coeffs(), 4)
+            if len(coeffs) == 0:                      # empty polynomial: identity, nothing to enqueue
+                if prev is not None:
+                    yield end(prev)
+                    prev = None
+                yield np.zeros(8, dtype=np.uint64)
+                continue
+            slot = k & 1
+            k += 1
+            rc = lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, _lib.ptr(coeffs), len(coeffs), slot)
+            ctx.check_device(rc)
+            if rc != _lib.OK:
+                raise CommitError(_lib.status_message(rc))
+            if prev is not None:
+                yield end(prev)
+            prev = slot
+        if prev is not None:
+            yield end(prev)
+
     # kzg.rs:182-185
     def commit_blob(self, blob, srs):
         """Bytes in, point out: bytes -> Fr, IFFT and MSM all on the device (`kzg_commit_blob`)."""

@@ -570,3 +570,17 @@ def test_msm_begin_end_pipeline(k, tau_srs, ref_srs, test_srs_wire):
     assert lib.kzg_msm_g1_srs_device_begin(ref_srs.ctx.handle, ref_srs.handle, 0, C.c_void_p(d.data_ptr()), m, 1) == 0
     assert lib.kzg_msm_g1_srs_end(ref_srs.ctx.handle, 1, k._lib.ptr(out), C.byref(inf), None) == 0
     assert np.array_equal(out, orc.msm_pippenger(test_srs_wire[:m], sc))
+
+
+def test_commit_coeff_form_stream_host_buffers(k, tau_srs):
+    """KZG.commit_coeff_form_stream (kzg_msm_g1_srs_begin/_end with host scalars): same points as commit_coeff_form, in order,
+    for polynomials of different lengths."""
+    kz = k.KZG.new()
+    rnd = random.Random(31)
+    polys = [k.PolynomialCoeffForm(pyref.frs_to_mont([rnd.randrange(R_) for _ in range(n)])) for n in (4096, 1, 333, 65536, 2048, 7)]
+    want = [kz.commit_coeff_form(p, tau_srs) for p in polys]
+    got = list(kz.commit_coeff_form_stream(polys, tau_srs))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert list(kz.commit_coeff_form_stream([], tau_srs)) == []
