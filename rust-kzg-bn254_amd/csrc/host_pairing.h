@@ -7,7 +7,9 @@
 // the identity of GT).  Any bilinear non-degenerate pairing decides that predicate identically, so this file implements
 // the simplest one to verify: the reduced Tate pairing  t(P, Q) = f_{r,P}(psi(Q))^((p^12 - 1)/r)  with the G1 point as the
 // Miller-loop point (affine arithmetic in Fq), psi the untwist G2 -> E(Fq12), and Fq12 = Fq[w]/(w^12 - 18 w^6 + 82)
-// (w^6 = 9 + u).  Not performance tuned (~50 ms per check): it closes the API, the hot path is elsewhere.
+// (w^6 = 9 + u).  Two constructions: a literal one (affine Miller loop, generic square-and-multiply final exponentiation)
+// and the one the library uses (shared projective Miller loop, (p^6-1)(p^2+1) easy part, base-p Straus hard part); the
+// self-check build compares them.
 #pragma once
 #include "host_curve.h"
 #include "pairing_constants.h"
@@ -246,8 +248,158 @@ inline Fq12 miller_tate(const G1& p, const G2& q2) {
 inline Fq12 final_exponentiation(const Fq12& f) { return fq12_pow(f, FINAL_EXP, FINAL_EXP_WORDS); }
 inline Fq12 pairing(const G1& p, const G2& q) { return final_exponentiation(miller_tate(p, q)); }
 
+// ---- fast path: shared projective Miller loop + decomposed final exponentiation ------------------------------------------------
+// Product of Miller functions prod_k f_{r,P_k}(psi(Q_k)) with one squaring of f per bit for all pairs and the loop points in
+// Jacobian coordinates: each line is scaled by an element of Fq (2YZ^3 for tangents, HZ for chords), which the final
+// exponentiation kills, so no field inversion is needed.  Line through/at T=(X,Y,Z) evaluated at (x', y'):
+//   tangent: (2Y^2 - 3X^3) + 3X^2 Z^2 x' - Z3 Z^2 y'        with Z3 = 2YZ
+//   chord T,P: (Z3 yp - r xp) + r x' - Z3 y'                  with H = xp Z^2 - X, r = yp Z^3 - Y, Z3 = HZ
+struct MillerPoint { Fq X, Y, Z; G1 p; UntwistedQ q; bool done; };
+inline Fq12 line_from_coeffs(const Fq& c0, const Fq& cx, const Fq& cy, const UntwistedQ& q) {
+    Fq12 l; memset(&l, 0, sizeof l);
+    l.c[0] = c0;
+    l.c[2] = mul(cx, q.x2); l.c[8] = mul(cx, q.x8);
+    l.c[3] = mul(cy, q.y3); l.c[9] = mul(cy, q.y9);
+    return l;
+}
+inline Fq12 miller_tate_product(const G1* ps, const G2* qs, int count) {
+    Fq12 f = fq12_one();
+    MillerPoint pts[4];
+    int m = 0;
+    for (int k = 0; k < count && m < 4; ++k) {
+        if (ps[k].inf || qs[k].inf) continue;                   // e(O, Q) = e(P, O) = 1
+        pts[m].X = ps[k].x; pts[m].Y = ps[k].y; pts[m].Z = FQ_ONE; pts[m].p = ps[k]; pts[m].q = untwist(qs[k]); pts[m].done = false;
+        ++m;
+    }
+    if (m == 0) return f;
+    int top = 255;
+    while (!((FR_MODULUS_WORDS[top >> 6] >> (top & 63)) & 1)) --top;
+    for (int i = top - 1; i >= 0; --i) {
+        f = mul(f, f);
+        for (int k = 0; k < m; ++k) {
+            MillerPoint& t = pts[k];
+            if (t.done) continue;
+            // doubling step (a = 0): dbl-2009-l
+            Fq A = sqr(t.X), B = sqr(t.Y), C = sqr(B);
+            Fq D = dbl(sub(sub(sqr(add(t.X, B)), A), C));
+            Fq E = add(dbl(A), A);
+            Fq Z2 = sqr(t.Z);
+            Fq X3 = sub(sqr(E), dbl(D));
+            Fq Y3 = sub(mul(E, sub(D, X3)), dbl(dbl(dbl(C))));
+            Fq Z3 = dbl(mul(t.Y, t.Z));
+            f = mul(f, line_from_coeffs(sub(dbl(B), mul(E, t.X)), mul(E, Z2), neg(mul(Z3, Z2)), t.q));
+            t.X = X3; t.Y = Y3; t.Z = Z3;
+        }
+        if ((FR_MODULUS_WORDS[i >> 6] >> (i & 63)) & 1) {
+            for (int k = 0; k < m; ++k) {
+                MillerPoint& t = pts[k];
+                if (t.done) continue;
+                Fq Z2 = sqr(t.Z);
+                Fq H = sub(mul(t.p.x, Z2), t.X);
+                Fq r = sub(mul(t.p.y, mul(Z2, t.Z)), t.Y);
+                if (is_zero(H)) { t.done = true; continue; }   // T = -P (last step, r P = O): vertical line, in Fq6
+                Fq Z3 = mul(t.Z, H);
+                f = mul(f, line_from_coeffs(sub(mul(Z3, t.p.y), mul(r, t.p.x)), r, neg(Z3), t.q));
+                Fq HH = sqr(H), HHH = mul(H, HH), V = mul(t.X, HH);
+                Fq X3 = sub(sub(sqr(r), HHH), dbl(V));
+                t.Y = sub(mul(r, sub(V, X3)), mul(t.Y, HHH));
+                t.X = X3; t.Z = Z3;
+            }
+        }
+    }
+    return f;
+}
+
+// f^-1 by solving (multiplication-by-f) x = 1 over Fq: 12 x 12 Gauss-Jordan elimination
+inline bool fq12_inverse(const Fq12& f, Fq12& out) {
+    Fq M[12][13];
+    Fq12 col = f;                                               // column j = f * w^j
+    for (int j = 0; j < 12; ++j) {
+        for (int i = 0; i < 12; ++i) M[i][j] = col.c[i];
+        Fq top = col.c[11];                                     // multiply by w: shift up, w^12 = 18 w^6 - 82
+        for (int i = 11; i > 0; --i) col.c[i] = col.c[i - 1];
+        col.c[0] = neg(mul(top, FQ_EIGHTYTWO));
+        col.c[6] = add(col.c[6], mul(top, FQ_EIGHTEEN));
+    }
+    for (int i = 0; i < 12; ++i) M[i][12] = (i == 0) ? FQ_ONE : fq_zero();
+    for (int c = 0; c < 12; ++c) {
+        int piv = -1;
+        for (int r = c; r < 12; ++r) if (!is_zero(M[r][c])) { piv = r; break; }
+        if (piv < 0) return false;
+        if (piv != c) for (int j = 0; j < 13; ++j) { Fq t = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = t; }
+        Fq iv = inv(M[c][c]);
+        for (int j = c; j < 13; ++j) M[c][j] = mul(M[c][j], iv);
+        for (int r = 0; r < 12; ++r) {
+            if (r == c || is_zero(M[r][c])) continue;
+            Fq fac = M[r][c];
+            for (int j = c; j < 13; ++j) M[r][j] = sub(M[r][j], mul(fac, M[c][j]));
+        }
+    }
+    for (int i = 0; i < 12; ++i) out.c[i] = M[i][12];
+    return true;
+}
+
+// Frobenius maps x -> x^(p^k), k = 1..3, in the polynomial basis: coefficients are fixed, (w^i)^(p^k) are precomputed
+struct FrobeniusTables {
+    Fq12 w[3][12];
+    FrobeniusTables() {
+        Fq12 wgen; memset(&wgen, 0, sizeof wgen); wgen.c[1] = FQ_ONE;
+        Fq12 g = fq12_pow(wgen, FQ_MODULUS_WORDS, 4);           // w^p
+        for (int k = 0; k < 3; ++k) {
+            w[k][0] = fq12_one();
+            for (int i = 1; i < 12; ++i) w[k][i] = mul(w[k][i - 1], g);
+            if (k < 2) { Fq12 n; memset(&n, 0, sizeof n); for (int i = 0; i < 12; ++i) if (!is_zero(g.c[i])) for (int j = 0; j < 12; ++j) n.c[j] = add(n.c[j], mul(g.c[i], w[0][i].c[j])); g = n; }   // g <- g^p
+        }
+    }
+};
+inline const FrobeniusTables& frobenius_tables() { static const FrobeniusTables t; return t; }
+inline Fq12 frobenius(const Fq12& a, int k /* 1..3 */) {
+    const FrobeniusTables& t = frobenius_tables();
+    Fq12 r; memset(&r, 0, sizeof r);
+    for (int i = 0; i < 12; ++i) {
+        if (is_zero(a.c[i])) continue;
+        for (int j = 0; j < 12; ++j) r.c[j] = add(r.c[j], mul(a.c[i], t.w[k - 1][i].c[j]));
+    }
+    return r;
+}
+inline Fq12 conjugate_p6(const Fq12& a) {                       // x -> x^(p^6): w -> -w
+    Fq12 r = a;
+    for (int i = 1; i < 12; i += 2) r.c[i] = neg(r.c[i]);
+    return r;
+}
+// f^((p^12-1)/r) = ((f^(p^6-1))^(p^2+1))^hard, hard = sum_i d_i p^i evaluated by interleaved (Straus) exponentiation of
+// g, g^p, g^(p^2), g^(p^3): ~254 squarings + <= 254 multiplications by one of 15 precomputed products.
+inline Fq12 final_exponentiation_fast(const Fq12& f) {
+    Fq12 fi;
+    if (!fq12_inverse(f, fi)) return f;                         // f = 0 cannot occur for valid inputs
+    Fq12 g = mul(conjugate_p6(f), fi);                          // f^(p^6 - 1)
+    g = mul(frobenius(g, 2), g);                                // ^(p^2 + 1)
+    Fq12 tab[16];
+    tab[0] = fq12_one();
+    Fq12 base[4] = {g, frobenius(g, 1), frobenius(g, 2), frobenius(g, 3)};
+    for (int msk = 1; msk < 16; ++msk) {
+        int low = msk & -msk, idx = low == 1 ? 0 : low == 2 ? 1 : low == 4 ? 2 : 3;
+        tab[msk] = (msk == low) ? base[idx] : mul(tab[msk ^ low], base[idx]);
+    }
+    Fq12 acc = fq12_one();
+    bool started = false;
+    for (int i = 255; i >= 0; --i) {
+        if (started) acc = mul(acc, acc);
+        int msk = 0;
+        for (int d = 0; d < 4; ++d) msk |= (int)((HARD_EXP_DIGITS[d][i >> 6] >> (i & 63)) & 1) << d;
+        if (msk) { acc = started ? mul(acc, tab[msk]) : tab[msk]; started = true; }
+    }
+    return acc;
+}
+
 // helpers::pairings_verify(a1, a2, b1, b2): e(a1, a2) * e(-b1, b2) == 1   (helpers.rs:392-398)
 inline bool pairings_verify(const G1& a1, const G2& a2, const G1& b1, const G2& b2) {
+    G1 ps[2] = {a1, g1_neg(b1)};
+    G2 qs[2] = {a2, b2};
+    return fq12_is_one(final_exponentiation_fast(miller_tate_product(ps, qs, 2)));
+}
+// the straightforward construction (affine Miller loops, generic final exponentiation), kept as the cross-check of the fast path
+inline bool pairings_verify_reference(const G1& a1, const G2& a2, const G1& b1, const G2& b2) {
     Fq12 f = mul(miller_tate(a1, a2), miller_tate(g1_neg(b1), b2));
     return fq12_is_one(final_exponentiation(f));
 }

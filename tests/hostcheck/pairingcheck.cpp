@@ -30,6 +30,26 @@ int main() {
     printf("verify_true %d\n", (int)pairings_verify(g1_mul(g, a), g2_mul(h, b), g1_mul(g, b), g2_mul(h, a)));
     printf("verify_false %d\n", (int)!pairings_verify(g1_mul(g, a), g2_mul(h, b), g1_mul(g, b), h));
     printf("identity_pairs %d\n", (int)pairings_verify(g1_mul(g, r), h, g, g2_inf()));
+    // fast path vs literal construction
+    {
+        G1 pa = g1_mul(g, a), pb = g1_mul(g, b);
+        G2 qa = g2_mul(h, a), qb = g2_mul(h, b);
+        G1 one_p[1] = {pa}; G2 one_q[1] = {qb};
+        Fq12 fast = final_exponentiation_fast(miller_tate_product(one_p, one_q, 1));
+        printf("fast_equals_literal %d\n", (int)fq12_eq(fast, pairing(pa, qb)));
+        printf("final_exp_fast_equals_generic %d\n", (int)fq12_eq(final_exponentiation_fast(miller_tate(pa, qb)), final_exponentiation(miller_tate(pa, qb))));
+        Fq12 fi; bool okinv = fq12_inverse(e, fi);
+        printf("fq12_inverse %d\n", (int)(okinv && fq12_is_one(mul(e, fi))));
+        printf("frobenius %d\n", (int)fq12_eq(frobenius(e, 1), fq12_pow(e, FQ_MODULUS_WORDS, 4)));
+        printf("frobenius3 %d\n", (int)fq12_eq(frobenius(e, 3), frobenius(frobenius(frobenius(e, 1), 1), 1)));
+        printf("reference_verify_true %d\n", (int)pairings_verify_reference(pa, qb, pb, qa));
+        printf("reference_verify_false %d\n", (int)!pairings_verify_reference(pa, qb, pb, h));
+        auto t2 = std::chrono::steady_clock::now();
+        bool okv = pairings_verify(pa, qb, pb, qa);
+        auto t3 = std::chrono::steady_clock::now();
+        printf("fast_verify %d\n", (int)okv);
+        fprintf(stderr, "pairings_verify (fast): %.1f ms\n", std::chrono::duration<double, std::milli>(t3 - t2).count());
+    }
     fprintf(stderr, "one pairing: %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
     return 0;
 }
