@@ -170,6 +170,15 @@ int32_t kzg_g1_ifft(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy
 int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
                           const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4],
                           uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont);
+/* Multi-GPU forms of the two calls above (BASELINE config 4).  srs_shard holds the SRS powers
+ * [shard_lo, shard_lo + kzg_srs_len(srs_shard)); every rank passes the whole polynomial, performs the O(n) field work
+ * (IFFT, quotient) redundantly and commits only its slice of the coefficients; out = the unconverted partial sum (16 u64)
+ * that the ranks all-gather and fold with kzg_g1_fold_partials.  The shards must jointly cover [0, n). */
+int32_t kzg_commit_eval_form_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo,
+                                     const uint64_t* evals_mont, size_t n, uint64_t out_xyzz_mont[16]);
+int32_t kzg_compute_proof_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo,
+                                  const uint64_t* evals_mont, size_t n, const uint64_t* roots_mont, size_t n_roots,
+                                  const uint64_t z_mont[4], uint64_t out_xyzz_mont[16], uint64_t* out_y_mont);
 /* helpers::evaluate_polynomial_in_evaluation_form (helpers.rs:475-535) on the domain of size n. */
 int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t* evals_mont, size_t n,
                                                    const uint64_t z_mont[4], uint64_t out_y_mont[4]);

@@ -3,6 +3,7 @@
 #include "host_curve.h"
 #include "host_pairing.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -22,7 +23,7 @@ int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where) {
 
 // polynomial pipeline (poly.hip)
 int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
-                  uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof);
+                  uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof, size_t coeff_lo, uint64_t* out_xyzz);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
 int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out);
 
@@ -492,6 +493,36 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_a.p, n, out_xy_mont, out_is_infinity, nullptr);
 }
 
+// ---- multi-GPU forms: this rank's SRS shard holds the powers [shard_lo, shard_lo + len(srs_shard)) -----------------------
+int32_t kzg_commit_eval_form_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo, const uint64_t* evals_mont, size_t n,
+                                     uint64_t out_xyzz_mont[16]) {
+    if (!ctx || !srs_shard || srs_shard->ctx->device != ctx->device || !out_xyzz_mont || (n && !evals_mont)) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
+    if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = ntt_run(ctx, ctx->poly_a.p, n, true);               // every rank transforms the whole polynomial (32 B/element; not sharded)
+    if (rc != KZG_OK) return rc;
+    if (shard_lo >= n) { KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); memset(out_xyzz_mont, 0, 128); return KZG_OK; }
+    const size_t len = std::min(srs_shard->n, n - shard_lo);
+    return msm_run(ctx, srs_bases(srs_shard, 0, ctx->msm_c_override == 0), ctx->poly_a.as<uint4>() + 2 * shard_lo, len, nullptr, nullptr, out_xyzz_mont);
+}
+
+int32_t kzg_compute_proof_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo, const uint64_t* evals_mont, size_t n,
+                                  const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4],
+                                  uint64_t out_xyzz_mont[16], uint64_t* out_y_mont) {
+    (void)roots_mont;
+    if (!ctx || !srs_shard || srs_shard->ctx != ctx || !out_xyzz_mont || !z_mont || (n && !evals_mont)) return KZG_ERR_INVALID_ARG;
+    if (n != n_roots) return KZG_ERR_ROOTS_LENGTH;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;
+    if (n > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return proof_run(ctx, srs_shard, evals_mont, n, z_mont, nullptr, nullptr, out_y_mont, true, shard_lo, out_xyzz_mont);
+}
+
 static size_t next_pow2_sz(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
 
 int32_t kzg_blob_to_fr(kzg_ctx* ctx, const uint8_t* blob_bytes, size_t len, uint64_t* out_mont, size_t cap, size_t* n_out) {
@@ -550,7 +581,7 @@ int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* eval
     if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return proof_run(ctx, srs, evals_mont, n, z_mont, out_xy_mont, out_is_infinity, out_y_mont, true);
+    return proof_run(ctx, srs, evals_mont, n, z_mont, out_xy_mont, out_is_infinity, out_y_mont, true, 0, nullptr);
 }
 
 int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t* evals_mont, size_t n,
@@ -561,7 +592,7 @@ int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t*
     if (n > ((size_t)1 << 28)) return KZG_ERR_SRS_LENGTH;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return proof_run(ctx, nullptr, evals_mont, n, z_mont, nullptr, nullptr, out_y_mont, false);
+    return proof_run(ctx, nullptr, evals_mont, n, z_mont, nullptr, nullptr, out_y_mont, false, 0, nullptr);
 }
 
 int32_t kzg_calculate_roots_of_unity(kzg_ctx* ctx, uint64_t length_of_data_after_padding, uint64_t* out_mont, size_t cap, size_t* n_out) {

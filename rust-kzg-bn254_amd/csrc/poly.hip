@@ -10,6 +10,7 @@
 #include "engine.h"
 #include "field29.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -324,7 +325,7 @@ int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_
 }
 
 int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
-                  uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof) {
+                  uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof, size_t coeff_lo, uint64_t* out_xyzz) {
     int log_n = ilog2_exact(n);
     NttTables tb;
     int32_t rc = ntt_get_tables(ctx, log_n, false, &tb);
@@ -378,7 +379,15 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
     // commit_eval_form(quotient): coefficients = IFFT(q), then MSM over the monomial SRS (kzg.rs:176-177)
     rc = ntt_run(ctx, ctx->poly_c.p, n, true);
     if (rc != KZG_OK) return rc;
-    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_c.p, n, out_xy, out_inf, nullptr);
+    // the whole SRS commits the whole quotient; a shard holding powers [coeff_lo, coeff_lo + srs->n) commits its slice of it
+    if (coeff_lo >= n) {
+        KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (out_xyzz) memset(out_xyzz, 0, 128);
+        if (out_xy) { memset(out_xy, 0, 64); if (out_inf) *out_inf = 1; }
+        return KZG_OK;
+    }
+    const size_t len = std::min(srs->n, n - coeff_lo);
+    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_c.as<uint4>() + 2 * coeff_lo, len, out_xy, out_inf, out_xyzz);
 }
 
 }  // namespace kzg

@@ -108,3 +108,42 @@ class ShardedMsm:
             prev = k & 1
         if prev is not None:
             yield self.end(prev)
+
+
+class ShardedKzg:
+    """`KZG::commit_eval_form` / `KZG::compute_proof` with the MSM sharded over `world` ranks (BASELINE config 4).
+    Every rank holds SRS powers [lo, hi) (`srs_shard`), receives the whole polynomial, does the O(n) field work redundantly
+    (IFFT / quotient: 32 B per element, cheaper than exchanging it) and commits its slice of the coefficients; the ranks
+    all-gather their 128-byte partials and fold them on the host."""
+
+    def __init__(self, ctx, srs_shard, n: int, rank: int = 0, world: int = 1, gather_device="cuda"):
+        self.ctx, self.srs, self.n, self.rank, self.world = ctx, srs_shard, n, rank, world
+        self.lo, self.hi = shard_bounds(n, rank, world)
+        if len(srs_shard) < self.hi - self.lo:
+            raise ValueError("SRS shard shorter than this rank's slice")
+        self.gather_device = gather_device
+
+    def _finish(self, part):
+        return fold_partials(gather_partials(part, self.world, self.gather_device))
+
+    def commit_eval_form(self, polynomial):
+        ev = _lib.as_u64(polynomial.evaluations(), 4)
+        part = np.zeros(16, dtype=np.uint64)
+        rc = _lib.load().kzg_commit_eval_form_partial(self.ctx.handle, self.srs.handle, self.lo, _lib.ptr(ev), len(ev), _lib.ptr(part))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+        return self._finish(part)
+
+    def compute_proof(self, polynomial, z_fr, want_y=False):
+        ev = _lib.as_u64(polynomial.evaluations(), 4)
+        z = np.ascontiguousarray(_lib.as_u64(z_fr, 0).reshape(4))
+        part = np.zeros(16, dtype=np.uint64)
+        y = np.zeros(4, dtype=np.uint64)
+        rc = _lib.load().kzg_compute_proof_partial(self.ctx.handle, self.srs.handle, self.lo, _lib.ptr(ev), len(ev), None, len(ev),
+                                                    _lib.ptr(z), _lib.ptr(part), _lib.ptr(y))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+        proof = self._finish(part)
+        return (proof, y) if want_y else proof

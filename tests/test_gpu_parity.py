@@ -584,3 +584,44 @@ def test_commit_coeff_form_stream_host_buffers(k, tau_srs):
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     assert list(kz.commit_coeff_form_stream([], tau_srs)) == []
+
+
+def test_sharded_commit_and_proof_partials(k, tau_srs):
+    """kzg_commit_eval_form_partial / kzg_compute_proof_partial (config 4): three SRS shards [0,a), [a,b), [b,n) generated with
+    first_power, each commits its slice; the folded partials equal the single-GPU commitment / proof bit for bit."""
+    from rust_kzg_bn254_amd.sharding import fold_partials
+    lib = k._lib.load()
+    ctx = tau_srs.ctx
+    n = 1 << 13
+    evals = rand_scalars(n, 2024)
+    poly = k.PolynomialEvalForm(evals)
+    kz = k.KZG.new()
+    kz.calculate_and_store_roots_of_unity(n * 32)
+    want_c = kz.commit_eval_form(poly, tau_srs)
+    z = k.fr.fr_from_int(0x1234567890ABCDEF1234567)
+    want_p = kz.compute_proof(poly, z, tau_srs)
+    bounds = [0, 3000, 3001, n]                       # uneven shards, one of a single point
+    parts_c, parts_p, ys = [], [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        shard = k.SRS.generate(TAU, hi - lo, first_power=lo, ctx=ctx)
+        pc = np.zeros(16, np.uint64); pp = np.zeros(16, np.uint64); y = np.zeros(4, np.uint64)
+        ev = np.ascontiguousarray(evals)
+        assert lib.kzg_commit_eval_form_partial(ctx.handle, shard.handle, lo, k._lib.ptr(ev), n, k._lib.ptr(pc)) == 0
+        assert lib.kzg_compute_proof_partial(ctx.handle, shard.handle, lo, k._lib.ptr(ev), n, None, n, k._lib.ptr(np.ascontiguousarray(z)),
+                                             k._lib.ptr(pp), k._lib.ptr(y)) == 0
+        parts_c.append(pc); parts_p.append(pp); ys.append(y)
+        shard.close()
+    assert np.array_equal(fold_partials(np.stack(parts_c)), want_c)
+    assert np.array_equal(fold_partials(np.stack(parts_p)), want_p)
+    y_want = k.helpers.evaluate_polynomial_in_evaluation_form(poly, z)
+    assert all(np.array_equal(y, y_want) for y in ys)
+    # a shard that starts beyond the polynomial contributes the identity
+    shard = k.SRS.generate(TAU, 16, first_power=n, ctx=ctx)
+    pc = np.ones(16, np.uint64)
+    assert lib.kzg_commit_eval_form_partial(ctx.handle, shard.handle, n, k._lib.ptr(np.ascontiguousarray(evals)), n, k._lib.ptr(pc)) == 0
+    assert not pc.any()
+    # ShardedKzg with world = 1 is the plain call
+    from rust_kzg_bn254_amd.sharding import ShardedKzg
+    sk = ShardedKzg(ctx, tau_srs, n)
+    assert np.array_equal(sk.commit_eval_form(poly), want_c)
+    assert np.array_equal(sk.compute_proof(poly, z), want_p)
