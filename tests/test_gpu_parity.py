@@ -625,3 +625,40 @@ def test_sharded_commit_and_proof_partials(k, tau_srs):
     sk = ShardedKzg(ctx, tau_srs, n)
     assert np.array_equal(sk.commit_eval_form(poly), want_c)
     assert np.array_equal(sk.compute_proof(poly, z), want_p)
+
+
+def test_msm_2_20_edge_sets(k):
+    """SURVEY.md §8d edge sets at the full BASELINE size (2^20), checked by size-independent properties on a known-tau SRS:
+    uniform scalars; all = r-1; one-hot; 2^20 copies of one point with scalar 1 (P+P everywhere, one bucket holds everything);
+    (P, -P) pairs with equal scalars (identity inside every bucket)."""
+    n = 1 << 20
+    srs = k.SRS.generate(TAU, n)
+    G = (1, 2)
+    rng = np.random.default_rng(2020)
+    # uniform in [0, r): rejection-free construction from 4 limbs reduced mod r
+    raw = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    vals = [((int(a) << 189) ^ (int(b) << 126) ^ (int(c) << 63) ^ int(d)) % R_ for a, b, c, d in raw]
+    got = msm_srs(k, srs, pyref.frs_to_mont(vals))
+    ptau, cur = 0, 1
+    for v in vals:
+        ptau = (ptau + v * cur) % R_
+        cur = cur * TAU % R_
+    assert pyref.point_from_wire(got) == pyref.ec_mul(ptau, G)
+    geo = (pow(TAU, n, R_) - 1) * pow(TAU - 1, -1, R_) % R_
+    rm1 = np.ascontiguousarray(np.broadcast_to(pyref.fr_to_mont(R_ - 1), (n, 4)))
+    assert pyref.point_from_wire(msm_srs(k, srs, rm1)) == pyref.ec_mul((-geo) % R_, G)
+    onehot = np.zeros((n, 4), np.uint64)
+    onehot[777777] = pyref.fr_to_mont(0xABCDEF0123456789ABCDEF)
+    assert pyref.point_from_wire(msm_srs(k, srs, onehot)) == pyref.ec_mul(0xABCDEF0123456789ABCDEF * pow(TAU, 777777, R_) % R_, G)
+    assert not msm_srs(k, srs, np.zeros((n, 4), np.uint64)).any()
+    srs.close()
+    # caller bases (generic mode): one point 2^20 times, scalars 1  ->  2^20 * P
+    p7 = pyref.ec_mul(7, G)
+    dup = np.ascontiguousarray(np.broadcast_to(pyref.point_to_wire(p7), (n, 8)))
+    ones = np.ascontiguousarray(np.broadcast_to(pyref.fr_to_mont(1), (n, 4)))
+    assert pyref.point_from_wire(k.helpers.g1_lincomb(dup, ones)) == pyref.ec_mul(7 * n % R_, G)
+    # (P, -P) pairs with equal scalars -> identity
+    pm = dup.copy()
+    pm[1::2] = pyref.point_to_wire((p7[0], (-p7[1]) % P))
+    sc = np.repeat(pyref.frs_to_mont(vals[: n // 2]), 2, axis=0)
+    assert not k.helpers.g1_lincomb(pm, sc).any()
