@@ -129,7 +129,8 @@ def main():
         return res
 
     result = run_steps(args.warmup)
-    lib.kzg_ctx_set_profiling(ctx.handle, 1)
+    if os.environ.get("KZG_BENCH_NOPROF", "0") == "0":
+        lib.kzg_ctx_set_profiling(ctx.handle, 1)
     barrier()
     t0 = time.perf_counter()
     result = run_steps(args.steps)

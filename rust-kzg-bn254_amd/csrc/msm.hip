@@ -209,18 +209,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     }
     const uint32_t gg = (p.G + 255) / 256;
     KZG_MARK(3);
-    hipLaunchKernelGGL(k_msm_segments, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,
-                       ws.seg_bucket.as<uint32_t>());
     const uint32_t gs = (p.segcap + 255) / 256;
+    hipLaunchKernelGGL(k_msm_segments, dim3(gs), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,
+                       ws.seg_bucket.as<uint32_t>());
     if (wait_acc) KZG_HIP_TRY(ctx, hipStreamWaitEvent(st, wait_acc, 0));
     KZG_MARK(4);
-    static int acc_lds = -1;              // EXPERIMENT: dynamic LDS request that caps resident blocks per CU (KZG_ACC_LDS bytes)
-    if (acc_lds < 0) {
-        const char* env = getenv("KZG_ACC_LDS");
-        acc_lds = env ? atoi(env) : 0;
-        if (acc_lds > 0) KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, acc_lds));
-    }
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), (size_t)acc_lds, st, bases.points, ws.sorted.as<uint32_t>(),
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(),
                        ws.seg_bucket.as<uint32_t>(), ws.offs.as<unsigned long long>(), p.G, p.L,
                        ws.segsum.as<int32_t>(), (size_t)p.segcap);
     KZG_MARK(5);

@@ -297,12 +297,20 @@ k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__
 // -------------------------------------------------------------------------------------------------
 // 4. segment -> bucket map
 // -------------------------------------------------------------------------------------------------
+// One thread per SEGMENT: binary search of its id in the per-bucket segment offsets (high words of offs[]).  A thread per
+// bucket looping over its segments serialised ~40 dependent stores when few buckets hold many segments (shard-sized MSMs:
+// 77 us at 2^17 pairs against 6 us at 2^20).
 __global__ void __launch_bounds__(256)
 k_msm_segments(const unsigned long long* __restrict__ offs, uint32_t G, uint32_t* __restrict__ seg_bucket) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    uint32_t s0 = (uint32_t)(offs[g] >> 32), s1 = (uint32_t)(offs[g + 1] >> 32);
-    for (uint32_t s = s0; s < s1; ++s) seg_bucket[s] = g;
+    const uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nseg = (uint32_t)(offs[G] >> 32);
+    if (sid >= nseg) return;
+    uint32_t lo = 0, hi = G;                       // invariant: segstart(lo) <= sid < segstart(hi)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)(offs[mid] >> 32) <= sid) lo = mid; else hi = mid;
+    }
+    seg_bucket[sid] = lo;
 }
 
 // -------------------------------------------------------------------------------------------------

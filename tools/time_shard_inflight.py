@@ -28,4 +28,17 @@ for log_n in (17, 18, 19, 20):
             list(ex.map(one, [j % inflight for j in range(steps)]))
             dt = time.perf_counter() - t0
         print(f"n=2^{log_n} in flight {inflight}: {dt/steps*1e3:.3f} ms/MSM", flush=True)
+    # the library's own two-slot pipeline (one host thread), as bench.py uses it
+    ctx = ctxs[0]
+    def pipe(steps):
+        prev = None
+        for i in range(steps):
+            assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, srs.handle, 0, C.c_void_p(d.data_ptr()), n, i & 1) == 0
+            if prev is not None:
+                assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, None, None, _lib.ptr(outs[0])) == 0
+            prev = i & 1
+        assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, None, None, _lib.ptr(outs[0])) == 0
+    pipe(6)
+    t0 = time.perf_counter(); pipe(60); dt = time.perf_counter() - t0
+    print(f"n=2^{log_n} begin/end pipeline: {dt/60*1e3:.3f} ms/MSM", flush=True)
     srs.close()
