@@ -34,7 +34,7 @@ FR = 218882428718392752222464057452572750885483644004160343436982041865758084956
 LOG_N = int(os.environ.get("KZG_BENCH_LOG_N", "20"))
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 BYTES_PER_PAIR = 96            # 64 B packed affine point + 32 B scalar, each read once
-PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r01_v3_pmc_summary.json")
 
 
 def pmc_traffic_bytes(log_n):
@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,7 +187,7 @@ def main():
             "phases_ms_per_launch": {name: phase[i] / max(1, launches.value) for i, name in enumerate(
                 ["digits", "scan", "scatter", "segments", "accumulate", "bucket_fin", "reduce", "device_total"])},
         }
-        if world == 1:
+        if world == 1 and not args.no_secondary:
             # secondary figures of the same run (outside the timed region; BASELINE configs 3 and 4 on one GPU)
             def avg_ms(fn, reps=10, warm=2):
                 for _ in range(warm):
