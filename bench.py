@@ -224,6 +224,18 @@ def main():
             blob_bytes = np.frombuffer(b"".join(b"\x00" + bytes(r) for r in np.random.default_rng(7).integers(32, 127, size=(n, 31), dtype=np.uint8)), dtype=np.uint8).copy()
             u8p = C.POINTER(C.c_uint8)
             cb_ms = avg_ms(lambda: lib.kzg_commit_blob(ctx.handle, srs.handle, blob_bytes.ctypes.data_as(u8p), blob_bytes.size, _lib.ptr(o8), C.byref(oi)), reps=5)
+            def stream_blob(reps=8):
+                prev = None
+                for i in range(reps):
+                    assert lib.kzg_commit_blob_begin(ctx.handle, srs.handle, blob_bytes.ctypes.data_as(u8p), blob_bytes.size, i & 1) == 0
+                    if prev is not None:
+                        assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), None) == 0
+                    prev = i & 1
+                assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), None) == 0
+            want_blob = o8.copy()
+            stream_blob(2)
+            t = time.perf_counter(); stream_blob(8); cb_stream_ms = (time.perf_counter() - t) / 8 * 1e3
+            assert np.array_equal(o8, want_blob), "streamed blob commitment differs"
             # config 5 shape: verify_kzg_proof_batch core at n = 4096 (three 4096-point MSMs batched on the GPU + host pairing check)
             nb = 4096
             g1w = np.zeros((nb, 8), dtype=np.uint64)
@@ -245,7 +257,7 @@ def main():
             del big, big2
             out["secondary"] = {
                 "host_buffers_commit_coeff_streamed_ms": cc_stream_ms,
-                "commit_blob_from_host_bytes_ms": cb_ms,
+                "commit_blob_from_host_bytes_ms": cb_ms, "commit_blob_from_host_bytes_streamed_ms": cb_stream_ms,
                 "batch_verify_4096_core_ms": bv_ms, "batch_verify_4096_three_msms_ms": m3_ms,
                 "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,

@@ -160,6 +160,12 @@ int32_t kzg_blob_to_fr(kzg_ctx* ctx, const uint8_t* blob_bytes, size_t len, uint
 /* KZG::commit_blob (kzg.rs:182-185) = Blob::to_polynomial_eval_form + commit_eval_form, bytes in, point out. */
 int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len,
                         uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* Asynchronous forms of the two calls above for streams of blobs: the whole chain (H2D copy, bytes -> Fr, IFFT, MSM) is
+ * enqueued on the stream of `slot` (0 / 1); collect the commitment with kzg_msm_g1_srs_end(ctx, slot, ...).  Host input
+ * buffers follow the rule of kzg_msm_g1_srs_begin.  Same error codes as the synchronous calls; n (resp. the padded blob
+ * length) <= 2^24. */
+int32_t kzg_commit_eval_form_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n, int32_t slot);
+int32_t kzg_commit_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len, int32_t slot);
 /* KZG::g1_ifft (kzg.rs:263-285): Lagrange-basis SRS L_i = n^-1 sum_j w^(-ij) P_j of the first n SRS points, natural
  * order, n x 8 u64 written to out.  n not a power of two -> KZG_ERR_NOT_POWER_OF_TWO ("length provided is not a
  * power of 2"); n > 2^28 -> KZG_ERR_DOMAIN.  Not used by the commit / proof path of this library. */

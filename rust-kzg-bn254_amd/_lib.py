@@ -72,6 +72,8 @@ PROTOTYPES = {
     "kzg_fr_ntt_device": (i32, [vp, vp, sz, i32]),
     "kzg_commit_coeff_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
     "kzg_commit_eval_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
+    "kzg_commit_eval_form_begin": (i32, [vp, vp, u64p, sz, i32]),
+    "kzg_commit_blob_begin": (i32, [vp, vp, u8p, sz, i32]),
     "kzg_g1_ifft": (i32, [vp, vp, sz, u64p]),
     "kzg_blob_to_fr": (i32, [vp, u8p, sz, u64p, sz, C.POINTER(sz)]),
     "kzg_commit_blob": (i32, [vp, vp, u8p, sz, u64p, u8p]),

@@ -25,7 +25,8 @@ int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where) {
 int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
                   uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof, size_t coeff_lo, uint64_t* out_xyzz);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
-int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out);
+int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out,
+                       hipStream_t st = nullptr, DeviceBuffer* d_bytes = nullptr, DeviceBuffer* d_elems = nullptr);
 
 }  // namespace kzg
 
@@ -89,6 +90,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     ctx->msm2.release();
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_inputs); (void)hipEventDestroy(ctx->ev_acc); }
     ctx->ntt.release();
+    ctx->ntt2.release();
     ctx->poly_a.release(); ctx->poly_b.release(); ctx->poly_c.release(); ctx->poly_small.release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -557,6 +559,47 @@ int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_by
     rc = ntt_run(ctx, d, n, true);                                                   // commit_eval_form: IFFT ...
     if (rc != KZG_OK) return rc;
     return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), d, n, out_xy_mont, out_is_infinity, nullptr);   // ... + MSM
+}
+
+// asynchronous forms of commit_eval_form / commit_blob: the whole chain (H2D, bytes -> Fr, IFFT, MSM) goes onto the slot's stream
+static int32_t commit_begin_common(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, const uint8_t* blob_bytes, size_t len,
+                                   size_t n, int32_t slot) {
+    if (slot < 0 || slot > 1) return KZG_ERR_INVALID_ARG;
+    if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;                            // kzg.rs:89-94
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
+    if (n > ((size_t)1 << 24)) return KZG_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
+    hipStream_t st = nullptr;
+    int32_t rc = msm_slot_stream(ctx, slot, &st);
+    if (rc != KZG_OK) return rc;
+    MsmWorkspace& ws = slot ? ctx->msm2 : ctx->msm;
+    void* d = nullptr;
+    if (blob_bytes || !evals_mont) {
+        rc = blob_to_fr_run(ctx, blob_bytes, len, n, &d, st, &ws.blob, &ws.scalars);
+        if (rc != KZG_OK) return rc;
+    } else {
+        KZG_HIP_TRY(ctx, ws.scalars.reserve(n * 32 + 32));
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.scalars.p, evals_mont, n * 32, hipMemcpyHostToDevice, st));
+        d = ws.scalars.p;
+    }
+    NttTables tb;                                                                    // make sure the tables exist before the slot stream reads them
+    int log_n = 0; while (((size_t)1 << log_n) < n) ++log_n;
+    if (n > 1) { rc = ntt_get_tables(ctx, log_n, true, &tb); if (rc != KZG_OK) return rc; }
+    rc = ntt_run(ctx, d, n, true, st, slot ? &ctx->ntt2 : &ctx->ntt);
+    if (rc != KZG_OK) return rc;
+    return msm_begin(ctx, slot, srs_bases(srs, 0, ctx->msm_c_override == 0), d, n);
+}
+int32_t kzg_commit_eval_form_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n, int32_t slot) {
+    if (!ctx || !srs || srs->ctx->device != ctx->device || !evals_mont) return KZG_ERR_INVALID_ARG;
+    return commit_begin_common(ctx, srs, evals_mont, nullptr, 0, n, slot);
+}
+int32_t kzg_commit_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len, int32_t slot) {
+    if (!ctx || !srs || srs->ctx->device != ctx->device || (len && !blob_bytes)) return KZG_ERR_INVALID_ARG;
+    const size_t n_elems = (len + 31) / 32;
+    if (n_elems > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    return commit_begin_common(ctx, srs, nullptr, blob_bytes, len, next_pow2_sz(n_elems), slot);
 }
 
 int32_t kzg_g1_ifft(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy_mont) {

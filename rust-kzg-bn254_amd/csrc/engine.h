@@ -38,6 +38,7 @@ struct MsmPlan {
 
 struct MsmWorkspace {
     DeviceBuffer scalars;      // staging for host scalars (n x 32 B)
+    DeviceBuffer blob;         // staging for blob bytes (asynchronous commit_blob)
     DeviceBuffer bases;        // staging for ad-hoc bases (n x 64 B, device format)
     DeviceBuffer bases_wire;   // staging for ad-hoc bases in wire format
     DeviceBuffer digits, sorted, count, cursor, blockbase, sort_tmp, sort_small, offs, block_sums, seg_bucket, segsum, bucket, chunkS, chunkTmp, chunkA, out_wire;
@@ -76,6 +77,7 @@ struct kzg_ctx {
     hipEvent_t ev_inputs = nullptr, ev_acc = nullptr;
     kzg::MsmPending* slot_pending[2] = {nullptr, nullptr};   // kzg_msm_g1_srs_device_begin / _end (slot 0: stream + msm, slot 1: stream2 + msm2)
     kzg::NttWorkspace ntt;
+    kzg::NttWorkspace ntt2;             // slot 1 of the asynchronous commitment calls
     kzg::DeviceBuffer poly_a, poly_b, poly_c, poly_small;   // proof pipeline scratch
 };
 
@@ -135,7 +137,7 @@ struct NttTables {
 int32_t ntt_get_tables(kzg_ctx* ctx, int log_n, bool inverse, NttTables* out);
 
 // In-place NTT on device data (wire format), natural order in/out.
-int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse);
+int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t st = nullptr, NttWorkspace* ws = nullptr);
 
 // synthetic SRS P_i = tau^i * G1 written to d_points (device format); device SRS -> wire on the host
 int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_power, size_t n, uint4* d_points);

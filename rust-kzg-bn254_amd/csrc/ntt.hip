@@ -235,12 +235,15 @@ int32_t ntt_get_tables(kzg_ctx* ctx, int log_n, bool inverse, NttTables* out) {
     hipLaunchKernelGGL(k_ntt_build_table, dim3((t.lo_len + 255) / 256), dim3(256), 0, ctx->stream, t.lo, t.lo_len, log_n, inverse ? 1 : 0, 1u);
     hipLaunchKernelGGL(k_ntt_build_table, dim3((t.hi_len + 255) / 256), dim3(256), 0, ctx->stream, t.hi, t.hi_len, log_n, inverse ? 1 : 0, t.lo_len);
     KZG_HIP_TRY(ctx, hipGetLastError());
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // built once; afterwards read from any stream of the device
     g_tables[key] = t;
     *out = t;
     return KZG_OK;
 }
 
-int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse) {
+int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t st, NttWorkspace* ws) {
+    if (!st) st = ctx->stream;
+    if (!ws) ws = &ctx->ntt;
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
     if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
     if (n == 1) return KZG_OK;
@@ -254,10 +257,10 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse) {
     int P = (log_n + NTT_KMAX - 1) / NTT_KMAX;
     int base = log_n / P, extra = log_n % P;
     if (P > 1) {
-        KZG_HIP_TRY(ctx, ctx->ntt.data.reserve(n * NL * 4));
-        if (P > 2) KZG_HIP_TRY(ctx, ctx->ntt.tmp.reserve(n * NL * 4));
+        KZG_HIP_TRY(ctx, ws->data.reserve(n * NL * 4));
+        if (P > 2) KZG_HIP_TRY(ctx, ws->tmp.reserve(n * NL * 4));
     }
-    int32_t* bufs[2] = {ctx->ntt.data.as<int32_t>(), ctx->ntt.tmp.as<int32_t>()};
+    int32_t* bufs[2] = {ws->data.as<int32_t>(), ws->tmp.as<int32_t>()};
     int Ks[8];
     for (int pi = 0; pi < P; ++pi) Ks[pi] = base;
     {
@@ -278,7 +281,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse) {
         uint32_t n_units = (uint32_t)(n >> K);
         uint32_t C = 1u << (NTT_TILE_LOG - K);
         uint32_t tiles = (n_units + C - 1) / C;
-        hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(NTT_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(NTT_THREADS), 0, st,
                            reinterpret_cast<const uint4*>(d_data), in_planes, reinterpret_cast<uint4*>(d_data), out_planes,
                            log_n, K, log_s, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len,
                            first ? 1 : 0, last ? 1 : 0, (last && inverse) ? log_n : -1);

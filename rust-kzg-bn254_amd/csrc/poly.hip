@@ -311,16 +311,20 @@ int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n) {
     return KZG_OK;
 }
 
-// bytes (host) -> n_padded wire elements in ctx->poly_a (device); returns the device pointer
-int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out) {
+// bytes (host) -> n_padded wire elements (device).  Default buffers: ctx->poly_c (bytes), ctx->poly_a (elements), ctx->stream.
+int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out,
+                       hipStream_t st, DeviceBuffer* d_bytes, DeviceBuffer* d_elems) {
+    if (!st) st = ctx->stream;
+    if (!d_bytes) d_bytes = &ctx->poly_c;
+    if (!d_elems) d_elems = &ctx->poly_a;
     const size_t n_elems = (len + 31) / 32;
-    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n_padded * 32 + 32));
-    KZG_HIP_TRY(ctx, ctx->poly_c.reserve(len + 32));
-    if (len) KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_c.p, bytes, len, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_blob_to_fr, dim3((unsigned)((n_padded + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, ctx->stream,
-                       ctx->poly_c.as<uint8_t>(), len, (uint32_t)n_elems, (uint32_t)n_padded, ctx->poly_a.as<uint4>());
+    KZG_HIP_TRY(ctx, d_elems->reserve(n_padded * 32 + 32));
+    KZG_HIP_TRY(ctx, d_bytes->reserve(len + 32));
+    if (len) KZG_HIP_TRY(ctx, hipMemcpyAsync(d_bytes->p, bytes, len, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_blob_to_fr, dim3((unsigned)((n_padded + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st,
+                       d_bytes->as<uint8_t>(), len, (uint32_t)n_elems, (uint32_t)n_padded, d_elems->as<uint4>());
     KZG_HIP_TRY(ctx, hipGetLastError());
-    *d_out = ctx->poly_a.p;
+    *d_out = d_elems->p;
     return KZG_OK;
 }
 

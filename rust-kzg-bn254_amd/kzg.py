@@ -62,9 +62,9 @@ class KZG:
         ctx.check_device(rc)
         return out
 
-    def commit_coeff_form_stream(self, polynomials, srs):
-        """`commit_coeff_form` over a stream of polynomials, two in flight (`kzg_msm_g1_srs_begin` / `_end`): the H2D copy and
-        the sort of polynomial k+1 run beside the bucket accumulation of polynomial k.  Yields the commitments in order."""
+    # ---- streams of commitments, two in flight (kzg_*_begin(slot) / kzg_msm_g1_srs_end(slot)) --------------------------
+    def _pipelined(self, items, begin):
+        """begin(item, slot) -> status, or None when the item needs no device work (yields the identity)."""
         ctx = self._ctx()
         lib = _lib.load()
 
@@ -78,19 +78,20 @@ class KZG:
 
         prev = None
         k = 0
-        for polynomial in polynomials:
-            if len(polynomial) > len(srs):
-                raise SerializationError("polynomial length is not correct")
-            coeffs = _lib.as_u64(polynomial.coeffs(), 4)
-            if len(coeffs) == 0:                      # empty polynomial: identity, nothing to enqueue
+        for item in items:
+            slot = k & 1
+            rc = begin(item, slot)
+            if rc is None:
                 if prev is not None:
                     yield end(prev)
                     prev = None
                 yield np.zeros(8, dtype=np.uint64)
                 continue
-            slot = k & 1
             k += 1
-            rc = lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, _lib.ptr(coeffs), len(coeffs), slot)
+            if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
+                raise SrsCapacityExceeded(len(item), 0)
+            if rc == _lib.ERR_NOT_POWER_OF_TWO:
+                raise FFTError("length provided is not a power of 2")
             ctx.check_device(rc)
             if rc != _lib.OK:
                 raise CommitError(_lib.status_message(rc))
@@ -99,6 +100,48 @@ class KZG:
             prev = slot
         if prev is not None:
             yield end(prev)
+
+    def commit_coeff_form_stream(self, polynomials, srs):
+        """`commit_coeff_form` over a stream of polynomials: the H2D copy and the sort of polynomial k+1 run beside the bucket
+        accumulation of polynomial k.  Yields the commitments in order."""
+        ctx = self._ctx()
+        lib = _lib.load()
+
+        def begin(polynomial, slot):
+            if len(polynomial) > len(srs):
+                raise SerializationError("polynomial length is not correct")
+            coeffs = _lib.as_u64(polynomial.coeffs(), 4)
+            if len(coeffs) == 0:
+                return None
+            return lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, _lib.ptr(coeffs), len(coeffs), slot)
+        return self._pipelined(polynomials, begin)
+
+    def commit_eval_form_stream(self, polynomials, srs):
+        """`commit_eval_form` over a stream of evaluation-form polynomials (H2D, IFFT and MSM of each on its slot's stream)."""
+        ctx = self._ctx()
+        lib = _lib.load()
+
+        def begin(polynomial, slot):
+            ev = _lib.as_u64(polynomial.evaluations(), 4)
+            if len(ev) > len(srs):
+                raise SrsCapacityExceeded(len(ev), len(srs))
+            return lib.kzg_commit_eval_form_begin(ctx.handle, srs.handle, _lib.ptr(ev), len(ev), slot)
+        return self._pipelined(polynomials, begin)
+
+    def commit_blob_stream(self, blobs, srs):
+        """`commit_blob` over a stream of blobs: bytes in, points out, nothing but the 32-byte-per-element blob crosses PCIe."""
+        ctx = self._ctx()
+        lib = _lib.load()
+
+        def begin(blob, slot):
+            data = np.frombuffer(blob.data(), dtype=np.uint8)
+            n = 1
+            while n < -(-len(data) // 32):
+                n <<= 1
+            if n > len(srs):
+                raise SrsCapacityExceeded(n, len(srs))
+            return lib.kzg_commit_blob_begin(ctx.handle, srs.handle, data.ctypes.data_as(_lib.u8p) if len(data) else None, len(data), slot)
+        return self._pipelined(blobs, begin)
 
     # kzg.rs:182-185
     def commit_blob(self, blob, srs):

@@ -662,3 +662,29 @@ def test_msm_2_20_edge_sets(k):
     pm[1::2] = pyref.point_to_wire((p7[0], (-p7[1]) % P))
     sc = np.repeat(pyref.frs_to_mont(vals[: n // 2]), 2, axis=0)
     assert not k.helpers.g1_lincomb(pm, sc).any()
+
+
+def test_commit_eval_and_blob_streams(k, tau_srs, gettysburg):
+    """kzg_commit_eval_form_begin / kzg_commit_blob_begin + kzg_msm_g1_srs_end: streamed commitments equal the synchronous ones."""
+    kz = k.KZG.new()
+    rnd = random.Random(77)
+    blobs = [k.Blob.from_raw_data(bytes(rnd.randrange(32, 127) for _ in range(m))) for m in (31 * 4096, 40, 31 * 1000 + 5, 31 * 65536, 1)]
+    blobs.append(k.Blob.from_raw_data(gettysburg))
+    want = [kz.commit_blob(b, tau_srs) for b in blobs]
+    assert all(np.array_equal(g, w) for g, w in zip(kz.commit_blob_stream(blobs, tau_srs), want))
+    polys = [b.to_polynomial_eval_form() for b in blobs]
+    want_e = [kz.commit_eval_form(p, tau_srs) for p in polys]
+    assert all(np.array_equal(a, b) for a, b in zip(want, want_e))
+    got_e = list(kz.commit_eval_form_stream(polys, tau_srs))
+    assert len(got_e) == len(want_e) and all(np.array_equal(g, w) for g, w in zip(got_e, want_e))
+    # slot already in flight -> rejected; SRS too short -> SrsCapacityExceeded
+    lib = k._lib.load(); ctx = tau_srs.ctx
+    ev = np.ascontiguousarray(polys[0].evaluations())
+    assert lib.kzg_commit_eval_form_begin(ctx.handle, tau_srs.handle, k._lib.ptr(ev), len(ev), 0) == 0
+    assert lib.kzg_commit_eval_form_begin(ctx.handle, tau_srs.handle, k._lib.ptr(ev), len(ev), 0) == k._lib.ERR_INVALID_ARG
+    out = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+    assert lib.kzg_msm_g1_srs_end(ctx.handle, 0, k._lib.ptr(out), C.byref(inf), None) == 0
+    assert np.array_equal(out, want[0])
+    big = np.zeros((1 << 17, 4), np.uint64)
+    assert lib.kzg_commit_eval_form_begin(ctx.handle, tau_srs.handle, k._lib.ptr(big), len(big), 1) == k._lib.ERR_SRS_CAPACITY_EXCEEDED
+    assert lib.kzg_commit_eval_form_begin(ctx.handle, tau_srs.handle, k._lib.ptr(big), 3, 1) == k._lib.ERR_NOT_POWER_OF_TWO
