@@ -123,7 +123,9 @@ int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
  * (out_xy_mont / out_is_infinity) and/or the unconverted partial sum (out_xyzz_mont, 16 u64); either may be NULL.
  * With begin(k+1) issued before end(k), the sort / bucket-reduction phases of one MSM run beside the accumulation of the
  * other and the host epilogue leaves the critical path.  d_scalars_mont must be complete before `begin` and stay
- * untouched until `end`.  1 <= n <= 2^24; a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG. */
+ * untouched until `end`.  1 <= n <= 2^24; a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG.
+ * The synchronous MSM / commit / proof calls use slot 0's workspace: while slot 0 is in flight they return
+ * KZG_ERR_INVALID_ARG (text in kzg_ctx_last_error); slot 1 may be in flight beside them. */
 int32_t kzg_msm_g1_srs_device_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
                                     const void* d_scalars_mont, size_t n, int32_t slot);
 /* Same with the scalars in host memory (n x 4 u64): the H2D copy is issued on the slot's stream into the slot's staging

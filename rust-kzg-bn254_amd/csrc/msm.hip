@@ -392,6 +392,10 @@ static const size_t MSM_SPLIT_MIN = (size_t)1 << 19;
 
 int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n,
                 uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
+    if (ctx->slot_pending[0]) {           // the synchronous calls share slot 0's workspace and result buffer
+        ctx->last_error = "a kzg_*_begin on slot 0 is still in flight: call kzg_msm_g1_srs_end(ctx, 0, ..) first";
+        return KZG_ERR_INVALID_ARG;
+    }
     kzg_host::Xyzz total = kzg_host::xyzz_inf();
     const uint4* sc = reinterpret_cast<const uint4*>(d_scalars);
     bool split = false;
@@ -437,6 +441,10 @@ int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size
 int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars, size_t n, uint32_t batch,
                       uint64_t* out_xy /* batch x 8 */, uint8_t* out_inf /* batch */) {
     if (n > MSM_MAX_LAUNCH / batch) return KZG_ERR_TOO_LARGE;
+    if (ctx->slot_pending[0]) {
+        ctx->last_error = "a kzg_*_begin on slot 0 is still in flight: call kzg_msm_g1_srs_end(ctx, 0, ..) first";
+        return KZG_ERR_INVALID_ARG;
+    }
     MsmBases b;
     b.points = d_points;
     kzg_host::Xyzz res[64];

@@ -554,6 +554,10 @@ def test_msm_begin_end_pipeline(k, tau_srs, ref_srs, test_srs_wire):
     assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, 0, C.c_void_p(dev[0].data_ptr()), n, 0) == 0
     assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, 0, C.c_void_p(dev[1].data_ptr()), n, 1) == 0
     assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, 0, C.c_void_p(dev[2].data_ptr()), n, 1) == k._lib.ERR_INVALID_ARG
+    # a synchronous call would reuse slot 0's workspace: refused while slot 0 is in flight
+    o8 = np.zeros(8, np.uint64); i8 = C.c_uint8(0)
+    assert lib.kzg_msm_g1_srs_device(ctx.handle, tau_srs.handle, 0, C.c_void_p(dev[2].data_ptr()), n, k._lib.ptr(o8), C.byref(i8)) == k._lib.ERR_INVALID_ARG
+    assert "slot 0" in ctx.last_error()
     part = np.zeros(16, np.uint64)
     assert lib.kzg_msm_g1_srs_end(ctx.handle, 1, None, None, k._lib.ptr(part)) == 0
     assert np.array_equal(k.sharding.fold_partials(part.reshape(1, 16)), want[1])
