@@ -55,7 +55,35 @@ def _worker(rank, world, port, n, q):
     gathered = sharding.gather_partials(part, world, device=None)
     got = sharding.fold_partials(gathered)
     want = orc.msm_pippenger(srs, sc, threads=1)
-    q.put((rank, bool(np.array_equal(got, want)), gathered.shape))
+    ok = bool(np.array_equal(got, want))
+
+    # the pipelined stream (ShardedMsm.commit_stream, world > 1 branch: exchange started after MSM k, collected one step later)
+    # with the two GPU calls replaced by oracle stand-ins; the ordering / drain logic and the collectives are the real ones
+    def to_partial(aff):
+        part = np.zeros(16, np.uint64)
+        if aff.any():
+            part[:8] = aff
+            part[8:12] = pyref.fq_to_mont(1)
+            part[12:16] = pyref.fq_to_mont(1)
+        return part
+
+    sets = [pyref.frs_to_mont([(v * (j + 2) + j) % pyref.R_ for v in vals]) for j in range(4)]
+
+    class Fake(sharding.ShardedMsm):
+        def begin(self, srs_shard, ptr, slot):
+            assert slot not in self.inflight
+            self.inflight[slot] = ptr
+
+        def _end_partial(self, slot):
+            j = self.inflight.pop(slot)
+            return to_partial(orc.msm_pippenger(srs[lo:hi], sets[j][lo:hi], threads=1))
+
+    fake = Fake(None, n, rank, world, gather_device=None)
+    fake.inflight = {}
+    outs = list(fake.commit_stream(None, range(len(sets))))
+    ok = ok and len(outs) == len(sets) and all(np.array_equal(o, orc.msm_pippenger(srs, sets[j], threads=1)) for j, o in enumerate(outs))
+    ok = ok and list(fake.commit_stream(None, [])) == [] and not fake.inflight
+    q.put((rank, ok, gathered.shape))
     dist.destroy_process_group()
 
 
