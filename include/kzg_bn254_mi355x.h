@@ -178,6 +178,12 @@ int32_t kzg_g1_ifft(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy
 int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
                           const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4],
                           uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont);
+/* Asynchronous form of kzg_compute_proof for streams of proofs (two slots, like kzg_msm_g1_srs_begin): upload, batch inversion,
+ * y, quotient, IFFT and MSM are all enqueued on the slot's stream; `end` waits and returns the proof point and y = p(z). */
+int32_t kzg_compute_proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
+                                const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4], int32_t slot);
+int32_t kzg_compute_proof_end(kzg_ctx* ctx, int32_t slot, uint64_t out_xy_mont[8], uint8_t* out_is_infinity,
+                              uint64_t* out_y_mont);
 /* Multi-GPU forms of the two calls above (BASELINE config 4).  srs_shard holds the SRS powers
  * [shard_lo, shard_lo + kzg_srs_len(srs_shard)); every rank passes the whole polynomial, performs the O(n) field work
  * (IFFT, quotient) redundantly and commits only its slice of the coefficients; out = the unconverted partial sum (16 u64)

@@ -78,6 +78,8 @@ PROTOTYPES = {
     "kzg_blob_to_fr": (i32, [vp, u8p, sz, u64p, sz, C.POINTER(sz)]),
     "kzg_commit_blob": (i32, [vp, vp, u8p, sz, u64p, u8p]),
     "kzg_compute_proof": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, u64p, u8p, u64p]),
+    "kzg_compute_proof_begin": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, i32]),
+    "kzg_compute_proof_end": (i32, [vp, i32, u64p, u8p, u64p]),
     "kzg_commit_eval_form_partial": (i32, [vp, vp, sz, u64p, sz, u64p]),
     "kzg_compute_proof_partial": (i32, [vp, vp, sz, u64p, sz, u64p, sz, u64p, u64p, u64p]),
     "kzg_evaluate_polynomial_in_evaluation_form": (i32, [vp, u64p, sz, u64p, u64p]),

@@ -24,6 +24,8 @@ int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where) {
 // polynomial pipeline (poly.hip)
 int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
                   uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof, size_t coeff_lo, uint64_t* out_xyzz);
+int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot);
+int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
 int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out,
                        hipStream_t st = nullptr, DeviceBuffer* d_bytes = nullptr, DeviceBuffer* d_elems = nullptr);
@@ -91,7 +93,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_inputs); (void)hipEventDestroy(ctx->ev_acc); }
     ctx->ntt.release();
     ctx->ntt2.release();
-    ctx->poly_a.release(); ctx->poly_b.release(); ctx->poly_c.release(); ctx->poly_small.release();
+    ctx->poly[0].release(); ctx->poly[1].release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -463,11 +465,11 @@ int32_t kzg_fr_ntt(kzg_ctx* ctx, uint64_t* data_mont, size_t n, int32_t inverse)
     if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_a.p, data_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    int32_t rc = ntt_run(ctx, ctx->poly_a.p, n, inverse != 0);
+    KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].a.p, data_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = ntt_run(ctx, ctx->poly[0].a.p, n, inverse != 0);
     if (rc != KZG_OK) return rc;
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(data_mont, ctx->poly_a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(data_mont, ctx->poly[0].a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KZG_OK;
 }
@@ -488,11 +490,11 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    int32_t rc = ntt_run(ctx, ctx->poly_a.p, n, true);               // coefficients = IFFT(evaluations)
+    KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = ntt_run(ctx, ctx->poly[0].a.p, n, true);               // coefficients = IFFT(evaluations)
     if (rc != KZG_OK) return rc;
-    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_a.p, n, out_xy_mont, out_is_infinity, nullptr);
+    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
 }
 
 // ---- multi-GPU forms: this rank's SRS shard holds the powers [shard_lo, shard_lo + len(srs_shard)) -----------------------
@@ -503,13 +505,13 @@ int32_t kzg_commit_eval_form_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, siz
     if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    int32_t rc = ntt_run(ctx, ctx->poly_a.p, n, true);               // every rank transforms the whole polynomial (32 B/element; not sharded)
+    KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = ntt_run(ctx, ctx->poly[0].a.p, n, true);               // every rank transforms the whole polynomial (32 B/element; not sharded)
     if (rc != KZG_OK) return rc;
     if (shard_lo >= n) { KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); memset(out_xyzz_mont, 0, 128); return KZG_OK; }
     const size_t len = std::min(srs_shard->n, n - shard_lo);
-    return msm_run(ctx, srs_bases(srs_shard, 0, ctx->msm_c_override == 0), ctx->poly_a.as<uint4>() + 2 * shard_lo, len, nullptr, nullptr, out_xyzz_mont);
+    return msm_run(ctx, srs_bases(srs_shard, 0, ctx->msm_c_override == 0), ctx->poly[0].a.as<uint4>() + 2 * shard_lo, len, nullptr, nullptr, out_xyzz_mont);
 }
 
 int32_t kzg_compute_proof_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo, const uint64_t* evals_mont, size_t n,
@@ -625,6 +627,25 @@ int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* eval
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return proof_run(ctx, srs, evals_mont, n, z_mont, out_xy_mont, out_is_infinity, out_y_mont, true, 0, nullptr);
+}
+
+int32_t kzg_compute_proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
+                                const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4], int32_t slot) {
+    (void)roots_mont;
+    if (!ctx || !srs || srs->ctx != ctx || !z_mont || (n && !evals_mont)) return KZG_ERR_INVALID_ARG;
+    if (n != n_roots) return KZG_ERR_ROOTS_LENGTH;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;
+    if (n > ((size_t)1 << 24)) return KZG_ERR_TOO_LARGE;
+    if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return proof_begin(ctx, srs, evals_mont, n, z_mont, slot);
+}
+int32_t kzg_compute_proof_end(kzg_ctx* ctx, int32_t slot, uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont) {
+    if (!ctx || !out_xy_mont) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return proof_end(ctx, slot, out_xy_mont, out_is_infinity, out_y_mont);
 }
 
 int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t* evals_mont, size_t n,

@@ -53,6 +53,14 @@ struct MsmWorkspace {
     void release();
 };
 
+// scratch of the polynomial kernels: a = evaluations / bytes->Fr output, b = inverses | denominators (limb planes),
+// c = quotient / blob bytes, small = scalars and per-block partial sums; pinned = 4 KiB host staging (init image, z, y readback)
+struct PolySet {
+    DeviceBuffer a, b, c, small;
+    void* pinned = nullptr;
+    void release() { a.release(); b.release(); c.release(); small.release(); if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; } }
+};
+
 struct NttWorkspace {
     DeviceBuffer data, tmp;
     void release() { data.release(); tmp.release(); }
@@ -78,7 +86,7 @@ struct kzg_ctx {
     kzg::MsmPending* slot_pending[2] = {nullptr, nullptr};   // kzg_msm_g1_srs_device_begin / _end (slot 0: stream + msm, slot 1: stream2 + msm2)
     kzg::NttWorkspace ntt;
     kzg::NttWorkspace ntt2;             // slot 1 of the asynchronous commitment calls
-    kzg::DeviceBuffer poly_a, poly_b, poly_c, poly_small;   // proof pipeline scratch
+    kzg::PolySet poly[2];               // polynomial / proof pipeline scratch; [1] belongs to slot 1 of the asynchronous calls
 };
 
 struct kzg_srs {

@@ -164,9 +164,9 @@ int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy
         int32_t rc = ntt_get_tables(ctx, log_n, true, &tb);
         if (rc != KZG_OK) return rc;
     }
-    KZG_HIP_TRY(ctx, ctx->poly_b.reserve(n * 36 * 4));
+    KZG_HIP_TRY(ctx, ctx->poly[0].b.reserve(n * 36 * 4));
     KZG_HIP_TRY(ctx, ctx->msm.bases_wire.reserve(n * 64));
-    int32_t* planes = ctx->poly_b.as<int32_t>();
+    int32_t* planes = ctx->poly[0].b.as<int32_t>();
     hipStream_t st = ctx->stream;
     const unsigned gn = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, log_n, planes);

@@ -302,21 +302,21 @@ int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n) {
     NttTables tb;
     int32_t rc = ntt_get_tables(ctx, log_n, false, &tb);
     if (rc != KZG_OK) return rc;
-    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32));
+    KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32));
     hipLaunchKernelGGL(k_poly_roots, dim3((unsigned)((n + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, ctx->stream,
-                       ctx->poly_a.as<uint4>(), (uint32_t)n, tb);
+                       ctx->poly[0].a.as<uint4>(), (uint32_t)n, tb);
     KZG_HIP_TRY(ctx, hipGetLastError());
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->poly_a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->poly[0].a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KZG_OK;
 }
 
-// bytes (host) -> n_padded wire elements (device).  Default buffers: ctx->poly_c (bytes), ctx->poly_a (elements), ctx->stream.
+// bytes (host) -> n_padded wire elements (device).  Default buffers: ctx->poly[0].c (bytes), ctx->poly[0].a (elements), ctx->stream.
 int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out,
                        hipStream_t st, DeviceBuffer* d_bytes, DeviceBuffer* d_elems) {
     if (!st) st = ctx->stream;
-    if (!d_bytes) d_bytes = &ctx->poly_c;
-    if (!d_elems) d_elems = &ctx->poly_a;
+    if (!d_bytes) d_bytes = &ctx->poly[0].c;
+    if (!d_elems) d_elems = &ctx->poly[0].a;
     const size_t n_elems = (len + 31) / 32;
     KZG_HIP_TRY(ctx, d_elems->reserve(n_padded * 32 + 32));
     KZG_HIP_TRY(ctx, d_bytes->reserve(len + 32));
@@ -328,70 +328,104 @@ int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_
     return KZG_OK;
 }
 
-int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
-                  uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof, size_t coeff_lo, uint64_t* out_xyzz) {
+// Enqueue the O(n) part of a proof on `st` with the buffers of `ps_set`, without waiting: upload, denominators + batch
+// inversion, y, quotient (+ on-domain entry), IFFT of the quotient.  y is copied back into ps_set.pinned + 2048 (valid once the
+// stream has been synchronised); the quotient's coefficients are left in ps_set.c.
+static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWorkspace* nttws, const uint64_t* evals, size_t n,
+                             const uint64_t z[4], bool want_proof) {
     int log_n = ilog2_exact(n);
     NttTables tb;
     int32_t rc = ntt_get_tables(ctx, log_n, false, &tb);
     if (rc != KZG_OK) return rc;
-    hipStream_t st = ctx->stream;
+    if (want_proof && n > 1) { NttTables tbi; rc = ntt_get_tables(ctx, log_n, true, &tbi); if (rc != KZG_OK) return rc; }
     // lanes: about `per_lane` elements each, at least one block.  Every lane pays one Fermat inversion (~380 dependent multiplies,
     // the latency floor of this kernel), so fewer elements per lane shorten the serial part until the extra waves cost more.
     static int per_lane = 0;
     if (per_lane == 0) { const char* env = getenv("KZG_POLY_PER_LANE"); per_lane = env && atoi(env) > 0 ? atoi(env) : 16; }   // measured at 2^20: 32 -> 3.42 ms, 16 -> 3.32 ms, 8 -> 3.41 ms per proof
     uint32_t blocks = (uint32_t)((n + (size_t)POLY_THREADS * per_lane - 1) / ((size_t)POLY_THREADS * per_lane));
     if (blocks == 0) blocks = 1;
-    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32));                 // evaluations (wire)
-    KZG_HIP_TRY(ctx, ctx->poly_b.reserve(n * NL * 4 * 2));         // inverses | denominators (planes)
-    KZG_HIP_TRY(ctx, ctx->poly_c.reserve(n * 32));                 // quotient (wire)
-    KZG_HIP_TRY(ctx, ctx->poly_small.reserve(4096 + (size_t)blocks * NL * 4 * 2));
-    uint8_t* small = ctx->poly_small.as<uint8_t>();
+    KZG_HIP_TRY(ctx, set.a.reserve(n * 32));                 // evaluations (wire)
+    KZG_HIP_TRY(ctx, set.b.reserve(n * NL * 4 * 2));         // inverses | denominators (planes)
+    KZG_HIP_TRY(ctx, set.c.reserve(n * 32));                 // quotient (wire)
+    KZG_HIP_TRY(ctx, set.small.reserve(4096 + (size_t)blocks * NL * 4 * 2));
+    if (!set.pinned) KZG_HIP_TRY(ctx, hipHostMalloc(&set.pinned, 4096, hipHostMallocDefault));
+    uint8_t* small = set.small.as<uint8_t>();
     ProofScalars* ps = reinterpret_cast<ProofScalars*>(small);
     uint4* d_z = reinterpret_cast<uint4*>(small + 1024);
     int32_t* partial = reinterpret_cast<int32_t*>(small + 4096);
-    int32_t* d_inv = ctx->poly_b.as<int32_t>();
+    int32_t* d_inv = set.b.as<int32_t>();
     int32_t* d_den = d_inv + n * NL;
 
-    ProofScalars init;
-    memset(&init, 0, sizeof init);
-    init.on_domain_index = NO_INDEX;
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, &init, sizeof init, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_z, z, 32, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_a.p, evals, n * 32, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipStreamSynchronize(st));                      // `init` lives on this stack frame
+    uint8_t* pin = static_cast<uint8_t*>(set.pinned);       // [0, 1024): init image, [1024, 1056): z, [2048, ..): y readback
+    ProofScalars* init = reinterpret_cast<ProofScalars*>(pin);
+    memset(init, 0, sizeof *init);
+    init->on_domain_index = NO_INDEX;
+    memcpy(pin + 1024, z, 32);
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_z, pin + 1024, 32, hipMemcpyHostToDevice, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));
 
-    hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, ctx->poly_a.as<uint4>(), (uint32_t)n, tb, d_z,
+    hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, d_z,
                        d_inv, d_den, partial, ps);
-    hipLaunchKernelGGL(k_poly_finish_y, dim3(1), dim3(POLY_THREADS), 0, st, ctx->poly_a.as<uint4>(), (uint32_t)n, log_n, d_z,
+    hipLaunchKernelGGL(k_poly_finish_y, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, d_z,
                        partial, blocks, ps);
     KZG_HIP_TRY(ctx, hipGetLastError());
-    if (out_y) {
-        ProofScalars host;
-        KZG_HIP_TRY(ctx, hipMemcpyAsync(&host, ps, sizeof host, hipMemcpyDeviceToHost, st));
-        KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        memcpy(out_y, host.y_wire, 32);
-    }
-    if (!want_proof) {
-        KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        return KZG_OK;
-    }
-    hipLaunchKernelGGL(k_poly_quotient, dim3(blocks), dim3(POLY_THREADS), 0, st, ctx->poly_a.as<uint4>(), (uint32_t)n, tb, d_inv,
-                       ps, ctx->poly_c.as<uint4>(), partial);
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + 2048, ps, sizeof(ProofScalars), hipMemcpyDeviceToHost, st));
+    if (!want_proof) return KZG_OK;
+    hipLaunchKernelGGL(k_poly_quotient, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, d_inv,
+                       ps, set.c.as<uint4>(), partial);
     hipLaunchKernelGGL(k_poly_quotient_on_domain, dim3(1), dim3(POLY_THREADS), 0, st, (uint32_t)n, tb, partial, blocks, ps,
-                       ctx->poly_c.as<uint4>());
+                       set.c.as<uint4>());
     KZG_HIP_TRY(ctx, hipGetLastError());
     // commit_eval_form(quotient): coefficients = IFFT(q), then MSM over the monomial SRS (kzg.rs:176-177)
-    rc = ntt_run(ctx, ctx->poly_c.p, n, true);
-    if (rc != KZG_OK) return rc;
+    return ntt_run(ctx, set.c.p, n, true, st, nttws);
+}
+static void proof_read_y(const PolySet& set, uint64_t* out_y) {
+    const ProofScalars* host = reinterpret_cast<const ProofScalars*>(static_cast<const uint8_t*>(set.pinned) + 2048);
+    memcpy(out_y, host->y_wire, 32);
+}
+
+int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
+                  uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof, size_t coeff_lo, uint64_t* out_xyzz) {
+    if (ctx->slot_pending[0]) {
+        ctx->last_error = "a kzg_*_begin on slot 0 is still in flight: call its end first";
+        return KZG_ERR_INVALID_ARG;
+    }
+    PolySet& set = ctx->poly[0];
+    hipStream_t st = ctx->stream;
+    int32_t rc = proof_enqueue(ctx, set, st, &ctx->ntt, evals, n, z, want_proof);
+    if (rc != KZG_OK) { (void)hipStreamSynchronize(st); return rc; }
     // the whole SRS commits the whole quotient; a shard holding powers [coeff_lo, coeff_lo + srs->n) commits its slice of it
-    if (coeff_lo >= n) {
+    if (!want_proof || coeff_lo >= n) {
         KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (out_xyzz) memset(out_xyzz, 0, 128);
-        if (out_xy) { memset(out_xy, 0, 64); if (out_inf) *out_inf = 1; }
+        if (out_y) proof_read_y(set, out_y);
+        if (want_proof) {
+            if (out_xyzz) memset(out_xyzz, 0, 128);
+            if (out_xy) { memset(out_xy, 0, 64); if (out_inf) *out_inf = 1; }
+        }
         return KZG_OK;
     }
     const size_t len = std::min(srs->n, n - coeff_lo);
-    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly_c.as<uint4>() + 2 * coeff_lo, len, out_xy, out_inf, out_xyzz);
+    rc = msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), set.c.as<uint4>() + 2 * coeff_lo, len, out_xy, out_inf, out_xyzz);
+    if (rc == KZG_OK && out_y) proof_read_y(set, out_y);      // msm_run has synchronised the stream
+    return rc;
+}
+
+// asynchronous form: everything on the slot's stream; proof_end collects the point and y
+int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot) {
+    if (slot < 0 || slot > 1 || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
+    hipStream_t st = nullptr;
+    int32_t rc = msm_slot_stream(ctx, slot, &st);
+    if (rc != KZG_OK) return rc;
+    PolySet& set = ctx->poly[slot];
+    rc = proof_enqueue(ctx, set, st, slot ? &ctx->ntt2 : &ctx->ntt, evals, n, z, true);
+    if (rc != KZG_OK) { (void)hipStreamSynchronize(st); return rc; }
+    return msm_begin(ctx, slot, srs_bases(srs, 0, ctx->msm_c_override == 0), set.c.p, n);
+}
+int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y) {
+    int32_t rc = msm_end(ctx, slot, out_xy, out_inf, nullptr);
+    if (rc == KZG_OK && out_y) proof_read_y(ctx->poly[slot], out_y);
+    return rc;
 }
 
 }  // namespace kzg

@@ -262,14 +262,14 @@ k_points_device_to_wire(const uint4* __restrict__ in, uint4* __restrict__ out, s
 
 int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau[4], uint64_t first_power, size_t n, uint4* d_points) {
     if (n == 0) return KZG_OK;
-    KZG_HIP_TRY(ctx, ctx->poly_a.reserve(n * 32 + 64));
-    KZG_HIP_TRY(ctx, ctx->poly_small.reserve(4096));
-    uint4* d_tau = ctx->poly_small.as<uint4>();
+    KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32 + 64));
+    KZG_HIP_TRY(ctx, ctx->poly[0].small.reserve(4096));
+    uint4* d_tau = ctx->poly[0].small.as<uint4>();
     KZG_HIP_TRY(ctx, hipMemcpyAsync(d_tau, tau, 32, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t per = 64;
     uint32_t lanes = (uint32_t)((n + per - 1) / per);
-    hipLaunchKernelGGL(k_fr_powers, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, d_tau, ctx->poly_a.as<uint4>(), first_power, (uint32_t)n, per);
-    hipLaunchKernelGGL(k_srs_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly_a.as<uint4>(), d_points, (uint32_t)n);
+    hipLaunchKernelGGL(k_fr_powers, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, d_tau, ctx->poly[0].a.as<uint4>(), first_power, (uint32_t)n, per);
+    hipLaunchKernelGGL(k_srs_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly[0].a.as<uint4>(), d_points, (uint32_t)n);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KZG_OK;
@@ -314,12 +314,12 @@ int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_po
     *err_kind = 0;
     *err_index = 0;
     if (n == 0) return KZG_OK;
-    KZG_HIP_TRY(ctx, ctx->poly_c.reserve(n * 32));
-    KZG_HIP_TRY(ctx, ctx->poly_small.reserve(4096));
-    uint32_t* d_status = ctx->poly_small.as<uint32_t>();
+    KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve(n * 32));
+    KZG_HIP_TRY(ctx, ctx->poly[0].small.reserve(4096));
+    uint32_t* d_status = ctx->poly[0].small.as<uint32_t>();
     KZG_HIP_TRY(ctx, hipMemsetAsync(d_status, 0, 8, ctx->stream));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_c.p, bytes, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_srs_decompress_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly_c.as<uint8_t>(), d_points,
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].c.p, bytes, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_srs_decompress_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly[0].c.as<uint8_t>(), d_points,
                        (uint32_t)n, d_status);
     KZG_HIP_TRY(ctx, hipGetLastError());
     uint32_t st[2] = {0, 0};

@@ -143,6 +143,37 @@ class KZG:
             return lib.kzg_commit_blob_begin(ctx.handle, srs.handle, data.ctypes.data_as(_lib.u8p) if len(data) else None, len(data), slot)
         return self._pipelined(blobs, begin)
 
+    def compute_proof_stream(self, items, srs, want_y=False):
+        """`compute_proof` over a stream of (polynomial, z_fr) pairs, two in flight (`kzg_compute_proof_begin` / `_end`): upload,
+        batch inversion and quotient of proof k+1 run beside the MSM of proof k.  Yields proofs (or (proof, y)) in order."""
+        ctx = self._ctx()
+        lib = _lib.load()
+
+        def end(slot):
+            out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0); y = np.zeros(4, dtype=np.uint64)
+            rc = lib.kzg_compute_proof_end(ctx.handle, slot, _lib.ptr(out), C.byref(inf), _lib.ptr(y))
+            ctx.check_device(rc)
+            if rc != _lib.OK:
+                raise GenericError(_lib.status_message(rc))
+            return (out, y) if want_y else out
+
+        prev = None
+        for k, (polynomial, z_fr) in enumerate(items):
+            ev = _lib.as_u64(polynomial.evaluations(), 4)
+            z = np.ascontiguousarray(_lib.as_u64(z_fr, 0).reshape(4))
+            slot = k & 1
+            rc = lib.kzg_compute_proof_begin(ctx.handle, srs.handle, _lib.ptr(ev), len(ev), None, len(ev), _lib.ptr(z), slot)
+            if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
+                raise SrsCapacityExceeded(len(ev), len(srs))
+            ctx.check_device(rc)
+            if rc != _lib.OK:
+                raise GenericError(_lib.status_message(rc))
+            if prev is not None:
+                yield end(prev)
+            prev = slot
+        if prev is not None:
+            yield end(prev)
+
     # kzg.rs:182-185
     def commit_blob(self, blob, srs):
         """Bytes in, point out: bytes -> Fr, IFFT and MSM all on the device (`kzg_commit_blob`)."""

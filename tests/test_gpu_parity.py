@@ -692,3 +692,39 @@ def test_commit_eval_and_blob_streams(k, tau_srs, gettysburg):
     big = np.zeros((1 << 17, 4), np.uint64)
     assert lib.kzg_commit_eval_form_begin(ctx.handle, tau_srs.handle, k._lib.ptr(big), len(big), 1) == k._lib.ERR_SRS_CAPACITY_EXCEEDED
     assert lib.kzg_commit_eval_form_begin(ctx.handle, tau_srs.handle, k._lib.ptr(big), 3, 1) == k._lib.ERR_NOT_POWER_OF_TWO
+
+
+def test_compute_proof_stream(k, tau_srs, ref_srs, gettysburg):
+    """kzg_compute_proof_begin / _end: streamed proofs (off-domain and on-domain z, different sizes) equal the synchronous call,
+    y included; the golden on-domain proofs of kzg.proof.eq.input come out of the stream too."""
+    kz = k.KZG.new()
+    rnd = random.Random(123)
+    items = []
+    for n in (64, 4096, 1 << 15, 512, 1 << 16):
+        poly = k.PolynomialEvalForm(pyref.frs_to_mont([rnd.randrange(R_) for _ in range(n)]))
+        items.append((poly, k.fr.fr_from_int(rnd.randrange(R_))))
+    # an on-domain point: z = w^5 of the 4096 domain
+    w = pyref.root_of_unity(12)
+    items.append((items[1][0], k.fr.fr_from_int(pow(w, 5, R_))))
+    want = []
+    for p, z in items:
+        kz.calculate_and_store_roots_of_unity(len(p) * 32)
+        want.append(kz._compute_proof_impl(p, z, tau_srs, want_y=True))
+    got = list(kz.compute_proof_stream(items, tau_srs, want_y=True))
+    assert len(got) == len(want)
+    for (gp, gy), (wp, wy) in zip(got, want):
+        assert np.array_equal(gp, wp) and np.array_equal(gy, wy)
+    assert np.array_equal(got[-1][1], items[1][0].evaluations()[5])          # on-domain: y = f_5
+    # reference golden vectors through the stream (SRS = first 64 Lagrange points is not what they used: compute via ref_srs)
+    blob = k.Blob.from_raw_data(gettysburg)
+    poly = blob.to_polynomial_eval_form()
+    kz.calculate_and_store_roots_of_unity(len(blob))
+    rows = []
+    for line in open(os.path.join(GOLDEN, "kzg.proof.eq.input")):
+        if line.strip():
+            idx, x, y = line.strip().split(",")
+            rows.append((int(idx), (int(x), int(y))))
+    sel = rows[:8]
+    proofs = list(kz.compute_proof_stream([(poly, kz.get_nth_root_of_unity(i)) for i, _ in sel], ref_srs))
+    for (i, pt), pr in zip(sel, proofs):
+        assert pyref.point_from_wire(pr) == pt, i
