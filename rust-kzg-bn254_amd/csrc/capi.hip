@@ -90,7 +90,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     msm_drop_slots(ctx);
     ctx->msm.release();
     ctx->msm2.release();
-    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); (void)hipEventDestroy(ctx->ev_inputs); (void)hipEventDestroy(ctx->ev_acc); }
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     ctx->ntt.release();
     ctx->ntt2.release();
     ctx->poly[0].release(); ctx->poly[1].release();

@@ -80,9 +80,8 @@ struct kzg_ctx {
     bool profiling = false;
     bool lds_attr_set = false;
     kzg::MsmWorkspace msm;
-    kzg::MsmWorkspace msm2;             // second half of a split MSM (own stream)
+    kzg::MsmWorkspace msm2;             // slot 1 of the asynchronous calls (own stream)
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_inputs = nullptr, ev_acc = nullptr;
     kzg::MsmPending* slot_pending[2] = {nullptr, nullptr};   // kzg_msm_g1_srs_device_begin / _end (slot 0: stream + msm, slot 1: stream2 + msm2)
     kzg::NttWorkspace ntt;
     kzg::NttWorkspace ntt2;             // slot 1 of the asynchronous commitment calls

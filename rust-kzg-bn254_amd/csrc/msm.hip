@@ -112,9 +112,8 @@ struct Pending {
 };
 
 // Enqueue every kernel of one MSM (or batch) plus the D2H copy of its O(100) result points on `st`, using `ws`.
-// wait_acc / signal_acc (optional) order this launch's accumulate kernel after / before another stream's.
 static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
-                           uint32_t batch, hipEvent_t wait_acc, hipEvent_t signal_acc, Pending* pend) {
+                           uint32_t batch, Pending* pend) {
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
     const Plan p = make_plan(ctx, n, bases, batch);
     const size_t entries = (size_t)p.W * n * batch;
@@ -212,13 +211,11 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     const uint32_t gs = (p.segcap + 255) / 256;
     hipLaunchKernelGGL(k_msm_segments, dim3(gs), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,
                        ws.seg_bucket.as<uint32_t>());
-    if (wait_acc) KZG_HIP_TRY(ctx, hipStreamWaitEvent(st, wait_acc, 0));
     KZG_MARK(4);
     hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(),
                        ws.seg_bucket.as<uint32_t>(), ws.offs.as<unsigned long long>(), p.G, p.L,
                        ws.segsum.as<int32_t>(), (size_t)p.segcap);
     KZG_MARK(5);
-    if (signal_acc) KZG_HIP_TRY(ctx, hipEventRecord(signal_acc, st));
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
         hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, 0u, 0u,
@@ -334,8 +331,6 @@ struct MsmPending : Pending {};
 static int32_t ensure_stream2(kzg_ctx* ctx) {
     if (ctx->stream2) return KZG_OK;
     KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inputs, hipEventDisableTiming));
-    KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming));
     return KZG_OK;
 }
 
@@ -353,7 +348,7 @@ int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_s
     MsmPending* pend = new (std::nothrow) MsmPending();
     if (!pend) return KZG_ERR_DEVICE;
     int32_t rc = msm_enqueue(ctx, slot ? ctx->msm2 : ctx->msm, slot ? ctx->stream2 : ctx->stream, bases,
-                             reinterpret_cast<const uint4*>(d_scalars), n, 1, nullptr, nullptr, pend);
+                             reinterpret_cast<const uint4*>(d_scalars), n, 1, pend);
     if (rc != KZG_OK) { delete pend; return rc; }
     ctx->slot_pending[slot] = pend;
     return KZG_OK;
@@ -383,13 +378,10 @@ int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, s
     return KZG_OK;
 }
 
-// EXPERIMENT, off by default (KZG_MSM_SPLIT=1 enables): cut a large table-mode MSM in two halves by scalar index and
-// enqueue them on two streams with their own workspaces, so that the latency-bound sort / bucket reduction of one half
-// run beside the issue-bound accumulate of the other (accumulates ordered by an event).  Measured on MI355X at 2^20:
-// 2.36 ms against 2.09 ms unsplit -- the small kernels stretch 3-4x when they share SIMDs with accumulate waves
-// (reduce 0.12 -> 0.43 ms) and slow the accumulate (0.78 -> 0.91 ms per half), so nothing is hidden for free.
-static const size_t MSM_SPLIT_MIN = (size_t)1 << 19;
-
+// Negative result kept for the record (measured on MI355X at 2^20, removed from the code): cutting one large table-mode MSM
+// in two halves on two streams, so that the sort / bucket reduction of one half runs beside the accumulate of the other, took
+// 2.36 ms against 2.09 ms unsplit -- inside ONE MSM the halves' small kernels stretch 3-4x and the accumulates slow each other.
+// Overlap pays across INDEPENDENT MSMs instead (the two slots below).
 int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n,
                 uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
     if (ctx->slot_pending[0]) {           // the synchronous calls share slot 0's workspace and result buffer
@@ -398,39 +390,16 @@ int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size
     }
     kzg_host::Xyzz total = kzg_host::xyzz_inf();
     const uint4* sc = reinterpret_cast<const uint4*>(d_scalars);
-    bool split = false;
-    { const char* env = getenv("KZG_MSM_SPLIT"); if (env && atoi(env) != 0) split = bases.table_stride != 0 && n >= MSM_SPLIT_MIN && n <= MSM_MAX_LAUNCH; }
-    if (split) {
-        { int32_t rc0 = ensure_stream2(ctx); if (rc0 != KZG_OK) return rc0; }
-        const size_t na = n / 2, nb_ = n - na;
-        // stream 2 must see whatever produced the scalars on the main stream (e.g. a staged H2D copy)
-        KZG_HIP_TRY(ctx, hipEventRecord(ctx->ev_inputs, ctx->stream));
-        KZG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_inputs, 0));
-        Pending pa, pb;
-        MsmBases ba = bases, bb = bases;
-        bb.points = bases.points + 4 * na;
-        int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, ba, sc, na, 1, nullptr, ctx->ev_acc, &pa);
+    for (size_t off = 0; off < n; off += MSM_MAX_LAUNCH) {
+        size_t len = std::min(MSM_MAX_LAUNCH, n - off);
+        kzg_host::Xyzz part;
+        MsmBases b = bases;
+        b.points = bases.points + 4 * off;
+        Pending pend;
+        int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, b, sc + 2 * off, len, 1, &pend);
+        if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, &part);
         if (rc != KZG_OK) return rc;
-        rc = msm_enqueue(ctx, ctx->msm2, ctx->stream2, bb, sc + 2 * na, nb_, 1, ctx->ev_acc, nullptr, &pb);
-        if (rc != KZG_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-        kzg_host::Xyzz ra, rb;
-        rc = msm_finish(ctx, ctx->msm, ctx->stream, pa, &ra);
-        int32_t rc2 = msm_finish(ctx, ctx->msm2, ctx->stream2, pb, &rb);
-        if (rc != KZG_OK) return rc;
-        if (rc2 != KZG_OK) return rc2;
-        total = kzg_host::xyzz_add(ra, rb);
-    } else {
-        for (size_t off = 0; off < n; off += MSM_MAX_LAUNCH) {
-            size_t len = std::min(MSM_MAX_LAUNCH, n - off);
-            kzg_host::Xyzz part;
-            MsmBases b = bases;
-            b.points = bases.points + 4 * off;
-            Pending pend;
-            int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, b, sc + 2 * off, len, 1, nullptr, nullptr, &pend);
-            if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, &part);
-            if (rc != KZG_OK) return rc;
-            total = kzg_host::xyzz_add(total, part);
-        }
+        total = kzg_host::xyzz_add(total, part);
     }
     if (out_xyzz) memcpy(out_xyzz, &total, 128);
     if (out_xy) kzg_host::xyzz_to_affine(total, out_xy, out_inf);
@@ -450,7 +419,7 @@ int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars
     kzg_host::Xyzz res[64];
     if (batch > 64) return KZG_ERR_INVALID_ARG;
     Pending pend;
-    int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, b, reinterpret_cast<const uint4*>(d_scalars), n, batch, nullptr, nullptr, &pend);
+    int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, b, reinterpret_cast<const uint4*>(d_scalars), n, batch, &pend);
     if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, res);
     if (rc != KZG_OK) return rc;
     for (uint32_t i = 0; i < batch; ++i) kzg_host::xyzz_to_affine(res[i], out_xy + 8 * i, out_inf ? out_inf + i : nullptr);
