@@ -117,15 +117,17 @@ int32_t kzg_msm_g1_srs_partial_device(kzg_ctx* ctx, const kzg_srs* srs, size_t o
                                       const void* d_scalars_mont, size_t n, uint64_t out_xyzz_mont[16]);
 int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
                                const uint64_t* scalars_mont, size_t n, uint64_t out_xyzz_mont[16]);
+#define KZG_NUM_SLOTS 4
 /* Asynchronous form for streams of commitments (software pipelining): `begin` enqueues the whole kernel sequence of one
- * MSM over srs[offset .. offset + n) on the stream of `slot` (0 or 1; each slot has its own stream and workspace) and
+ * MSM over srs[offset .. offset + n) on the stream of `slot` (0 .. KZG_NUM_SLOTS-1; each slot has its own stream and workspace) and
  * returns without waiting; `end` waits for that slot, runs the O(1) host epilogue and writes the affine point
  * (out_xy_mont / out_is_infinity) and/or the unconverted partial sum (out_xyzz_mont, 16 u64); either may be NULL.
  * With begin(k+1) issued before end(k), the sort / bucket-reduction phases of one MSM run beside the accumulation of the
  * other and the host epilogue leaves the critical path.  d_scalars_mont must be complete before `begin` and stay
  * untouched until `end`.  1 <= n <= 2^24; a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG.
  * The synchronous MSM / commit / proof calls use slot 0's workspace: while slot 0 is in flight they return
- * KZG_ERR_INVALID_ARG (text in kzg_ctx_last_error); slot 1 may be in flight beside them. */
+ * KZG_ERR_INVALID_ARG (text in kzg_ctx_last_error); the other slots may be in flight beside them.  Two slots hide the latency-bound
+ * phases of a 2^20-pair MSM; shard-sized MSMs (2^17 .. 2^18 pairs per GPU) keep gaining up to four. */
 int32_t kzg_msm_g1_srs_device_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
                                     const void* d_scalars_mont, size_t n, int32_t slot);
 /* Same with the scalars in host memory (n x 4 u64): the H2D copy is issued on the slot's stream into the slot's staging
@@ -163,7 +165,7 @@ int32_t kzg_blob_to_fr(kzg_ctx* ctx, const uint8_t* blob_bytes, size_t len, uint
 int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len,
                         uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
 /* Asynchronous forms of the two calls above for streams of blobs: the whole chain (H2D copy, bytes -> Fr, IFFT, MSM) is
- * enqueued on the stream of `slot` (0 / 1); collect the commitment with kzg_msm_g1_srs_end(ctx, slot, ...).  Host input
+ * enqueued on the stream of `slot`; collect the commitment with kzg_msm_g1_srs_end(ctx, slot, ...).  Host input
  * buffers follow the rule of kzg_msm_g1_srs_begin.  Same error codes as the synchronous calls; n (resp. the padded blob
  * length) <= 2^24. */
 int32_t kzg_commit_eval_form_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n, int32_t slot);
@@ -178,7 +180,7 @@ int32_t kzg_g1_ifft(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy
 int32_t kzg_compute_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
                           const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4],
                           uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont);
-/* Asynchronous form of kzg_compute_proof for streams of proofs (two slots, like kzg_msm_g1_srs_begin): upload, batch inversion,
+/* Asynchronous form of kzg_compute_proof for streams of proofs (same slots as kzg_msm_g1_srs_begin): upload, batch inversion,
  * y, quotient, IFFT and MSM are all enqueued on the slot's stream; `end` waits and returns the proof point and y = p(z). */
 int32_t kzg_compute_proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n,
                                 const uint64_t* roots_mont, size_t n_roots, const uint64_t z_mont[4], int32_t slot);

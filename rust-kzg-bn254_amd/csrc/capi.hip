@@ -86,14 +86,14 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (auto st : ctx->stream_x) if (st) (void)hipStreamSynchronize(st);
     msm_drop_slots(ctx);
     ctx->msm.release();
-    ctx->msm2.release();
-    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    for (auto& w : ctx->msm_x) w.release();
+    for (auto& st : ctx->stream_x) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
     ctx->ntt.release();
-    ctx->ntt2.release();
-    ctx->poly[0].release(); ctx->poly[1].release();
+    for (auto& w : ctx->ntt_x) w.release();
+    for (auto& ps : ctx->poly) ps.release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -112,10 +112,11 @@ int32_t kzg_ctx_set_profiling(kzg_ctx* ctx, int32_t enable) {
     if (!ctx) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->profiling = enable != 0;
-    for (auto* w : {&ctx->msm, &ctx->msm2}) {
-        for (auto& v : w->phase_ms) v = 0;
-        w->profiled_launches = 0;
-        w->profiled_pairs = 0;
+    for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) {
+        MsmWorkspace& w = ctx->slot_msm(sl);
+        for (auto& v : w.phase_ms) v = 0;
+        w.profiled_launches = 0;
+        w.profiled_pairs = 0;
     }
     return KZG_OK;
 }
@@ -123,9 +124,16 @@ int32_t kzg_ctx_set_profiling(kzg_ctx* ctx, int32_t enable) {
 int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* launches, uint64_t* pairs) {
     if (!ctx || !phase_ms_out) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    for (int i = 0; i < 8; ++i) phase_ms_out[i] = ctx->msm.phase_ms[i] + ctx->msm2.phase_ms[i];
-    if (launches) *launches = ctx->msm.profiled_launches + ctx->msm2.profiled_launches;
-    if (pairs) *pairs = ctx->msm.profiled_pairs + ctx->msm2.profiled_pairs;
+    for (int i = 0; i < 8; ++i) phase_ms_out[i] = 0;
+    uint64_t nl = 0, np = 0;
+    for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) {
+        MsmWorkspace& w = ctx->slot_msm(sl);
+        for (int i = 0; i < 8; ++i) phase_ms_out[i] += w.phase_ms[i];
+        nl += w.profiled_launches;
+        np += w.profiled_pairs;
+    }
+    if (launches) *launches = nl;
+    if (pairs) *pairs = np;
     return KZG_OK;
 }
 
@@ -320,15 +328,15 @@ int32_t kzg_msm_g1_srs_device_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t off
     return msm_begin(ctx, slot, srs_bases(srs, offset, ctx->msm_c_override == 0), d_scalars_mont, n);
 }
 int32_t kzg_msm_g1_srs_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const uint64_t* scalars_mont, size_t n, int32_t slot) {
-    if (!ctx || !srs || srs->ctx->device != ctx->device || !scalars_mont || slot < 0 || slot > 1) return KZG_ERR_INVALID_ARG;
+    if (!ctx || !srs || srs->ctx->device != ctx->device || !scalars_mont || slot < 0 || slot >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
     if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
     // H2D copy on the slot's own stream into the slot's own staging buffer: it overlaps the other slot's kernels
-    hipStream_t st = ctx->stream;
-    if (slot == 1) { int32_t rc = msm_slot_stream(ctx, 1, &st); if (rc != KZG_OK) return rc; }
-    MsmWorkspace& ws = slot ? ctx->msm2 : ctx->msm;
+    hipStream_t st = nullptr;
+    { int32_t rc = msm_slot_stream(ctx, slot, &st); if (rc != KZG_OK) return rc; }
+    MsmWorkspace& ws = ctx->slot_msm(slot);
     KZG_HIP_TRY(ctx, ws.scalars.reserve(n * 32 + 32));
     if (n) KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, st));
     return msm_begin(ctx, slot, srs_bases(srs, offset, ctx->msm_c_override == 0), ws.scalars.p, n);
@@ -566,7 +574,7 @@ int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_by
 // asynchronous forms of commit_eval_form / commit_blob: the whole chain (H2D, bytes -> Fr, IFFT, MSM) goes onto the slot's stream
 static int32_t commit_begin_common(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, const uint8_t* blob_bytes, size_t len,
                                    size_t n, int32_t slot) {
-    if (slot < 0 || slot > 1) return KZG_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
     if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;                            // kzg.rs:89-94
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
     if (n > ((size_t)1 << 24)) return KZG_ERR_TOO_LARGE;
@@ -576,7 +584,7 @@ static int32_t commit_begin_common(kzg_ctx* ctx, const kzg_srs* srs, const uint6
     hipStream_t st = nullptr;
     int32_t rc = msm_slot_stream(ctx, slot, &st);
     if (rc != KZG_OK) return rc;
-    MsmWorkspace& ws = slot ? ctx->msm2 : ctx->msm;
+    MsmWorkspace& ws = ctx->slot_msm(slot);
     void* d = nullptr;
     if (blob_bytes || !evals_mont) {
         rc = blob_to_fr_run(ctx, blob_bytes, len, n, &d, st, &ws.blob, &ws.scalars);
@@ -589,7 +597,7 @@ static int32_t commit_begin_common(kzg_ctx* ctx, const kzg_srs* srs, const uint6
     NttTables tb;                                                                    // make sure the tables exist before the slot stream reads them
     int log_n = 0; while (((size_t)1 << log_n) < n) ++log_n;
     if (n > 1) { rc = ntt_get_tables(ctx, log_n, true, &tb); if (rc != KZG_OK) return rc; }
-    rc = ntt_run(ctx, d, n, true, st, slot ? &ctx->ntt2 : &ctx->ntt);
+    rc = ntt_run(ctx, d, n, true, st, &ctx->slot_ntt(slot));
     if (rc != KZG_OK) return rc;
     return msm_begin(ctx, slot, srs_bases(srs, 0, ctx->msm_c_override == 0), d, n);
 }

@@ -69,6 +69,9 @@ struct NttWorkspace {
 }  // namespace kzg
 
 namespace kzg { struct MsmPending; }
+#ifndef KZG_NUM_SLOTS
+#define KZG_NUM_SLOTS 4      // slots of the asynchronous calls (include/kzg_bn254_mi355x.h: KZG_NUM_SLOTS)
+#endif
 
 struct kzg_ctx {
     int device = 0;
@@ -80,12 +83,14 @@ struct kzg_ctx {
     bool profiling = false;
     bool lds_attr_set = false;
     kzg::MsmWorkspace msm;
-    kzg::MsmWorkspace msm2;             // slot 1 of the asynchronous calls (own stream)
-    hipStream_t stream2 = nullptr;
-    kzg::MsmPending* slot_pending[2] = {nullptr, nullptr};   // kzg_msm_g1_srs_device_begin / _end (slot 0: stream + msm, slot 1: stream2 + msm2)
+    kzg::MsmWorkspace msm_x[KZG_NUM_SLOTS - 1];   // slots 1.. of the asynchronous calls, each with its own stream
+    hipStream_t stream_x[KZG_NUM_SLOTS - 1] = {};
+    kzg::MsmPending* slot_pending[KZG_NUM_SLOTS] = {};   // what each slot of the asynchronous calls has in flight
     kzg::NttWorkspace ntt;
-    kzg::NttWorkspace ntt2;             // slot 1 of the asynchronous commitment calls
-    kzg::PolySet poly[2];               // polynomial / proof pipeline scratch; [1] belongs to slot 1 of the asynchronous calls
+    kzg::NttWorkspace ntt_x[KZG_NUM_SLOTS - 1];   // slots 1.. of the asynchronous commitment / proof calls
+    kzg::PolySet poly[KZG_NUM_SLOTS];   // polynomial / proof pipeline scratch, one set per slot ([0] also serves the synchronous calls)
+    kzg::MsmWorkspace& slot_msm(int slot) { return slot ? msm_x[slot - 1] : msm; }
+    kzg::NttWorkspace& slot_ntt(int slot) { return slot ? ntt_x[slot - 1] : ntt; }
 };
 
 struct kzg_srs {

@@ -328,26 +328,23 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
 // ---- two-slot asynchronous form: begin enqueues, end waits and runs the host epilogue ---------------------------------
 struct MsmPending : Pending {};
 
-static int32_t ensure_stream2(kzg_ctx* ctx) {
-    if (ctx->stream2) return KZG_OK;
-    KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    return KZG_OK;
-}
-
 int32_t msm_slot_stream(kzg_ctx* ctx, int slot, hipStream_t* out) {
-    if (slot == 1) { int32_t rc = ensure_stream2(ctx); if (rc != KZG_OK) return rc; }
-    *out = slot ? ctx->stream2 : ctx->stream;
+    if (slot < 0 || slot >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
+    if (slot == 0) { *out = ctx->stream; return KZG_OK; }
+    if (!ctx->stream_x[slot - 1]) KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_x[slot - 1], hipStreamNonBlocking));
+    *out = ctx->stream_x[slot - 1];
     return KZG_OK;
 }
 
 int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_scalars, size_t n) {
-    if (slot < 0 || slot > 1 || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;     // slot still in flight
+    if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;     // slot still in flight
     if (n == 0) return KZG_ERR_INVALID_ARG;
     if (n > MSM_MAX_LAUNCH) return KZG_ERR_TOO_LARGE;
-    if (slot == 1) { int32_t rc = ensure_stream2(ctx); if (rc != KZG_OK) return rc; }
+    hipStream_t st = nullptr;
+    { int32_t rc0 = msm_slot_stream(ctx, slot, &st); if (rc0 != KZG_OK) return rc0; }
     MsmPending* pend = new (std::nothrow) MsmPending();
     if (!pend) return KZG_ERR_DEVICE;
-    int32_t rc = msm_enqueue(ctx, slot ? ctx->msm2 : ctx->msm, slot ? ctx->stream2 : ctx->stream, bases,
+    int32_t rc = msm_enqueue(ctx, ctx->slot_msm(slot), st, bases,
                              reinterpret_cast<const uint4*>(d_scalars), n, 1, pend);
     if (rc != KZG_OK) { delete pend; return rc; }
     ctx->slot_pending[slot] = pend;
@@ -355,11 +352,13 @@ int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_s
 }
 
 int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
-    if (slot < 0 || slot > 1 || !ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;    // nothing in flight
+    if (slot < 0 || slot >= KZG_NUM_SLOTS || !ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;    // nothing in flight
     MsmPending* pend = ctx->slot_pending[slot];
     ctx->slot_pending[slot] = nullptr;
     kzg_host::Xyzz total;
-    int32_t rc = msm_finish(ctx, slot ? ctx->msm2 : ctx->msm, slot ? ctx->stream2 : ctx->stream, *pend, &total);
+    hipStream_t st = nullptr;
+    (void)msm_slot_stream(ctx, slot, &st);
+    int32_t rc = msm_finish(ctx, ctx->slot_msm(slot), st, *pend, &total);
     delete pend;
     if (rc != KZG_OK) return rc;
     if (out_xyzz) memcpy(out_xyzz, &total, 128);
@@ -368,7 +367,7 @@ int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, ui
 }
 
 void msm_drop_slots(kzg_ctx* ctx) {
-    for (int s = 0; s < 2; ++s) { delete ctx->slot_pending[s]; ctx->slot_pending[s] = nullptr; }
+    for (int s = 0; s < KZG_NUM_SLOTS; ++s) { delete ctx->slot_pending[s]; ctx->slot_pending[s] = nullptr; }
 }
 
 int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, size_t n) {

@@ -413,12 +413,12 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
 
 // asynchronous form: everything on the slot's stream; proof_end collects the point and y
 int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot) {
-    if (slot < 0 || slot > 1 || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
     hipStream_t st = nullptr;
     int32_t rc = msm_slot_stream(ctx, slot, &st);
     if (rc != KZG_OK) return rc;
     PolySet& set = ctx->poly[slot];
-    rc = proof_enqueue(ctx, set, st, slot ? &ctx->ntt2 : &ctx->ntt, evals, n, z, true);
+    rc = proof_enqueue(ctx, set, st, &ctx->slot_ntt(slot), evals, n, z, true);
     if (rc != KZG_OK) { (void)hipStreamSynchronize(st); return rc; }
     return msm_begin(ctx, slot, srs_bases(srs, 0, ctx->msm_c_override == 0), set.c.p, n);
 }

@@ -4,6 +4,7 @@ its slice and emits ONE extended-Jacobian partial (16 x u64).  The only exchange
 partials (G x 128 B over RCCL / xGMI; RCCL has no EC-add reduction op, so "all-reduce" = all-gather + fold);
 every rank then folds them on the host (G - 1 point additions + one inversion, kzg_g1_fold_partials).
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -162,39 +163,43 @@ class ShardedMsm:
             raise ValueError(_lib.status_message(rc))
         return part
 
-    def commit_stream(self, srs_shard, d_scalars_ptrs):
-        """Commitments of a stream of scalar buffers (device pointers to this rank's slices), two MSMs in flight:
-        MSM k+1 is enqueued before MSM k is waited for, so its sort runs beside MSM k's accumulation.  With world > 1 the
-        exchange of partial k is started as soon as MSM k is done and collected one step later (fold on the host), so neither
-        its latency nor the host fold sit between two MSMs.  Yields the commitments in order."""
-        if self.world == 1:
-            prev = None
-            for k, ptr in enumerate(d_scalars_ptrs):
-                self.begin(srs_shard, ptr, k & 1)
-                if prev is not None:
-                    yield self.end(prev)
-                prev = k & 1
-            if prev is not None:
-                yield self.end(prev)
-            return
-        if self._gatherer is None:
-            self._gatherer = PartialGatherer(self.world, self.gather_device)
-        g = self._gatherer
-        prev, exchanging = None, False
-        for k, ptr in enumerate(d_scalars_ptrs):
-            self.begin(srs_shard, ptr, k & 1)
-            if prev is not None:
-                part = self._end_partial(prev)
-                if exchanging:
-                    yield fold_partials(g.finish())
-                g.start(part)
-                exchanging = True
-            prev = k & 1
-        if prev is not None:
-            part = self._end_partial(prev)
-            if exchanging:
-                yield fold_partials(g.finish())
+    def commit_stream(self, srs_shard, d_scalars_ptrs, depth=None):
+        """Commitments of a stream of scalar buffers (device pointers to this rank's slices) with `depth` MSMs in flight
+        (default: 2 for slices of >= 2^20 pairs, which saturate the GPU's integer pipes, else 4 — shard-sized MSMs are bound by
+        dependent-latency chains and keep gaining up to KZG_NUM_SLOTS).  MSM k+depth-1 is enqueued before MSM k is waited for.
+        With world > 1 the exchange of partial k is started as soon as MSM k is done and collected one step later (fold on
+        the host), so neither its latency nor the host fold sit between two MSMs.  Yields the commitments in order."""
+        if depth is None:
+            depth = 2 if self.len >= (1 << 20) else _lib.NUM_SLOTS
+        depth = max(1, min(int(depth), _lib.NUM_SLOTS))
+        inflight = collections.deque()
+        g = None
+        if self.world > 1:
+            if self._gatherer is None:
+                self._gatherer = PartialGatherer(self.world, self.gather_device)
+            g = self._gatherer
+        exchanging = False
+
+        def retire():
+            nonlocal exchanging
+            slot = inflight.popleft()
+            if g is None:
+                return [self.end(slot)]
+            part = self._end_partial(slot)
+            out = [fold_partials(g.finish())] if exchanging else []
             g.start(part)
+            exchanging = True
+            return out
+
+        for k, ptr in enumerate(d_scalars_ptrs):
+            if len(inflight) == depth:
+                yield from retire()
+            slot = k % depth
+            self.begin(srs_shard, ptr, slot)
+            inflight.append(slot)
+        while inflight:
+            yield from retire()
+        if exchanging:
             yield fold_partials(g.finish())
 
 class ShardedKzg:

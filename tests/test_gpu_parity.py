@@ -548,8 +548,9 @@ def test_msm_begin_end_pipeline(k, tau_srs, ref_srs, test_srs_wire):
     dev = [torch.from_numpy(np.ascontiguousarray(b).view(np.int64)).cuda() for b in bufs]
     torch.cuda.synchronize()
     sh = ShardedMsm(ctx, n)
-    got = list(sh.commit_stream(tau_srs, [d.data_ptr() for d in dev]))
-    assert len(got) == 5 and all(np.array_equal(g, w) for g, w in zip(got, want))
+    for depth in (None, 1, 2, 3, 4):
+        got = list(sh.commit_stream(tau_srs, [d.data_ptr() for d in dev], depth=depth))
+        assert len(got) == 5 and all(np.array_equal(g, w) for g, w in zip(got, want)), depth
     # both slots busy at once, ended in the opposite order; partial (XYZZ) output folds to the same point
     assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, 0, C.c_void_p(dev[0].data_ptr()), n, 0) == 0
     assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, 0, C.c_void_p(dev[1].data_ptr()), n, 1) == 0
@@ -565,7 +566,7 @@ def test_msm_begin_end_pipeline(k, tau_srs, ref_srs, test_srs_wire):
     assert lib.kzg_msm_g1_srs_end(ctx.handle, 0, k._lib.ptr(out), C.byref(inf), None) == 0
     assert np.array_equal(out, want[0]) and inf.value == 0
     assert lib.kzg_msm_g1_srs_end(ctx.handle, 0, k._lib.ptr(out), C.byref(inf), None) == k._lib.ERR_INVALID_ARG   # idle slot
-    assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, 0, C.c_void_p(dev[0].data_ptr()), n, 2) == k._lib.ERR_INVALID_ARG
+    assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, 0, C.c_void_p(dev[0].data_ptr()), n, k._lib.NUM_SLOTS) == k._lib.ERR_INVALID_ARG
     assert lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, (1 << 16) - 5, C.c_void_p(dev[0].data_ptr()), n, 0) == k._lib.ERR_MSM_LENGTH_MISMATCH
     # small generic-mode SRS (no tables) through the same path, against the oracle
     m = 700

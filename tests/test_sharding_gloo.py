@@ -67,7 +67,7 @@ def _worker(rank, world, port, n, q):
             part[12:16] = pyref.fq_to_mont(1)
         return part
 
-    sets = [pyref.frs_to_mont([(v * (j + 2) + j) % pyref.R_ for v in vals]) for j in range(4)]
+    sets = [pyref.frs_to_mont([(v * (j + 2) + j) % pyref.R_ for v in vals]) for j in range(7)]
 
     class Fake(sharding.ShardedMsm):
         def begin(self, srs_shard, ptr, slot):

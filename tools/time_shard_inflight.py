@@ -41,4 +41,10 @@ for log_n in (17, 18, 19, 20):
     pipe(6)
     t0 = time.perf_counter(); pipe(60); dt = time.perf_counter() - t0
     print(f"n=2^{log_n} begin/end pipeline: {dt/60*1e3:.3f} ms/MSM", flush=True)
+    from rust_kzg_bn254_amd.sharding import ShardedMsm
+    sh = ShardedMsm(ctx, n)
+    for depth in (2, 3, 4):
+        list(sh.commit_stream(srs, [d.data_ptr()] * 8, depth=depth))
+        t0 = time.perf_counter(); list(sh.commit_stream(srs, [d.data_ptr()] * 60, depth=depth)); dt = time.perf_counter() - t0
+        print(f"n=2^{log_n} commit_stream depth {depth}: {dt/60*1e3:.3f} ms/MSM", flush=True)
     srs.close()
