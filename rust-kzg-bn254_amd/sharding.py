@@ -39,6 +39,10 @@ class PartialGatherer:
     (most of it a synchronous pageable H2D copy) -> see tools/rehearse_rccl_world1.py.  CPU backends (gloo) take the list form."""
 
     def __init__(self, world: int, device="cuda"):
+        import sys
+        if device is not None and "torch" not in sys.modules and _lib._lib is not None:
+            raise RuntimeError("import torch before the first call into libkzg_bn254_mi355x.so (two HIP runtimes in one process: "
+                               "INTEGRATION.md section 5)")
         import torch
         self.world, self.device = world, device
         self.torch = torch

@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# Load order matters in a process that uses both PyTorch-ROCm and libkzg_bn254_mi355x.so: the torch wheel bundles its own
+# libamdhip64, and if the system HIP runtime (which the library links) initialises first, torch later reports "No HIP GPUs are
+# available".  Some GPU tests use torch for device buffers, so torch is imported before anything can load the library.
+try:
+    import torch  # noqa: F401
+except ImportError:                      # the product itself does not need torch
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 for p in (ROOT, os.path.join(ROOT, "tests")):

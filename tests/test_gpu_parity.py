@@ -729,3 +729,71 @@ def test_compute_proof_stream(k, tau_srs, ref_srs, gettysburg):
     proofs = list(kz.compute_proof_stream([(poly, kz.get_nth_root_of_unity(i)) for i, _ in sel], ref_srs))
     for (i, pt), pr in zip(sel, proofs):
         assert pyref.point_from_wire(pr) == pt, i
+
+
+def test_slots_mixed_stress(k, tau_srs):
+    """All KZG_NUM_SLOTS slots busy with a random mix of asynchronous calls (MSM from device / host scalars, eval-form and blob
+    commitments, proofs) of random sizes, ended in random order: every result equals the synchronous call's."""
+    import torch
+    lib = k._lib.load(); ctx = tau_srs.ctx
+    rnd = random.Random(2026)
+    kz = k.KZG.new()
+    u8p = k._lib.u8p
+    jobs = []
+    for j in range(40):
+        kind = rnd.choice(["msm_dev", "msm_host", "eval", "blob", "proof"])
+        n = 1 << rnd.randrange(0, 15)
+        if kind == "blob":
+            raw = bytes(rnd.randrange(32, 127) for _ in range(rnd.randrange(1, 31 * 4096)))
+            blob = k.Blob.from_raw_data(raw)
+            want = kz.commit_blob(blob, tau_srs)
+            jobs.append((kind, np.frombuffer(blob.data(), dtype=np.uint8).copy(), None, want, None))
+            continue
+        sc = rand_scalars(n, 5000 + j)
+        if kind in ("msm_dev", "msm_host"):
+            m = rnd.randrange(1, n + 1)
+            sc = np.ascontiguousarray(sc[:m])
+            want = msm_srs(k, tau_srs, sc)
+            dev = torch.from_numpy(sc.view(np.int64)).cuda() if kind == "msm_dev" else None
+            jobs.append((kind, sc, dev, want, None))
+        elif kind == "eval":
+            want = kz.commit_eval_form(k.PolynomialEvalForm(sc), tau_srs)
+            jobs.append((kind, np.ascontiguousarray(sc), None, want, None))
+        else:
+            z = k.fr.fr_from_int(rnd.randrange(R_))
+            kz.calculate_and_store_roots_of_unity(n * 32)
+            wp, wy = kz._compute_proof_impl(k.PolynomialEvalForm(sc), z, tau_srs, want_y=True)
+            jobs.append((kind, np.ascontiguousarray(sc), np.ascontiguousarray(z), wp, wy))
+    torch.cuda.synchronize()
+    busy = {}                                        # slot -> job index
+    todo = list(range(len(jobs)))
+    done = 0
+    while todo or busy:
+        free = [s for s in range(k._lib.NUM_SLOTS) if s not in busy]
+        if todo and free and (not busy or rnd.random() < 0.7):
+            s = rnd.choice(free); j = todo.pop(0)
+            kind, data, aux, _, _ = jobs[j]
+            if kind == "msm_dev":
+                rc = lib.kzg_msm_g1_srs_device_begin(ctx.handle, tau_srs.handle, 0, C.c_void_p(aux.data_ptr()), len(data), s)
+            elif kind == "msm_host":
+                rc = lib.kzg_msm_g1_srs_begin(ctx.handle, tau_srs.handle, 0, k._lib.ptr(data), len(data), s)
+            elif kind == "eval":
+                rc = lib.kzg_commit_eval_form_begin(ctx.handle, tau_srs.handle, k._lib.ptr(data), len(data), s)
+            elif kind == "blob":
+                rc = lib.kzg_commit_blob_begin(ctx.handle, tau_srs.handle, data.ctypes.data_as(u8p), data.size, s)
+            else:
+                rc = lib.kzg_compute_proof_begin(ctx.handle, tau_srs.handle, k._lib.ptr(data), len(data), None, len(data), k._lib.ptr(aux), s)
+            assert rc == 0, (kind, rc, ctx.last_error())
+            busy[s] = j
+        else:
+            s = rnd.choice(list(busy)); j = busy.pop(s)
+            kind, _, _, want, want_y = jobs[j]
+            out = np.zeros(8, np.uint64); inf = C.c_uint8(0); y = np.zeros(4, np.uint64)
+            if kind == "proof":
+                assert lib.kzg_compute_proof_end(ctx.handle, s, k._lib.ptr(out), C.byref(inf), k._lib.ptr(y)) == 0
+                assert np.array_equal(y, want_y), (j, kind)
+            else:
+                assert lib.kzg_msm_g1_srs_end(ctx.handle, s, k._lib.ptr(out), C.byref(inf), None) == 0
+            assert np.array_equal(out, want), (j, kind)
+            done += 1
+    assert done == len(jobs)
