@@ -21,6 +21,8 @@
 #include "field29.h"
 
 #include <map>
+#include <mutex>
+#include <tuple>
 
 namespace kzg {
 
@@ -61,6 +63,17 @@ k_ntt_build_table(int32_t* __restrict__ planes, uint32_t len, int log_n, int inv
     for (int j = 0; j < NL; ++j) planes[(size_t)j * len + t] = w.l[j];
 }
 
+// last-pass separable twiddles: sep[uu * R + j] = w_N^(uu * j), uu < C = 2048 / R, j < R = 2^K (tile-independent)
+__global__ void __launch_bounds__(256)
+k_ntt_build_sep(int32_t* __restrict__ planes, int log_n, int inverse, int K) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint32_t)NTT_TILE) return;
+    Fr w;
+    fr_pow_root(w, log_n, inverse != 0, (t >> K) * (t & ((1u << K) - 1)));
+#pragma unroll
+    for (int j = 0; j < NL; ++j) planes[(size_t)j * NTT_TILE + t] = w.l[j];
+}
+
 __device__ __forceinline__ void load_planes(Fr& v, const int32_t* __restrict__ planes, size_t stride, size_t i) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) v.l[j] = planes[(size_t)j * stride + i];
@@ -84,7 +97,8 @@ k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_pla
            uint4* __restrict__ out_wire, int32_t* __restrict__ out_planes,
            int log_n, int K, int log_s,
            const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
-           int first, int last, int scale_log_n /* >= 0: multiply by (2^scale_log_n)^-1 at the end */) {
+           int first, int last, int scale_log_n /* >= 0: multiply by (2^scale_log_n)^-1 at the end */,
+           const int32_t* __restrict__ sep /* last pass (s = 1): w_N^(uu j) table, or nullptr */) {
     __shared__ int32_t lds[NL * NTT_PL];
     // twiddle scratch: entries [0, R/2) = per-tile w_R^t; entries [64, 64 + R) = inter-pass row (only when R <= 32...64 fits)
     __shared__ int32_t twl[NL * NTT_TW];
@@ -118,6 +132,16 @@ k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_pla
     }
     if (row_tw) __syncthreads();
 
+    // Last pass (s = 1): every unit of the tile has its own p = tile_u0 + uu, so the inter-pass twiddle w_N^(p j) differs per
+    // element.  A two-level table lookup per element was 18 scattered 4-byte loads (the slowest part of the pass: +29 us at
+    // 2^20).  w_N^(p j) = w_N^(tile_u0 j) * w_N^(uu j): the first factor depends only on j, which is FIXED per thread here
+    // (j = t mod R, NTT_THREADS a multiple of R) -> one lookup per thread, kept in registers; the second is a tile-independent
+    // 2048-entry table read with consecutive lanes on consecutive entries.
+    const bool sep_tw = !first && s == 1 && sep != nullptr;
+    Fr tw_a;
+    fe_set_one(tw_a);
+    if (sep_tw && tile_u0 != 0) twiddle(tw_a, tlo, lo_len, lo_bits, thi, hi_len, tile_u0 * (tid & (R - 1)));
+
     // ---- gather -------------------------------------------------------------------------------
     for (uint32_t t = tid; t < (uint32_t)NTT_TILE; t += NTT_THREADS) {
         uint32_t uu, j;
@@ -135,7 +159,14 @@ k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_pla
                 fe_unpack(v, w32);
             } else {
                 load_planes(v, in_planes, N, idx);
-                if (p != 0 && j != 0) {
+                if (sep_tw) {
+                    if (p != 0 && j != 0) {
+                        Fr w;
+                        load_planes(w, sep, NTT_TILE, (size_t)uu * R + j);
+                        if (tile_u0 != 0) fe_mul(w, w, tw_a);
+                        fe_mul(v, v, w);
+                    }
+                } else if (p != 0 && j != 0) {
                     Fr w;
                     if (row_tw) {
 #pragma unroll
@@ -155,8 +186,64 @@ k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_pla
     }
     __syncthreads();
 
-    // ---- K radix-2 DIT stages in LDS ---------------------------------------------------------------
-    for (uint32_t h = 1, log_h = 0; h < R; h <<= 1, ++log_h) {
+    // ---- K DIT stages in LDS: pairs of stages as radix-4 steps in registers, a last radix-2 stage when K is odd ---------
+    // Radix-4 step over half-sizes h and 2h on rows i0, i0+h, i0+2h, i0+3h (same butterflies and twiddles as two radix-2 stages,
+    // so the results are identical): one LDS round trip, one barrier and four limb normalisations per four elements instead of
+    // two, eight and eight.  The intermediate values are multiplied un-normalised (limbs < 2^30 against twiddle limbs < 2^29).
+    uint32_t log_h = 0;
+    for (; log_h + 1 < (uint32_t)K; log_h += 2) {
+        const uint32_t h = 1u << log_h;
+        for (uint32_t gt = tid; gt < (uint32_t)(NTT_TILE / 4); gt += NTT_THREADS) {
+            const uint32_t g = gt >> log_c, uu = gt & (C - 1);
+            const uint32_t lowb = g & (h - 1);
+            const uint32_t i0 = ((g >> log_h) << (log_h + 2)) | lowb;
+            const uint32_t e0 = i0 * Cp + uu, e1 = e0 + h * Cp, e2 = e1 + h * Cp, e3 = e2 + h * Cp;
+            const uint32_t t1 = lowb << (K - 1 - log_h);                 // stage h:  w_R^(lowb R / 2h)
+            const uint32_t t2 = lowb << (K - 2 - log_h);                 // stage 2h: w_R^(lowb R / 4h), rows i0 / i0+2h
+            const uint32_t t3 = (lowb + h) << (K - 2 - log_h);           //           w_R^((lowb+h) R / 4h), rows i0+h / i0+3h
+            Fr a0, a1, a2, a3, w;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                a0.l[l] = lds[l * NTT_PL + e0];
+                a1.l[l] = lds[l * NTT_PL + e1];
+                a2.l[l] = lds[l * NTT_PL + e2];
+                a3.l[l] = lds[l * NTT_PL + e3];
+            }
+            Fr p, q;
+            if (h == 1) { p = a1; q = a3; }                              // first stage: every twiddle is 1
+            else {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + t1];
+                fe_mul(p, a1, w);
+                fe_mul(q, a3, w);
+            }
+            Fr b0, b1, b2, b3;
+            fe_add(b0, a0, p); fe_sub(b1, a0, p);
+            fe_add(b2, a2, q); fe_sub(b3, a2, q);
+            Fr u, v;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + t2];
+            fe_mul(u, b2, w);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + t3];
+            fe_mul(v, b3, w);
+            Fr c0, c1, c2, c3;
+            fe_add(c0, b0, u); fe_norm(c0);
+            fe_sub(c2, b0, u); fe_norm(c2);
+            fe_add(c1, b1, v); fe_norm(c1);
+            fe_sub(c3, b1, v); fe_norm(c3);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                lds[l * NTT_PL + e0] = c0.l[l];
+                lds[l * NTT_PL + e1] = c1.l[l];
+                lds[l * NTT_PL + e2] = c2.l[l];
+                lds[l * NTT_PL + e3] = c3.l[l];
+            }
+        }
+        __syncthreads();
+    }
+    if (log_h < (uint32_t)K) {
+        const uint32_t h = 1u << log_h;
         for (uint32_t bt = tid; bt < (uint32_t)(NTT_TILE / 2); bt += NTT_THREADS) {
             uint32_t b = bt >> log_c, uu = bt & (C - 1);
             uint32_t lowb = b & (h - 1);
@@ -241,6 +328,23 @@ int32_t ntt_get_tables(kzg_ctx* ctx, int log_n, bool inverse, NttTables* out) {
     return KZG_OK;
 }
 
+struct SepKey { int dev, log_n, inverse, K; bool operator<(const SepKey& o) const { return std::tie(dev, log_n, inverse, K) < std::tie(o.dev, o.log_n, o.inverse, o.K); } };
+static std::map<SepKey, int32_t*> g_sep;
+static int32_t ntt_get_sep(kzg_ctx* ctx, int log_n, bool inverse, int K, const int32_t** out) {
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    SepKey key{ctx->device, log_n, inverse ? 1 : 0, K};
+    auto it = g_sep.find(key);
+    if (it != g_sep.end()) { *out = it->second; return KZG_OK; }
+    int32_t* p = nullptr;
+    KZG_HIP_TRY(ctx, hipMalloc(&p, (size_t)NTT_TILE * NL * 4));
+    hipLaunchKernelGGL(k_ntt_build_sep, dim3(NTT_TILE / 256), dim3(256), 0, ctx->stream, p, log_n, inverse ? 1 : 0, K);
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // built once; afterwards read from any stream of the device
+    g_sep[key] = p;
+    *out = p;
+    return KZG_OK;
+}
+
 int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t st, NttWorkspace* ws) {
     if (!st) st = ctx->stream;
     if (!ws) ws = &ctx->ntt;
@@ -270,6 +374,8 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
         for (int pi = 1; pi + 1 < P; ++pi) order[no++] = pi;
         for (int e = 0; e < extra; ++e) Ks[order[e]] += 1;
     }
+    const int32_t* sep = nullptr;
+    if (P > 1) { rc = ntt_get_sep(ctx, log_n, inverse, Ks[P - 1], &sep); if (rc != KZG_OK) return rc; }
     int log_ncur = 0;
     for (int pi = 0; pi < P; ++pi) {
         int K = Ks[pi];
@@ -284,7 +390,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
         hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(NTT_THREADS), 0, st,
                            reinterpret_cast<const uint4*>(d_data), in_planes, reinterpret_cast<uint4*>(d_data), out_planes,
                            log_n, K, log_s, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len,
-                           first ? 1 : 0, last ? 1 : 0, (last && inverse) ? log_n : -1);
+                           first ? 1 : 0, last ? 1 : 0, (last && inverse) ? log_n : -1, (last && !first) ? sep : nullptr);
     }
     KZG_HIP_TRY(ctx, hipGetLastError());
     return KZG_OK;
