@@ -1,6 +1,6 @@
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/v3; mkdir -p $O
-test -n "$SKIP_BENCH" || (cd $R && timeout -k 10 280 python bench.py --steps 40 --warmup 5 > $O/bench_line.json 2> $O/bench.err) || exit 1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PROF_TAG:-v4}; mkdir -p $O
+test -n "$SKIP_BENCH" || (cd $R && timeout -k 10 280 python bench.py > $O/bench_line.json 2> $O/bench.err) || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/kt.log 2>&1 || exit 2
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc_fetch.log 2>&1 || exit 3
