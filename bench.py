@@ -176,7 +176,7 @@ def main():
             "data": "synthetic: SRS P_i = tau^i G1 with known tau (generated on device); blob-like scalars < 2^248, seeded",
             "config": {"workload": "G1 MSM 2^%d scalars (KZG::commit_coeff_form), scalars resident in HBM" % LOG_N,
                        "sharding": "by scalar index over %d GPU(s); all-gather of XYZZ partials + host fold" % world,
-                       "pipeline_depth": (2 if sh.len >= (1 << 20) else _lib.NUM_SLOTS) if pipelined else 1,
+                       "pipeline_depth": (2 if sh.len >= (1 << 20) else 3) if pipelined else 1,
                        "bit_exact_vs_oracle": None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(LOG_N) if world == 1 else None,

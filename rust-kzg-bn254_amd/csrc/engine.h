@@ -47,6 +47,7 @@ struct MsmWorkspace {
     static constexpr int N_PHASES = 8;   // digits, scan, scatter, segments, accumulate, bucket_fin, reduce, whole launch
     hipEvent_t ev[N_PHASES] = {};
     bool ev_ready = false;
+    hipEvent_t ev_done = nullptr;   // recorded behind the result copy of the MSM in flight on this workspace
     double phase_ms[N_PHASES] = {};
     uint64_t profiled_launches = 0;
     uint64_t profiled_pairs = 0;
@@ -83,8 +84,8 @@ struct kzg_ctx {
     bool profiling = false;
     bool lds_attr_set = false;
     kzg::MsmWorkspace msm;
-    kzg::MsmWorkspace msm_x[KZG_NUM_SLOTS - 1];   // slots 1.. of the asynchronous calls, each with its own stream
-    hipStream_t stream_x[KZG_NUM_SLOTS - 1] = {};
+    kzg::MsmWorkspace msm_x[KZG_NUM_SLOTS - 1];   // workspaces of slots 1.. of the asynchronous calls
+    hipStream_t stream_x[KZG_NUM_SLOTS - 1] = {}; // one stream per slot (slot 0: `stream`), created on first use
     kzg::MsmPending* slot_pending[KZG_NUM_SLOTS] = {};   // what each slot of the asynchronous calls has in flight
     kzg::NttWorkspace ntt;
     kzg::NttWorkspace ntt_x[KZG_NUM_SLOTS - 1];   // slots 1.. of the asynchronous commitment / proof calls

@@ -25,6 +25,7 @@ void MsmWorkspace::release() {
     for (auto* b : all) b->release();
     if (pinned_out) { (void)hipHostFree(pinned_out); pinned_out = nullptr; }
     if (ev_ready) { for (auto& e : ev) (void)hipEventDestroy(e); ev_ready = false; }
+    if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
 }
 
 static int ilog2_floor(size_t n) { int k = 0; while ((n >> (k + 1)) != 0) ++k; return k; }
@@ -257,6 +258,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     KZG_MARK(7);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.pinned_out, ws.out_wire.p, (size_t)n_out * 128, hipMemcpyDeviceToHost, st));
+    if (!ws.ev_done) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
+    KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_done, st));        // msm_finish waits for THIS launch, not for the stream: a later MSM may already be queued behind it
 #undef KZG_MARK
     pend->p = p;
     pend->n_out = n_out;
@@ -269,7 +272,8 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     const Plan& p = pend.p;
     const uint32_t n_out = pend.n_out, batch = pend.batch;
     const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
-    KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    (void)st;
+    KZG_HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
     if (ctx->profiling && ws.ev_ready) {
         for (int i = 0; i < 7; ++i) {
             float ms = 0;
@@ -330,6 +334,10 @@ struct MsmPending : Pending {};
 
 int32_t msm_slot_stream(kzg_ctx* ctx, int slot, hipStream_t* out) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
+    // One stream per slot.  How much a third / fourth MSM in flight gains depends on how HIP maps the streams onto its hardware
+    // queues (4 by default, shared with every other stream of the process): at 2^17 pairs per MSM, depth 2 gives 0.43-0.45 ms per
+    // MSM, depth 3 0.37-0.38 (0.5 in one mapping), depth 4 anything from 0.34 to 0.46.  Sharing streams between slots (2 or 3
+    // streams for 4 slots, any assignment) made depth 4 mapping-independent but no faster than depth 2-3 (tools/queue_probe.py).
     if (slot == 0) { *out = ctx->stream; return KZG_OK; }
     if (!ctx->stream_x[slot - 1]) KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_x[slot - 1], hipStreamNonBlocking));
     *out = ctx->stream_x[slot - 1];

@@ -169,12 +169,12 @@ class ShardedMsm:
 
     def commit_stream(self, srs_shard, d_scalars_ptrs, depth=None):
         """Commitments of a stream of scalar buffers (device pointers to this rank's slices) with `depth` MSMs in flight
-        (default: 2 for slices of >= 2^20 pairs, which saturate the GPU's integer pipes, else 4 — shard-sized MSMs are bound by
-        dependent-latency chains and keep gaining up to KZG_NUM_SLOTS).  MSM k+depth-1 is enqueued before MSM k is waited for.
+        (default: 2 for slices of >= 2^20 pairs, which saturate the GPU's integer pipes, else 3 — shard-sized MSMs are bound by
+        dependent-latency chains; a fourth in flight gains or loses depending on the stream -> hardware-queue mapping).  MSM k+depth-1 is enqueued before MSM k is waited for.
         With world > 1 the exchange of partial k is started as soon as MSM k is done and collected one step later (fold on
         the host), so neither its latency nor the host fold sit between two MSMs.  Yields the commitments in order."""
         if depth is None:
-            depth = 2 if self.len >= (1 << 20) else _lib.NUM_SLOTS
+            depth = 2 if self.len >= (1 << 20) else 3
         depth = max(1, min(int(depth), _lib.NUM_SLOTS))
         inflight = collections.deque()
         g = None

@@ -22,9 +22,14 @@ for log_n in (17, 18, 19):
                 assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, None, None, _lib.ptr(out)) == 0
             prev = i & 1
         assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, None, None, _lib.ptr(out)) == 0
-    pipe(6)
-    t0 = time.perf_counter(); pipe(60); dt = time.perf_counter() - t0
-    print("c=%%s n=2^%%d pipelined %%.3f ms/MSM" %% (os.environ.get("KZG_TABLE_C", "auto"), log_n, dt / 60 * 1e3), flush=True)
+    from rust_kzg_bn254_amd.sharding import ShardedMsm
+    sh = ShardedMsm(ctx, n)
+    res = []
+    for depth in (2, 4):
+        list(sh.commit_stream(srs, [d.data_ptr()] * 8, depth=depth))
+        t0 = time.perf_counter(); list(sh.commit_stream(srs, [d.data_ptr()] * 80, depth=depth)); dt = time.perf_counter() - t0
+        res.append(dt / 80 * 1e3)
+    print("c=%%s n=2^%%d pipelined depth2 %%.3f depth4 %%.3f ms/MSM" %% (os.environ.get("KZG_TABLE_C", "auto"), log_n, res[0], res[1]), flush=True)
     srs.close()
 ''' % ROOT
 for c in os.environ.get("SWEEP_C", "auto,11,12,13,14,15,16").split(","):
