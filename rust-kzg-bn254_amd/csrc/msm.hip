@@ -74,6 +74,9 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         // from serialising ~100 dependent mixed adds (10 us each) in a handful of waves
         size_t want = (entries + (size_t)64 * 2730 - 1) / ((size_t)64 * 2730);      // measured best at 2^20 (L = 96); the kernel is issue bound, so the split matters little
         L = (int)std::min<size_t>(96, std::max<size_t>(4, want));
+        // shard-sized MSMs (2^17 pairs x 20 windows): below 24 entries per lane the six-step suffix scan costs more than the
+        // extra waves buy (measured one at a time: L = 15 -> 0.655 ms, 24 -> 0.582 ms, 48 -> 0.656 ms)
+        if (entries >= ((size_t)1 << 21) && L < 24) L = 24;
     }
     p.L = (uint32_t)L;
     p.set_len = (uint32_t)(p.tables ? entries : n);
