@@ -41,7 +41,7 @@ struct MsmWorkspace {
     DeviceBuffer blob;         // staging for blob bytes (asynchronous commit_blob)
     DeviceBuffer bases;        // staging for ad-hoc bases (n x 64 B, device format)
     DeviceBuffer bases_wire;   // staging for ad-hoc bases in wire format
-    DeviceBuffer digits, sorted, count, cursor, blockbase, sort_tmp, sort_small, offs, block_sums, seg_bucket, segsum, bucket, chunkS, chunkTmp, chunkA, out_wire;
+    DeviceBuffer digits, sorted, count, cursor, blockbase, sort_tmp, sort_small, offs, block_sums, seg_bucket, segsum, fold_start, foldsum, bucket, chunkS, chunkTmp, chunkA, out_wire;
     void* pinned_out = nullptr;   // pinned host buffer for window sums
     // optional per-phase timing with HIP events on the launch stream (kzg_ctx_set_profiling)
     static constexpr int N_PHASES = 8;   // digits, scan, scatter, segments, accumulate, bucket_fin, reduce, whole launch

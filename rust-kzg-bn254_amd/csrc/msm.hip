@@ -21,7 +21,7 @@ namespace kzg {
 
 void MsmWorkspace::release() {
     DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &cursor, &blockbase, &sort_tmp, &sort_small, &offs, &block_sums,
-                           &seg_bucket, &segsum, &bucket, &chunkS, &chunkTmp, &chunkA, &out_wire};
+                           &seg_bucket, &segsum, &fold_start, &foldsum, &blob, &bucket, &chunkS, &chunkTmp, &chunkA, &out_wire};
     for (auto* b : all) b->release();
     if (pinned_out) { (void)hipHostFree(pinned_out); pinned_out = nullptr; }
     if (ev_ready) { for (auto& e : ev) (void)hipEventDestroy(e); ev_ready = false; }
@@ -45,6 +45,8 @@ struct Plan {
     uint32_t Hb, tile1, tiles1, tiles2cap;
     uint32_t T, m;       // generic-mode reduction: chunks per window, buckets per chunk
     uint32_t segcap;
+    bool fold;           // many segments per bucket: per-segment partials + k_msm_fold instead of the in-wave suffix scan
+    uint32_t foldcap;
 };
 
 static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint32_t batch) {
@@ -101,6 +103,15 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     p.T = std::min<uint32_t>(p.B, RED_T);
     p.m = p.B / p.T;
     p.segcap = (uint32_t)(entries / p.L + entries / (2 * (size_t)p.L) + std::min<size_t>(p.G, entries) + 1);   // round(cnt / L) <= 1.5 cnt / L + 1
+    {
+        // Fold mode is OFF unless KZG_MSM_FOLD=1: it removes 20-30 % of the arithmetic of a shard-sized MSM (no suffix scan) but
+        // lengthens the dependent chain (8 serial additions + a deeper bucket_fin), and shard-sized MSMs are bound by those chains,
+        // not by arithmetic -- measured per MSM, scan / fold: 2^17 pairs 0.64 / 0.75 ms alone, 0.345 / 0.362 ms with three in
+        // flight; 2^18: 0.82 / 0.92 and 0.544 / 0.526.  Kept (and tested in both modes) for tuning on other shapes.
+        const char* env = getenv("KZG_MSM_FOLD");
+        p.fold = env && atoi(env) != 0;
+        p.foldcap = (uint32_t)(p.segcap / FOLD_F + p.G + 1);
+    }
     return p;
 }
 
@@ -142,6 +153,10 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     KZG_HIP_TRY(ctx, ws.block_sums.reserve((size_t)SCAN_TILE * 8));
     KZG_HIP_TRY(ctx, ws.seg_bucket.reserve((size_t)p.segcap * 4));
     KZG_HIP_TRY(ctx, ws.segsum.reserve((size_t)p.segcap * 36 * 4));
+    if (p.fold) {
+        KZG_HIP_TRY(ctx, ws.fold_start.reserve(((size_t)p.G + 1) * 4));
+        KZG_HIP_TRY(ctx, ws.foldsum.reserve((size_t)p.foldcap * 36 * 4));
+    }
     KZG_HIP_TRY(ctx, ws.bucket.reserve((size_t)p.G * 36 * 4));
     if (p.tables) {
         KZG_HIP_TRY(ctx, ws.chunkS.reserve((size_t)7 * G1 * 36 * 4));          // X1
@@ -218,14 +233,26 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     KZG_MARK(4);
     hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(),
                        ws.seg_bucket.as<uint32_t>(), ws.offs.as<unsigned long long>(), p.G, p.L,
-                       ws.segsum.as<int32_t>(), (size_t)p.segcap);
+                       ws.segsum.as<int32_t>(), (size_t)p.segcap, p.fold ? 0u : 1u);
+    const int32_t* parts = ws.segsum.as<int32_t>();          // what bucket_fin reads
+    size_t parts_stride = (size_t)p.segcap;
+    const uint32_t* fold_start = nullptr;
+    if (p.fold) {
+        hipLaunchKernelGGL(k_fold_offsets, dim3(1), dim3(1024), 0, st, ws.offs.as<unsigned long long>(), p.G, ws.fold_start.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_fold, dim3((p.foldcap + 255) / 256), dim3(256), 0, st, ws.offs.as<unsigned long long>(),
+                           ws.fold_start.as<uint32_t>(), p.G, ws.segsum.as<int32_t>(), (size_t)p.segcap,
+                           ws.foldsum.as<int32_t>(), (size_t)p.foldcap);
+        parts = ws.foldsum.as<int32_t>();
+        parts_stride = (size_t)p.foldcap;
+        fold_start = ws.fold_start.as<uint32_t>();
+    }
     KZG_MARK(5);
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
         hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, 0u, 0u,
-                           ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
+                           parts, parts_stride, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>(), fold_start);
         hipLaunchKernelGGL(k_msm_bucket_fin_heavy, dim3(256), dim3(256), 0, st, ws.offs.as<unsigned long long>(), 0u, 0u,
-                           ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
+                           parts, parts_stride, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>(), fold_start);
         KZG_MARK(6);
         const uint32_t waves1 = G1;
         hipLaunchKernelGGL(k_red_bits1, dim3((waves1 * 64 + 255) / 256), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, p.B, G1,
@@ -243,9 +270,9 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         }
     } else {
         hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, p.m, n_chunks,
-                           ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
+                           parts, parts_stride, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>(), fold_start);
         hipLaunchKernelGGL(k_msm_bucket_fin_heavy, dim3(256), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.m, n_chunks,
-                           ws.segsum.as<int32_t>(), (size_t)p.segcap, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>());
+                           parts, parts_stride, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>(), fold_start);
         const uint32_t gc = (n_chunks + 255) / 256;
         KZG_MARK(6);
         hipLaunchKernelGGL(k_red_chunk_sums, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, n_chunks, p.m,

@@ -334,7 +334,7 @@ __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))        // 4 waves/SIMD (<= 128 VGPRs): 3 waves/SIMD issues ~20 % slower per instruction
 k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted,
                  const uint32_t* __restrict__ seg_bucket, const unsigned long long* __restrict__ offs, uint32_t G, uint32_t L,
-                 int32_t* __restrict__ segsum, size_t seg_stride) {
+                 int32_t* __restrict__ segsum, size_t seg_stride, uint32_t do_scan) {
     const uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t nseg = (uint32_t)(offs[G] >> 32);
@@ -377,6 +377,10 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
             xyzz_madd<true>(acc, p, neg);
         }
     }
+    if (!do_scan) {                                      // fold mode: every segment's partial goes to memory, k_msm_fold combines them
+        if (active) xyzz_store(segsum, seg_stride, sid, acc);
+        return;
+    }
     // segmented suffix scan: acc_lane = sum of the partials of lanes lane .. end of its bucket run in this wave
 #pragma unroll 1
     for (int d = 1; d < 64; d <<= 1) {
@@ -408,17 +412,79 @@ __device__ __forceinline__ uint32_t partial_count(uint32_t s0, uint32_t s1) {
 __device__ __forceinline__ uint32_t partial_sid(uint32_t s0, uint32_t k) { return k == 0 ? s0 : (s0 / 64 + k) * 64; }
 
 constexpr uint32_t FIN_SERIAL_MAX = 4;
+constexpr uint32_t FOLD_F = 8;            // partials one lane of k_msm_fold sums serially
+constexpr uint32_t FOLD_SERIAL_MAX = 8;   // fold mode: bucket_fin sums up to 8 folded partials serially (64 segments)
+
+// ---- fold mode (many segments per bucket: shard-sized MSMs) -------------------------------------------------------------
+// The in-wave suffix scan costs log2(run) full additions on EVERY lane (5-6 steps x 14 multiplies against ~24 mixed adds of
+// 10: +30-55 % work when a bucket spans 27-43 lanes).  Here each lane stores its partial; a second, tiny launch lets one lane
+// sum FOLD_F consecutive partials of one bucket (one addition per partial: work-efficient, longer dependent chain), and
+// bucket_fin adds the <= 8 results of a normal bucket.
+// fold_start[g] = first folded partial of bucket g (exclusive prefix sum of ceil(ns / FOLD_F)), fold_start[G] = total
+__global__ void __launch_bounds__(1024)
+k_fold_offsets(const unsigned long long* __restrict__ offs, uint32_t G, uint32_t* __restrict__ fold_start) {
+    __shared__ uint32_t sums[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (G + 1023) / 1024;
+    const uint32_t lo = min(G, t * per), hi = min(G, lo + per);
+    uint32_t acc = 0;
+    for (uint32_t g = lo; g < hi; ++g) {
+        const uint32_t ns = (uint32_t)(offs[g + 1] >> 32) - (uint32_t)(offs[g] >> 32);
+        acc += (ns + FOLD_F - 1) / FOLD_F;
+    }
+    sums[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {           // inclusive scan of the per-thread totals
+        uint32_t v = t >= d ? sums[t - d] : 0;
+        __syncthreads();
+        sums[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = sums[t] - acc;                       // exclusive prefix of this thread's chunk
+    for (uint32_t g = lo; g < hi; ++g) {
+        fold_start[g] = run;
+        const uint32_t ns = (uint32_t)(offs[g + 1] >> 32) - (uint32_t)(offs[g] >> 32);
+        run += (ns + FOLD_F - 1) / FOLD_F;
+    }
+    if (t == 1023) fold_start[G] = sums[1023];
+}
+// one lane per folded partial: sum of FOLD_F consecutive segment partials of one bucket
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_msm_fold(const unsigned long long* __restrict__ offs, const uint32_t* __restrict__ fold_start, uint32_t G,
+           const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ foldsum, size_t fold_stride) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= fold_start[G]) return;
+    uint32_t lo = 0, hi = G;                             // largest g with fold_start[g] <= t (empty buckets have equal starts)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (fold_start[mid] <= t) lo = mid; else hi = mid;
+    }
+    const uint32_t s0 = (uint32_t)(offs[lo] >> 32), s1 = (uint32_t)(offs[lo + 1] >> 32);
+    const uint32_t a = s0 + (t - fold_start[lo]) * FOLD_F, b = min(a + FOLD_F, s1);
+    Xyzz acc;
+    xyzz_load(acc, segsum, seg_stride, a);
+    for (uint32_t i = a + 1; i < b; ++i) {
+        Xyzz v, r;
+        xyzz_load(v, segsum, seg_stride, i);
+        xyzz_add<true>(r, acc, v);
+        acc = r;
+    }
+    xyzz_store(foldsum, fold_stride, t, acc);
+}
+
 // thread per bucket: buckets with <= 4 surviving partials (the normal case: 1-2) are summed serially; heavier ones
 // (skewed scalars: few distinct digits) are queued for k_msm_bucket_fin_heavy.
 __global__ void __launch_bounds__(256)
 k_msm_bucket_fin(const unsigned long long* __restrict__ offs, uint32_t G, uint32_t m, uint32_t n_chunks,
                  const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ bucket, size_t bucket_stride,
-                 uint32_t* __restrict__ heavy /* [0] = count, [1..] = bucket ids */) {
+                 uint32_t* __restrict__ heavy /* [0] = count, [1..] = bucket ids */,
+                 const uint32_t* __restrict__ fold_start /* fold mode: partials of bucket g = segsum[fold_start[g] .. fold_start[g+1]) */) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
-    const uint32_t s0 = (uint32_t)(offs[g] >> 32), s1 = (uint32_t)(offs[g + 1] >> 32);
-    const uint32_t np = partial_count(s0, s1);
-    if (np > FIN_SERIAL_MAX) {
+    uint32_t s0, s1, np;
+    if (fold_start) { s0 = fold_start[g]; s1 = fold_start[g + 1]; np = s1 - s0; }
+    else { s0 = (uint32_t)(offs[g] >> 32); s1 = (uint32_t)(offs[g + 1] >> 32); np = partial_count(s0, s1); }
+    if (np > (fold_start ? FOLD_SERIAL_MAX : FIN_SERIAL_MAX)) {
         heavy[1 + atomicAdd(&heavy[0], 1u)] = g;
         return;
     }
@@ -426,7 +492,7 @@ k_msm_bucket_fin(const unsigned long long* __restrict__ offs, uint32_t G, uint32
     xyzz_set_inf(acc);
     for (uint32_t k = 0; k < np; ++k) {
         Xyzz v, t;
-        xyzz_load(v, segsum, seg_stride, partial_sid(s0, k));
+        xyzz_load(v, segsum, seg_stride, fold_start ? s0 + k : partial_sid(s0, k));
         xyzz_add<true>(t, acc, v);
         acc = t;
     }
@@ -436,19 +502,20 @@ k_msm_bucket_fin(const unsigned long long* __restrict__ offs, uint32_t G, uint32
 __global__ void __launch_bounds__(256)
 k_msm_bucket_fin_heavy(const unsigned long long* __restrict__ offs, uint32_t m, uint32_t n_chunks,
                        const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ bucket, size_t bucket_stride,
-                       const uint32_t* __restrict__ heavy) {
+                       const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ fold_start) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t count = heavy[0];
     for (uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; h < count; h += n_waves) {
         const uint32_t g = heavy[1 + h];
-        const uint32_t s0 = (uint32_t)(offs[g] >> 32), s1 = (uint32_t)(offs[g + 1] >> 32);
-        const uint32_t np = partial_count(s0, s1);
+        uint32_t s0, s1, np;
+        if (fold_start) { s0 = fold_start[g]; s1 = fold_start[g + 1]; np = s1 - s0; }
+        else { s0 = (uint32_t)(offs[g] >> 32); s1 = (uint32_t)(offs[g + 1] >> 32); np = partial_count(s0, s1); }
         Xyzz acc;
         xyzz_set_inf(acc);
         for (uint32_t k = lane; k < np; k += 64) {
             Xyzz v, t;
-            xyzz_load(v, segsum, seg_stride, partial_sid(s0, k));
+            xyzz_load(v, segsum, seg_stride, fold_start ? s0 + k : partial_sid(s0, k));
             xyzz_add<true>(t, acc, v);
             acc = t;
         }
