@@ -331,7 +331,13 @@ __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
 // the lanes of a wave that share a bucket fold their partials with a SEGMENTED suffix scan over ds_bpermute
 // shuffles (all lanes busy; ~log2(segments per bucket) extra adds).  Only the first lane of each run stores:
 // the surviving partials of bucket g sit at segment ids  s0(g)  and the multiples of 64 inside (s0, s1).
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))        // 4 waves/SIMD (<= 128 VGPRs): 3 waves/SIMD issues ~20 % slower per instruction
+// Waves per SIMD of the accumulate kernel.  3 (<= 168 VGPRs: 4 spilled dwords instead of 12) beats 4 (128 VGPRs) in the real kernel:
+// 1.33 ms against 1.45-1.52 ms per 2^20-pair launch, flat over L = 88..100; unpipelined MSM 1.84 against 2.01 ms, pipelined equal.
+// (The instruction-rate microbenchmark had suggested the opposite; the spills and the second resident round of a 4-wave grid cost more.)
+#ifndef KZG_ACC_WAVES
+#define KZG_ACC_WAVES 3
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KZG_ACC_WAVES, KZG_ACC_WAVES)))
 k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted,
                  const uint32_t* __restrict__ seg_bucket, const unsigned long long* __restrict__ offs, uint32_t G, uint32_t L,
                  int32_t* __restrict__ segsum, size_t seg_stride, uint32_t do_scan) {
