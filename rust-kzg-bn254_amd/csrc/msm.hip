@@ -231,7 +231,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     hipLaunchKernelGGL(k_msm_segments, dim3(gs), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,
                        ws.seg_bucket.as<uint32_t>());
     KZG_MARK(4);
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st,    // 64- / 128-thread workgroups measured the same bases.points, ws.sorted.as<uint32_t>(),
+    // (64- and 128-thread workgroups measured the same as 256)
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(),
                        ws.seg_bucket.as<uint32_t>(), ws.offs.as<unsigned long long>(), p.G, p.L,
                        ws.segsum.as<int32_t>(), (size_t)p.segcap, p.fold ? 0u : 1u);
     const int32_t* parts = ws.segsum.as<int32_t>();          // what bucket_fin reads
