@@ -212,6 +212,20 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_MARK(2);
         hipLaunchKernelGGL(k_sort2_scatter2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
                            ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), ws.sorted.as<uint32_t>());
+    } else if (entries < ((size_t)1 << 18)) {
+        const uint32_t ge = (uint32_t)((entries + 255) / 256);
+        KZG_HIP_TRY(ctx, ws.blockbase.reserve((size_t)p.G * 4));
+        KZG_HIP_TRY(ctx, hipMemsetAsync(ws.blockbase.p, 0, (size_t)p.G * 4, st));
+        hipLaunchKernelGGL(k_sort_small_hist, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.set_len, p.B,
+                           ws.count.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
+                           ws.block_sums.as<unsigned long long>());
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
+        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
+                           ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
+        KZG_MARK(2);
+        hipLaunchKernelGGL(k_sort_small_scatter, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.n, p.set_len, p.B,
+                           ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), bases.table_stride, (uint32_t)p.W, ws.sorted.as<uint32_t>());
     } else {
         hipLaunchKernelGGL(k_sort_hist, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.set_len, p.tile_len,
                            p.tiles_per_set, p.B, ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());

@@ -182,6 +182,33 @@ k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len
     }
 }
 
+// Small problems (< 2^18 entries): the LDS-privatised sort above is sized by the BUCKET count (every tile zeroes and flushes B
+// counters: 57 + 64 us for a 2048-coefficient commitment against a 2^19-point SRS, B = 16384), while a few 10^4 global atomics
+// take microseconds.  One thread per entry; the order inside a bucket is arbitrary (the bucket sum does not depend on it).
+__global__ void __launch_bounds__(256)
+k_sort_small_hist(const uint32_t* __restrict__ digits, uint32_t n_entries, uint32_t set_len, uint32_t B, uint32_t* __restrict__ count) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint32_t v = digits[e];
+    if (v != DIGIT_NONE) atomicAdd(&count[(size_t)(e / set_len) * B + (v & 0x7FFFFFFFu)], 1u);
+}
+__global__ void __launch_bounds__(256)
+k_sort_small_scatter(const uint32_t* __restrict__ digits, uint32_t n_entries, uint32_t n, uint32_t set_len, uint32_t B,
+                     const unsigned long long* __restrict__ offs, uint32_t* __restrict__ cursor /* G zeros */, uint32_t table_stride,
+                     uint32_t windows_per_msm, uint32_t* __restrict__ sorted) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint32_t v = digits[e];
+    if (v == DIGIT_NONE) return;
+    const uint32_t set = e / set_len, es = e - set * set_len;
+    const size_t gb = (size_t)set * B + (v & 0x7FFFFFFFu);
+    const uint32_t pos = (uint32_t)offs[gb] + atomicAdd(&cursor[gb], 1u);
+    uint32_t idx;
+    if (table_stride) { const uint32_t w = es / n; idx = w * table_stride + (es - w * n); }
+    else idx = (set / windows_per_msm) * n + es;
+    sorted[pos] = idx | (v & 0x80000000u);
+}
+
 // -------------------------------------------------------------------------------------------------
 // 3b. two-level counting sort (table mode): coarse bins first, then the low key bits inside every bin
 // -------------------------------------------------------------------------------------------------
