@@ -34,7 +34,7 @@ FR = 218882428718392752222464057452572750885483644004160343436982041865758084956
 LOG_N = int(os.environ.get("KZG_BENCH_LOG_N", "20"))
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 BYTES_PER_PAIR = 96            # 64 B packed affine point + 32 B scalar, each read once
-PMC_JSON = os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r01_v5_pmc_summary.json")
 
 
 def pmc_traffic_bytes(log_n):
