@@ -819,3 +819,34 @@ def test_msm_fold_mode(k, ref_srs, tau_srs, test_srs_wire):
         ref_srs.ctx.set_msm_window(0, 0)
         del os.environ["KZG_MSM_FOLD"]
     assert np.array_equal(got, msm_srs(k, tau_srs, sc))
+
+
+def test_msm_adversarial_digit_patterns(k, tau_srs):
+    """Signed-window recoding corner cases in table mode (one bucket set for all windows): every window digit at the signed
+    boundary (2^(c-1): recoded to -2^(c-1) with a carry), all ones (carry chains through every window), the largest scalar
+    r-1, alternating boundary / zero digits, single top-window digits -- for c = 12 (2^16-point SRS) and c = 16 (2^20-point SRS).
+    Checked against sum_i s_i tau^i on the known-tau SRS (independent big-integer arithmetic)."""
+    def patterns(c):
+        full = (1 << 254) - 1
+        half = sum(1 << (c * w + c - 1) for w in range(0, 254 // c + 1))
+        alt = sum(1 << (c * w + c - 1) for w in range(0, 254 // c + 1, 2))
+        return [half % R_, (half - 1) % R_, full % R_, R_ - 1, R_ - 2, alt % R_, 1 << 253, (1 << 253) - 1, (1 << (c * 3)) - 1, 1, 0]
+
+    def check(srs, n, c):
+        pats = patterns(c)
+        vals = [pats[i % len(pats)] for i in range(n)]
+        got = msm_srs(k, srs, pyref.frs_to_mont(vals))
+        ptau, cur = 0, 1
+        for v in vals:
+            ptau = (ptau + v * cur) % R_
+            cur = cur * TAU % R_
+        assert pyref.point_from_wire(got) == pyref.ec_mul(ptau, (1, 2)), c
+        # all scalars equal to the boundary pattern: every window has one bucket with n entries
+        same = pyref.frs_to_mont([pats[0]] * n)
+        geo = (pow(TAU, n, R_) - 1) * pow(TAU - 1, -1, R_) % R_
+        assert pyref.point_from_wire(msm_srs(k, srs, same)) == pyref.ec_mul(pats[0] * geo % R_, (1, 2)), c
+
+    check(tau_srs, 1 << 16, 12)
+    big = k.SRS.generate(TAU, 1 << 20)
+    check(big, 1 << 18, 16)
+    big.close()
