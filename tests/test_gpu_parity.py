@@ -850,3 +850,35 @@ def test_msm_adversarial_digit_patterns(k, tau_srs):
     big = k.SRS.generate(TAU, 1 << 20)
     check(big, 1 << 18, 16)
     big.close()
+
+
+@pytest.mark.parametrize("log_n", [14, 20, 22])
+def test_ntt_extreme_values(k, log_n):
+    """Magnitude corner cases of the lazy-reduction NTT (values grow by 2m per butterfly stage before the next multiply):
+    a constant vector of r-1 (every butterfly adds two maximal values; transform = n (r-1) at index 0, zero elsewhere), the
+    alternating vector (r-1, 1, r-1, 1, ..) (energy at indices 0 and n/2), and a round trip of a vector of maximal canonical values."""
+    n = 1 << log_n
+    ctx = k.default_context(); lib = k._lib.load()
+    top = pyref.fr_to_mont(R_ - 1)
+    a = np.ascontiguousarray(np.broadcast_to(top, (n, 4))).copy()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(a), n, 0) == 0
+    assert pyref.fr_from_mont(a[0]) == n * (R_ - 1) % R_
+    assert not a[1:].any()
+    b = np.ascontiguousarray(np.broadcast_to(top, (n, 4))).copy()
+    b[1::2] = pyref.fr_to_mont(1)
+    orig = b.copy()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(b), n, 0) == 0
+    half = n // 2
+    assert pyref.fr_from_mont(b[0]) == half * ((R_ - 1) + 1) % R_            # = 0
+    assert pyref.fr_from_mont(b[half]) == half * ((R_ - 1) - 1) % R_
+    mask = np.ones(n, bool); mask[[0, half]] = False
+    assert not b[mask].any()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(b), n, 1) == 0
+    assert np.array_equal(b, orig)
+    rng = np.random.default_rng(log_n)
+    vals = [R_ - 1 - int(x) for x in rng.integers(0, 1000, size=64)]
+    c = np.ascontiguousarray(np.tile(pyref.frs_to_mont(vals), (n // 64, 1)))
+    orig = c.copy()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(c), n, 1) == 0
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(c), n, 0) == 0
+    assert np.array_equal(c, orig)
