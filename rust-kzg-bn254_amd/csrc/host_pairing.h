@@ -82,13 +82,21 @@ inline G1 g1_add(const G1& a, const G1& b) {
     r.y = sub(mul(lam, sub(a.x, r.x)), a.y);
     return r;
 }
-inline G1 g1_mul(const G1& p, const uint64_t k[4]) {
-    G1 acc; acc.x = fq_zero(); acc.y = fq_zero(); acc.inf = true;
+inline G1 g1_mul(const G1& p, const uint64_t k[4]) {             // XYZZ double-and-add, one inversion at the end
+    G1 out; out.x = fq_zero(); out.y = fq_zero(); out.inf = true;
+    if (p.inf) return out;
+    Xyzz base; base.x = p.x; base.y = p.y; base.zz = FQ_ONE; base.zzz = FQ_ONE;
+    Xyzz acc = xyzz_inf();
     for (int i = 255; i >= 0; --i) {
-        acc = g1_add(acc, acc);
-        if ((k[i >> 6] >> (i & 63)) & 1) acc = g1_add(acc, p);
+        acc = xyzz_dbl(acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) acc = xyzz_add(acc, base);
     }
-    return acc;
+    if (is_inf(acc)) return out;
+    Fq iz = inv(mul(acc.zz, acc.zzz));
+    out.x = mul(acc.x, mul(iz, acc.zzz));
+    out.y = mul(acc.y, mul(iz, acc.zz));
+    out.inf = false;
+    return out;
 }
 inline void g1_to_wire(const G1& p, uint64_t xy[8]) {
     if (p.inf) { memset(xy, 0, 64); return; }
@@ -146,13 +154,49 @@ inline G2 g2_add(const G2& a, const G2& b) {
     r.y = sub(mul(lam, sub(a.x, r.x)), a.y);
     return r;
 }
-inline G2 g2_mul(const G2& p, const uint64_t k[4]) {
-    G2 acc = g2_inf();
-    for (int i = 255; i >= 0; --i) {
-        acc = g2_add(acc, acc);
-        if ((k[i >> 6] >> (i & 63)) & 1) acc = g2_add(acc, p);
+// Jacobian double-and-add over Fq2 (a = 0), one inversion at the end; the affine g2_add above stays for single additions
+struct G2Jac { Fq2 X, Y, Z; bool inf; };
+inline Fq2 dbl2(const Fq2& a) { return add(a, a); }
+inline G2Jac g2j_dbl(const G2Jac& t) {                             // dbl-2009-l
+    if (t.inf || is_zero(t.Y)) { G2Jac r = t; r.inf = true; return r; }
+    Fq2 A = sqr(t.X), B = sqr(t.Y), C = sqr(B);
+    Fq2 D = dbl2(sub(sub(sqr(add(t.X, B)), A), C));
+    Fq2 E = add(dbl2(A), A);
+    G2Jac r; r.inf = false;
+    r.X = sub(sqr(E), dbl2(D));
+    r.Y = sub(mul(E, sub(D, r.X)), dbl2(dbl2(dbl2(C))));
+    r.Z = dbl2(mul(t.Y, t.Z));
+    return r;
+}
+inline G2Jac g2j_madd(const G2Jac& t, const G2& p) {               // mixed addition with an affine point
+    if (p.inf) return t;
+    if (t.inf) { G2Jac r; r.X = p.x; r.Y = p.y; r.Z = {FQ_ONE, fq_zero()}; r.inf = false; return r; }
+    Fq2 Z2 = sqr(t.Z);
+    Fq2 H = sub(mul(p.x, Z2), t.X);
+    Fq2 rr = sub(mul(p.y, mul(Z2, t.Z)), t.Y);
+    if (is_zero(H)) {
+        if (is_zero(rr)) return g2j_dbl(t);
+        G2Jac r = t; r.inf = true; return r;
     }
-    return acc;
+    Fq2 HH = sqr(H), HHH = mul(H, HH), V = mul(t.X, HH);
+    G2Jac r; r.inf = false;
+    r.X = sub(sub(sqr(rr), HHH), dbl2(V));
+    r.Y = sub(mul(rr, sub(V, r.X)), mul(t.Y, HHH));
+    r.Z = mul(t.Z, H);
+    return r;
+}
+inline G2 g2_mul(const G2& p, const uint64_t k[4]) {
+    G2Jac acc; acc.inf = true; acc.X = {fq_zero(), fq_zero()}; acc.Y = acc.X; acc.Z = acc.X;
+    for (int i = 255; i >= 0; --i) {
+        acc = g2j_dbl(acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) acc = g2j_madd(acc, p);
+    }
+    if (acc.inf) return g2_inf();
+    Fq2 zi = inv(acc.Z), zi2 = sqr(zi);
+    G2 r; r.inf = false;
+    r.x = mul(acc.X, zi2);
+    r.y = mul(acc.Y, mul(zi2, zi));
+    return r;
 }
 
 // ---- Fq12 = Fq[w] / (w^12 - 18 w^6 + 82) ----------------------------------------------------------------------------------------
