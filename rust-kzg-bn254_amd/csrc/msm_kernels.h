@@ -361,6 +361,12 @@ __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
 // Waves per SIMD of the accumulate kernel.  3 (<= 168 VGPRs: 4 spilled dwords instead of 12) beats 4 (128 VGPRs) in the real kernel:
 // 1.33 ms against 1.45-1.52 ms per 2^20-pair launch, flat over L = 88..100; unpipelined MSM 1.84 against 2.01 ms, pipelined equal.
 // (The instruction-rate microbenchmark had suggested the opposite; the spills and the second resident round of a 4-wave grid cost more.)
+// experiment switch: -DKZG_ACC_NOGATHER makes every lane read the same few table points (no HBM gather) to time the arithmetic alone
+#ifdef KZG_ACC_NOGATHER
+#define KZG_ACC_IDX(v) ((v) & 0xFFu)
+#else
+#define KZG_ACC_IDX(v) ((v) & 0x7FFFFFFFu)
+#endif
 #ifndef KZG_ACC_WAVES
 #define KZG_ACC_WAVES 3
 #endif
@@ -390,7 +396,7 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
         // load (dependent address) nor the 64-byte gather is waited for inside an iteration
         uint32_t v = sorted[begin];
         uint32_t v1 = (begin + 1 < end) ? sorted[begin + 1] : 0u;
-        const uint4* src = points + 4 * (size_t)(v & 0x7FFFFFFFu);
+        const uint4* src = points + 4 * (size_t)(KZG_ACC_IDX(v));
         uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
         for (uint32_t e = begin; e < end; ++e) {
             const uint32_t neg = v >> 31;
@@ -399,7 +405,7 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
             const uint32_t any = q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x | q2.y | q2.z | q2.w | q3.x | q3.y | q3.z | q3.w;
             if (e + 1 < end) {
                 v = v1;
-                src = points + 4 * (size_t)(v & 0x7FFFFFFFu);
+                src = points + 4 * (size_t)(KZG_ACC_IDX(v));
                 q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
                 if (e + 2 < end) v1 = sorted[e + 2];
             }
