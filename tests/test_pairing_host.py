@@ -152,3 +152,52 @@ def test_compute_r_powers_transcript_layout(test_srs_wire):
     r = int.from_bytes(orc.sha256(data), "big") % R_
     assert kzg.fr.frs_to_ints(got) == [1, r]
     assert len(verifier.compute_r_powers([], [], [], [], [])) == 0
+
+
+def test_g2_tau_matches_reference_g2_powers_fixture():
+    """The reference tree ships mainnet G2 powers [tau^(2^i)]G2 (prover/tests/test-files/mainnet-data/g2.point.powerOf2, gnark
+    compressed form: 64 bytes = X.A1 || X.A0 big-endian, top two bits = infinity / smaller-y / larger-y).  Entry 0 must be
+    consts::G2_TAU (primitives/src/consts.rs:55-64) as this library holds it; every entry must lie on the twist."""
+    P = pyref.P
+    data = open(os.path.join(GOLDEN, "g2.point.powerOf2"), "rb").read()
+    assert len(data) == 28 * 64
+
+    def sqrt_fq(a):
+        r = pow(a, (P + 1) // 4, P)
+        return r if r * r % P == a % P else None
+
+    def mul2(a, b):
+        return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+    def fq2_sqrt(a0, a1):
+        if a1 == 0:
+            r = sqrt_fq(a0)
+            return (r, 0) if r is not None else (0, sqrt_fq((-a0) % P))
+        alpha = sqrt_fq((a0 * a0 + a1 * a1) % P)
+        assert alpha is not None
+        half = pow(2, -1, P)
+        x0 = sqrt_fq((a0 + alpha) * half % P)
+        if x0 is None:
+            x0 = sqrt_fq((a0 - alpha) * half % P)
+        return (x0, a1 * pow(2 * x0, -1, P) % P)
+
+    inv82 = pow(82, -1, P)
+    b2 = (27 * inv82 % P, (-3 * inv82) % P)                       # 3 / (9 + u)
+    larger = lambda v: (v[1] > (P - 1) // 2) if v[1] else (v[0] > (P - 1) // 2)     # noqa: E731
+    points = []
+    for i in range(28):
+        ch = data[64 * i:64 * i + 64]
+        flag = ch[0] >> 6
+        assert flag in (2, 3)
+        x = (int.from_bytes(ch[32:64], "big"), int.from_bytes(bytes([ch[0] & 0x3F]) + ch[1:32], "big"))
+        x3 = mul2(mul2(x, x), x)
+        rhs = ((x3[0] + b2[0]) % P, (x3[1] + b2[1]) % P)
+        y = fq2_sqrt(*rhs)
+        assert mul2(y, y) == rhs, i                               # on the twist
+        neg = ((-y[0]) % P, (-y[1]) % P)
+        y = (y if larger(y) else neg) if flag == 3 else (neg if larger(y) else y)
+        points.append((x, y))
+    lib_tau = helpers.g2_tau()
+    got = tuple(kzg.fr.fq_to_int(lib_tau[4 * j:4 * j + 4]) for j in range(4))       # x.c0, x.c1, y.c0, y.c1
+    assert got == (points[0][0][0], points[0][0][1], points[0][1][0], points[0][1][1])
+    assert len(set(points)) == 28
