@@ -358,15 +358,10 @@ __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
 // the lanes of a wave that share a bucket fold their partials with a SEGMENTED suffix scan over ds_bpermute
 // shuffles (all lanes busy; ~log2(segments per bucket) extra adds).  Only the first lane of each run stores:
 // the surviving partials of bucket g sit at segment ids  s0(g)  and the multiples of 64 inside (s0, s1).
-// Waves per SIMD of the accumulate kernel.  3 (<= 168 VGPRs: 4 spilled dwords instead of 12) beats 4 (128 VGPRs) in the real kernel:
-// 1.33 ms against 1.45-1.52 ms per 2^20-pair launch, flat over L = 88..100; unpipelined MSM 1.84 against 2.01 ms, pipelined equal.
-// (The instruction-rate microbenchmark had suggested the opposite; the spills and the second resident round of a 4-wave grid cost more.)
-// experiment switch: -DKZG_ACC_NOGATHER makes every lane read the same few table points (no HBM gather) to time the arithmetic alone
-#ifdef KZG_ACC_NOGATHER
-#define KZG_ACC_IDX(v) ((v) & 0xFFu)
-#else
-#define KZG_ACC_IDX(v) ((v) & 0x7FFFFFFFu)
-#endif
+// Waves per SIMD of the accumulate kernel: 3 (<= 168 VGPRs, 4 spilled dwords) or 4 (128 VGPRs, ~50 spilled dwords).  Measured back to
+// back on one box they are equal (1.499 / 1.494 ms per 2^20-pair launch at L = 96), as are variants without the point prefetch: the
+// kernel is bound by instruction issue, and the GPU boxes of the pool differ by +-6 % among themselves (1.33 .. 1.50 ms for the same
+// binary), which is more than any of these variants.  3 is kept for the smaller scratch traffic (1.29 vs 1.63 GB per launch, PMC).
 #ifndef KZG_ACC_WAVES
 #define KZG_ACC_WAVES 3
 #endif
