@@ -362,6 +362,12 @@ __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
 // back on one box they are equal (1.499 / 1.494 ms per 2^20-pair launch at L = 96), as are variants without the point prefetch: the
 // kernel is bound by instruction issue, and the GPU boxes of the pool differ by +-6 % among themselves (1.33 .. 1.50 ms for the same
 // binary), which is more than any of these variants.  3 is kept for the smaller scratch traffic (1.29 vs 1.63 GB per launch, PMC).
+// experiment switch: -DKZG_ACC_NOGATHER makes every lane read the same few table points (no HBM gather) to time the arithmetic alone
+#ifdef KZG_ACC_NOGATHER
+#define KZG_ACC_IDX(v) ((v) & 0xFFu)
+#else
+#define KZG_ACC_IDX(v) ((v) & 0x7FFFFFFFu)
+#endif
 #ifndef KZG_ACC_WAVES
 #define KZG_ACC_WAVES 3
 #endif
