@@ -83,7 +83,7 @@ inline void fe_check_mul_operands(const Fe<F>& a, const Fe<F>& b, const char* wh
 // signed one, gives up v_mad_i64_i32 for a v_mad_u64_u32 + sign-correction pair (2 mads + 2 moves per product: +7 % VALU
 // instructions in the mixed add).  Passing operand limbs through an empty asm hides the range without emitting code.
 KZG_HD int32_t fe_opaque(int32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_OPAQUE)      // -DKZG_NO_OPAQUE: A/B switch for the measurement in DESIGN.md section 4
     asm("" : "+v"(x));
 #endif
     return x;
