@@ -12,7 +12,7 @@ import numpy as np
 from .errors import DeviceError
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkzg_bn254_mi355x.so")
+LIB_PATH = os.environ.get("KZG_LIB_PATH") or os.path.join(HERE, "libkzg_bn254_mi355x.so")   # KZG_LIB_PATH: A/B builds of the same library (tools/)
 
 # status codes (include/kzg_bn254_mi355x.h)
 OK = 0

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -77,6 +78,14 @@ int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out) {
     kzg_ctx* ctx = new (std::nothrow) kzg_ctx();
     if (!ctx) return KZG_ERR_INVALID_ARG;
     ctx->device = device_id;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+            ctx->acc_wave_slots = (uint32_t)cus * 4u * 3u;                // k_msm_accumulate: 3 waves per SIMD (KZG_ACC_WAVES)
+        else (void)hipGetLastError();
+        const char* env = getenv("KZG_ACC_SLOTS");
+        if (env && atoi(env) > 0) ctx->acc_wave_slots = (uint32_t)atoi(env);
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete ctx; return KZG_ERR_DEVICE; }
     *out = ctx;
     return KZG_OK;

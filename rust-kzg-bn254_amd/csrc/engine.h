@@ -24,27 +24,16 @@ struct DeviceBuffer {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct MsmPlan {
-    uint32_t n;        // pairs in this launch
-    int c;             // window bits
-    int W;             // windows = ceil(255 / c)
-    uint32_t B;        // buckets per window = 2^(c-1)
-    uint32_t G;        // W * B
-    uint32_t L;        // segment length
-    uint32_t T;        // chunks per window in the reduction
-    uint32_t m;        // buckets per chunk
-    uint32_t segcap;   // upper bound on #segments
-};
-
 struct MsmWorkspace {
     DeviceBuffer scalars;      // staging for host scalars (n x 32 B)
     DeviceBuffer blob;         // staging for blob bytes (asynchronous commit_blob)
     DeviceBuffer bases;        // staging for ad-hoc bases (n x 64 B, device format)
     DeviceBuffer bases_wire;   // staging for ad-hoc bases in wire format
-    DeviceBuffer digits, sorted, count, cursor, blockbase, sort_tmp, sort_small, offs, block_sums, seg_bucket, segsum, fold_start, foldsum, bucket, chunkS, chunkTmp, chunkA, out_wire;
+    DeviceBuffer digits, sorted, count, blockbase, sort_tmp, sort_small, offs, block_sums, bucket, chunkS, chunkTmp, chunkA, out_wire;
+    DeviceBuffer head, cont;   // accumulate partials: head[g] per bucket, cont[t] per lane (36 limb planes each; msm_kernels.h section 4)
     void* pinned_out = nullptr;   // pinned host buffer for window sums
     // optional per-phase timing with HIP events on the launch stream (kzg_ctx_set_profiling)
-    static constexpr int N_PHASES = 8;   // digits, scan, scatter, segments, accumulate, bucket_fin, reduce, whole launch
+    static constexpr int N_PHASES = 8;   // digits, sort (histograms + scan), scatter, (unused), accumulate, bucket sums + reduce level 1, reduce level 2, whole launch
     hipEvent_t ev[N_PHASES] = {};
     bool ev_ready = false;
     hipEvent_t ev_done = nullptr;   // recorded behind the result copy of the MSM in flight on this workspace
@@ -83,6 +72,7 @@ struct kzg_ctx {
     int msm_seg_override = 0;
     bool profiling = false;
     bool lds_attr_set = false;
+    uint32_t acc_wave_slots = 3 * 1024;   // resident waves of the accumulate kernel on this device: 3 per SIMD x 4 SIMDs x CUs (set at kzg_ctx_create)
     kzg::MsmWorkspace msm;
     kzg::MsmWorkspace msm_x[KZG_NUM_SLOTS - 1];   // workspaces of slots 1.. of the asynchronous calls
     hipStream_t stream_x[KZG_NUM_SLOTS - 1] = {}; // one stream per slot (slot 0: `stream`), created on first use

@@ -94,6 +94,18 @@ KZG_HD void fe_opaque_limbs(int32_t (&o)[NL], const Fe<F>& a) {
     for (int j = 0; j < NL; ++j) o[j] = fe_opaque(a.l[j]);
 }
 
+// One multiply-accumulate step of a column sum.  The empty asm on the accumulator keeps the additions in SOURCE order: LLVM's
+// reassociation sorts the operands of a long integer sum by rank, which moves the carry of the previous column (the latest
+// value) to the END of the chain -- where it can no longer be the addend of a v_mad_i64_i32 and costs one 64-bit add per
+// column (146 v_lshl_add_u64 per mixed addition, 6.5 % of its instructions).  With the barrier every column is ONE chain of
+// mads that starts from the carry.  -DKZG_NO_CHAIN: A/B switch.
+KZG_HD void fe_mac(int64_t& acc, int32_t a, int32_t b) {
+    acc += (int64_t)a * (int64_t)b;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_CHAIN)
+    asm("" : "+v"(acc));
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Montgomery product a * b * 2^-261 mod m.  Finely-integrated product scanning: column k sums
 // a_j b_(k-j) and m_j p_(k-j); its low 29 bits are cancelled by m_k p_0; the rest carries on.
@@ -110,19 +122,19 @@ KZG_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
-        for (int j = 0; j <= k; ++j) acc += (int64_t)al[j] * (int64_t)bl[k - j];
+        for (int j = 0; j <= k; ++j) fe_mac(acc, al[j], bl[k - j]);
 #pragma unroll
-        for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        for (int j = 0; j < k; ++j) fe_mac(acc, m[j], (int32_t)F::P[k - j]);
         m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
-        acc += (int64_t)m[k] * (int64_t)(int32_t)F::P[0];
+        fe_mac(acc, m[k], (int32_t)F::P[0]);
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
-        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)al[j] * (int64_t)bl[k - j];
+        for (int j = k - NL + 1; j < NL; ++j) fe_mac(acc, al[j], bl[k - j]);
 #pragma unroll
-        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        for (int j = k - NL + 1; j < NL; ++j) fe_mac(acc, m[j], (int32_t)F::P[k - j]);
         out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
         acc >>= LB;
     }
@@ -168,24 +180,24 @@ KZG_HD void fe_mulsub(Fe<F>& r, const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, 
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
         for (int j = 0; j <= k; ++j) {
-            acc += (int64_t)al[j] * (int64_t)bl[k - j];
-            acc += (int64_t)ncl[j] * (int64_t)dl[k - j];
+            fe_mac(acc, al[j], bl[k - j]);
+            fe_mac(acc, ncl[j], dl[k - j]);
         }
 #pragma unroll
-        for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        for (int j = 0; j < k; ++j) fe_mac(acc, m[j], (int32_t)F::P[k - j]);
         m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
-        acc += (int64_t)m[k] * (int64_t)(int32_t)F::P[0];
+        fe_mac(acc, m[k], (int32_t)F::P[0]);
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
         for (int j = k - NL + 1; j < NL; ++j) {
-            acc += (int64_t)al[j] * (int64_t)bl[k - j];
-            acc += (int64_t)ncl[j] * (int64_t)dl[k - j];
+            fe_mac(acc, al[j], bl[k - j]);
+            fe_mac(acc, ncl[j], dl[k - j]);
         }
 #pragma unroll
-        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        for (int j = k - NL + 1; j < NL; ++j) fe_mac(acc, m[j], (int32_t)F::P[k - j]);
         out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
         acc >>= LB;
     }
@@ -209,21 +221,21 @@ KZG_HD void fe_sqr(Fe<F>& r, const Fe<F>& a) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
-        for (int j = 0; 2 * j < k; ++j) acc += (int64_t)a2[j] * (int64_t)al[k - j];
-        if ((k & 1) == 0) acc += (int64_t)al[k / 2] * (int64_t)al[k / 2];
+        for (int j = 0; 2 * j < k; ++j) fe_mac(acc, a2[j], al[k - j]);
+        if ((k & 1) == 0) fe_mac(acc, al[k / 2], al[k / 2]);
 #pragma unroll
-        for (int j = 0; j < k; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        for (int j = 0; j < k; ++j) fe_mac(acc, m[j], (int32_t)F::P[k - j]);
         m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
-        acc += (int64_t)m[k] * (int64_t)(int32_t)F::P[0];
+        fe_mac(acc, m[k], (int32_t)F::P[0]);
         acc >>= LB;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
-        for (int j = k - NL + 1; 2 * j < k; ++j) acc += (int64_t)a2[j] * (int64_t)al[k - j];
-        if ((k & 1) == 0) acc += (int64_t)al[k / 2] * (int64_t)al[k / 2];
+        for (int j = k - NL + 1; 2 * j < k; ++j) fe_mac(acc, a2[j], al[k - j]);
+        if ((k & 1) == 0) fe_mac(acc, al[k / 2], al[k / 2]);
 #pragma unroll
-        for (int j = k - NL + 1; j < NL; ++j) acc += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        for (int j = k - NL + 1; j < NL; ++j) fe_mac(acc, m[j], (int32_t)F::P[k - j]);
         out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
         acc >>= LB;
     }

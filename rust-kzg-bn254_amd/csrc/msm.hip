@@ -16,12 +16,16 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace kzg {
 
+constexpr uint32_t MSM_MAX_OUT = 4096;         // XYZZ values one launch may hand to the host epilogue (generic mode: W * batch window sums)
+constexpr size_t SORT1_MAX_LDS = 131072;       // single-pass sort: one LDS counter per bucket (<= 2^15 buckets)
+
 void MsmWorkspace::release() {
-    DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &cursor, &blockbase, &sort_tmp, &sort_small, &offs, &block_sums,
-                           &seg_bucket, &segsum, &fold_start, &foldsum, &blob, &bucket, &chunkS, &chunkTmp, &chunkA, &out_wire};
+    DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &blockbase, &sort_tmp, &sort_small, &offs, &block_sums,
+                           &head, &cont, &blob, &bucket, &chunkS, &chunkTmp, &chunkA, &out_wire};
     for (auto* b : all) b->release();
     if (pinned_out) { (void)hipHostFree(pinned_out); pinned_out = nullptr; }
     if (ev_ready) { for (auto& e : ev) (void)hipEventDestroy(e); ev_ready = false; }
@@ -38,16 +42,21 @@ struct Plan {
     uint32_t B;          // buckets per set
     uint32_t sets;       // bucket sets (1 in table mode, W otherwise)
     uint32_t G;          // sets * B
-    uint32_t L;          // segment length
+    uint32_t nl;         // lanes of the accumulate kernel (a multiple of 256); each adds ceil(E / nl) sorted entries
     uint32_t set_len;    // digit entries per set
     uint32_t tile_len, tiles_per_set, tiles;
-    bool sort2;          // two-level sort (table mode, index fits 25 bits)
+    bool sort2;          // two-level sort (table mode, index fits 24 bits)
+    bool sort_small;     // global-atomic sort (few entries)
     uint32_t Hb, tile1, tiles1, tiles2cap;
     uint32_t T, m;       // generic-mode reduction: chunks per window, buckets per chunk
-    uint32_t segcap;
-    bool fold;           // many segments per bucket: per-segment partials + k_msm_fold instead of the in-wave suffix scan
-    uint32_t foldcap;
 };
+
+// Window bits of the generic mode for `batch` MSMs of n pairs: W * batch window sums leave the device (<= MSM_MAX_OUT).
+static int generic_window(size_t n, uint32_t batch) {
+    int c = std::min(14, std::max(4, ilog2_floor(n) - 6));
+    while (c < 16 && (size_t)((255 + c - 1) / c) * batch > MSM_MAX_OUT) ++c;
+    return c;
+}
 
 static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint32_t batch) {
     Plan p;
@@ -60,7 +69,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     } else {
         c = ctx->msm_c_override;
         if (c == 0) { const char* env = getenv("KZG_MSM_C"); if (env) c = atoi(env); }
-        if (c == 0) c = std::min(14, std::max(4, ilog2_floor(n) - 6));
+        if (c == 0) c = generic_window(n, batch);
         c = std::min(16, std::max(2, c));
     }
     p.c = c;
@@ -68,21 +77,26 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     p.B = 1u << (c - 1);
     p.sets = p.tables ? 1u : (uint32_t)p.W * batch;
     p.G = p.sets * p.B;
-    int L = ctx->msm_seg_override;
-    if (L == 0) { const char* env = getenv("KZG_MSM_SEG"); if (env) L = atoi(env); }
     const size_t entries = (size_t)p.W * n * batch;
-    if (L <= 0) {
-        // one lane per segment: aim at ~2 700 waves; short segments keep small MSMs
-        // from serialising ~100 dependent mixed adds (10 us each) in a handful of waves
-        size_t want = (entries + (size_t)64 * 2730 - 1) / ((size_t)64 * 2730);      // measured best at 2^20 (L = 96); the kernel is issue bound, so the split matters little
-        L = (int)std::min<size_t>(96, std::max<size_t>(4, want));
-        // shard-sized MSMs (2^17 pairs x 20 windows): below 24 entries per lane the six-step suffix scan costs more than the
-        // extra waves buy (measured one at a time: L = 15 -> 0.655 ms, 24 -> 0.582 ms, 48 -> 0.656 ms)
-        if (entries >= ((size_t)1 << 21) && L < 24) L = 24;
+    {
+        // Lanes of the accumulate kernel.  Large MSMs: one full round of resident waves (ctx->acc_wave_slots = 3 per SIMD), every
+        // lane with the same trip count.  Small MSMs: at least Lmin entries per lane -- short trips keep them from serialising
+        // ~100 dependent mixed adds (10 us each) in a handful of waves; from 2^21 entries on, below 24 entries per lane the
+        // folding of the lane partials costs more than the extra waves buy (measured in round 1: 15 -> 0.655 ms, 24 -> 0.582 ms).
+        int L = ctx->msm_seg_override;
+        if (L == 0) { const char* env = getenv("KZG_MSM_SEG"); if (env) L = atoi(env); }
+        size_t lanes;
+        if (L > 0) {
+            lanes = (entries + (size_t)L - 1) / (size_t)L;                 // forced trip count (tests, sweeps): no cap
+        } else {
+            const size_t lmin = entries >= ((size_t)1 << 21) ? 24 : 4;
+            lanes = std::min<size_t>((size_t)ctx->acc_wave_slots * 64, (entries + lmin - 1) / lmin);
+        }
+        lanes = std::max<size_t>(256, (lanes + 255) / 256 * 256);
+        p.nl = (uint32_t)std::min<size_t>(lanes, (size_t)1 << 24);
     }
-    p.L = (uint32_t)L;
     p.set_len = (uint32_t)(p.tables ? entries : n);
-    // sort tiles: large against the bucket count (one contiguous flush of B counters per tile), and not too many
+    // single-pass sort tiles: large against the bucket count (one contiguous flush of B counters per tile), and not too many
     size_t mult = 2;
     { const char* env = getenv("KZG_SORT_TILE_MULT"); if (env && atoi(env) > 0) mult = (size_t)atoi(env); }
     size_t tile = std::max<size_t>(4096, mult * p.B);
@@ -93,8 +107,13 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     {
         const char* env = getenv("KZG_SORT2");
         const bool want = !(env && atoi(env) == 0);
-        p.sort2 = want && p.tables && p.c - 1 > SORT2_LO_BITS + 1 && p.c - 1 - SORT2_LO_BITS <= 9 &&
-                  (size_t)p.W * bases.table_stride <= ((size_t)1 << 25) && entries >= ((size_t)1 << 23);   // ~0.1 ms of extra launches: only pays on large sorts
+        const bool lds_fits = (size_t)p.B * 4 <= SORT1_MAX_LDS;            // single-pass sort: one LDS counter per bucket
+        p.sort_small = entries < ((size_t)1 << 18);
+        const bool can2 = p.tables && p.c - 1 > SORT2_LO_BITS && (p.B >> SORT2_LO_BITS) <= SORT2_MAX_BINS &&
+                          (size_t)p.W * bases.table_stride <= ((size_t)1 << SORT2_IDX_BITS);
+        // ~0.05 ms of extra launches: pays on large sorts, and is the only LDS sort for 2^16 buckets
+        p.sort2 = !p.sort_small && can2 && ((want && entries >= ((size_t)1 << 23)) || !lds_fits);
+        if (!p.sort2 && !lds_fits) p.sort_small = true;                    // (slow but correct: a forced odd configuration)
         p.Hb = p.sort2 ? (p.B >> SORT2_LO_BITS) : 0;
         p.tile1 = 32768;
         p.tiles1 = (uint32_t)((entries + p.tile1 - 1) / p.tile1);
@@ -102,16 +121,6 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     }
     p.T = std::min<uint32_t>(p.B, RED_T);
     p.m = p.B / p.T;
-    p.segcap = (uint32_t)(entries / p.L + entries / (2 * (size_t)p.L) + std::min<size_t>(p.G, entries) + 1);   // round(cnt / L) <= 1.5 cnt / L + 1
-    {
-        // Fold mode is OFF unless KZG_MSM_FOLD=1: it removes 20-30 % of the arithmetic of a shard-sized MSM (no suffix scan) but
-        // lengthens the dependent chain (8 serial additions + a deeper bucket_fin), and shard-sized MSMs are bound by those chains,
-        // not by arithmetic -- measured per MSM, scan / fold: 2^17 pairs 0.64 / 0.75 ms alone, 0.345 / 0.362 ms with three in
-        // flight; 2^18: 0.82 / 0.92 and 0.544 / 0.526.  Kept (and tested in both modes) for tuning on other shapes.
-        const char* env = getenv("KZG_MSM_FOLD");
-        p.fold = env && atoi(env) != 0;
-        p.foldcap = (uint32_t)(p.segcap / FOLD_F + p.G + 1);
-    }
     return p;
 }
 
@@ -133,44 +142,46 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     const Plan p = make_plan(ctx, n, bases, batch);
     const size_t entries = (size_t)p.W * n * batch;
     const uint32_t n_windows = (uint32_t)p.W * batch;          // window sums produced in generic mode
-    if (!p.tables && n_windows > 1024) return KZG_ERR_INVALID_ARG;
+    if (!p.tables && n_windows > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
     const uint32_t n_chunks = n_windows * p.T;
     const uint32_t nb = (p.G + SCAN_TILE - 1) / SCAN_TILE;
-    if (nb > SCAN_TILE) return KZG_ERR_INVALID_ARG;
+    if (p.G > SCAN1_MAX && nb > SCAN_TILE) return KZG_ERR_INVALID_ARG;
     const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
+    if (p.tables && G1 > 1 && 13 * G1p > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
 
     KZG_HIP_TRY(ctx, ws.digits.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.sorted.reserve(entries * 4));
-    KZG_HIP_TRY(ctx, ws.count.reserve((size_t)p.G * 4));
-    KZG_HIP_TRY(ctx, ws.blockbase.reserve((size_t)p.tiles * p.B * 4));
-    KZG_HIP_TRY(ctx, ws.cursor.reserve(((size_t)p.G + 1) * 4));          // queue of heavy buckets
+    KZG_HIP_TRY(ctx, ws.count.reserve((size_t)p.G * 4 + 16));
     if (p.sort2) {
         KZG_HIP_TRY(ctx, ws.sort_tmp.reserve(entries * 4));
         KZG_HIP_TRY(ctx, ws.sort_small.reserve(((size_t)3 * (p.Hb + 1) + p.tiles2cap) * 4 + 64));
         KZG_HIP_TRY(ctx, ws.blockbase.reserve(std::max((size_t)p.tiles1 * p.Hb, (size_t)p.tiles2cap * SORT2_LO) * 4));
+    } else if (p.sort_small) {
+        KZG_HIP_TRY(ctx, ws.blockbase.reserve((size_t)p.G * 4));
+    } else {
+        KZG_HIP_TRY(ctx, ws.blockbase.reserve((size_t)p.tiles * p.B * 4));
     }
-    KZG_HIP_TRY(ctx, ws.offs.reserve(((size_t)p.G + 1) * 8));
-    KZG_HIP_TRY(ctx, ws.block_sums.reserve((size_t)SCAN_TILE * 8));
-    KZG_HIP_TRY(ctx, ws.seg_bucket.reserve((size_t)p.segcap * 4));
-    KZG_HIP_TRY(ctx, ws.segsum.reserve((size_t)p.segcap * 36 * 4));
-    if (p.fold) {
-        KZG_HIP_TRY(ctx, ws.fold_start.reserve(((size_t)p.G + 1) * 4));
-        KZG_HIP_TRY(ctx, ws.foldsum.reserve((size_t)p.foldcap * 36 * 4));
-    }
-    KZG_HIP_TRY(ctx, ws.bucket.reserve((size_t)p.G * 36 * 4));
+    KZG_HIP_TRY(ctx, ws.offs.reserve(((size_t)p.G + 1) * 4 + 16));
+    KZG_HIP_TRY(ctx, ws.block_sums.reserve((size_t)SCAN_TILE * 4));
+    KZG_HIP_TRY(ctx, ws.head.reserve((size_t)p.G * 36 * 4));
+#ifdef KZG_ACC_STAMPS
+    KZG_HIP_TRY(ctx, ws.cont.reserve((size_t)p.nl * 36 * 4 + (size_t)(p.nl / 64) * 64));
+#else
+    KZG_HIP_TRY(ctx, ws.cont.reserve((size_t)p.nl * 36 * 4));
+#endif
     if (p.tables) {
         KZG_HIP_TRY(ctx, ws.chunkS.reserve((size_t)7 * G1 * 36 * 4));          // X1
-        KZG_HIP_TRY(ctx, ws.chunkA.reserve((size_t)13 * G1p * 36 * 4));        // Y | X2
     } else {
+        KZG_HIP_TRY(ctx, ws.bucket.reserve((size_t)p.G * 36 * 4));
         KZG_HIP_TRY(ctx, ws.chunkS.reserve((size_t)n_chunks * 36 * 4));
         KZG_HIP_TRY(ctx, ws.chunkTmp.reserve((size_t)n_chunks * 36 * 4));
         KZG_HIP_TRY(ctx, ws.chunkA.reserve((size_t)n_chunks * 36 * 4));
     }
-    KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)1024 * 32 * 4));
-    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, 1024 * 32 * 4, hipHostMallocDefault));
+    KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)MSM_MAX_OUT * 32 * 4));
+    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, (size_t)MSM_MAX_OUT * 32 * 4, hipHostMallocDefault));
     if (!ctx->lds_attr_set) {
-        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
         ctx->lds_attr_set = true;
     }
 
@@ -181,9 +192,19 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     }
 #define KZG_MARK(i) do { if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[i], st)); } while (0)
 
+    uint32_t* d_offs = ws.offs.as<uint32_t>();
+    auto scan_counts = [&]() {
+        if (p.G <= SCAN1_MAX) {
+            hipLaunchKernelGGL(k_scan_counts_1wg, dim3(1), dim3(SCAN1_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, d_offs);
+        } else {
+            hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, ws.block_sums.as<uint32_t>());
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<uint32_t>(), nb);
+            hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, ws.block_sums.as<uint32_t>(), d_offs);
+        }
+    };
+
     KZG_MARK(0);
     KZG_HIP_TRY(ctx, hipMemsetAsync(ws.count.p, 0, (size_t)p.G * 4, st));
-    KZG_HIP_TRY(ctx, hipMemsetAsync(ws.cursor.p, 0, 4, st));
     const uint32_t n_total = p.n * batch;
     const uint32_t gn = (n_total + 255) / 256;
     hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, n_total, p.n, p.c, p.W, ws.digits.as<uint32_t>());
@@ -198,96 +219,56 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_HIP_TRY(ctx, hipMemsetAsync(ccount, 0, (size_t)p.Hb * 4, st));
         hipLaunchKernelGGL(k_sort2_hist1, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.tile1, p.Hb,
                            ccount, ws.blockbase.as<uint32_t>());
-        hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart);
+        hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart, tile_bin);
         hipLaunchKernelGGL(k_sort2_scatter1, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, ws.digits.as<uint32_t>(), p.n, (uint32_t)entries, p.tile1,
                            p.Hb, cstart, ws.blockbase.as<uint32_t>(), bases.table_stride, ws.sort_tmp.as<uint32_t>());
-        hipLaunchKernelGGL(k_sort2_tiles, dim3((p.Hb + 255) / 256), dim3(256), 0, st, tstart, p.Hb, tile_bin);
         hipLaunchKernelGGL(k_sort2_hist2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
                            ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
-                           ws.block_sums.as<unsigned long long>());
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
-        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
-                           ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
+        scan_counts();
         KZG_MARK(2);
         hipLaunchKernelGGL(k_sort2_scatter2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
-                           ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), ws.sorted.as<uint32_t>());
-    } else if (entries < ((size_t)1 << 18)) {
+                           d_offs, ws.blockbase.as<uint32_t>(), ws.sorted.as<uint32_t>());
+    } else if (p.sort_small) {
         const uint32_t ge = (uint32_t)((entries + 255) / 256);
-        KZG_HIP_TRY(ctx, ws.blockbase.reserve((size_t)p.G * 4));
         KZG_HIP_TRY(ctx, hipMemsetAsync(ws.blockbase.p, 0, (size_t)p.G * 4, st));
         hipLaunchKernelGGL(k_sort_small_hist, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.set_len, p.B,
                            ws.count.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
-                           ws.block_sums.as<unsigned long long>());
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
-        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
-                           ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
+        scan_counts();
         KZG_MARK(2);
         hipLaunchKernelGGL(k_sort_small_scatter, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.n, p.set_len, p.B,
-                           ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), bases.table_stride, (uint32_t)p.W, ws.sorted.as<uint32_t>());
+                           d_offs, ws.blockbase.as<uint32_t>(), bases.table_stride, (uint32_t)p.W, ws.sorted.as<uint32_t>());
     } else {
         hipLaunchKernelGGL(k_sort_hist, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.set_len, p.tile_len,
                            p.tiles_per_set, p.B, ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
-                           ws.block_sums.as<unsigned long long>());
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, st, ws.block_sums.as<unsigned long long>(), nb);
-        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, ws.count.as<uint32_t>(), p.G, p.L,
-                           ws.block_sums.as<unsigned long long>(), ws.offs.as<unsigned long long>());
+        scan_counts();
         KZG_MARK(2);
         hipLaunchKernelGGL(k_sort_scatter, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.n, p.set_len, p.tile_len,
-                           p.tiles_per_set, p.B, ws.offs.as<unsigned long long>(), ws.blockbase.as<uint32_t>(), bases.table_stride,
+                           p.tiles_per_set, p.B, d_offs, ws.blockbase.as<uint32_t>(), bases.table_stride,
                            (uint32_t)p.W, ws.sorted.as<uint32_t>());
     }
-    const uint32_t gg = (p.G + 255) / 256;
     KZG_MARK(3);
-    const uint32_t gs = (p.segcap + 255) / 256;
-    hipLaunchKernelGGL(k_msm_segments, dim3(gs), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G,
-                       ws.seg_bucket.as<uint32_t>());
     KZG_MARK(4);
     // (64- and 128-thread workgroups measured the same as 256)
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(gs), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(),
-                       ws.seg_bucket.as<uint32_t>(), ws.offs.as<unsigned long long>(), p.G, p.L,
-                       ws.segsum.as<int32_t>(), (size_t)p.segcap, p.fold ? 0u : 1u);
-    const int32_t* parts = ws.segsum.as<int32_t>();          // what bucket_fin reads
-    size_t parts_stride = (size_t)p.segcap;
-    const uint32_t* fold_start = nullptr;
-    if (p.fold) {
-        hipLaunchKernelGGL(k_fold_offsets, dim3(1), dim3(1024), 0, st, ws.offs.as<unsigned long long>(), p.G, ws.fold_start.as<uint32_t>());
-        hipLaunchKernelGGL(k_msm_fold, dim3((p.foldcap + 255) / 256), dim3(256), 0, st, ws.offs.as<unsigned long long>(),
-                           ws.fold_start.as<uint32_t>(), p.G, ws.segsum.as<int32_t>(), (size_t)p.segcap,
-                           ws.foldsum.as<int32_t>(), (size_t)p.foldcap);
-        parts = ws.foldsum.as<int32_t>();
-        parts_stride = (size_t)p.foldcap;
-        fold_start = ws.fold_start.as<uint32_t>();
-    }
+    hipLaunchKernelGGL(k_msm_accumulate, dim3(p.nl / 256), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.G,
+                       ws.head.as<int32_t>(), (size_t)p.G, ws.cont.as<int32_t>(), (size_t)p.nl);
     KZG_MARK(5);
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
-        hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, 0u, 0u,
-                           parts, parts_stride, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>(), fold_start);
-        hipLaunchKernelGGL(k_msm_bucket_fin_heavy, dim3(256), dim3(256), 0, st, ws.offs.as<unsigned long long>(), 0u, 0u,
-                           parts, parts_stride, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>(), fold_start);
+        hipLaunchKernelGGL(k_msm_bucket_bits1, dim3((G1 * 64 + 255) / 256), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
+                           ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, ws.out_wire.as<uint32_t>());
         KZG_MARK(6);
-        const uint32_t waves1 = G1;
-        hipLaunchKernelGGL(k_red_bits1, dim3((waves1 * 64 + 255) / 256), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, p.B, G1,
-                           ws.chunkS.as<int32_t>(), (size_t)7 * G1);
         if (G1 == 1) {
             n_out = 7;
-            hipLaunchKernelGGL(k_xyzz_to_wire, dim3(1), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, n_out, ws.out_wire.as<uint32_t>());
         } else {
             const uint32_t waves2 = 7 * G1p;
-            int32_t* y = ws.chunkA.as<int32_t>();
             hipLaunchKernelGGL(k_red_bits2, dim3((waves2 * 64 + 255) / 256), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p,
-                               y, y + (size_t)6 * G1p, (size_t)13 * G1p);
+                               ws.out_wire.as<uint32_t>());
             n_out = 13 * G1p;
-            hipLaunchKernelGGL(k_xyzz_to_wire, dim3(1), dim3(256), 0, st, y, (size_t)13 * G1p, n_out, ws.out_wire.as<uint32_t>());
         }
     } else {
-        hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.G, p.m, n_chunks,
-                           parts, parts_stride, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>(), fold_start);
-        hipLaunchKernelGGL(k_msm_bucket_fin_heavy, dim3(256), dim3(256), 0, st, ws.offs.as<unsigned long long>(), p.m, n_chunks,
-                           parts, parts_stride, ws.bucket.as<int32_t>(), (size_t)p.G, ws.cursor.as<uint32_t>(), fold_start);
+        const uint32_t gg = (p.G + 255) / 256;
+        hipLaunchKernelGGL(k_msm_bucket_fin, dim3(gg), dim3(256), 0, st, d_offs, p.G, p.nl, p.m, n_chunks, ws.head.as<int32_t>(), (size_t)p.G,
+                           ws.cont.as<int32_t>(), (size_t)p.nl, ws.bucket.as<int32_t>(), (size_t)p.G);
         const uint32_t gc = (n_chunks + 255) / 256;
         KZG_MARK(6);
         hipLaunchKernelGGL(k_red_chunk_sums, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G, n_chunks, p.m,
@@ -334,7 +315,9 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
 
     // host epilogue on O(100) points
     using kzg_host::Xyzz;
-    static thread_local Xyzz vals[1024];
+    static thread_local std::vector<Xyzz> vals_store;
+    if (vals_store.size() < n_out) vals_store.resize(n_out);
+    Xyzz* vals = vals_store.data();
     const uint64_t* w = reinterpret_cast<const uint64_t*>(ws.pinned_out);
     for (uint32_t i = 0; i < n_out; ++i) memcpy(&vals[i], w + 16 * i, 128);
     if (!p.tables) {
@@ -418,6 +401,16 @@ int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, ui
     if (out_xy) kzg_host::xyzz_to_affine(total, out_xy, out_inf);
     return KZG_OK;
 }
+
+#ifdef KZG_ACC_STAMPS
+}  // namespace kzg
+// diagnostic build only: per-wave {start, end (100 MHz ticks), HW_ID, XCC_ID} of the last accumulate launch of slot 0
+extern "C" int32_t kzg_debug_acc_stamps(kzg_ctx* ctx, uint64_t* out, size_t n_waves, size_t nl) {
+    if (hipMemcpy(out, static_cast<const char*>(ctx->msm.cont.p) + nl * 36 * 4, n_waves * 64, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    return 0;
+}
+namespace kzg {
+#endif
 
 void msm_drop_slots(kzg_ctx* ctx) {
     for (int s = 0; s < KZG_NUM_SLOTS; ++s) { delete ctx->slot_pending[s]; ctx->slot_pending[s] = nullptr; }

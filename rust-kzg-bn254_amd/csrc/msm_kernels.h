@@ -4,12 +4,11 @@
 //
 // Pipeline (Pippenger, signed c-bit windows, sort-by-bucket):
 //   k_msm_digits      scalars (wire) -> canonical integer -> W signed digits; bucket histogram
-//   k_scan_*          exclusive scan of (count, #segments) per bucket            (3 small kernels)
-//   k_msm_scatter     entries (point index | sign) grouped by bucket             (counting sort)
-//   k_msm_segments    heavy buckets are cut into segments of <= L entries (load balance, degenerate inputs)
-//   k_msm_accumulate  one lane per segment: XYZZ mixed adds of 64-byte affine points (4 x 128-bit loads)
-//   k_msm_bucket_fin  segment partials -> bucket sums
-//   k_red_*           per window sum_k (k+1) * B_k by chunked running sums + block suffix scan + tree
+//   k_scan_*          exclusive scan of the bucket counts                        (one single-workgroup kernel)
+//   k_sort*           entries (point index | sign) grouped by bucket             (counting sort, one or two levels)
+//   k_msm_accumulate  equal split of the sorted entries over the lanes: XYZZ mixed adds of 64-byte affine points
+//   k_msm_bucket_*    lane partials -> bucket sums (fused with the first reduction level in table mode)
+//   k_red_*           sum_k (k+1) * B_k: zeta transform over shuffles (table mode) / chunked running sums (generic mode)
 // The W window sums leave the device as wire-format XYZZ; the O(W*c) Horner doublings and the single
 // field inversion of `into_affine()` run on the host (host_curve.h) next to the D2H copy.
 //
@@ -54,74 +53,95 @@ k_msm_digits(const uint4* __restrict__ scalars, uint32_t n_total, uint32_t n, in
 }
 
 // -------------------------------------------------------------------------------------------------
-// 2. exclusive scan over G buckets of the packed pair (count, ceil(count / L)); out has G + 1 entries
+// 2. exclusive scan of the bucket counts: offs[g] = first sorted entry of bucket g, offs[G] = E (entries)
 // -------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
-// segments of a bucket with cnt entries: round(cnt / L) (>= 1 if cnt > 0); the accumulate kernel cuts the bucket into
-// that many EQUAL parts, so every lane of a wave runs nearly the same trip count (<= 1.5 L) and the segment total
-// stays ~ entries / L (a ceil() here made 6 % extra, tiny segments and a ragged second round of waves)
-__device__ __forceinline__ uint32_t seg_count(uint32_t cnt, uint32_t L) {
-    if (cnt == 0) return 0;
-    uint32_t s = (cnt + L / 2) / L;
-    return s ? s : 1u;
-}
-__device__ __forceinline__ unsigned long long scan_pack(uint32_t cnt, uint32_t L) {
-    return (unsigned long long)cnt | ((unsigned long long)seg_count(cnt, L) << 32);
-}
-// block-wide exclusive scan of one u64 per thread; returns the exclusive prefix, *total = block sum
-__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long* total,
-                                                              unsigned long long* lds /* SCAN_THREADS */) {
-    int t = threadIdx.x;
+// block-wide exclusive scan of one u32 per thread; returns the exclusive prefix, *total = block sum
+template <int T>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total, uint32_t* lds /* T */) {
+    const int t = threadIdx.x;
     lds[t] = v;
     __syncthreads();
-    for (int d = 1; d < SCAN_THREADS; d <<= 1) {
-        unsigned long long x = (t >= d) ? lds[t - d] : 0ull;
+    for (int d = 1; d < T; d <<= 1) {
+        uint32_t x = (t >= d) ? lds[t - d] : 0u;
         __syncthreads();
         lds[t] += x;
         __syncthreads();
     }
-    unsigned long long incl = lds[t];
-    *total = lds[SCAN_THREADS - 1];
+    uint32_t incl = lds[t];
+    *total = lds[T - 1];
     __syncthreads();
     return incl - v;
 }
+// ONE workgroup does the whole scan (G <= SCAN1_MAX: every table-mode MSM and most generic ones): a dependent chain of three
+// tiny launches (block sums, top, final) cost ~3 boundaries of 1.5 us plus their own latency for a few 10^4 counters.
+constexpr int SCAN1_THREADS = 1024;
+constexpr uint32_t SCAN1_MAX = 1u << 17;
+__global__ void __launch_bounds__(SCAN1_THREADS)
+k_scan_counts_1wg(const uint32_t* __restrict__ count, uint32_t G, uint32_t* __restrict__ offs /* G + 1 */) {
+    __shared__ uint32_t lds[SCAN1_THREADS];
+    const uint32_t t = threadIdx.x;
+    // thread t owns the 4-aligned chunk [lo, hi): 16-byte loads, a few per thread
+    const uint32_t per = (((G + SCAN1_THREADS - 1) / SCAN1_THREADS) + 3u) & ~3u;
+    const uint32_t lo = min(G, t * per), hi = min(G, lo + per);
+    uint32_t s = 0;
+    for (uint32_t g = lo; g < hi; g += 4) {
+        if (g + 4 <= hi) { const uint4 v = *reinterpret_cast<const uint4*>(count + g); s += v.x + v.y + v.z + v.w; }
+        else for (uint32_t q = g; q < hi; ++q) s += count[q];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan<SCAN1_THREADS>(s, &total, lds);
+    for (uint32_t g = lo; g < hi; g += 4) {
+        if (g + 4 <= hi) {
+            const uint4 v = *reinterpret_cast<const uint4*>(count + g);
+            uint4 o;
+            o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+            run = o.w + v.w;
+            *reinterpret_cast<uint4*>(offs + g) = o;
+        } else {
+            for (uint32_t q = g; q < hi; ++q) { offs[q] = run; run += count[q]; }
+        }
+    }
+    if (t == SCAN1_THREADS - 1) offs[G] = total;
+}
+// multi-block form for larger G (generic mode with many windows x buckets)
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_block_sums(const uint32_t* __restrict__ count, uint32_t G, uint32_t L, unsigned long long* __restrict__ block_sums) {
-    __shared__ unsigned long long lds[SCAN_THREADS];
+k_scan_block_sums(const uint32_t* __restrict__ count, uint32_t G, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds[SCAN_THREADS];
     size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    unsigned long long s = 0;
+    uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) if (base + j < G) s += scan_pack(count[base + j], L);
-    unsigned long long total;
-    block_excl_scan(s, &total, lds);
+    for (int j = 0; j < SCAN_ITEMS; ++j) if (base + j < G) s += count[base + j];
+    uint32_t total;
+    block_excl_scan<SCAN_THREADS>(s, &total, lds);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 // single block: exclusive scan of nb block sums in place (nb <= SCAN_TILE)
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_top(unsigned long long* __restrict__ block_sums, uint32_t nb) {
-    __shared__ unsigned long long lds[SCAN_THREADS];
+k_scan_top(uint32_t* __restrict__ block_sums, uint32_t nb) {
+    __shared__ uint32_t lds[SCAN_THREADS];
     size_t base = (size_t)threadIdx.x * SCAN_ITEMS;
-    unsigned long long v[SCAN_ITEMS], s = 0;
+    uint32_t v[SCAN_ITEMS], s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) { v[j] = (base + j < nb) ? block_sums[base + j] : 0ull; s += v[j]; }
-    unsigned long long total;
-    unsigned long long pre = block_excl_scan(s, &total, lds);
+    for (int j = 0; j < SCAN_ITEMS; ++j) { v[j] = (base + j < nb) ? block_sums[base + j] : 0u; s += v[j]; }
+    uint32_t total;
+    uint32_t pre = block_excl_scan<SCAN_THREADS>(s, &total, lds);
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) { if (base + j < nb) block_sums[base + j] = pre; pre += v[j]; }
 }
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_scan_final(const uint32_t* __restrict__ count, uint32_t G, uint32_t L, const unsigned long long* __restrict__ block_sums,
-             unsigned long long* __restrict__ offs /* G + 1 */) {
-    __shared__ unsigned long long lds[SCAN_THREADS];
+k_scan_final(const uint32_t* __restrict__ count, uint32_t G, const uint32_t* __restrict__ block_sums,
+             uint32_t* __restrict__ offs /* G + 1 */) {
+    __shared__ uint32_t lds[SCAN_THREADS];
     size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    unsigned long long v[SCAN_ITEMS], s = 0;
+    uint32_t v[SCAN_ITEMS], s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) { v[j] = (base + j < G) ? scan_pack(count[base + j], L) : 0ull; s += v[j]; }
-    unsigned long long total;
-    unsigned long long pre = block_excl_scan(s, &total, lds) + block_sums[blockIdx.x];
+    for (int j = 0; j < SCAN_ITEMS; ++j) { v[j] = (base + j < G) ? count[base + j] : 0u; s += v[j]; }
+    uint32_t total;
+    uint32_t pre = block_excl_scan<SCAN_THREADS>(s, &total, lds) + block_sums[blockIdx.x];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) { if (base + j < G) offs[base + j] = pre; pre += v[j]; }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) offs[G] = pre;   // grand total
@@ -160,7 +180,7 @@ k_sort_hist(const uint32_t* __restrict__ digits, uint32_t set_len, uint32_t tile
 //   table_stride  > 0 : index = w * table_stride + i    (precomputed tables T_w[i] = 2^(c w) P_i, one bucket set)
 __global__ void __launch_bounds__(256)
 k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len, uint32_t tile_len, uint32_t tiles_per_set, uint32_t B,
-               const unsigned long long* __restrict__ offs, const uint32_t* __restrict__ blockbase, uint32_t table_stride,
+               const uint32_t* __restrict__ offs, const uint32_t* __restrict__ blockbase, uint32_t table_stride,
                uint32_t windows_per_msm, uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lds_u32[];
     const uint32_t set = blockIdx.x / tiles_per_set, tile = blockIdx.x % tiles_per_set;
@@ -168,7 +188,7 @@ k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len
     const uint32_t lo = tile * tile_len;
     const uint32_t hi = (set_len - lo < tile_len) ? set_len : lo + tile_len;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x)
-        lds_u32[b] = (uint32_t)offs[(size_t)set * B + b] + blockbase[(size_t)blockIdx.x * B + b];
+        lds_u32[b] = offs[(size_t)set * B + b] + blockbase[(size_t)blockIdx.x * B + b];
     __syncthreads();
     const uint32_t* d = digits + (size_t)set * set_len;
     for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
@@ -194,7 +214,7 @@ k_sort_small_hist(const uint32_t* __restrict__ digits, uint32_t n_entries, uint3
 }
 __global__ void __launch_bounds__(256)
 k_sort_small_scatter(const uint32_t* __restrict__ digits, uint32_t n_entries, uint32_t n, uint32_t set_len, uint32_t B,
-                     const unsigned long long* __restrict__ offs, uint32_t* __restrict__ cursor /* G zeros */, uint32_t table_stride,
+                     const uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor /* G zeros */, uint32_t table_stride,
                      uint32_t windows_per_msm, uint32_t* __restrict__ sorted) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) return;
@@ -202,7 +222,7 @@ k_sort_small_scatter(const uint32_t* __restrict__ digits, uint32_t n_entries, ui
     if (v == DIGIT_NONE) return;
     const uint32_t set = e / set_len, es = e - set * set_len;
     const size_t gb = (size_t)set * B + (v & 0x7FFFFFFFu);
-    const uint32_t pos = (uint32_t)offs[gb] + atomicAdd(&cursor[gb], 1u);
+    const uint32_t pos = offs[gb] + atomicAdd(&cursor[gb], 1u);
     uint32_t idx;
     if (table_stride) { const uint32_t w = es / n; idx = w * table_stride + (es - w * n); }
     else idx = (set / windows_per_msm) * n + es;
@@ -213,13 +233,16 @@ k_sort_small_scatter(const uint32_t* __restrict__ digits, uint32_t n_entries, ui
 // 3b. two-level counting sort (table mode): coarse bins first, then the low key bits inside every bin
 // -------------------------------------------------------------------------------------------------
 // The single-pass scatter above writes 4-byte entries to ~2^15 different bucket regions: rocprofv3 counted 486 MiB
-// written for 64 MiB of payload (partial-line writes).  Here pass 1 groups entries by the high key bits (<= 512
-// bins: every tile writes runs of >= 256 B per bin), pass 2 sorts each bin's entries by the low 6 key bits (runs of
-// ~512 B per bucket).  Between the passes an entry is one u32: sign << 31 | low key << 25 | point index (< 2^25).
-constexpr int SORT2_LO_BITS = 6;
+// written for 64 MiB of payload (partial-line writes), and its LDS histogram holds at most 2^15 buckets.  Here pass 1
+// groups entries by the high key bits (<= 512 bins: every tile writes runs of >= 256 B per bin), pass 2 sorts each
+// bin's entries by the low 7 key bits (runs of ~512 B per bucket): up to 2^16 buckets (c = 17).  Between the passes an
+// entry is one u32: sign << 31 | low key << 24 | point index (< 2^24).
+constexpr int SORT2_LO_BITS = 7;
 constexpr uint32_t SORT2_LO = 1u << SORT2_LO_BITS;
-constexpr uint32_t SORT2_IDX_MASK = (1u << 25) - 1u;
+constexpr int SORT2_IDX_BITS = 24;
+constexpr uint32_t SORT2_IDX_MASK = (1u << SORT2_IDX_BITS) - 1u;
 constexpr uint32_t SORT2_CHUNK = 16384;         // entries per pass-2 tile
+constexpr uint32_t SORT2_MAX_BINS = 512;
 
 __global__ void __launch_bounds__(256)
 k_sort2_hist1(const uint32_t* __restrict__ digits, uint32_t E, uint32_t tile_len, uint32_t Hb,
@@ -239,9 +262,11 @@ k_sort2_hist1(const uint32_t* __restrict__ digits, uint32_t E, uint32_t tile_len
         blockbase1[(size_t)blockIdx.x * Hb + b] = h ? atomicAdd(&ccount[b], h) : 0u;
     }
 }
-// single block: cstart[h] = exclusive scan of the coarse counts, tstart[h] = exclusive scan of ceil(count / CHUNK)
+// single block: cstart[h] = exclusive scan of the coarse counts, tstart[h] = exclusive scan of ceil(count / CHUNK), and the
+// pass-2 tile -> coarse bin map (tile_bin), which used to be a launch of its own
 __global__ void __launch_bounds__(512)
-k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restrict__ cstart, uint32_t* __restrict__ tstart) {
+k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restrict__ cstart, uint32_t* __restrict__ tstart,
+             uint32_t* __restrict__ tile_bin) {
     __shared__ uint32_t a[512], b[512];
     const uint32_t t = threadIdx.x;
     uint32_t c = t < Hb ? ccount[t] : 0u;
@@ -254,7 +279,10 @@ k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restr
         a[t] += x; b[t] += y;
         __syncthreads();
     }
-    if (t < Hb) { cstart[t] = a[t] - c; tstart[t] = b[t] - k; }
+    if (t < Hb) {
+        cstart[t] = a[t] - c; tstart[t] = b[t] - k;
+        for (uint32_t q = b[t] - k; q < b[t]; ++q) tile_bin[q] = t;
+    }
     if (t == Hb - 1) { cstart[Hb] = a[t]; tstart[Hb] = b[t]; }
 }
 __global__ void __launch_bounds__(256)
@@ -273,15 +301,8 @@ k_sort2_scatter1(const uint32_t* __restrict__ digits, uint32_t n, uint32_t E, ui
         uint32_t pos = atomicAdd(&lds_u32[key >> SORT2_LO_BITS], 1u);
         uint32_t w = e / n;
         uint32_t idx = w * table_stride + (e - w * n);
-        tmp1[pos] = (v & 0x80000000u) | ((key & (SORT2_LO - 1)) << 25) | idx;
+        tmp1[pos] = (v & 0x80000000u) | ((key & (SORT2_LO - 1)) << SORT2_IDX_BITS) | idx;
     }
-}
-// pass-2 tile -> coarse bin
-__global__ void __launch_bounds__(256)
-k_sort2_tiles(const uint32_t* __restrict__ tstart, uint32_t Hb, uint32_t* __restrict__ tile_bin) {
-    uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= Hb) return;
-    for (uint32_t t = tstart[h]; t < tstart[h + 1]; ++t) tile_bin[t] = h;
 }
 __global__ void __launch_bounds__(256)
 k_sort2_hist2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
@@ -294,7 +315,7 @@ k_sort2_hist2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cs
     const uint32_t hi = (cstart[h + 1] - lo < SORT2_CHUNK) ? cstart[h + 1] : lo + SORT2_CHUNK;
     if (threadIdx.x < SORT2_LO) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&hist[(tmp1[e] >> 25) & (SORT2_LO - 1)], 1u);
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&hist[(tmp1[e] >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
     __syncthreads();
     if (threadIdx.x < SORT2_LO) {
         uint32_t c = hist[threadIdx.x];
@@ -303,7 +324,7 @@ k_sort2_hist2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cs
 }
 __global__ void __launch_bounds__(256)
 k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
-                 const uint32_t* __restrict__ tile_bin, uint32_t Hb, const unsigned long long* __restrict__ offs,
+                 const uint32_t* __restrict__ tile_bin, uint32_t Hb, const uint32_t* __restrict__ offs,
                  const uint32_t* __restrict__ blockbase2, uint32_t* __restrict__ sorted) {
     __shared__ uint32_t cur[SORT2_LO];
     const uint32_t tile = blockIdx.x;
@@ -312,37 +333,33 @@ k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__
     const uint32_t lo = cstart[h] + (tile - tstart[h]) * SORT2_CHUNK;
     const uint32_t hi = (cstart[h + 1] - lo < SORT2_CHUNK) ? cstart[h + 1] : lo + SORT2_CHUNK;
     if (threadIdx.x < SORT2_LO)
-        cur[threadIdx.x] = (uint32_t)offs[(size_t)h * SORT2_LO + threadIdx.x] + blockbase2[(size_t)tile * SORT2_LO + threadIdx.x];
+        cur[threadIdx.x] = offs[(size_t)h * SORT2_LO + threadIdx.x] + blockbase2[(size_t)tile * SORT2_LO + threadIdx.x];
     __syncthreads();
     for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
         uint32_t v = tmp1[e];
-        uint32_t pos = atomicAdd(&cur[(v >> 25) & (SORT2_LO - 1)], 1u);
+        uint32_t pos = atomicAdd(&cur[(v >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
         sorted[pos] = v & (0x80000000u | SORT2_IDX_MASK);
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// 4. segment -> bucket map
+// 4. bucket accumulation: EQUAL SPLIT of the sorted entries over the lanes
 // -------------------------------------------------------------------------------------------------
-// One thread per SEGMENT: binary search of its id in the per-bucket segment offsets (high words of offs[]).  A thread per
-// bucket looping over its segments serialised ~40 dependent stores when few buckets hold many segments (shard-sized MSMs:
-// 77 us at 2^17 pairs against 6 us at 2^20).
-__global__ void __launch_bounds__(256)
-k_msm_segments(const unsigned long long* __restrict__ offs, uint32_t G, uint32_t* __restrict__ seg_bucket) {
-    const uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nseg = (uint32_t)(offs[G] >> 32);
-    if (sid >= nseg) return;
-    uint32_t lo = 0, hi = G;                       // invariant: segstart(lo) <= sid < segstart(hi)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if ((uint32_t)(offs[mid] >> 32) <= sid) lo = mid; else hi = mid;
-    }
-    seg_bucket[sid] = lo;
-}
-
-// -------------------------------------------------------------------------------------------------
-// 5. bucket accumulation: one lane per segment
-// -------------------------------------------------------------------------------------------------
+// The sorted array holds E entries grouped by bucket (offs[]).  Lane t of the nl launched lanes adds the entries
+// [t L, (t+1) L), L = ceil(E / nl), whatever buckets they belong to: every lane of the chip runs the same trip count, and the
+// host sizes nl to the number of resident wave slots (3 per SIMD), so there is exactly one full round of waves.
+// (Round 1 cut every bucket into round(count / L) segments: at 2^20 pairs all buckets hold ~510 entries, so the segment count
+// jumped between 5 and 6 per bucket, i.e. 2 560 waves of 102 additions or 3 072 + a second round: 1.36 ms where the equal
+// split needs 86 additions on 3 072 waves.)
+// A lane's partial sums go to
+//   head[g]  the part of bucket g that starts inside the lane's range (every non-empty bucket has exactly one)
+//   cont[t]  the part of the bucket that was already open at the lane's first entry (at most one per lane)
+// so bucket g = head[g] + sum of cont[t], t in (t1, t2], t1 = offs[g] / L, t2 = (offs[g+1] - 1) / L.
+// Runs of more than RUN_SERIAL continuation lanes (heavy buckets: skewed or repeated scalars, the short top window) are folded
+// inside each wave by a segmented suffix scan over ds_bpermute shuffles first, so that only the first lane of the run and the
+// lanes 0 of the following waves hold a partial: bucket_partial() below enumerates them.
+constexpr uint32_t RUN_SERIAL = 8;        // continuation lanes a bucket's owner adds one by one
+constexpr uint32_t NP_SERIAL = 10;        // partials (head included) above which a wave sums a bucket cooperatively
 
 __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
     const Fq* s[4] = {&v.x, &v.y, &v.zz, &v.zzz};
@@ -353,15 +370,8 @@ __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
         for (int j = 0; j < NL; ++j) t[q]->l[j] = __shfl_down(s[q]->l[j], d, 64);
     r.inf = __shfl_down((int)v.inf, d, 64) != 0;
 }
+__device__ __forceinline__ uint32_t acc_seg_len(uint32_t E, uint32_t nl) { return (E + nl - 1) / nl; }
 
-// One lane per segment (<= L entries of one bucket).  Segments of a bucket are consecutive, so after the serial part
-// the lanes of a wave that share a bucket fold their partials with a SEGMENTED suffix scan over ds_bpermute
-// shuffles (all lanes busy; ~log2(segments per bucket) extra adds).  Only the first lane of each run stores:
-// the surviving partials of bucket g sit at segment ids  s0(g)  and the multiples of 64 inside (s0, s1).
-// Waves per SIMD of the accumulate kernel: 3 (<= 168 VGPRs, 4 spilled dwords) or 4 (128 VGPRs, ~50 spilled dwords).  Measured back to
-// back on one box they are equal (1.499 / 1.494 ms per 2^20-pair launch at L = 96), as are variants without the point prefetch: the
-// kernel is bound by instruction issue, and the GPU boxes of the pool differ by +-6 % among themselves (1.33 .. 1.50 ms for the same
-// binary), which is more than any of these variants.  3 is kept for the smaller scratch traffic (1.29 vs 1.63 GB per launch, PMC).
 // experiment switch: -DKZG_ACC_NOGATHER makes every lane read the same few table points (no HBM gather) to time the arithmetic alone
 #ifdef KZG_ACC_NOGATHER
 #define KZG_ACC_IDX(v) ((v) & 0xFFu)
@@ -369,74 +379,157 @@ __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
 #define KZG_ACC_IDX(v) ((v) & 0x7FFFFFFFu)
 #endif
 #ifndef KZG_ACC_WAVES
-#define KZG_ACC_WAVES 3
+#define KZG_ACC_WAVES 3        // waves per SIMD (<= 168 VGPRs); 4 (128 VGPRs, more spills) measured equal in round 1
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KZG_ACC_WAVES, KZG_ACC_WAVES)))
-k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted,
-                 const uint32_t* __restrict__ seg_bucket, const unsigned long long* __restrict__ offs, uint32_t G, uint32_t L,
-                 int32_t* __restrict__ segsum, size_t seg_stride, uint32_t do_scan) {
-    const uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
+k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs, uint32_t G,
+                 int32_t* __restrict__ head, size_t head_stride, int32_t* __restrict__ cont, size_t cont_stride) {
+    const uint32_t nl = gridDim.x * blockDim.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t nseg = (uint32_t)(offs[G] >> 32);
-    const bool active = sid < nseg;
-    uint32_t g = 0xFFFFFFFFu, begin = 0, end = 0;
+#ifdef KZG_ACC_STAMPS     // diagnostic build only (tools/acc_stamps.py): when and where does every wave run
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(cont + cont_stride * 36) + 8 * (size_t)(t >> 6);
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long flush_ticks = 0, flush_events = 0, stamp_loop = 0;
+#endif
+    const uint32_t E = offs[G];
+    const uint32_t L = acc_seg_len(E, nl);
+    const unsigned long long b64 = (unsigned long long)t * L;
+    const uint32_t begin = b64 < E ? (uint32_t)b64 : E;
+    const uint32_t end = (b64 + L < E) ? (uint32_t)(b64 + L) : E;
+    const bool active = begin < end;
+    uint32_t g = 0, next = 0, g0 = 0xFFFFFFFFu;
+    bool is_cont = false, long_run = false;
     if (active) {
-        g = seg_bucket[sid];
-        unsigned long long o0 = offs[g], o1 = offs[g + 1];
-        const uint32_t s = sid - (uint32_t)(o0 >> 32), ns = (uint32_t)(o1 >> 32) - (uint32_t)(o0 >> 32);
-        const uint32_t cnt = (uint32_t)o1 - (uint32_t)o0;
-        begin = (uint32_t)o0 + (uint32_t)(((unsigned long long)s * cnt) / ns);
-        end = (uint32_t)o0 + (uint32_t)(((unsigned long long)(s + 1) * cnt) / ns);
+        uint32_t lo = 0, hi = G;                       // invariant: offs[lo] <= begin < offs[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (offs[mid] <= begin) lo = mid; else hi = mid;
+        }
+        g = lo;
+        const uint32_t o0 = offs[g];
+        next = offs[g + 1];
+        is_cont = o0 < begin;
+        if (is_cont) { long_run = ((next - 1) / L - o0 / L) > RUN_SERIAL; g0 = g; }
     }
+    // Partials completed INSIDE the loop (a bucket ends before the lane's range does) are parked in LDS, one slot per lane, and
+    // written to global memory after the loop: 36 global stores in the loop made the next iteration's load wait (vmcnt counts
+    // in order) wait for their write acknowledgements as well -- 8.3 us per boundary, 15 % of a wave's lifetime at 2^20 pairs
+    // (tools/acc_stamps.py).  A lane that crosses a second boundary (buckets shorter than its trip count) stores directly.
+    __shared__ int32_t park[4 * NL * 256];
+    const uint32_t tl = threadIdx.x;
+    bool parked = false, parked_cont = false;          // slot in use; it holds the continuation partial (else head[park_g])
+    uint32_t park_g = 0;
+    bool cont_in_regs = false;                         // long-run continuation partial still in `acc` after the loop (scan input)
     Xyzz acc;
     xyzz_set_inf(acc);
-    if (begin < end) {
-        // software pipeline: the 64-byte point of entry e+1 is requested before the ~2 700-instruction mixed add of
-        // entry e, so the random gather (HBM-resident tables) is hidden behind arithmetic
-        // two-deep pipeline: index e+2 and point e+1 are in flight while entry e is added, so neither the index
-        // load (dependent address) nor the 64-byte gather is waited for inside an iteration
+    uint32_t next2 = 0;                                // offs[g + 2], loaded ahead: no dependent load at a boundary
+    if (active) next2 = offs[g + 2 <= G ? g + 2 : G];
+    // the partial of bucket g is complete for this lane: `more` = the lane goes on into the next bucket
+    auto flush = [&](bool more) {
+        const bool as_cont = is_cont && g == g0;
+        if (more && !parked) {
+            const Fq* c4[4] = {&acc.x, &acc.y, &acc.zz, &acc.zzz};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < NL; ++j) park[(q * NL + j) * 256 + tl] = acc.inf ? 0 : c4[q]->l[j];
+            parked = true; parked_cont = as_cont; park_g = g;
+        } else if (!as_cont) {
+            xyzz_store(head, head_stride, g, acc);
+        } else if (!long_run || more) {
+            xyzz_store(cont, cont_stride, t, acc);
+        } else {
+            cont_in_regs = true;                       // kept in registers for the segmented scan below
+        }
+    };
+    if (active) {
+        // two-deep software pipeline: index e+2 and point e+1 are in flight while entry e is added, so neither the index
+        // load (dependent address) nor the 64-byte gather from the 1 GiB table is waited for inside an iteration.  The
+        // prefetches are UNCONDITIONAL (indices clamped to the lane's last entry): with `if (e + 1 < end)` around them the
+        // register allocator copied the freshly loaded registers right behind the loads, i.e. an s_waitcnt vmcnt(1) directly
+        // after issue.
+        const uint32_t last = end - 1;
         uint32_t v = sorted[begin];
-        uint32_t v1 = (begin + 1 < end) ? sorted[begin + 1] : 0u;
+        uint32_t v1 = sorted[begin + 1 < end ? begin + 1 : last];
         const uint4* src = points + 4 * (size_t)(KZG_ACC_IDX(v));
         uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
         for (uint32_t e = begin; e < end; ++e) {
+#ifdef KZG_ACC_STAMPS
+            const bool any_cross = __any(e == next);
+            unsigned long long f0 = 0;
+            if (any_cross) f0 = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (__builtin_expect(e == next, 0)) {      // bucket boundary inside the lane's range
+                flush(true);
+                xyzz_set_inf(acc);
+                ++g; next = next2;
+                while (next == e) { ++g; next = offs[g + 1]; }         // empty buckets; e < end <= E = offs[G]: terminates
+                next2 = offs[g + 2 <= G ? g + 2 : G];
+            }
+#ifdef KZG_ACC_STAMPS
+            if (any_cross) { flush_ticks += __builtin_amdgcn_s_memrealtime() - f0; flush_events += 1; }
+#endif
             const uint32_t neg = v >> 31;
             uint32_t wx[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
             uint32_t wy[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
             const uint32_t any = q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x | q2.y | q2.z | q2.w | q3.x | q3.y | q3.z | q3.w;
-            if (e + 1 < end) {
-                v = v1;
-                src = points + 4 * (size_t)(KZG_ACC_IDX(v));
-                q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
-                if (e + 2 < end) v1 = sorted[e + 2];
-            }
-            if (any == 0) continue;                                                       // identity base
             Affine p;
             fe_unpack(p.x, wx);
             fe_unpack(p.y, wy);
+            v = v1;                                    // entry e + 1 (the last iteration re-reads entry `last`: unused)
+            src = points + 4 * (size_t)(KZG_ACC_IDX(v));
+            q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+            v1 = sorted[e + 2 < end ? e + 2 : last];
+            if (any == 0) continue;                                                       // identity base
             xyzz_madd<true>(acc, p, neg);
         }
+        flush(false);
     }
-    if (!do_scan) {                                      // fold mode: every segment's partial goes to memory, k_msm_fold combines them
-        if (active) xyzz_store(segsum, seg_stride, sid, acc);
-        return;
+    const bool in_scan = active && is_cont && long_run;
+    Xyzz c;                                            // scan input
+    xyzz_set_inf(c);
+    if (cont_in_regs) c = acc;
+    if (parked) {                                      // parked partial -> its place (or into the scan)
+        Xyzz v;
+        Fq* c4[4] = {&v.x, &v.y, &v.zz, &v.zzz};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < NL; ++j) c4[q]->l[j] = park[(q * NL + j) * 256 + tl];
+        v.inf = fe_is_literal_zero(v.zz);
+        if (!parked_cont) xyzz_store(head, head_stride, park_g, v);
+        else if (!long_run) xyzz_store(cont, cont_stride, t, v);
+        else c = v;
     }
-    // segmented suffix scan: acc_lane = sum of the partials of lanes lane .. end of its bucket run in this wave
+#ifdef KZG_ACC_STAMPS
+    if (lane == 0) {
+        unsigned int hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamps[0] = stamp0; stamps[1] = __builtin_amdgcn_s_memrealtime(); stamps[2] = hwid; stamps[3] = xcc;
+        stamps[4] = flush_ticks; stamps[5] = flush_events; stamps[6] = stamp_loop;
+    }
+#endif
+    // segmented suffix scan over the continuation partials of long runs: lane = sum of the partials of lanes lane .. end of its
+    // run in this wave; the first lane of each run stores
+    if (!__any(in_scan)) return;                       // wave-uniform: the normal case (no heavy bucket in this wave)
+    const uint32_t key = in_scan ? g0 : 0xFFFFFFFFu;
 #pragma unroll 1
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t gd = __shfl_down(g, d, 64);
-        const bool join = active && (lane + d < 64) && gd == g;
-        if (!__any(join)) continue;                      // wave-uniform: nobody has a partner at this distance
+        const uint32_t kd = __shfl_down(key, d, 64);
+        const bool join = in_scan && (lane + d < 64) && kd == key;
+        if (!__any(join)) continue;                    // wave-uniform: nobody has a partner at this distance
         Xyzz u;
-        xyzz_shfl_down(u, acc, d);
+        xyzz_shfl_down(u, c, d);
         if (join) {
             Xyzz r;
-            xyzz_add<true>(r, acc, u);
-            acc = r;
+            xyzz_add<true>(r, c, u);
+            c = r;
         }
     }
-    const uint32_t gprev = __shfl_up(g, 1, 64);
-    if (active && (lane == 0 || gprev != g)) xyzz_store(segsum, seg_stride, sid, acc);
+    const uint32_t kprev = __shfl_up(key, 1, 64);
+    if (in_scan && (lane == 0 || kprev != key)) xyzz_store(cont, cont_stride, t, c);
 }
 
 // Bucket g of the G = W * B buckets is stored at a transposed position so that the reduction kernels,
@@ -444,130 +537,97 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
 __device__ __forceinline__ size_t bucket_pos(uint32_t g, uint32_t m, uint32_t n_chunks) {
     return (size_t)(g % m) * n_chunks + (g / m);
 }
-// surviving partial k of a bucket whose segments are [s0, s1): k = 0 -> s0, k >= 1 -> the k-th multiple of 64 above s0
-__device__ __forceinline__ uint32_t partial_count(uint32_t s0, uint32_t s1) {
-    if (s1 == s0) return 0;
-    return 1 + ((s1 - 1) / 64 - s0 / 64);
+// the partials of one bucket, as the accumulate kernel leaves them
+struct BucketSpan {
+    uint32_t g, t1, np;      // np = number of partials, head included (0 for an empty bucket)
+    bool long_run;
+};
+__device__ __forceinline__ BucketSpan bucket_span(const uint32_t* __restrict__ offs, uint32_t g, uint32_t L) {
+    BucketSpan s;
+    s.g = g;
+    const uint32_t o0 = offs[g], o1 = offs[g + 1];
+    s.t1 = 0; s.np = 0; s.long_run = false;
+    if (o1 == o0) return s;
+    s.t1 = o0 / L;
+    const uint32_t t2 = (o1 - 1) / L, r = t2 - s.t1;
+    s.long_run = r > RUN_SERIAL;
+    // long run: the first continuation lane t1 + 1 and the lanes 0 of the later waves of (t1 + 1, t2]
+    s.np = 1 + (s.long_run ? 1 + (t2 / 64 - (s.t1 + 1) / 64) : r);
+    return s;
 }
-__device__ __forceinline__ uint32_t partial_sid(uint32_t s0, uint32_t k) { return k == 0 ? s0 : (s0 / 64 + k) * 64; }
-
-constexpr uint32_t FIN_SERIAL_MAX = 4;
-constexpr uint32_t FOLD_F = 8;            // partials one lane of k_msm_fold sums serially
-constexpr uint32_t FOLD_SERIAL_MAX = 8;   // fold mode: bucket_fin sums up to 8 folded partials serially (64 segments)
-
-// ---- fold mode (many segments per bucket: shard-sized MSMs) -------------------------------------------------------------
-// The in-wave suffix scan costs log2(run) full additions on EVERY lane (5-6 steps x 14 multiplies against ~24 mixed adds of
-// 10: +30-55 % work when a bucket spans 27-43 lanes).  Here each lane stores its partial; a second, tiny launch lets one lane
-// sum FOLD_F consecutive partials of one bucket (one addition per partial: work-efficient, longer dependent chain), and
-// bucket_fin adds the <= 8 results of a normal bucket.
-// fold_start[g] = first folded partial of bucket g (exclusive prefix sum of ceil(ns / FOLD_F)), fold_start[G] = total
-__global__ void __launch_bounds__(1024)
-k_fold_offsets(const unsigned long long* __restrict__ offs, uint32_t G, uint32_t* __restrict__ fold_start) {
-    __shared__ uint32_t sums[1024];
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (G + 1023) / 1024;
-    const uint32_t lo = min(G, t * per), hi = min(G, lo + per);
-    uint32_t acc = 0;
-    for (uint32_t g = lo; g < hi; ++g) {
-        const uint32_t ns = (uint32_t)(offs[g + 1] >> 32) - (uint32_t)(offs[g] >> 32);
-        acc += (ns + FOLD_F - 1) / FOLD_F;
-    }
-    sums[t] = acc;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {           // inclusive scan of the per-thread totals
-        uint32_t v = t >= d ? sums[t - d] : 0;
-        __syncthreads();
-        sums[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = sums[t] - acc;                       // exclusive prefix of this thread's chunk
-    for (uint32_t g = lo; g < hi; ++g) {
-        fold_start[g] = run;
-        const uint32_t ns = (uint32_t)(offs[g + 1] >> 32) - (uint32_t)(offs[g] >> 32);
-        run += (ns + FOLD_F - 1) / FOLD_F;
-    }
-    if (t == 1023) fold_start[G] = sums[1023];
+__device__ __forceinline__ void bucket_partial(Xyzz& v, const BucketSpan& s, uint32_t k, const int32_t* __restrict__ head, size_t head_stride,
+                                               const int32_t* __restrict__ cont, size_t cont_stride) {
+    if (k == 0) { xyzz_load(v, head, head_stride, s.g); return; }
+    const uint32_t first = s.t1 + 1;
+    const uint32_t t = !s.long_run ? s.t1 + k : (k == 1 ? first : (first / 64 + (k - 1)) * 64);
+    xyzz_load(v, cont, cont_stride, t);
 }
-// one lane per folded partial: sum of FOLD_F consecutive segment partials of one bucket
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_msm_fold(const unsigned long long* __restrict__ offs, const uint32_t* __restrict__ fold_start, uint32_t G,
-           const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ foldsum, size_t fold_stride) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= fold_start[G]) return;
-    uint32_t lo = 0, hi = G;                             // largest g with fold_start[g] <= t (empty buckets have equal starts)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (fold_start[mid] <= t) lo = mid; else hi = mid;
-    }
-    const uint32_t s0 = (uint32_t)(offs[lo] >> 32), s1 = (uint32_t)(offs[lo + 1] >> 32);
-    const uint32_t a = s0 + (t - fold_start[lo]) * FOLD_F, b = min(a + FOLD_F, s1);
-    Xyzz acc;
-    xyzz_load(acc, segsum, seg_stride, a);
-    for (uint32_t i = a + 1; i < b; ++i) {
-        Xyzz v, r;
-        xyzz_load(v, segsum, seg_stride, i);
-        xyzz_add<true>(r, acc, v);
-        acc = r;
-    }
-    xyzz_store(foldsum, fold_stride, t, acc);
-}
-
-// thread per bucket: buckets with <= 4 surviving partials (the normal case: 1-2) are summed serially; heavier ones
-// (skewed scalars: few distinct digits) are queued for k_msm_bucket_fin_heavy.
-__global__ void __launch_bounds__(256)
-k_msm_bucket_fin(const unsigned long long* __restrict__ offs, uint32_t G, uint32_t m, uint32_t n_chunks,
-                 const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ bucket, size_t bucket_stride,
-                 uint32_t* __restrict__ heavy /* [0] = count, [1..] = bucket ids */,
-                 const uint32_t* __restrict__ fold_start /* fold mode: partials of bucket g = segsum[fold_start[g] .. fold_start[g+1]) */) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    uint32_t s0, s1, np;
-    if (fold_start) { s0 = fold_start[g]; s1 = fold_start[g + 1]; np = s1 - s0; }
-    else { s0 = (uint32_t)(offs[g] >> 32); s1 = (uint32_t)(offs[g + 1] >> 32); np = partial_count(s0, s1); }
-    if (np > (fold_start ? FOLD_SERIAL_MAX : FIN_SERIAL_MAX)) {
-        heavy[1 + atomicAdd(&heavy[0], 1u)] = g;
-        return;
-    }
-    Xyzz acc;
+// Sum of all partials of this lane's bucket.  Buckets with up to NP_SERIAL partials are summed by their lane; heavier ones
+// (skewed scalars: few distinct digits) one after the other by the whole wave (lanes take partials round-robin, then a
+// shuffle tree).  Every lane of the wave must call this.
+__device__ __forceinline__ void bucket_sum_wave(Xyzz& acc, const BucketSpan& s, uint32_t lane, const int32_t* __restrict__ head, size_t head_stride,
+                                                const int32_t* __restrict__ cont, size_t cont_stride) {
     xyzz_set_inf(acc);
-    for (uint32_t k = 0; k < np; ++k) {
-        Xyzz v, t;
-        xyzz_load(v, segsum, seg_stride, fold_start ? s0 + k : partial_sid(s0, k));
-        xyzz_add<true>(t, acc, v);
-        acc = t;
+    const bool heavy = s.np > NP_SERIAL;
+    if (!heavy) {
+#pragma unroll 1
+        for (uint32_t k = 0; k < s.np; ++k) {
+            Xyzz v, r;
+            bucket_partial(v, s, k, head, head_stride, cont, cont_stride);
+            xyzz_add<true>(r, acc, v);
+            acc = r;
+        }
     }
-    xyzz_store(bucket, bucket_stride, m ? bucket_pos(g, m, n_chunks) : (size_t)g, acc);
-}
-// one wave per queued bucket (grid-stride over the queue): lanes take partials round-robin, then a shuffle tree
-__global__ void __launch_bounds__(256)
-k_msm_bucket_fin_heavy(const unsigned long long* __restrict__ offs, uint32_t m, uint32_t n_chunks,
-                       const int32_t* __restrict__ segsum, size_t seg_stride, int32_t* __restrict__ bucket, size_t bucket_stride,
-                       const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ fold_start) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t count = heavy[0];
-    for (uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; h < count; h += n_waves) {
-        const uint32_t g = heavy[1 + h];
-        uint32_t s0, s1, np;
-        if (fold_start) { s0 = fold_start[g]; s1 = fold_start[g + 1]; np = s1 - s0; }
-        else { s0 = (uint32_t)(offs[g] >> 32); s1 = (uint32_t)(offs[g + 1] >> 32); np = partial_count(s0, s1); }
-        Xyzz acc;
-        xyzz_set_inf(acc);
-        for (uint32_t k = lane; k < np; k += 64) {
-            Xyzz v, t;
-            xyzz_load(v, segsum, seg_stride, fold_start ? s0 + k : partial_sid(s0, k));
-            xyzz_add<true>(t, acc, v);
-            acc = t;
+    unsigned long long todo = __ballot(heavy);
+    while (todo) {                                     // wave-uniform
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        BucketSpan h;
+        h.g = __shfl(s.g, src, 64);
+        h.t1 = __shfl(s.t1, src, 64);
+        h.np = __shfl(s.np, src, 64);
+        h.long_run = __shfl((int)s.long_run, src, 64) != 0;
+        Xyzz part;
+        xyzz_set_inf(part);
+#pragma unroll 1
+        for (uint32_t k = lane; k < h.np; k += 64) {
+            Xyzz v, r;
+            bucket_partial(v, h, k, head, head_stride, cont, cont_stride);
+            xyzz_add<true>(r, part, v);
+            part = r;
         }
 #pragma unroll 1
         for (int d = 32; d >= 1; d >>= 1) {
             Xyzz u, r;
-            xyzz_shfl_down(u, acc, d);
-            xyzz_add<true>(r, acc, u);
-            acc = r;
+            xyzz_shfl_down(u, part, d);
+            xyzz_add<true>(r, part, u);
+            part = r;
         }
-        if (lane == 0) xyzz_store(bucket, bucket_stride, m ? bucket_pos(g, m, n_chunks) : (size_t)g, acc);
+        Xyzz tot;                                      // lane 0 holds the sum
+        const Fq* sp[4] = {&part.x, &part.y, &part.zz, &part.zzz};
+        Fq* tp[4] = {&tot.x, &tot.y, &tot.zz, &tot.zzz};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < NL; ++j) tp[q]->l[j] = __shfl(sp[q]->l[j], 0, 64);
+        tot.inf = __shfl((int)part.inf, 0, 64) != 0;
+        if ((int)lane == src) acc = tot;
     }
+}
+
+// generic mode: one lane per bucket -> bucket[] (transposed for the chunked reduction when m > 0)
+__global__ void __launch_bounds__(256)
+k_msm_bucket_fin(const uint32_t* __restrict__ offs, uint32_t G, uint32_t nl, uint32_t m, uint32_t n_chunks,
+                 const int32_t* __restrict__ head, size_t head_stride, const int32_t* __restrict__ cont, size_t cont_stride,
+                 int32_t* __restrict__ bucket, size_t bucket_stride) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const uint32_t L = acc_seg_len(offs[G], nl);
+    BucketSpan s;
+    s.g = g; s.t1 = 0; s.np = 0; s.long_run = false;
+    if (g < G && L) s = bucket_span(offs, g, L);
+    Xyzz acc;
+    bucket_sum_wave(acc, s, lane, head, head_stride, cont, cont_stride);
+    if (g < G) xyzz_store(bucket, bucket_stride, m ? bucket_pos(g, m, n_chunks) : (size_t)g, acc);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -690,25 +750,39 @@ __device__ __forceinline__ int zeta_role(uint32_t lane) {       // lane 0 -> rol
     if ((lane & (lane - 1)) != 0) return -1;
     return __ffs((int)lane) - 1;
 }
-// level 1: X1[role * G1 + g] for the bucket group g (64 buckets): role k < 6 = S_k, role 6 = T.   One wave per group.
+__device__ __forceinline__ void xyzz_store_wire(uint32_t* __restrict__ out_wire, size_t i, const Xyzz& v) {
+    uint32_t w[32];
+    xyzz_to_wire(w, v);
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) *reinterpret_cast<uint4*>(out_wire + i * 32 + j) = make_uint4(w[j], w[j + 1], w[j + 2], w[j + 3]);
+}
+// level 1, fused with the bucket sums (one launch instead of bucket_fin + heavy + bits1): one wave per group g of 64 buckets;
+// lane = bucket: sum of its partials (bucket_sum_wave), then the zeta transform.  X1[role * G1 + g]: role k < 6 = S_k, role 6 = T.
+// With a single group (B = 64) the seven results leave as wire words at once.
 __global__ void __launch_bounds__(256)
-k_red_bits1(const int32_t* __restrict__ bucket, size_t bucket_stride, uint32_t B, uint32_t G1,
-            int32_t* __restrict__ x1, size_t x_stride) {
+k_msm_bucket_bits1(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
+                   const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
+                   uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
     const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (g >= G1) return;
+    if (g >= G1) return;                               // wave-uniform
+    const uint32_t L = acc_seg_len(offs[B], nl);
+    const uint32_t bkt = g * 64 + lane;
+    BucketSpan s;
+    s.g = bkt; s.t1 = 0; s.np = 0; s.long_run = false;
+    if (bkt < B && L) s = bucket_span(offs, bkt, L);
     Xyzz v;
-    if (g * 64 + lane < B) xyzz_load(v, bucket, bucket_stride, (size_t)g * 64 + lane);
-    else xyzz_set_inf(v);
+    bucket_sum_wave(v, s, lane, head, head_stride, cont, cont_stride);
     wave_zeta(v, lane);
     const int role = zeta_role(lane);
-    if (role >= 0) xyzz_store(x1, x_stride, (size_t)role * G1 + g, v);
+    if (role < 0) return;
+    if (G1 == 1) xyzz_store_wire(out_wire, (size_t)role, v);
+    else xyzz_store(x1, x_stride, (size_t)role * G1 + g, v);
 }
-// level 2 (one launch, two kinds of job): with G1p = ceil(G1 / 64)
-//   wave <  6 G1p : Y[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                      (a < 6: finishes bits 0..5)
-//   wave >= 6 G1p : X2[role * G1p + g2], role 0..6, zeta transform of the totals X1[6][g2 * 64 .. +64)  (bits 6..11, totals)
+// level 2 (one launch, two kinds of job), results straight to wire words: with G1p = ceil(G1 / 64)
+//   wave <  6 G1p : out[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                                  (a < 6: finishes bits 0..5)
+//   wave >= 6 G1p : out[6 G1p + role * G1p + g2], role 0..6, zeta transform of the totals X1[6][g2 * 64 .. +64)  (bits 6..11, totals)
 __global__ void __launch_bounds__(256)
-k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p,
-            int32_t* __restrict__ y, int32_t* __restrict__ x2, size_t out_stride) {
+k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= 7u * G1p) return;
     const bool sum_job = wave < 6u * G1p;
@@ -720,23 +794,11 @@ k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32
     else xyzz_set_inf(v);
     wave_zeta(v, lane);
     if (sum_job) {
-        if (lane == 0) xyzz_store(y, out_stride, wave, v);
+        if (lane == 0) xyzz_store_wire(out_wire, wave, v);
     } else {
         const int role = zeta_role(lane);
-        if (role >= 0) xyzz_store(x2, out_stride, (size_t)role * G1p + g, v);
+        if (role >= 0) xyzz_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + g, v);
     }
-}
-// stored-form XYZZ planes -> wire words (32 u32 per element)
-__global__ void __launch_bounds__(256)
-k_xyzz_to_wire(const int32_t* __restrict__ in, size_t stride, uint32_t n, uint32_t* __restrict__ out_wire) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Xyzz v;
-    xyzz_load(v, in, stride, i);
-    uint32_t w[32];
-    xyzz_to_wire(w, v);
-#pragma unroll
-    for (int j = 0; j < 32; ++j) out_wire[(size_t)i * 32 + j] = w[j];
 }
 
 // -------------------------------------------------------------------------------------------------

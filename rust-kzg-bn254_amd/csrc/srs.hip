@@ -276,7 +276,7 @@ int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau[4], uint64_t first_power, 
 }
 
 // Window tables T_w = 2^(c w) * SRS for w < W, contiguous after the SRS itself.  Spends HBM capacity (W x 64 B per
-// point: 1 GiB for 2^20 points at c = 16) to turn the MSM into W n mixed adds into a single bucket set.
+// point: 0.94 GiB for 2^20 points at c = 17) to turn the MSM into W n mixed adds into a single bucket set.
 int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
     const char* env = getenv("KZG_NO_PRECOMPUTE");
     if (env && atoi(env) != 0) return KZG_OK;
@@ -284,11 +284,14 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
     if (n < 128) return KZG_OK;
     int lg = 0;
     while ((n >> (lg + 1)) != 0) ++lg;
+    // window bits: about log2(n) - 4 keeps the bucket reduction small against the n * ceil(255 / c) additions; at 2^20 points
+    // c = 17 (15 windows, 2^16 buckets) has 6 % fewer additions than c = 16 and the same reduction latency (one wave per SIMD)
     int c = lg - 4;
     if (c < 7) c = 7;
     if (c > 16) c = 16;
+    if (lg == 20) c = 17;
     const char* envc = getenv("KZG_TABLE_C");
-    if (envc && atoi(envc) >= 7 && atoi(envc) <= 16) c = atoi(envc);
+    if (envc && atoi(envc) >= 7 && atoi(envc) <= 17) c = atoi(envc);
     const int W = (255 + c - 1) / c;
     const size_t bytes = (size_t)W * n * 64;
     if (bytes > ((size_t)48 << 30) || (size_t)W * n >= ((size_t)1 << 31)) return KZG_OK;
