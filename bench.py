@@ -32,6 +32,7 @@ import torch.distributed as dist
 
 FR = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 LOG_N = int(os.environ.get("KZG_BENCH_LOG_N", "20"))
+DEPTH = int(os.environ["KZG_BENCH_DEPTH"]) if os.environ.get("KZG_BENCH_DEPTH") else None    # MSMs in flight (default: sharding.py)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 BYTES_PER_PAIR = 96            # 64 B packed affine point + 32 B scalar, each read once
 PMC_JSON = os.path.join(ROOT, "profiles", "r01_v5_pmc_summary.json")
@@ -122,7 +123,7 @@ def main():
     def run_steps(count):
         res = None
         if pipelined:
-            for res in sh.commit_stream(srs, [d_scalars.data_ptr()] * count):
+            for res in sh.commit_stream(srs, [d_scalars.data_ptr()] * count, depth=DEPTH):
                 pass
         else:
             for _ in range(count):

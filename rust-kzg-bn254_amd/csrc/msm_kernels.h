@@ -616,7 +616,7 @@ __device__ __forceinline__ void bucket_sum_wave(Xyzz& acc, const BucketSpan& s, 
 }
 
 // generic mode: one lane per bucket -> bucket[] (transposed for the chunked reduction when m > 0)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_msm_bucket_fin(const uint32_t* __restrict__ offs, uint32_t G, uint32_t nl, uint32_t m, uint32_t n_chunks,
                  const int32_t* __restrict__ head, size_t head_stride, const int32_t* __restrict__ cont, size_t cont_stride,
                  int32_t* __restrict__ bucket, size_t bucket_stride) {
@@ -759,7 +759,8 @@ __device__ __forceinline__ void xyzz_store_wire(uint32_t* __restrict__ out_wire,
 // level 1, fused with the bucket sums (one launch instead of bucket_fin + heavy + bits1): one wave per group g of 64 buckets;
 // lane = bucket: sum of its partials (bucket_sum_wave), then the zeta transform.  X1[role * G1 + g]: role k < 6 = S_k, role 6 = T.
 // With a single group (B = 64) the seven results leave as wire words at once.
-__global__ void __launch_bounds__(256)
+// (<= 168 VGPRs like the accumulate kernel: a wave of this kernel fits beside two accumulate waves of the other MSM in flight)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_msm_bucket_bits1(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
                    const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
                    uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
@@ -781,7 +782,7 @@ k_msm_bucket_bits1(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, c
 // level 2 (one launch, two kinds of job), results straight to wire words: with G1p = ceil(G1 / 64)
 //   wave <  6 G1p : out[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                                  (a < 6: finishes bits 0..5)
 //   wave >= 6 G1p : out[6 G1p + role * G1p + g2], role 0..6, zeta transform of the totals X1[6][g2 * 64 .. +64)  (bits 6..11, totals)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= 7u * G1p) return;
