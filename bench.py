@@ -35,34 +35,69 @@ LOG_N = int(os.environ.get("KZG_BENCH_LOG_N", "20"))
 DEPTH = int(os.environ["KZG_BENCH_DEPTH"]) if os.environ.get("KZG_BENCH_DEPTH") else None    # MSMs in flight (default: sharding.py)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 BYTES_PER_PAIR = 96            # 64 B packed affine point + 32 B scalar, each read once
-PMC_JSON = os.path.join(ROOT, "profiles", "r01_v5_pmc_summary.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+MADS_PER_MIXED_ADD = 1467      # v_mad_i64_i32 per xyzz_madd (8 x 162 + 2 x 126 - 81 for the fused Y3)
+MAD_NS_PER_WAVE_INSTR_PER_SIMD = 2.0   # measured v_mad_u64_u32 issue rate on MI355X (profiles/r01_valu_rates_mi355x.txt)
+N_SIMDS = 1024
 
 
 def pmc_traffic_bytes(log_n):
-    """HBM bytes per k_msm_accumulate launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, KB;
-    tools/pmc_summarize.py documents the gfx950 correction).  Only valid for the 2^20 workload it was measured on."""
+    """(HBM bytes per k_msm_accumulate launch, reason): from the committed rocprofv3 --pmc passes of this round (FETCH_SIZE +
+    WRITE_SIZE, KB; tools/pmc_summarize.py documents the gfx950 correction).  Only valid for the workload it was measured on."""
     try:
         d = json.load(open(PMC_JSON))
-        if d.get("log_n") != log_n:
-            return None
-        a = d["kernels"]["k_msm_accumulate"]
-        return (a["FETCH_SIZE_KB"] + a["WRITE_SIZE_KB"]) * 1024.0
-    except Exception:
-        return None
+    except Exception as e:
+        return None, "no PMC summary committed for this round (%s)" % type(e).__name__
+    if d.get("log_n") != log_n:
+        return None, "the committed PMC passes were collected at 2^%s pairs, this run is 2^%d" % (d.get("log_n"), log_n)
+    a = d["kernels"]["k_msm_accumulate"]
+    return (a["FETCH_SIZE_KB"] + a["WRITE_SIZE_KB"]) * 1024.0, "profiles/" + os.path.basename(PMC_JSON)
+
+
+def ints_to_wire(vals):
+    """canonical python ints -> (n, 4) uint64 wire array (Montgomery, R = 2^256)."""
+    R = (1 << 256) % FR
+    buf = b"".join((v * R % FR).to_bytes(32, "little") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+
+
+def uniform_scalars(n, seed):
+    """Scalars-B of SURVEY.md 8(d): i.i.d. uniform in [0, r) (models quotient polynomials and verifier r-powers).
+    Returns (canonical ints, wire array)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vals = []
+    while len(vals) < n:
+        raw = rng.integers(0, 1 << 63, size=(n - len(vals) + 1024, 5), dtype=np.uint64)
+        for a, b, c, d, e in raw.tolist():
+            v = (a | (b << 63) | (c << 126) | (d << 189) | (e << 252)) & ((1 << 254) - 1)       # rejection sampling of 254 bits
+            if v < FR:
+                vals.append(v)
+    vals = vals[:n]
+    return vals, ints_to_wire(vals)
+
+
+def expected_commitment(canonical_scalars, tau):
+    """Known-tau identity: sum_i c_i [tau^i] G1 == (sum_i c_i tau^i mod r) * G1 -- big-integer arithmetic plus ONE
+    scalar multiplication by an independent code path (tests/pyref.py, affine double-and-add); wire point (8 x u64)."""
+    import pyref
+    acc, cur = 0, 1
+    for v in canonical_scalars:
+        acc = (acc + v * cur) % FR
+        cur = cur * tau % FR
+    return pyref.point_to_wire(pyref.ec_mul(acc, (1, 2)))
+
+
+def blob_like_canonical(n, seed):
+    """Scalars-A of SURVEY.md 8(d): raw bytes uniform in [32,126] (bench_kzg_commit.rs:18), 31 per element behind
+    a zero byte (helpers.rs:823-840)  ->  canonical values < 2^248 (python ints)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    raw = rng.integers(32, 127, size=(n, 31), dtype=np.uint8).tobytes()
+    return [int.from_bytes(raw[31 * i:31 * i + 31], "big") for i in range(n)]
 
 
 def blob_like_scalars(n, seed):
-    """Scalars-A of SURVEY.md §8(d): raw bytes uniform in [32,126] (bench_kzg_commit.rs:18), 31 per element behind
-    a zero byte (helpers.rs:823-840)  ->  canonical values < 2^248, returned in wire (Montgomery) form."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    raw = rng.integers(32, 127, size=(n, 31), dtype=np.uint8)
-    out = np.empty((n, 4), dtype=np.uint64)
-    R = 1 << 256
-    M64 = (1 << 64) - 1
-    for i in range(n):
-        m = int.from_bytes(b"\x00" + raw[i].tobytes(), "big") * R % FR
-        out[i, 0] = m & M64; out[i, 1] = (m >> 64) & M64; out[i, 2] = (m >> 128) & M64; out[i, 3] = m >> 192
-    return out
+    """Scalars-A in wire (Montgomery) form."""
+    return ints_to_wire(blob_like_canonical(n, seed))
 
 
 def main():
@@ -77,8 +112,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        # one process per GPU: N > 1 needs the launcher (a process that has touched the GPU must not re-exec or fork ranks)
+        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d ranks (found WORLD_SIZE=%d): launch it as\n  python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d --steps %d --warmup %d"
+                         % (args.gpus, args.gpus, world, args.gpus, args.gpus, args.steps, args.warmup))
     # Rehearsal switch (one-GPU box): KZG_BENCH_BACKEND=gloo runs every rank on GPU 0 and gathers through host memory.
     backend = os.environ.get("KZG_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -103,12 +141,12 @@ def main():
     # ---- inputs: this rank's shard of the SRS (resident) and of the scalars (resident) ---------------------------
     sh = ShardedMsm(ctx, n, rank, world, gather_device="cuda" if backend == "nccl" else None)
     srs = k.SRS.generate(tau, sh.len, ctx=ctx, first_power=sh.lo)
-    scalars = blob_like_scalars(n, 0x4B5A472D424E3235 & 0x7FFFFFFF)      # identical on every rank (seeded)
+    canon_a = blob_like_canonical(n, 0x4B5A472D424E3235 & 0x7FFFFFFF)   # Scalars-A, identical on every rank (seeded)
+    scalars = ints_to_wire(canon_a)
+    canon_b, scalars_b = uniform_scalars(n, (0x4B5A472D424E3235 & 0x7FFFFFFF) + 1)   # Scalars-B (seed + 1)
     d_scalars = torch.from_numpy(scalars[sh.lo:sh.hi].view(np.int64)).cuda()
+    d_scalars_b = torch.from_numpy(scalars_b[sh.lo:sh.hi].view(np.int64)).cuda()
     torch.cuda.synchronize()
-
-    def step():
-        return sh.commit_device(srs, d_scalars.data_ptr())
 
     def barrier():
         torch.cuda.synchronize()
@@ -119,29 +157,30 @@ def main():
     # A step = one 2^LOG_N-pair commitment.  Steps are software-pipelined two deep (KZG_BENCH_PIPELINE=0 turns it off):
     # MSM k+1 is enqueued before MSM k is waited for, so every step is still computed and folded inside the timed region.
     pipelined = os.environ.get("KZG_BENCH_PIPELINE", "1") != "0"
+    depth_used = (DEPTH or (2 if sh.len >= (1 << 20) else 3)) if pipelined else 1
 
-    def run_steps(count):
+    def run_steps(count, ptr, depth):
         res = None
-        if pipelined:
-            for res in sh.commit_stream(srs, [d_scalars.data_ptr()] * count, depth=DEPTH):
-                pass
-        else:
-            for _ in range(count):
-                res = step()
+        for res in sh.commit_stream(srs, [ptr] * count, depth=depth):
+            pass
         return res
 
-    result = run_steps(args.warmup)
-    if os.environ.get("KZG_BENCH_NOPROF", "0") == "0":
-        lib.kzg_ctx_set_profiling(ctx.handle, 1)
-    barrier()
-    t0 = time.perf_counter()
-    result = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(count, ptr, depth):
+        barrier()
+        t0 = time.perf_counter()
+        res = run_steps(count, ptr, depth)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, res
+
+    run_steps(depth_used, d_scalars.data_ptr(), depth_used)             # set-up: every slot allocates its workspace once
+    run_steps(args.warmup, d_scalars.data_ptr(), depth_used)            # the W untimed warm-up steps
+    elapsed, result = timed(args.steps, d_scalars.data_ptr(), depth_used)            # THE timed region: exactly --steps steps
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # every rank must hold the same folded commitment
         chk = torch.from_numpy(result.view(np.int64).copy())
         if backend == "nccl":
@@ -150,22 +189,51 @@ def main():
         dist.broadcast(ref, src=0)
         assert torch.equal(ref, chk), "ranks disagree on the folded commitment"
 
+    # ---- outside the timed region: the other two headline numbers and the kernel profile -------------------------
+    side_steps = max(4, min(args.steps, 20))
+    run_steps(2, d_scalars_b.data_ptr(), depth_used)
+    elapsed_b, result_b = timed(side_steps, d_scalars_b.data_ptr(), depth_used)      # uniform scalars, same pipelining
+    run_steps(2, d_scalars.data_ptr(), 1)
+    elapsed_lat, result_lat = timed(side_steps, d_scalars.data_ptr(), 1)             # one commitment at a time: latency
+    # kernel durations: HIP events recorded by the library on its launch streams, one MSM at a time (no other MSM shares the GPU)
+    lib.kzg_ctx_set_profiling(ctx.handle, 1)
+    run_steps(side_steps, d_scalars.data_ptr(), 1)
+    barrier()
     phase = (C.c_double * 8)()
     launches, pairs = C.c_uint64(0), C.c_uint64(0)
     lib.kzg_ctx_get_msm_profile(ctx.handle, phase, C.byref(launches), C.byref(pairs))
     lib.kzg_ctx_set_profiling(ctx.handle, 0)
+    phase_alone = [phase[i] / max(1, launches.value) for i in range(8)]
+    units_per_launch = pairs.value / max(1, launches.value)
+    lib.kzg_ctx_set_profiling(ctx.handle, 1)
+    run_steps(side_steps, d_scalars.data_ptr(), depth_used)
+    barrier()
+    lib.kzg_ctx_get_msm_profile(ctx.handle, phase, C.byref(launches), C.byref(pairs))
+    lib.kzg_ctx_set_profiling(ctx.handle, 0)
+    phase_piped = [phase[i] / max(1, launches.value) for i in range(8)]
 
+    exit_code = 0
     if rank == 0:
+        # parity at EVERY world size: the folded commitment against big-integer arithmetic on the inputs
+        want_a = expected_commitment(canon_a, tau)
+        want_b = expected_commitment(canon_b, tau)
+        exact = bool(np.array_equal(result, want_a) and np.array_equal(result_lat, want_a) and np.array_equal(result_b, want_b))
+        if not exact:
+            exit_code = 3
         ms_per_step = elapsed / args.steps * 1e3
         pairs_per_s = n * args.steps / elapsed
-        acc_ms = phase[4] / max(1, launches.value)                # k_msm_accumulate, average launch duration
-        units_per_launch = pairs.value / max(1, launches.value)
+        acc_ms = phase_alone[4]                                   # k_msm_accumulate, average launch duration, running alone
         achieved = BYTES_PER_PAIR * units_per_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_bytes(LOG_N) if world == 1 else (None, "PMC passes are single-GPU")
+        plan = {"window_bits": 17, "windows": 15} if sh.len == (1 << 20) else None
+        phase_names = ["digits", "sort_histograms_scan", "scatter", "unused", "accumulate", "bucket_sums_reduce1", "reduce2", "device_total"]
         out = {
             "metric": "G1-MSM (scalar,point) pairs/s = 2^%d x KZG coeff-form commitments/s, 2^%d-point SRS" % (LOG_N, LOG_N),
             "value": pairs_per_s,
             "unit": "pairs/s",
             "commitments_per_s": args.steps / elapsed,
+            "value_uniform": n * side_steps / elapsed_b,
+            "latency_ms": elapsed_lat / side_steps * 1e3,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -174,20 +242,32 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int32x9 (29-bit limbs, 64-bit accumulate)",
-            "data": "synthetic: SRS P_i = tau^i G1 with known tau (generated on device); blob-like scalars < 2^248, seeded",
+            "data": "synthetic: SRS P_i = tau^i G1 with known tau (generated on device); value: blob-like scalars < 2^248 (Scalars-A), "
+                    "value_uniform: uniform scalars in [0, r) (Scalars-B, seed + 1); seeded",
             "config": {"workload": "G1 MSM 2^%d scalars (KZG::commit_coeff_form), scalars resident in HBM" % LOG_N,
                        "sharding": "by scalar index over %d GPU(s); all-gather of XYZZ partials + host fold" % world,
-                       "pipeline_depth": (2 if sh.len >= (1 << 20) else 3) if pipelined else 1,
-                       "bit_exact_vs_oracle": None},
+                       "pipeline_depth": depth_used,
+                       "latency_ms_is": "one commitment at a time (depth 1), %d steps" % side_steps,
+                       "bit_exact_vs_oracle": exact,
+                       "bit_exact_check": "folded commitment == (sum_i c_i tau^i mod r) * G1 by big-integer arithmetic + one affine scalar "
+                                          "multiplication (tests/pyref.py), for value, value_uniform and latency_ms, on rank 0 at every world size"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(LOG_N) if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_msm_accumulate", "avg_launch_ms": acc_ms,
+                         "avg_launch_ms_pipelined": phase_piped[4],
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIR * units_per_launch,
-                         "note": "integer-VALU bound (254-bit modular multiply); traffic (PMC) exceeds the algorithmic bytes by design: "
-                                 "one 64-byte precomputed-table point is gathered per (scalar, window)"},
-            "phases_ms_per_launch": {name: phase[i] / max(1, launches.value) for i, name in enumerate(
-                ["digits", "scan", "scatter", "segments", "accumulate", "bucket_fin", "reduce", "device_total"])},
+                         "note": "the binding resource is integer-VALU issue (254-bit modular multiply), see `valu`; traffic (PMC) exceeds the "
+                                 "algorithmic bytes by design: one 64-byte precomputed-table point is gathered per (scalar, window)"},
+            "phases_ms_per_launch": dict(zip(phase_names, phase_alone)),
+            "phases_ms_per_launch_pipelined": dict(zip(phase_names, phase_piped)),
         }
+        if plan and acc_ms > 0:
+            # VALU roofline of the same kernel: multiply-adds it must issue / the measured v_mad_i64_i32 issue rate of the chip
+            entries = plan["windows"] * units_per_launch
+            floor_ms = entries / 64.0 * MADS_PER_MIXED_ADD * MAD_NS_PER_WAVE_INSTR_PER_SIMD / N_SIMDS * 1e-6
+            out["roofline"]["valu"] = {"mixed_adds_per_launch": entries, "mads_per_mixed_add": MADS_PER_MIXED_ADD,
+                                       "mad_issue_floor_ms": floor_ms, "frac_of_mad_issue_floor": floor_ms / acc_ms,
+                                       "peak": "v_mad_i64_i32: %.1f ns per wave-instruction per SIMD, %d SIMDs (measured)" % (MAD_NS_PER_WAVE_INSTR_PER_SIMD, N_SIMDS)}
         if world == 1 and not args.no_secondary:
             # secondary figures of the same run (outside the timed region; BASELINE configs 3 and 4 on one GPU)
             def avg_ms(fn, reps=10, warm=2):
@@ -285,19 +365,43 @@ def main():
             t1 = time.perf_counter()
             want = orc.msm_pippenger(g1, scalars, threads=cores)
             cpu_s = time.perf_counter() - t1
-            out["config"]["bit_exact_vs_oracle"] = bool(np.array_equal(want, result))
+            if not np.array_equal(want, result):                   # second, independent check: the oracle's Pippenger
+                out["config"]["bit_exact_vs_oracle"] = False
+                exit_code = 3
             out["cpu_baseline"] = {"value": n / cpu_s, "unit": "pairs/s", "cores": min(cores, 17), "kind": "port",
                                    "sample": "the same 2^%d-pair MSM once: oracle/ C restatement of arkworks' signed-window "
                                              "Pippenger (c=15, one thread per window, 17 windows), %.2f s wall" % (LOG_N, cpu_s)}
-            m1 = 1 << 16                                           # single-thread sample (SURVEY.md §8d asks for both)
+            m1 = 1 << 16                                           # single-thread sample (SURVEY.md 8d asks for both)
             t1 = time.perf_counter()
             orc.msm_pippenger(g1[:m1], scalars[:m1], threads=1)
             cpu1_s = time.perf_counter() - t1
             out["cpu_baseline"]["single_thread"] = {"value": m1 / cpu1_s, "unit": "pairs/s", "cores": 1,
                                                     "sample": "2^16-pair MSM, same port, 1 thread, %.2f s wall" % cpu1_s}
+            # CPU baseline of the Fr NTT (primitives/src/polynomial.rs:130-140, :241-251): radix-2, every layer chunked over the cores
+            t1 = time.perf_counter()
+            cpu_f = orc.fr_ntt_mt(scalars_b, inverse=False, threads=cores)
+            ntt_all_s = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            orc.fr_ntt(scalars_b[:1 << 18], inverse=False)
+            ntt_1_s = time.perf_counter() - t1
+            d_chk = torch.from_numpy(scalars_b.view(np.int64)).cuda()
+            assert lib.kzg_fr_ntt_device(ctx.handle, C.c_void_p(d_chk.data_ptr()), n, 0) == 0
+            ntt_exact = bool(np.array_equal(d_chk.cpu().numpy().view(np.uint64), cpu_f))
+            if not ntt_exact:
+                exit_code = 3
+            out["cpu_baseline_ntt"] = {"value": n / ntt_all_s, "unit": "elements/s", "cores": cores, "kind": "port",
+                                       "sample": "one forward 2^%d NTT: oracle/ radix-2 with the layers chunked over %d threads, %.3f s wall" % (LOG_N, cores, ntt_all_s),
+                                       "single_thread": {"value": (1 << 18) / ntt_1_s, "unit": "elements/s", "cores": 1,
+                                                         "sample": "one forward 2^18 NTT, 1 thread, %.3f s wall" % ntt_1_s},
+                                       "gpu_bit_exact_vs_oracle": ntt_exact}
         print(json.dumps(out), flush=True)
     if world > 1:
+        code = torch.tensor([exit_code], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.broadcast(code, src=0)
+        exit_code = int(code.item())
         dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit("bench.py: the commitment differs from the expected point (exit %d)" % exit_code)
 
 
 if __name__ == "__main__":

@@ -289,6 +289,58 @@ static int fr_ntt_inplace(fe *a, size_t n, int inverse) {
     return 0;
 }
 
+/* The same transform with the butterflies of every layer chunked over `threads` pthreads (ark-poly with the `parallel`
+ * feature splits each layer over the rayon pool): identical results (exact arithmetic), used as the CPU baseline of the NTT. */
+typedef struct { fe *a; const fe *tw; size_t n; int ln, inverse, tid, threads; pthread_barrier_t *bar; fe ninv; } ntt_job;
+static void *ntt_worker(void *arg) {
+    ntt_job *J = (ntt_job *)arg;
+    const size_t n = J->n, nb = n / 2;
+    const size_t lo = nb * (size_t)J->tid / (size_t)J->threads, hi = nb * (size_t)(J->tid + 1) / (size_t)J->threads;
+    for (int s = 1; s <= J->ln; ++s) {
+        const size_t half = (size_t)1 << (s - 1), step = n >> s;           /* twiddle of butterfly j: w^(j n/m) */
+        for (size_t b = lo; b < hi; ++b) {
+            const size_t j = b & (half - 1), k = (b >> (s - 1)) << s;
+            fe t, u = J->a[k + j];
+            fe_mul(&FR, &t, &J->tw[j * step], &J->a[k + j + half]);
+            fe_add(&FR, &J->a[k + j], &u, &t);
+            fe_sub(&FR, &J->a[k + j + half], &u, &t);
+        }
+        pthread_barrier_wait(J->bar);
+    }
+    if (J->inverse) {
+        const size_t l2 = n * (size_t)J->tid / (size_t)J->threads, h2 = n * (size_t)(J->tid + 1) / (size_t)J->threads;
+        for (size_t i = l2; i < h2; ++i) fe_mul(&FR, &J->a[i], &J->a[i], &J->ninv);
+    }
+    return NULL;
+}
+static int fr_ntt_inplace_mt(fe *a, size_t n, int inverse, int threads) {
+    int ln = log2_exact(n);
+    if (ln < 0 || ln > 28) return -1;
+    if (threads < 1) threads = 1;
+    if (n < 2 || (size_t)threads > n / 2) return fr_ntt_inplace(a, n, inverse);
+    fe w; fr_root_of_unity(&w, ln);
+    if (inverse) fe_inv(&FR, &w, &w);
+    for (size_t i = 0; i < n; ++i) { size_t j = bitrev(i, ln); if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; } }
+    fe *tw = (fe *)malloc((n / 2) * sizeof(fe));                            /* w^j, j < n/2 (ark-poly precomputes the roots too) */
+    tw[0] = FR.one;
+    for (size_t j = 1; j < n / 2; ++j) fe_mul(&FR, &tw[j], &tw[j - 1], &w);
+    pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)threads);
+    ntt_job *jobs = (ntt_job *)malloc(sizeof(ntt_job) * (size_t)threads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    fe ninv = FR.one;
+    if (inverse) { fe_from_u64(&FR, &ninv, (uint64_t)n); fe_inv(&FR, &ninv, &ninv); }
+    for (int t = 0; t < threads; ++t) {
+        ntt_job j = {a, tw, n, ln, inverse, t, threads, &bar, ninv};
+        jobs[t] = j;
+    }
+    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, ntt_worker, &jobs[t]);
+    ntt_worker(&jobs[0]);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&bar);
+    free(th); free(jobs); free(tw);
+    return 0;
+}
+
 /* G1-group IFFT: the same butterflies with group elements as data (kzg.rs:275-279) */
 static int g1_ifft_inplace(g1j *a, size_t n) {
     int ln = log2_exact(n);
@@ -442,6 +494,7 @@ EXPORT unsigned orc_ark_window(size_t n) { return ark_window(n); }
 
 /* --- NTT --- */
 EXPORT int orc_fr_ntt(uint64_t *data, size_t n, int inverse) { oracle_init(); return fr_ntt_inplace((fe *)data, n, inverse); }
+EXPORT int orc_fr_ntt_mt(uint64_t *data, size_t n, int inverse, int threads) { oracle_init(); return fr_ntt_inplace_mt((fe *)data, n, inverse, threads); }
 EXPORT void orc_fr_root_of_unity(int log_n, uint64_t out[4]) { oracle_init(); fr_root_of_unity((fe *)out, log_n); }
 /* kzg.rs:263-285 g1_ifft: returns -1 on "length provided is not a power of 2" */
 EXPORT int orc_g1_ifft(const uint64_t *points, size_t n, uint64_t *out) {

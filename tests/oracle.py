@@ -150,6 +150,15 @@ def fr_ntt(data, inverse=False):
     return a
 
 
+def fr_ntt_mt(data, inverse=False, threads=None):
+    """The same transform, every layer chunked over `threads` pthreads (CPU baseline of the NTT)."""
+    a = _u64(data, (-1, 4)).copy()
+    rc = lib().orc_fr_ntt_mt(_p(a), C.c_size_t(len(a)), int(inverse), int(threads or os.cpu_count() or 1))
+    if rc:
+        raise ValueError("oracle NTT: length is not a power of two <= 2^28")
+    return a
+
+
 def fr_root_of_unity(log_n):
     out = np.zeros(4, np.uint64); lib().orc_fr_root_of_unity(log_n, _p(out)); return out
 

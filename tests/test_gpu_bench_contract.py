@@ -32,3 +32,34 @@ def test_bench_emits_the_contract_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] > 0
+    # round 2: the three headline numbers, the traffic reason, the VALU view of the roofline, the NTT baseline
+    assert d["value_uniform"] > 0 and d["latency_ms"] > 0
+    assert r["traffic"] is None and "2^20" in r["traffic_source"]      # PMC passes exist for the 2^20 workload only: null + reason
+    assert d["cpu_baseline_ntt"]["value"] > 0 and d["cpu_baseline_ntt"]["gpu_bit_exact_vs_oracle"] is True
+    assert "phases_ms_per_launch" in d and "phases_ms_per_launch_pipelined" in d
+
+
+def test_bench_refuses_n_gpus_without_launcher():
+    """`bench.py --gpus 2` without torchrun must not silently measure one GPU."""
+    env = dict(os.environ, KZG_BENCH_LOG_N="12")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "torch.distributed.run" in (res.stderr + res.stdout)
+
+
+def test_bench_two_ranks_gloo_is_bit_exact():
+    """The N > 1 path of bench.py rehearsed on one GPU: two ranks (gloo exchange, both on GPU 0), 2^18 pairs sharded by scalar
+    index, the folded commitment checked on rank 0 against sum_i c_i tau^i * G1 (big-integer arithmetic)."""
+    env = dict(os.environ, KZG_BENCH_LOG_N="18", KZG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(key, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-secondary"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bit_exact_vs_oracle"] is True
+    assert d["value"] > 0 and d["value_uniform"] > 0 and d["latency_ms"] > 0
