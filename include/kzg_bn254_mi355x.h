@@ -195,6 +195,28 @@ int32_t kzg_commit_eval_form_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, siz
 int32_t kzg_compute_proof_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo,
                                   const uint64_t* evals_mont, size_t n, const uint64_t* roots_mont, size_t n_roots,
                                   const uint64_t z_mont[4], uint64_t out_xyzz_mont[16], uint64_t* out_y_mont);
+/* helpers::compute_challenge (primitives/src/helpers.rs:411-472): the Fiat-Shamir evaluation point of a blob,
+ *   z = SHA-256( "EIGENDA_FSBLOBVERIFY_V1_" || u64be(n) || n x 32 B evaluations (big-endian, canonical) || commitment ) mod r,
+ * n = next_pow2(ceil(len / 32)); evaluations = the blob's 32-byte big-endian chunks mod r (Blob::to_polynomial_eval_form, last
+ * chunk right-padded with zeros, zero elements up to n); commitment = ark-serialize compressed G1Affine (32 B, x little-endian,
+ * flags in the top bits of the last byte).  Host only (x86 SHA extensions when present); the commitment must be on the curve
+ * (helpers::validate_g1_point, helpers.rs:694-708): else KZG_ERR_G1_NOT_ON_CURVE. */
+int32_t kzg_compute_challenge(const uint8_t* blob_bytes, size_t len, const uint64_t commitment_xy_mont[8], uint64_t out_z_mont[4]);
+/* KZG::compute_blob_proof (prover/src/kzg.rs:288-309): validate the commitment, z = compute_challenge(blob, commitment),
+ * proof = compute_proof_impl(blob.to_polynomial_eval_form(), z, srs).  n_roots = KZG::expanded_roots_of_unity.len()
+ * (KZG_ERR_ROOTS_LENGTH when it differs from the padded blob length, kzg.rs:135-139).  Bytes in, point out: the blob crosses
+ * PCIe once; its transcript hash runs on a host thread beside the upload / bytes->Fr kernels.  out_z_mont / out_y_mont
+ * (optional) receive the challenge and p(z). */
+int32_t kzg_compute_blob_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len, size_t n_roots,
+                               const uint64_t commitment_xy_mont[8], uint64_t out_proof_xy_mont[8], uint8_t* out_is_infinity,
+                               uint64_t* out_z_mont, uint64_t* out_y_mont);
+/* KZG::commit_blob (kzg.rs:182-185) followed by KZG::compute_blob_proof (kzg.rs:288-309) on the same blob in one call: the
+ * transcript prefix (tag, length, evaluations: everything but the commitment) is hashed on a host thread WHILE the GPU computes
+ * the commitment, and finalised with the 32 commitment bytes; then the proof.  Same results as the two separate calls. */
+int32_t kzg_commit_and_prove_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len, size_t n_roots,
+                                  uint64_t out_commitment_xy_mont[8], uint8_t* out_commitment_is_infinity,
+                                  uint64_t out_proof_xy_mont[8], uint8_t* out_proof_is_infinity,
+                                  uint64_t* out_z_mont, uint64_t* out_y_mont);
 /* helpers::evaluate_polynomial_in_evaluation_form (helpers.rs:475-535) on the domain of size n. */
 int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t* evals_mont, size_t n,
                                                    const uint64_t z_mont[4], uint64_t out_y_mont[4]);

@@ -81,6 +81,9 @@ PROTOTYPES = {
     "kzg_compute_proof": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, u64p, u8p, u64p]),
     "kzg_compute_proof_begin": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, i32]),
     "kzg_compute_proof_end": (i32, [vp, i32, u64p, u8p, u64p]),
+    "kzg_compute_challenge": (i32, [u8p, sz, u64p, u64p]),
+    "kzg_compute_blob_proof": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, u8p, u64p, u64p]),
+    "kzg_commit_and_prove_blob": (i32, [vp, vp, u8p, sz, sz, u64p, u8p, u64p, u8p, u64p, u64p]),
     "kzg_commit_eval_form_partial": (i32, [vp, vp, sz, u64p, sz, u64p]),
     "kzg_compute_proof_partial": (i32, [vp, vp, sz, u64p, sz, u64p, sz, u64p, u64p, u64p]),
     "kzg_evaluate_polynomial_in_evaluation_form": (i32, [vp, u64p, sz, u64p, u64p]),

@@ -2,12 +2,14 @@
 #include "engine.h"
 #include "host_curve.h"
 #include "host_pairing.h"
+#include "host_sha256.h"
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 namespace kzg {
@@ -663,6 +665,154 @@ int32_t kzg_compute_proof_end(kzg_ctx* ctx, int32_t slot, uint64_t out_xy_mont[8
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return proof_end(ctx, slot, out_xy_mont, out_is_infinity, out_y_mont);
+}
+
+// ---- Fiat-Shamir challenge and blob proofs (helpers.rs:411-472, kzg.rs:288-309) --------------------------------------------
+namespace {
+
+const char FS_DOMAIN[] = "EIGENDA_FSBLOBVERIFY_V1_";          // primitives/src/consts.rs:8 (24 bytes)
+const uint64_t FR_R2_WORDS[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};   // 2^512 mod r
+
+// Absorbs  tag || u64be(n) || n x 32 bytes, the evaluations of Blob::to_polynomial_eval_form in to_byte_array form: every
+// 32-byte big-endian chunk of the blob reduced mod r (helpers.rs:40-57 -> :80-119), zero elements up to the next power of two.
+// Canonical chunks (the normal case) are hashed straight from the caller's buffer.
+void challenge_absorb_prefix(kzg_host::Sha256& sh, const uint8_t* blob, size_t len, size_t n_padded) {
+    using namespace kzg_host;
+    sha256_update(sh, reinterpret_cast<const uint8_t*>(FS_DOMAIN), 24);
+    uint8_t nb[8];
+    for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)((uint64_t)n_padded >> (8 * (7 - i)));
+    sha256_update(sh, nb, 8);
+    const size_t n_full = len / 32;
+    uint8_t r_be[32];
+    for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) r_be[8 * i + b] = (uint8_t)(FR_MODULUS_WORDS[3 - i] >> (8 * (7 - b)));
+    auto reduce_and_absorb = [&](const uint8_t chunk[32]) {
+        uint64_t w[4];
+        for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int b = 0; b < 8; ++b) v = (v << 8) | chunk[8 * (3 - i) + b]; w[i] = v; }
+        while (fr_geq_r(w)) fr_sub_r(w);                                            // value < 2^256 < 6 r
+        uint8_t out[32];
+        for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) out[8 * i + b] = (uint8_t)(w[3 - i] >> (8 * (7 - b)));
+        sha256_update(sh, out, 32);
+    };
+    size_t run = 0;                                                                  // first chunk of the pending canonical run
+    for (size_t i = 0; i < n_full; ++i) {
+        if (memcmp(blob + 32 * i, r_be, 32) >= 0) {                                  // chunk >= r: flush the run, reduce this one
+            if (i > run) sha256_update(sh, blob + 32 * run, 32 * (i - run));
+            reduce_and_absorb(blob + 32 * i);
+            run = i + 1;
+        }
+    }
+    if (n_full > run) sha256_update(sh, blob + 32 * run, 32 * (n_full - run));
+    size_t done = n_full;
+    if (len % 32) {                                                                  // ragged tail: right-padded with zeros (helpers.rs:48-52)
+        uint8_t chunk[32] = {0};
+        memcpy(chunk, blob + 32 * n_full, len % 32);
+        reduce_and_absorb(chunk);
+        ++done;
+    }
+    static const uint8_t zeros[4096] = {0};
+    for (size_t left = (n_padded - done) * 32; left;) { size_t t = left < sizeof zeros ? left : sizeof zeros; sha256_update(sh, zeros, t); left -= t; }
+}
+// ark-serialize compressed G1Affine (helpers.rs:456-459): x little-endian, bit 7 of the last byte = y is the larger root, bit 6 = infinity
+void g1_serialize_compressed_ark(const kzg_host::G1& p, uint8_t out[32]) {
+    using namespace kzg_host;
+    memset(out, 0, 32);
+    if (p.inf) { out[31] = 0x40; return; }
+    Fq one_plain = {{1, 0, 0, 0}};
+    Fq x = mul(p.x, one_plain), y = mul(p.y, one_plain);                             // Montgomery -> canonical
+    memcpy(out, x.l, 32);                                                            // little-endian host
+    Fq ny = sub(FQ_P, y);                                                            // -y (y != 0 on this curve)
+    bool larger = false;
+    for (int i = 3; i >= 0; --i) if (y.l[i] != ny.l[i]) { larger = y.l[i] > ny.l[i]; break; }
+    if (larger) out[31] |= 0x80;
+}
+void challenge_finish(kzg_host::Sha256& sh, const kzg_host::G1& commitment, uint64_t out_z_mont[4]) {
+    using namespace kzg_host;
+    uint8_t cb[32], dig[32];
+    g1_serialize_compressed_ark(commitment, cb);
+    sha256_update(sh, cb, 32);
+    sha256_final(sh, dig);
+    uint64_t w[4];
+    for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int b = 0; b < 8; ++b) v = (v << 8) | dig[8 * (3 - i) + b]; w[i] = v; }
+    while (fr_geq_r(w)) fr_sub_r(w);                                                // Fr::from_be_bytes_mod_order (helpers.rs:382-390)
+    fr_mul(w, FR_R2_WORDS, out_z_mont);                                             // canonical -> Montgomery
+}
+size_t blob_padded_len(size_t len) { size_t e = (len + 31) / 32, p = 1; while (p < e) p <<= 1; return p; }
+
+}  // namespace
+
+int32_t kzg_compute_challenge(const uint8_t* blob_bytes, size_t len, const uint64_t commitment_xy_mont[8], uint64_t out_z_mont[4]) {
+    if (!commitment_xy_mont || !out_z_mont || (len && !blob_bytes)) return KZG_ERR_INVALID_ARG;
+    if ((len + 31) / 32 > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    kzg_host::G1 c = kzg_host::g1_from_wire(commitment_xy_mont);
+    if (!kzg_host::g1_on_curve(c)) return KZG_ERR_G1_NOT_ON_CURVE;                   // validate_g1_point (helpers.rs:694-708; cofactor 1)
+    kzg_host::Sha256 sh;
+    kzg_host::sha256_init(sh);
+    challenge_absorb_prefix(sh, blob_bytes, len, blob_padded_len(len));
+    challenge_finish(sh, c, out_z_mont);
+    return KZG_OK;
+}
+
+// shared body: `commitment_in` given (compute_blob_proof) or computed here beside the transcript hash (commit + proof)
+static int32_t blob_proof_common(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len, size_t n_roots,
+                                 const uint64_t* commitment_in, uint64_t* out_commitment_xy, uint8_t* out_commitment_inf,
+                                 uint64_t out_proof_xy[8], uint8_t* out_proof_inf, uint64_t* out_z_mont, uint64_t* out_y_mont) {
+    if (!ctx || !srs || srs->ctx != ctx || !out_proof_xy || (len && !blob_bytes)) return KZG_ERR_INVALID_ARG;
+    const size_t n_elems = (len + 31) / 32;
+    if (n_elems > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;                       // polynomial.rs:42-46
+    const size_t n = blob_padded_len(len);
+    kzg_host::G1 commitment;
+    if (commitment_in) {
+        commitment = kzg_host::g1_from_wire(commitment_in);
+        if (!kzg_host::g1_on_curve(commitment)) return KZG_ERR_G1_NOT_ON_CURVE;      // kzg.rs:295
+    }
+    if (n != n_roots) return KZG_ERR_ROOTS_LENGTH;                                   // kzg.rs:135-139 (compute_proof_impl)
+    if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;                            // kzg.rs:89-94 (commit_eval_form of the quotient)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->slot_pending[0]) { ctx->last_error = "a kzg_*_begin on slot 0 is still in flight: call its end first"; return KZG_ERR_INVALID_ARG; }
+    // the transcript prefix does not depend on the commitment: hash it on a host thread while the GPU works
+    kzg_host::Sha256 sh;
+    kzg_host::sha256_init(sh);
+    std::thread hasher([&] { challenge_absorb_prefix(sh, blob_bytes, len, n); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{hasher};
+    PolySet& set = ctx->poly[0];
+    void* d_evals = nullptr;
+    int32_t rc = blob_to_fr_run(ctx, blob_bytes, len, n, &d_evals, ctx->stream, &set.c, &set.a);    // evaluations (wire) in set.a
+    if (rc != KZG_OK) return rc;
+    if (!commitment_in) {
+        // commit_blob on a copy of the evaluations (the IFFT is in place); runs beside the hash
+        KZG_HIP_TRY(ctx, ctx->msm.scalars.reserve(n * 32 + 32));
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm.scalars.p, d_evals, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        rc = ntt_run(ctx, ctx->msm.scalars.p, n, true);
+        if (rc != KZG_OK) return rc;
+        uint64_t cxy[8]; uint8_t cinf = 0;
+        rc = msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->msm.scalars.p, n, cxy, &cinf, nullptr);
+        if (rc != KZG_OK) return rc;
+        commitment = kzg_host::g1_from_wire(cxy);
+        if (out_commitment_xy) memcpy(out_commitment_xy, cxy, 64);
+        if (out_commitment_inf) *out_commitment_inf = cinf;
+    }
+    hasher.join();
+    uint64_t z[4];
+    challenge_finish(sh, commitment, z);
+    if (out_z_mont) memcpy(out_z_mont, z, 32);
+    return proof_run(ctx, srs, nullptr, n, z, out_proof_xy, out_proof_inf, out_y_mont, true, 0, nullptr);   // evaluations already in set.a
+}
+
+int32_t kzg_compute_blob_proof(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len, size_t n_roots,
+                               const uint64_t commitment_xy_mont[8], uint64_t out_proof_xy_mont[8], uint8_t* out_is_infinity,
+                               uint64_t* out_z_mont, uint64_t* out_y_mont) {
+    if (!commitment_xy_mont) return KZG_ERR_INVALID_ARG;
+    return blob_proof_common(ctx, srs, blob_bytes, len, n_roots, commitment_xy_mont, nullptr, nullptr, out_proof_xy_mont, out_is_infinity,
+                             out_z_mont, out_y_mont);
+}
+
+int32_t kzg_commit_and_prove_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len, size_t n_roots,
+                                  uint64_t out_commitment_xy_mont[8], uint8_t* out_commitment_is_infinity,
+                                  uint64_t out_proof_xy_mont[8], uint8_t* out_proof_is_infinity, uint64_t* out_z_mont, uint64_t* out_y_mont) {
+    if (!out_commitment_xy_mont) return KZG_ERR_INVALID_ARG;
+    return blob_proof_common(ctx, srs, blob_bytes, len, n_roots, nullptr, out_commitment_xy_mont, out_commitment_is_infinity,
+                             out_proof_xy_mont, out_proof_is_infinity, out_z_mont, out_y_mont);
 }
 
 int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t* evals_mont, size_t n,

@@ -100,7 +100,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     size_t mult = 2;
     { const char* env = getenv("KZG_SORT_TILE_MULT"); if (env && atoi(env) > 0) mult = (size_t)atoi(env); }
     size_t tile = std::max<size_t>(4096, mult * p.B);
-    while (((size_t)p.set_len + tile - 1) / tile * p.sets > 1024) tile *= 2;
+    while (tile < p.set_len && ((size_t)p.set_len + tile - 1) / tile * p.sets > 1024) tile *= 2;   // (many small sets: one tile per set)
     p.tile_len = (uint32_t)tile;
     p.tiles_per_set = (uint32_t)(((size_t)p.set_len + tile - 1) / tile);
     p.tiles = p.tiles_per_set * p.sets;

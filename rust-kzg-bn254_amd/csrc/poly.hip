@@ -363,7 +363,7 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     memcpy(pin + 1024, z, 32);
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(d_z, pin + 1024, 32, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));
+    if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));   // nullptr: set.a already holds the n evaluations (blob proofs)
 
     hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, d_z,
                        d_inv, d_den, partial, ps);

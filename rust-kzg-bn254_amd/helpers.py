@@ -244,7 +244,21 @@ def compute_challenges_and_evaluate_polynomial(blobs, commitments, ctx=None):
 
 
 def compute_challenge(blob, commitment) -> np.ndarray:
-    """helpers.rs:411-472: SHA-256(tag || u64be(n) || n x 32-byte evaluations || compressed commitment) mod r."""
+    """helpers.rs:411-472: SHA-256(tag || u64be(n) || n x 32-byte evaluations || compressed commitment) mod r
+    (`kzg_compute_challenge`: the transcript is built and hashed in C on the host, no Python loop over the elements)."""
+    data = blob.data()
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    z = np.zeros(4, dtype=np.uint64)
+    rc = _lib.load().kzg_compute_challenge(buf.ctypes.data_as(_lib.u8p), len(data), _lib.ptr(_lib.as_u64(commitment, 0).reshape(8)), _lib.ptr(z))
+    if rc == _lib.ERR_G1_NOT_ON_CURVE:
+        raise NotOnCurveError("G1 point not on curve")
+    if rc != _lib.OK:
+        raise GenericError(_lib.status_message(rc))
+    return z
+
+
+def compute_challenge_py(blob, commitment) -> np.ndarray:
+    """The same transcript assembled in Python (hashlib): kept as an independent cross-check of the C path."""
     validate_g1_point(commitment)
     poly = blob.to_polynomial_eval_form()
     n = len(poly)

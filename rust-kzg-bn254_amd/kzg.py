@@ -10,6 +10,16 @@ from .fr import g1_is_identity
 from .polynomial import PolynomialCoeffForm, PolynomialEvalForm
 
 
+def _drain_slot(ctx, slot, proof=False):
+    """Wait for an asynchronous call left in flight on `slot` and drop its result (generator clean-up paths)."""
+    lib = _lib.load()
+    out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0); y = np.zeros(4, dtype=np.uint64)
+    if proof:
+        lib.kzg_compute_proof_end(ctx.handle, slot, _lib.ptr(out), C.byref(inf), _lib.ptr(y))
+    else:
+        lib.kzg_msm_g1_srs_end(ctx.handle, slot, _lib.ptr(out), C.byref(inf), None)
+
+
 class KZG:
     def __init__(self, ctx=None):
         self.ctx = ctx
@@ -47,6 +57,8 @@ class KZG:
         if rc == _lib.ERR_DOMAIN:
             raise FFTError("Could not perform IFFT due to domain consturction error")
         ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
         return out
 
     # kzg.rs:107-125
@@ -60,6 +72,8 @@ class KZG:
         if rc == _lib.ERR_MSM_LENGTH_MISMATCH:
             raise CommitError(str(min(len(coeffs), len(srs))))
         ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
         return out
 
     # ---- streams of commitments, two in flight (kzg_*_begin(slot) / kzg_msm_g1_srs_end(slot)) --------------------------
@@ -78,28 +92,37 @@ class KZG:
 
         prev = None
         k = 0
-        for item in items:
-            slot = k & 1
-            rc = begin(item, slot)
-            if rc is None:
+        try:
+            for item in items:
+                slot = k & 1
+                rc = begin(item, slot)
+                if rc is None:
+                    if prev is not None:
+                        p, prev = prev, None
+                        yield end(p)
+                    yield np.zeros(8, dtype=np.uint64)
+                    continue
+                k += 1
+                if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
+                    raise SrsCapacityExceeded(len(item), 0)
+                if rc == _lib.ERR_NOT_POWER_OF_TWO:
+                    raise FFTError("length provided is not a power of 2")
+                ctx.check_device(rc)
+                if rc != _lib.OK:
+                    raise CommitError(_lib.status_message(rc))
                 if prev is not None:
-                    yield end(prev)
-                    prev = None
-                yield np.zeros(8, dtype=np.uint64)
-                continue
-            k += 1
-            if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
-                raise SrsCapacityExceeded(len(item), 0)
-            if rc == _lib.ERR_NOT_POWER_OF_TWO:
-                raise FFTError("length provided is not a power of 2")
-            ctx.check_device(rc)
-            if rc != _lib.OK:
-                raise CommitError(_lib.status_message(rc))
+                    p, prev = prev, slot
+                    yield end(p)
+                else:
+                    prev = slot
             if prev is not None:
-                yield end(prev)
-            prev = slot
-        if prev is not None:
-            yield end(prev)
+                p, prev = prev, None
+                yield end(p)
+        finally:
+            # an exception in begin() for item k+1, or a consumer that stops early, must not leave a slot in flight: a pending
+            # slot can never be begun again and slot 0 blocks every synchronous call of the context
+            if prev is not None:
+                _drain_slot(ctx, prev)
 
     def commit_coeff_form_stream(self, polynomials, srs):
         """`commit_coeff_form` over a stream of polynomials: the H2D copy and the sort of polynomial k+1 run beside the bucket
@@ -158,21 +181,28 @@ class KZG:
             return (out, y) if want_y else out
 
         prev = None
-        for k, (polynomial, z_fr) in enumerate(items):
-            ev = _lib.as_u64(polynomial.evaluations(), 4)
-            z = np.ascontiguousarray(_lib.as_u64(z_fr, 0).reshape(4))
-            slot = k & 1
-            rc = lib.kzg_compute_proof_begin(ctx.handle, srs.handle, _lib.ptr(ev), len(ev), None, len(ev), _lib.ptr(z), slot)
-            if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
-                raise SrsCapacityExceeded(len(ev), len(srs))
-            ctx.check_device(rc)
-            if rc != _lib.OK:
-                raise GenericError(_lib.status_message(rc))
+        try:
+            for k, (polynomial, z_fr) in enumerate(items):
+                ev = _lib.as_u64(polynomial.evaluations(), 4)
+                z = np.ascontiguousarray(_lib.as_u64(z_fr, 0).reshape(4))
+                slot = k & 1
+                rc = lib.kzg_compute_proof_begin(ctx.handle, srs.handle, _lib.ptr(ev), len(ev), None, len(ev), _lib.ptr(z), slot)
+                if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
+                    raise SrsCapacityExceeded(len(ev), len(srs))
+                ctx.check_device(rc)
+                if rc != _lib.OK:
+                    raise GenericError(_lib.status_message(rc))
+                if prev is not None:
+                    p, prev = prev, slot
+                    yield end(p)
+                else:
+                    prev = slot
             if prev is not None:
-                yield end(prev)
-            prev = slot
-        if prev is not None:
-            yield end(prev)
+                p, prev = prev, None
+                yield end(p)
+        finally:
+            if prev is not None:
+                _drain_slot(ctx, prev, proof=True)
 
     # kzg.rs:182-185
     def commit_blob(self, blob, srs):
@@ -193,6 +223,8 @@ class KZG:
         if rc == _lib.ERR_TOO_LARGE:
             raise GenericError("Input size exceeds maximum polynomial size")
         ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
         return out
 
     # kzg.rs:128-178
@@ -245,11 +277,47 @@ class KZG:
         if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
             raise SrsCapacityExceeded(length, len(srs))
         ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
         return out
 
     # kzg.rs:288-309
-    def compute_blob_proof(self, blob, commitment, srs):
-        helpers.validate_g1_point(commitment)
-        poly = blob.to_polynomial_eval_form()
-        z = helpers.compute_challenge(blob, commitment)
-        return self._compute_proof_impl(poly, z, srs)
+    def compute_blob_proof(self, blob, commitment, srs, want_zy=False):
+        """Bytes in, proof out (`kzg_compute_blob_proof`): commitment validation, Fiat-Shamir challenge (hashed in C on a host
+        thread beside the upload) and the proof in one call."""
+        ctx = self._ctx()
+        data = blob.data()
+        buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0); z = np.zeros(4, dtype=np.uint64); y = np.zeros(4, dtype=np.uint64)
+        rc = _lib.load().kzg_compute_blob_proof(ctx.handle, srs.handle, buf.ctypes.data_as(_lib.u8p), len(data), len(self.expanded_roots_of_unity),
+                                                _lib.ptr(_lib.as_u64(commitment, 0).reshape(8)), _lib.ptr(out), C.byref(inf), _lib.ptr(z), _lib.ptr(y))
+        self._raise_proof_status(ctx, rc, blob, srs)
+        return (out, z, y) if want_zy else out
+
+    def commit_and_prove_blob(self, blob, srs):
+        """`commit_blob` + `compute_blob_proof` of the same blob in one call (`kzg_commit_and_prove_blob`): the transcript hash
+        runs on a host thread while the GPU computes the commitment.  Returns (commitment, proof, z, y)."""
+        ctx = self._ctx()
+        data = blob.data()
+        buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+        com = np.zeros(8, dtype=np.uint64); cinf = C.c_uint8(0)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0); z = np.zeros(4, dtype=np.uint64); y = np.zeros(4, dtype=np.uint64)
+        rc = _lib.load().kzg_commit_and_prove_blob(ctx.handle, srs.handle, buf.ctypes.data_as(_lib.u8p), len(data), len(self.expanded_roots_of_unity),
+                                                   _lib.ptr(com), C.byref(cinf), _lib.ptr(out), C.byref(inf), _lib.ptr(z), _lib.ptr(y))
+        self._raise_proof_status(ctx, rc, blob, srs)
+        return com, out, z, y
+
+    @staticmethod
+    def _raise_proof_status(ctx, rc, blob, srs):
+        if rc == _lib.OK:
+            return
+        if rc == _lib.ERR_G1_NOT_ON_CURVE:
+            raise NotOnCurveError("G1 point not on curve")
+        if rc == _lib.ERR_ROOTS_LENGTH:
+            raise GenericError("inconsistent length between blob and root of unities")
+        if rc == _lib.ERR_SRS_CAPACITY_EXCEEDED:
+            raise SrsCapacityExceeded(-(-len(blob.data()) // 32), len(srs))
+        if rc == _lib.ERR_TOO_LARGE:
+            raise GenericError("Input size exceeds maximum polynomial size")
+        ctx.check_device(rc)
+        raise GenericError(_lib.status_message(rc))

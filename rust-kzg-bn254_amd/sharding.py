@@ -195,16 +195,27 @@ class ShardedMsm:
             exchanging = True
             return out
 
-        for k, ptr in enumerate(d_scalars_ptrs):
-            if len(inflight) == depth:
+        try:
+            for k, ptr in enumerate(d_scalars_ptrs):
+                if len(inflight) == depth:
+                    yield from retire()
+                slot = k % depth
+                self.begin(srs_shard, ptr, slot)
+                inflight.append(slot)
+            while inflight:
                 yield from retire()
-            slot = k % depth
-            self.begin(srs_shard, ptr, slot)
-            inflight.append(slot)
-        while inflight:
-            yield from retire()
-        if exchanging:
-            yield fold_partials(g.finish())
+            if exchanging:
+                exchanging = False
+                yield fold_partials(g.finish())
+        finally:
+            # a failed begin() or a consumer that stops early must not leave slots (or an exchange) in flight
+            while inflight:
+                slot = inflight.popleft()
+                part = np.zeros(16, dtype=np.uint64)
+                _lib.load().kzg_msm_g1_srs_end(self.ctx.handle, slot, None, None, _lib.ptr(part))
+            if exchanging and g is not None and self.world == 1:
+                g.finish()
+
 
 class ShardedKzg:
     """`KZG::commit_eval_form` / `KZG::compute_proof` with the MSM sharded over `world` ranks (BASELINE config 4).

@@ -1,0 +1,83 @@
+"""Host-only (no GPU): `kzg_compute_challenge` -- the Fiat-Shamir transcript of helpers::compute_challenge
+(primitives/src/helpers.rs:411-472) assembled and hashed in C -- against the oracle's transcript and an independent
+hashlib construction; SHA-256 corner lengths through the same code."""
+import ctypes as C
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import pyref
+from pyref import P, R_
+
+TAG = b"EIGENDA_FSBLOBVERIFY_V1_"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import rust_kzg_bn254_amd as k
+    return k._lib.load(), k
+
+
+def challenge(lib_k, blob: bytes, commitment):
+    lib, k = lib_k
+    buf = np.frombuffer(blob, dtype=np.uint8).copy() if blob else np.zeros(1, np.uint8)
+    z = np.zeros(4, np.uint64)
+    c = np.ascontiguousarray(commitment, dtype=np.uint64).reshape(8)
+    rc = lib.kzg_compute_challenge(buf.ctypes.data_as(k._lib.u8p), len(blob), k._lib.ptr(c), k._lib.ptr(z))
+    return rc, z
+
+
+def transcript_py(blob: bytes, pt):
+    """tag || u64be(n) || n x 32 B (chunks mod r, big-endian) || ark-compressed commitment, by plain Python."""
+    n_el = -(-len(blob) // 32)
+    n = pyref.next_pow2(n_el)
+    padded = blob + bytes(n_el * 32 - len(blob))
+    evals = [int.from_bytes(padded[32 * i:32 * i + 32], "big") % R_ for i in range(n_el)] + [0] * (n - n_el)
+    if pt is None:
+        cb = bytes(31) + b"\x40"
+    else:
+        b = bytearray(pt[0].to_bytes(32, "little"))
+        if pt[1] > (P - 1) // 2:
+            b[31] |= 0x80
+        cb = bytes(b)
+    msg = TAG + n.to_bytes(8, "big") + b"".join(v.to_bytes(32, "big") for v in evals) + cb
+    return int.from_bytes(hashlib.sha256(msg).digest(), "big") % R_
+
+
+@pytest.mark.parametrize("length", [0, 1, 31, 32, 33, 64, 95, 1000, 32 * 64, 32 * 100 + 7, 32 * 4096])
+def test_challenge_matches_python_and_oracle(lib, length):
+    rnd = random.Random(length)
+    blob = bytes(rnd.randrange(256) for _ in range(length))            # arbitrary bytes: most chunks are >= r and get reduced
+    pt = pyref.ec_mul(rnd.randrange(1, R_), (1, 2))
+    rc, z = challenge(lib, blob, pyref.point_to_wire(pt))
+    assert rc == 0
+    assert pyref.fr_from_mont(z) == transcript_py(blob, pt)
+    if length:
+        assert np.array_equal(z, orc.compute_challenge(blob, pyref.point_to_wire(pt)))
+
+
+def test_challenge_canonical_blob_sign_flag_identity_and_errors(lib):
+    _, k = lib
+    rnd = random.Random(5)
+    raw = bytes(rnd.randrange(32, 127) for _ in range(31 * 300 + 11))
+    blob = orc.pad_payload(raw)                                        # canonical chunks: hashed straight from the buffer
+    for s in (3, 4, 5, 6):                                             # both signs of y occur
+        pt = pyref.ec_mul(s, (1, 2))
+        rc, z = challenge(lib, blob, pyref.point_to_wire(pt))
+        assert rc == 0 and pyref.fr_from_mont(z) == transcript_py(blob, pt)
+        neg = (pt[0], P - pt[1])
+        rc, z2 = challenge(lib, blob, pyref.point_to_wire(neg))
+        assert rc == 0 and pyref.fr_from_mont(z2) == transcript_py(blob, neg) and not np.array_equal(z, z2)
+    rc, z = challenge(lib, blob, np.zeros(8, np.uint64))               # identity commitment: is_on_curve() holds (helpers.rs:695)
+    assert rc == 0 and pyref.fr_from_mont(z) == transcript_py(blob, None)
+    bad = pyref.point_to_wire((1, 3))
+    rc, _ = challenge(lib, blob, bad)
+    assert rc == k._lib.ERR_G1_NOT_ON_CURVE
+    # a chunk equal to r, r - 1, 2^256 - 1
+    edge = R_.to_bytes(32, "big") + (R_ - 1).to_bytes(32, "big") + b"\xff" * 32 + bytes(32)
+    pt = pyref.ec_mul(9, (1, 2))
+    rc, z = challenge(lib, edge, pyref.point_to_wire(pt))
+    assert rc == 0 and pyref.fr_from_mont(z) == transcript_py(edge, pt)

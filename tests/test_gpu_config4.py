@@ -196,3 +196,60 @@ def test_sharded_msm_stream_2_20_folds_to_known_tau(k, case):
         parts.append(sh._end_partial(rank % k._lib.NUM_SLOTS))
         shard.close()
     assert pyref.point_from_wire(fold_partials(np.stack(parts))) == expect_point(ptau)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# KZG::compute_blob_proof / commit + proof in one call (prover/src/kzg.rs:288-309) behind the C-ABI
+# ---------------------------------------------------------------------------------------------------------
+def test_blob_proof_2_12_against_oracle(k):
+    """2^12 elements: challenge == oracle transcript, proof == oracle proof; the fused commit + proof call returns the same."""
+    import oracle as orc
+    n = 1 << 12
+    srs = k.SRS.generate(TAU, n)
+    rnd = random.Random(12)
+    raw = bytes(rnd.randrange(256) for _ in range(32 * n - 9))        # ragged tail, non-canonical chunks
+    blob = k.Blob.from_padded_unchecked(raw) if hasattr(k.Blob, "from_padded_unchecked") else k.Blob(raw)
+    kz = k.KZG.new()
+    kz.calculate_and_store_roots_of_unity(len(raw))
+    commitment = kz.commit_blob(blob, srs)
+    proof, z, y = kz.compute_blob_proof(blob, commitment, srs, want_zy=True)
+    assert np.array_equal(z, orc.compute_challenge(raw, commitment))
+    evals = orc.to_fr_array(raw)
+    evals = np.concatenate([evals, np.zeros((n - len(evals), 4), np.uint64)])
+    rc, roots = orc.calculate_roots_of_unity(len(raw))
+    rc, want, want_y = orc.compute_proof(srs.g1, evals, roots, z, literal=False)
+    assert rc == 0 and np.array_equal(proof, want) and np.array_equal(y, want_y)
+    c2, p2, z2, y2 = kz.commit_and_prove_blob(blob, srs)
+    assert np.array_equal(c2, commitment) and np.array_equal(p2, proof) and np.array_equal(z2, z) and np.array_equal(y2, y)
+    # guards: wrong root count, commitment off the curve, SRS too short
+    kz2 = k.KZG.new(); kz2.calculate_and_store_roots_of_unity(32 * 64)
+    with pytest.raises(k.errors.GenericError, match="inconsistent length between blob and root of unities"):
+        kz2.compute_blob_proof(blob, commitment, srs)
+    with pytest.raises(k.errors.NotOnCurveError):
+        kz.compute_blob_proof(blob, pyref.point_to_wire((1, 3)), srs)
+    short = k.SRS.generate(TAU, n // 2)
+    with pytest.raises(k.errors.SrsCapacityExceeded):
+        kz.compute_blob_proof(blob, commitment, short)
+    short.close(); srs.close()
+
+
+def test_blob_proof_2_20_known_tau(k, srs, dom):
+    """32 MiB blob: z == oracle transcript (SHA-256 over 32 MiB), proof == ((f^(tau) - y) / (tau - z)) * G1 by big-integer arithmetic."""
+    import oracle as orc
+    rng = np.random.default_rng(2020)
+    raw = rng.integers(0, 256, size=(N, 32), dtype=np.uint8)
+    raw[:, 0] &= 0x1F                                                  # canonical chunks (< 2^253 < r)
+    data = raw.tobytes()
+    evals = [int.from_bytes(data[32 * i:32 * i + 32], "big") for i in range(N)]
+    blob = k.Blob.from_padded_unchecked(data)
+    kz = k.KZG.new()
+    kz.calculate_and_store_roots_of_unity(len(data))
+    com, proof, z, y = kz.commit_and_prove_blob(blob, srs)
+    ftau = dom.evaluate(evals, TAU)
+    assert pyref.point_from_wire(com) == expect_point(ftau)
+    assert np.array_equal(z, orc.compute_challenge(data, com))
+    zi = pyref.fr_from_mont(z)
+    yi = dom.evaluate(evals, zi)
+    assert pyref.fr_from_mont(y) == yi
+    assert pyref.point_from_wire(proof) == expect_point(proof_scalar(ftau, yi, zi))
+    assert np.array_equal(kz.compute_blob_proof(blob, com, srs), proof)

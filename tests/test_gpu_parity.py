@@ -860,3 +860,50 @@ def test_ntt_extreme_values(k, log_n):
     assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(c), n, 1) == 0
     assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(c), n, 0) == 0
     assert np.array_equal(c, orig)
+
+
+def test_stream_error_does_not_poison_the_context(k, tau_srs):
+    """an item that fails mid-stream (here: a polynomial longer than the SRS) while another one is in flight, or a
+    consumer that stops early, must leave no slot pending: the next synchronous call on the same context works."""
+    kz = k.KZG.new()
+    rnd = random.Random(99)
+    ok = k.PolynomialEvalForm(pyref.frs_to_mont([rnd.randrange(R_) for _ in range(1024)]))
+    too_long = k.PolynomialEvalForm(np.zeros((1 << 17, 4), np.uint64))
+    want = kz.commit_eval_form(ok, tau_srs)
+    with pytest.raises(k.errors.SrsCapacityExceeded):
+        list(kz.commit_eval_form_stream([ok, too_long, ok], tau_srs))
+    assert np.array_equal(kz.commit_eval_form(ok, tau_srs), want)             # slot 0 was drained
+    gen = kz.commit_eval_form_stream([ok, ok, ok, ok], tau_srs)
+    assert np.array_equal(next(gen), want)
+    gen.close()                                                               # consumer stops with one commitment in flight
+    assert np.array_equal(kz.commit_eval_form(ok, tau_srs), want)
+    co = ok.to_coeff_form()
+    with pytest.raises(k.errors.SerializationError):
+        list(kz.commit_coeff_form_stream([co, k.PolynomialCoeffForm(np.zeros((1 << 17, 4), np.uint64))], tau_srs))
+    assert np.array_equal(kz.commit_coeff_form(co, tau_srs), want)
+    z = k.fr.fr_from_int(12345)
+    kz.calculate_and_store_roots_of_unity(1024 * 32)
+    wantp = kz.compute_proof(ok, z, tau_srs)
+    with pytest.raises(k.errors.SrsCapacityExceeded):
+        list(kz.compute_proof_stream([(ok, z), (too_long, z)], tau_srs))
+    assert np.array_equal(kz.compute_proof(ok, z, tau_srs), wantp)
+    # ShardedMsm.commit_stream: consumer stops early
+    import torch
+    from rust_kzg_bn254_amd.sharding import ShardedMsm
+    d = torch.from_numpy(np.ascontiguousarray(co.coeffs()).view(np.int64)).cuda(); torch.cuda.synchronize()
+    sh = ShardedMsm(tau_srs.ctx, 1024)
+    g2 = sh.commit_stream(tau_srs, [d.data_ptr()] * 6, depth=3)
+    assert np.array_equal(next(g2), want)
+    g2.close()
+    assert np.array_equal(kz.commit_coeff_form(co, tau_srs), want)
+
+
+def test_msm_batch_of_64_small_msms(k, test_srs_wire):
+    """kzg_msm_g1_batch advertises batch <= 64; 64 MSMs of 8 pairs (c = 4: 64 windows each) fit one launch."""
+    n, batch = 8, 64
+    rnd = random.Random(64)
+    pts = [test_srs_wire[rnd.randrange(3000 - n):][:n].copy() for _ in range(batch)]
+    scs = [rand_scalars(n, 6400 + i) for i in range(batch)]
+    got = k.helpers.g1_lincomb_batch(pts, scs)
+    for g, p, s_ in zip(got, pts, scs):
+        assert np.array_equal(g, orc.msm_pippenger(p, s_))
