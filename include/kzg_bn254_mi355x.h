@@ -174,6 +174,18 @@ int32_t kzg_commit_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* b
  * order, n x 8 u64 written to out.  n not a power of two -> KZG_ERR_NOT_POWER_OF_TWO ("length provided is not a
  * power of 2"); n > 2^28 -> KZG_ERR_DOMAIN.  Not used by the commit / proof path of this library. */
 int32_t kzg_g1_ifft(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy_mont);
+/* The same Lagrange basis kept ON THE DEVICE.  The reference recomputes g1_ifft inside every commit_eval_form
+ * (prover/src/kzg.rs:96-98); here it is computed once per (SRS, n):
+ *   kzg_srs_cache_lagrange  builds it (with its MSM window tables) and attaches it to `srs`; from then on kzg_commit_eval_form of
+ *                           exactly n evaluations is ONE MSM over it (the reference's literal form, kzg.rs:98-100) instead of
+ *                           IFFT + MSM over the monomial basis -- the same point either way;
+ *   kzg_srs_lagrange        returns it as an SRS handle of its own (free with kzg_srs_free): kzg_msm_g1_srs over it with the
+ *                           evaluations as scalars is commit_eval_form;
+ *   kzg_srs_drop_lagrange   releases what kzg_srs_cache_lagrange attached.
+ * Errors as kzg_g1_ifft. */
+int32_t kzg_srs_cache_lagrange(kzg_ctx* ctx, kzg_srs* srs, size_t n);
+int32_t kzg_srs_lagrange(kzg_ctx* ctx, const kzg_srs* srs, size_t n, kzg_srs** out);
+int32_t kzg_srs_drop_lagrange(kzg_ctx* ctx, kzg_srs* srs);
 /* KZG::compute_proof / compute_proof_impl (kzg.rs:128-178, :215-234, on-domain branch :237-260).
  * roots = KZG::expanded_roots_of_unity (n_roots entries); n != n_roots -> KZG_ERR_ROOTS_LENGTH.
  * out_y (optional, 4 u64) receives y = p(z) (helpers.rs:475-535). */
@@ -195,6 +207,25 @@ int32_t kzg_commit_eval_form_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, siz
 int32_t kzg_compute_proof_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo,
                                   const uint64_t* evals_mont, size_t n, const uint64_t* roots_mont, size_t n_roots,
                                   const uint64_t z_mont[4], uint64_t out_xyzz_mont[16], uint64_t* out_y_mont);
+/* ---- several GPUs behind one handle (no torch, no RCCL) ------------------------------------------------------
+ * One context, one resident SRS shard and one host thread per entry of device_ids (an id may appear more than once: several
+ * contexts on one GPU).  Device g holds the SRS powers [g N / G, (g+1) N / G) and commits that slice of every polynomial; the G
+ * partial sums are folded on the host.  Same results, same status codes as the single-GPU calls they mirror:
+ *   kzg_multi_commit_coeff_form  KZG::commit_coeff_form  (prover/src/kzg.rs:107-125)
+ *   kzg_multi_commit_eval_form   KZG::commit_eval_form   (kzg.rs:84-104; every device transforms the whole polynomial)
+ *   kzg_multi_compute_proof      KZG::compute_proof      (kzg.rs:215-234; the O(n) field work is done redundantly per device) */
+typedef struct kzg_multi kzg_multi;
+int32_t kzg_multi_create(const int32_t* device_ids, int32_t n_devices, kzg_multi** out);
+void kzg_multi_destroy(kzg_multi* m);
+int32_t kzg_multi_device_count(const kzg_multi* m);
+size_t kzg_multi_srs_len(const kzg_multi* m);
+int32_t kzg_multi_srs_upload(kzg_multi* m, const uint64_t* g1_xy_mont, size_t n_points);
+int32_t kzg_multi_srs_generate(kzg_multi* m, const uint64_t tau_mont[4], size_t n_points);        /* known-tau SRS (tests, bench) */
+int32_t kzg_multi_commit_coeff_form(kzg_multi* m, const uint64_t* coeffs_mont, size_t n, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+int32_t kzg_multi_commit_eval_form(kzg_multi* m, const uint64_t* evals_mont, size_t n, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+int32_t kzg_multi_compute_proof(kzg_multi* m, const uint64_t* evals_mont, size_t n, size_t n_roots, const uint64_t z_mont[4],
+                                uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont);
+
 /* helpers::compute_challenge (primitives/src/helpers.rs:411-472): the Fiat-Shamir evaluation point of a blob,
  *   z = SHA-256( "EIGENDA_FSBLOBVERIFY_V1_" || u64be(n) || n x 32 B evaluations (big-endian, canonical) || commitment ) mod r,
  * n = next_pow2(ceil(len / 32)); evaluations = the blob's 32-byte big-endian chunks mod r (Blob::to_polynomial_eval_form, last

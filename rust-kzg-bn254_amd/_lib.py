@@ -76,11 +76,23 @@ PROTOTYPES = {
     "kzg_commit_eval_form_begin": (i32, [vp, vp, u64p, sz, i32]),
     "kzg_commit_blob_begin": (i32, [vp, vp, u8p, sz, i32]),
     "kzg_g1_ifft": (i32, [vp, vp, sz, u64p]),
+    "kzg_srs_cache_lagrange": (i32, [vp, vp, sz]),
+    "kzg_srs_lagrange": (i32, [vp, vp, sz, C.POINTER(vp)]),
+    "kzg_srs_drop_lagrange": (i32, [vp, vp]),
     "kzg_blob_to_fr": (i32, [vp, u8p, sz, u64p, sz, C.POINTER(sz)]),
     "kzg_commit_blob": (i32, [vp, vp, u8p, sz, u64p, u8p]),
     "kzg_compute_proof": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, u64p, u8p, u64p]),
     "kzg_compute_proof_begin": (i32, [vp, vp, u64p, sz, u64p, sz, u64p, i32]),
     "kzg_compute_proof_end": (i32, [vp, i32, u64p, u8p, u64p]),
+    "kzg_multi_create": (i32, [C.POINTER(i32), i32, C.POINTER(vp)]),
+    "kzg_multi_destroy": (None, [vp]),
+    "kzg_multi_device_count": (i32, [vp]),
+    "kzg_multi_srs_len": (sz, [vp]),
+    "kzg_multi_srs_upload": (i32, [vp, u64p, sz]),
+    "kzg_multi_srs_generate": (i32, [vp, u64p, sz]),
+    "kzg_multi_commit_coeff_form": (i32, [vp, u64p, sz, u64p, u8p]),
+    "kzg_multi_commit_eval_form": (i32, [vp, u64p, sz, u64p, u8p]),
+    "kzg_multi_compute_proof": (i32, [vp, u64p, sz, sz, u64p, u64p, u8p, u64p]),
     "kzg_compute_challenge": (i32, [u8p, sz, u64p, u64p]),
     "kzg_compute_blob_proof": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, u8p, u64p, u64p]),
     "kzg_commit_and_prove_blob": (i32, [vp, vp, u8p, sz, sz, u64p, u8p, u64p, u8p, u64p, u64p]),

@@ -236,11 +236,62 @@ int32_t kzg_srs_download(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, size_t
 
 void kzg_srs_free(kzg_srs* srs) {
     if (!srs) return;
+    for (auto& kv : srs->lagrange) kzg_srs_free(kv.second);
+    srs->lagrange.clear();
     if (srs->d_points) { (void)hipSetDevice(srs->ctx->device); (void)hipFree(srs->d_points); }
     delete srs;
 }
 
 size_t kzg_srs_len(const kzg_srs* srs) { return srs ? srs->n : 0; }
+
+// Lagrange basis of the first n points as an SRS of its own (device resident, with its window tables)
+static int32_t build_lagrange(kzg_ctx* ctx, const kzg_srs* srs, size_t n, kzg_srs** out) {
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;             // kzg.rs:265-269
+    if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;                               // kzg.rs:275-278
+    if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
+    kzg_srs* s = new (std::nothrow) kzg_srs();
+    if (!s) return KZG_ERR_INVALID_ARG;
+    s->ctx = ctx;
+    s->n = n;
+    s->lagrange_of = n;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n * 64);
+    if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(lagrange srs)"); }
+    int32_t rc = g1_ifft_device(ctx, srs, n, s->d_points, false);
+    if (rc == KZG_OK) { hipError_t e2 = hipStreamSynchronize(ctx->stream); if (e2 != hipSuccess) rc = set_error(ctx, e2, "g1_ifft"); }
+    if (rc == KZG_OK) rc = srs_precompute(ctx, s);
+    if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
+    *out = s;
+    return KZG_OK;
+}
+
+int32_t kzg_srs_lagrange(kzg_ctx* ctx, const kzg_srs* srs, size_t n, kzg_srs** out) {
+    if (!ctx || !srs || srs->ctx != ctx || !out) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return build_lagrange(ctx, srs, n, out);
+}
+
+int32_t kzg_srs_cache_lagrange(kzg_ctx* ctx, kzg_srs* srs, size_t n) {
+    if (!ctx || !srs || srs->ctx != ctx) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (srs->lagrange.count(n)) return KZG_OK;
+    kzg_srs* l = nullptr;
+    int32_t rc = build_lagrange(ctx, srs, n, &l);
+    if (rc != KZG_OK) return rc;
+    srs->lagrange[n] = l;
+    return KZG_OK;
+}
+
+int32_t kzg_srs_drop_lagrange(kzg_ctx* ctx, kzg_srs* srs) {
+    if (!ctx || !srs || srs->ctx != ctx) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto& kv : srs->lagrange) kzg_srs_free(kv.second);
+    srs->lagrange.clear();
+    return KZG_OK;
+}
+
 
 // ---- MSM ------------------------------------------------------------------------------------------
 static int32_t stage_scalars(kzg_ctx* ctx, const uint64_t* scalars, size_t n, const void** d_out) {
@@ -511,6 +562,9 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    auto cached = srs->lagrange.find(n);
+    if (cached != srs->lagrange.end())                                   // the reference's literal form: MSM over the Lagrange basis (kzg.rs:98-100)
+        return msm_run(ctx, srs_bases(cached->second, 0, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
     int32_t rc = ntt_run(ctx, ctx->poly[0].a.p, n, true);               // coefficients = IFFT(evaluations)
     if (rc != KZG_OK) return rc;
     return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);

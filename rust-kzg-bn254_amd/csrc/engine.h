@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <map>
 #include <mutex>
 #include <string>
 #include "../../include/kzg_bn254_mi355x.h"
@@ -92,6 +93,10 @@ struct kzg_srs {
     size_t n = 0;
     int pre_c = 0;
     int pre_W = 0;
+    // Lagrange-basis copies of the first m points (KZG::g1_ifft(m), kzg.rs:263-285), built by kzg_srs_cache_lagrange and used by
+    // the eval-form commitments of exactly m evaluations instead of IFFT + MSM over the monomial basis; owned by this SRS
+    std::map<size_t, kzg_srs*> lagrange;
+    size_t lagrange_of = 0;      // this handle IS a Lagrange basis of that many points (0: monomial SRS)
 };
 
 namespace kzg {
@@ -147,8 +152,9 @@ int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_po
 int32_t srs_download(kzg_ctx* ctx, const uint4* d_points, size_t n, uint64_t* out_xy);
 int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_points, uint32_t* err_kind, uint32_t* err_index);
 
-// KZG::g1_ifft: Lagrange-basis SRS of size n (n a power of two <= srs->n), affine wire points to the host
+// KZG::g1_ifft: Lagrange-basis SRS of size n (n a power of two <= srs->n), affine wire points to the host / left on the device
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy);
+int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out, bool wire);
 
 int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);
 

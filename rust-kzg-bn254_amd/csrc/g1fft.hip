@@ -1,15 +1,27 @@
 // g1fft.hip — `KZG::g1_ifft` (prover/src/kzg.rs:263-285): the inverse FFT whose DATA are G1 points and whose
 // twiddles are Fr scalars,  L_i = n^-1 * sum_j w^(-ij) P_j  (natural order) — the Lagrange-basis SRS.
-// Reference: `GeneralEvaluationDomain::<Fr>::new(n).ifft(&[G1Projective])` + n `into_affine()` inversions.
-// The commit / proof path of this library never needs it (commit_eval_form == MSM(srs, IFFT(evals)));
-// it is provided because it is public API with its own bench (prover/benches/bench_g1_ifft.rs) and golden vector
-// (prover/tests/test-files/lagrangeG1SRS.txt).
+// Reference: `GeneralEvaluationDomain::<Fr>::new(n).ifft(&[G1Projective])` + n `into_affine()` inversions, recomputed on
+// every `commit_eval_form` (kzg.rs:96-98).  The commit / proof path of this library never needs it
+// (commit_eval_form == MSM(srs, IFFT(evals))); it is public API with its own bench
+// (prover/benches/bench_g1_ifft.rs) and golden vector (prover/tests/test-files/lagrangeG1SRS.txt), and the library can keep
+// its result on the device as an SRS of its own (kzg_srs_lagrange) so that eval-form commitments become one MSM.
 //
-// Radix-2 decimation in time on XYZZ points held as 36 limb planes: bit-reversed load, log2 n stages of n/2
-// butterflies (A, B) -> (A + [w]B, A - [w]B) with [w]B a 254-bit double-and-add (skipped for w = 1), then the scaling
-// by n^-1 and one inversion per point.  Work = (n/2) log2 n scalar multiplications: integer-VALU bound.
+// What bounds it on a GPU is DEPTH: every FFT stage multiplies points by full-width scalars, i.e. a chain of ~254 dependent
+// doublings (~4 us each on a lone wave), and radix 2 has log2 n such stages.  Work is spent to cut the depth:
+//   * small n (n * R <= 65536 lanes): Stockham stages of radix R = 2^k, k <= 5, each output as a DIRECT sum of its R inputs,
+//       y[u + j N/R] = sum_j' [w^-(s p j' + (N/R) j j')] x[q + s (R p + j')],   u = q + s p,
+//     one lane per (output, term): one scalar multiplication deep per stage plus a k-step shuffle tree, ceil(log2 n / 5) stages
+//     instead of log2 n (n = 2048: 3 instead of 11), for (2^k - 1)/k times the multiplications;
+//   * large n: radix-2 butterflies (A, B) -> (A + [w]B, A - [w]B), one multiplication per two outputs (work bound);
+//   * the scaling by n^-1 is folded into the scalars of the last stage (no chain of its own);
+//   * Jacobian -> affine by Montgomery's trick (one inversion per lane for 16 points) when there are many points.
 #include "engine.h"
 #include "curve.h"
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace kzg {
 
@@ -33,17 +45,7 @@ __device__ __forceinline__ void fe_inverse_fermat(Fe<F>& out, const Fe<F>& a) {
     out = acc;
 }
 
-// internal-form Fr (|v| < 169 m) -> canonical integer words
-__device__ __forceinline__ void fr_to_canonical_words(uint32_t k[8], const Fr& v) {
-    Fr one_plain, c;
-    fe_set_zero(one_plain);
-    one_plain.l[0] = 1;
-    fe_mul(c, v, one_plain);
-    fe_canon(c);
-    fe_pack(k, c);
-}
-
-// r = [k] * p, k canonical 256-bit words (MSB-first double-and-add)
+// r = [k] * p, k canonical 256-bit words (MSB-first double-and-add from the top set bit)
 __device__ __forceinline__ void xyzz_scalar_mul(Xyzz& r, const Xyzz& p, const uint32_t k[8]) {
     Xyzz acc;
     xyzz_set_inf(acc);
@@ -74,12 +76,36 @@ __device__ __forceinline__ void tw_load(Fr& w, const NttTables& tb, uint32_t E) 
     }
 }
 
-// planes[i] = P[bitrev(i)] as XYZZ
+// scal[e] = canonical integer of w^-e (plain = 1) or of w^-e / n (plain = 0), e < n: the scalars of every stage
 __global__ void __launch_bounds__(256)
-k_g1fft_load(const uint4* __restrict__ points, uint32_t n, int log_n, int32_t* __restrict__ planes) {
+k_g1fft_scalars(uint4* __restrict__ scal, uint32_t n, int log_n, NttTables tb_inv, int scaled) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Fr w;
+    if (log_n > 0) tw_load(w, tb_inv, e); else fe_set_one(w);
+    if (scaled) {
+        Fr ninv;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) ninv.l[j] = (int32_t)FrParams::NINV[log_n * NL + j];
+        fe_mul(w, w, ninv);
+    }
+    Fr one_plain, c;
+    fe_set_zero(one_plain);
+    one_plain.l[0] = 1;
+    fe_mul(c, w, one_plain);                       // internal Montgomery form -> plain integer
+    fe_canon(c);
+    uint32_t k[8];
+    fe_pack(k, c);
+    scal[2 * (size_t)e] = make_uint4(k[0], k[1], k[2], k[3]);
+    scal[2 * (size_t)e + 1] = make_uint4(k[4], k[5], k[6], k[7]);
+}
+
+// planes[i] = P[i] as XYZZ (natural order: the Stockham stages sort on the way)
+__global__ void __launch_bounds__(256)
+k_g1fft_load(const uint4* __restrict__ points, uint32_t n, int32_t* __restrict__ planes, int bitrev_log) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t j = log_n ? (__brev(i) >> (32 - log_n)) : 0;
+    uint32_t j = bitrev_log > 0 ? (__brev(i) >> (32 - bitrev_log)) : i;
     Affine p;
     Xyzz v;
     if (affine_load(p, points + 4 * (size_t)j)) xyzz_from_affine(v, p, 0);
@@ -87,9 +113,54 @@ k_g1fft_load(const uint4* __restrict__ points, uint32_t n, int log_n, int32_t* _
     xyzz_store(planes, n, i, v);
 }
 
-// stage s (block length m = 2^s): one butterfly per thread, in place
+// ---- small n: one Stockham stage of radix R = 2^K as direct sums, one lane per (output, term) ---------------------------
 __global__ void __launch_bounds__(256)
-k_g1fft_stage(int32_t* __restrict__ planes, uint32_t n, int log_n, int s, NttTables tb_inv) {
+k_g1fft_direct(const int32_t* __restrict__ x, int32_t* __restrict__ y, uint32_t n, int log_n, int K, int log_s,
+               const uint4* __restrict__ scal /* n canonical scalars: w^-e, or w^-e / n in the last stage */, int last) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const uint32_t R = 1u << K;
+    const uint32_t o = t >> K, jp = t & (R - 1);                 // output element, term j'
+    const bool active = o < n;
+    Xyzz term;
+    xyzz_set_inf(term);
+    if (active) {
+        const uint32_t nr = n >> K;                               // N / R
+        const uint32_t u = o & (nr - 1), j = o >> (log_n - K);
+        const uint32_t s = 1u << log_s;
+        const uint32_t q = u & (s - 1), p = u >> log_s;
+        const uint32_t e = (uint32_t)(((unsigned long long)p * jp << log_s) + (unsigned long long)nr * j * jp) & (n - 1);
+        Xyzz v;
+        xyzz_load(v, x, n, (size_t)q + ((size_t)(R * p + jp) << log_s));
+        if (e == 0 && !last) {
+            term = v;
+        } else {
+            const uint4 lo = scal[2 * (size_t)e], hi = scal[2 * (size_t)e + 1];
+            const uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            xyzz_scalar_mul(term, v, k);
+        }
+    }
+    // sum of the R terms of an output: R consecutive lanes (R <= 32 < 64: a wave holds whole outputs)
+#pragma unroll 1
+    for (int d = 1; d < (int)R; d <<= 1) {
+        Xyzz other, r;
+        const Fq* sp[4] = {&term.x, &term.y, &term.zz, &term.zzz};
+        Fq* tp[4] = {&other.x, &other.y, &other.zz, &other.zzz};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) tp[c]->l[l] = __shfl_down(sp[c]->l[l], d, 64);
+        other.inf = __shfl_down((int)term.inf, d, 64) != 0;
+        if ((lane & (2 * d - 1)) == 0) {
+            xyzz_add<true>(r, term, other);
+            term = r;
+        }
+    }
+    if (active && jp == 0) xyzz_store(y, n, o, term);
+}
+
+// ---- large n: radix-2 decimation in time on bit-reversed input, one butterfly per thread, in place ------------------------
+__global__ void __launch_bounds__(256)
+k_g1fft_stage(int32_t* __restrict__ planes, uint32_t n, int log_n, int s, const uint4* __restrict__ scal, int last) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n / 2) return;
     const uint32_t half = 1u << (s - 1);
@@ -99,13 +170,18 @@ k_g1fft_stage(int32_t* __restrict__ planes, uint32_t n, int log_n, int s, NttTab
     xyzz_load(A, planes, n, i0);
     xyzz_load(B, planes, n, i1);
     const uint32_t E = j << (log_n - s);                 // w_n^(-j n/m)
-    if (E == 0) {
+    if (last) {                                          // (A +- [w]B) / n = [1/n]A +- [w/n]B: both products in this stage
+        const uint4 l0 = scal[0], h0 = scal[1];
+        const uint32_t k0[8] = {l0.x, l0.y, l0.z, l0.w, h0.x, h0.y, h0.z, h0.w};
+        Xyzz a2;
+        xyzz_scalar_mul(a2, A, k0);
+        A = a2;
+    }
+    if (E == 0 && !last) {
         t = B;
     } else {
-        Fr w;
-        tw_load(w, tb_inv, E);
-        uint32_t k[8];
-        fr_to_canonical_words(k, w);
+        const uint4 lo = scal[2 * (size_t)E], hi = scal[2 * (size_t)E + 1];
+        const uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         xyzz_scalar_mul(t, B, k);
     }
     Xyzz r0, r1, tn = t;
@@ -116,67 +192,150 @@ k_g1fft_stage(int32_t* __restrict__ planes, uint32_t n, int log_n, int s, NttTab
     xyzz_store(planes, n, i1, r1);
 }
 
-// L_i = n^-1 * planes[i], converted to affine; out in wire format (16 u32 per point)
-__global__ void __launch_bounds__(256)
-k_g1fft_finish(const int32_t* __restrict__ planes, uint32_t n, int log_n, uint4* __restrict__ out_wire) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Xyzz v, r;
-    xyzz_load(v, planes, n, i);
-    if (log_n > 0) {
-        Fr ninv;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) ninv.l[j] = (int32_t)FrParams::NINV[log_n * NL + j];
-        uint32_t k[8];
-        fr_to_canonical_words(k, ninv);
-        xyzz_scalar_mul(r, v, k);
-    } else {
-        r = v;
-    }
+// ---- XYZZ -> affine ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void affine_emit(uint4* __restrict__ out, size_t i, const Xyzz& r, const Fq& inv_zz_zzz /* 1 / (ZZ ZZZ) */, bool wire) {
     uint32_t o[16];
     if (r.inf) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[j] = 0;
     } else {
-        Fq zi, t, x, y;
-        fe_mul(t, r.zz, r.zzz);
-        fe_inverse_fermat(zi, t);
-        fe_mul(t, zi, r.zzz);
+        Fq t, x, y;
+        fe_mul(t, inv_zz_zzz, r.zzz);              // 1 / ZZ
         fe_mul(x, r.x, t);
-        fe_mul(t, zi, r.zz);
+        fe_mul(t, inv_zz_zzz, r.zz);               // 1 / ZZZ
         fe_mul(y, r.y, t);
-        fe_norm(x);
-        fe_norm(y);
-        fe_to_wire(o, x);
-        fe_to_wire(o + 8, y);
+        if (wire) {
+            fe_norm(x); fe_norm(y);
+            fe_to_wire(o, x);
+            fe_to_wire(o + 8, y);
+        } else {                                   // device affine format (curve.h): canonical residues of the internal form
+            fe_canon(x); fe_canon(y);
+            fe_pack(o, x);
+            fe_pack(o + 8, y);
+        }
     }
-    out_wire[4 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);
-    out_wire[4 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
-    out_wire[4 * (size_t)i + 2] = make_uint4(o[8], o[9], o[10], o[11]);
-    out_wire[4 * (size_t)i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
+    out[4 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+    out[4 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    out[4 * i + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+    out[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
+}
+// lane t converts the points i = t, t + T, t + 2T, ... (T = number of lanes) with ONE inversion (Montgomery's trick): prefix
+// products of the denominators ZZ ZZZ go through `scratch` (9 limb planes, stride n).  per lane <= AFF_PER points.
+constexpr uint32_t AFF_PER = 16;
+__global__ void __launch_bounds__(256)
+k_g1fft_to_affine(const int32_t* __restrict__ planes, uint32_t n, uint4* __restrict__ out, int wire, int32_t* __restrict__ scratch) {
+    const uint32_t T = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fq run;
+    fe_set_one(run);
+    for (uint32_t i = t; i < n; i += T) {                 // forward: prefix products (identity points contribute 1)
+        Xyzz v;
+        xyzz_load(v, planes, n, i);
+        Fq d;
+        if (v.inf) fe_set_one(d); else fe_mul(d, v.zz, v.zzz);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) scratch[(size_t)j * n + i] = run.l[j];
+        fe_mul(run, run, d);
+    }
+    Fq rinv;
+    fe_inverse_fermat(rinv, run);
+    const uint32_t cnt = (n - 1 - t) / T + 1;
+    for (uint32_t k = cnt; k-- > 0;) {                    // backward: inv_i = rinv * prefix_i; rinv *= d_i
+        const uint32_t i = t + k * T;
+        Xyzz v;
+        xyzz_load(v, planes, n, i);
+        Fq pre, d, iv;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) pre.l[j] = scratch[(size_t)j * n + i];
+        if (v.inf) fe_set_one(d); else fe_mul(d, v.zz, v.zzz);
+        fe_mul(iv, rinv, pre);
+        fe_mul(rinv, rinv, d);
+        affine_emit(out, i, v, iv, wire != 0);
+    }
+}
+
+// ---- host -----------------------------------------------------------------------------------------------------------------
+struct ScalKey { int dev, log_n, scaled; bool operator<(const ScalKey& o) const { return dev != o.dev ? dev < o.dev : (log_n != o.log_n ? log_n < o.log_n : scaled < o.scaled); } };
+static std::map<ScalKey, uint4*> g_scal;
+static std::mutex g_scal_mu;
+static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** out) {
+    std::lock_guard<std::mutex> lk(g_scal_mu);
+    ScalKey key{ctx->device, log_n, scaled ? 1 : 0};
+    auto it = g_scal.find(key);
+    if (it != g_scal.end()) { *out = it->second; return KZG_OK; }
+    NttTables tb{};
+    if (log_n > 0) { int32_t rc = ntt_get_tables(ctx, log_n, true, &tb); if (rc != KZG_OK) return rc; }
+    const size_t n = (size_t)1 << log_n;
+    uint4* p = nullptr;
+    KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&p), n * 32));
+    hipLaunchKernelGGL(k_g1fft_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, (uint32_t)n, log_n, tb, scaled ? 1 : 0);
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    g_scal[key] = p;
+    *out = p;
+    return KZG_OK;
+}
+
+// Lagrange basis of the first n SRS points -> d_out (n affine points: wire format, or the device format of curve.h)
+int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out, bool wire) {
+    int log_n = 0;
+    while (((size_t)1 << log_n) < n) ++log_n;
+    hipStream_t st = ctx->stream;
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    KZG_HIP_TRY(ctx, ctx->poly[0].b.reserve(n * 36 * 4 * 2));                 // two XYZZ plane sets (ping-pong)
+    KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * NL * 4));                     // prefix products of the affine conversion
+    int32_t* bufA = ctx->poly[0].b.as<int32_t>();
+    int32_t* bufB = bufA + n * 36;
+    const uint4 *scal = nullptr, *scal_n = nullptr;
+    int32_t rc = get_scalars(ctx, log_n, false, &scal);
+    if (rc == KZG_OK) rc = get_scalars(ctx, log_n, true, &scal_n);
+    if (rc != KZG_OK) return rc;
+    const int32_t* result = bufA;
+    // small n: high-radix direct stages, at most 65536 lanes each (one wave per SIMD: the chains run at lone-wave latency)
+    int kmax = 0;
+    while (kmax < 5 && ((n << (kmax + 1)) <= 65536)) ++kmax;
+    const char* env = getenv("KZG_G1FFT_RADIX_BITS");
+    if (env) kmax = std::max(0, std::min(5, atoi(env)));
+    if (log_n == 0) {
+        hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, bufA, 0);
+    } else if (kmax >= 2) {
+        hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, bufA, 0);
+        const int stages = (log_n + kmax - 1) / kmax;
+        int done = 0;
+        int32_t* src = bufA;
+        int32_t* dst = bufB;
+        for (int i = 0; i < stages; ++i) {
+            const int K = (log_n - done + (stages - i) - 1) / (stages - i);   // balanced split of the remaining bits
+            done += K;
+            const int log_s = log_n - done;
+            const bool last = i == stages - 1;
+            const size_t lanes = n << K;
+            hipLaunchKernelGGL(k_g1fft_direct, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, src, dst, (uint32_t)n, log_n, K, log_s,
+                               last ? scal_n : scal, last ? 1 : 0);
+            std::swap(src, dst);
+        }
+        result = src;
+    } else {
+        hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, bufA, log_n);
+        for (int s = 1; s <= log_n; ++s) {
+            const bool last = s == log_n;
+            hipLaunchKernelGGL(k_g1fft_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, bufA, (uint32_t)n, log_n, s,
+                               last ? scal_n : scal, last ? 1 : 0);
+        }
+    }
+    const size_t lanes = std::max<size_t>(1, (n + AFF_PER - 1) / AFF_PER);
+    const unsigned blocks = (unsigned)std::min<size_t>((lanes + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_g1fft_to_affine, dim3(blocks), dim3(256), 0, st, result, (uint32_t)n, d_out, wire ? 1 : 0, ctx->poly[0].a.as<int32_t>());
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    return KZG_OK;
 }
 
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy) {
-    int log_n = 0;
-    while (((size_t)1 << log_n) < n) ++log_n;
-    NttTables tb;
-    if (log_n > 0) {
-        int32_t rc = ntt_get_tables(ctx, log_n, true, &tb);
-        if (rc != KZG_OK) return rc;
-    }
-    KZG_HIP_TRY(ctx, ctx->poly[0].b.reserve(n * 36 * 4));
     KZG_HIP_TRY(ctx, ctx->msm.bases_wire.reserve(n * 64));
-    int32_t* planes = ctx->poly[0].b.as<int32_t>();
-    hipStream_t st = ctx->stream;
-    const unsigned gn = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, log_n, planes);
-    for (int s = 1; s <= log_n; ++s) {
-        hipLaunchKernelGGL(k_g1fft_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, planes, (uint32_t)n, log_n, s, tb);
-    }
-    hipLaunchKernelGGL(k_g1fft_finish, dim3(gn), dim3(256), 0, st, planes, (uint32_t)n, log_n, ctx->msm.bases_wire.as<uint4>());
-    KZG_HIP_TRY(ctx, hipGetLastError());
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(out_xy, ctx->msm.bases_wire.p, n * 64, hipMemcpyDeviceToHost, st));
-    KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    int32_t rc = g1_ifft_device(ctx, srs, n, ctx->msm.bases_wire.as<uint4>(), true);
+    if (rc != KZG_OK) return rc;
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(out_xy, ctx->msm.bases_wire.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KZG_OK;
 }
 

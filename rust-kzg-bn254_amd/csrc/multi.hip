@@ -1,0 +1,150 @@
+// multi.hip — the multi-GPU split of SURVEY.md §8e behind the C-ABI, without torch: one context, one resident SRS shard and one
+// host thread per device; device g holds the SRS powers [g N / G, (g+1) N / G) and commits that slice of every polynomial; the G
+// partial sums (128 B each) are folded on the host (G - 1 point additions + one inversion).  No inter-GPU traffic at all: the
+// caller's buffers are read by every device's own H2D copy.  (bench.py --gpus N keeps the one-process-per-GPU / RCCL form that
+// BASELINE.json's north_star prescribes: rust-kzg-bn254_amd/sharding.py.)
+// Replaces, for a Rust host: the rayon-parallel `G1Projective::msm` of prover/src/kzg.rs:100,121 across several GPUs.
+#include "engine.h"
+#include "host_curve.h"
+
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+struct kzg_multi {
+    std::vector<kzg_ctx*> ctx;
+    std::vector<kzg_srs*> shard;
+    std::vector<size_t> lo;          // first SRS power of shard g; lo[G] = N
+    size_t n_total = 0;
+    std::mutex mu;
+};
+
+namespace {
+
+template <class Fn>
+int32_t for_each_device(kzg_multi* m, Fn fn) {
+    const size_t G = m->ctx.size();
+    std::vector<int32_t> rc(G, KZG_OK);
+    std::vector<std::thread> th;
+    th.reserve(G);
+    for (size_t g = 1; g < G; ++g) th.emplace_back([&, g] { rc[g] = fn(g); });
+    rc[0] = fn(0);
+    for (auto& t : th) t.join();
+    for (size_t g = 0; g < G; ++g) if (rc[g] != KZG_OK) return rc[g];
+    return KZG_OK;
+}
+void set_bounds(kzg_multi* m, size_t n) {
+    const size_t G = m->ctx.size();
+    m->lo.assign(G + 1, 0);
+    for (size_t g = 0; g <= G; ++g) m->lo[g] = g * n / G;
+    m->n_total = n;
+}
+void drop_shards(kzg_multi* m) {
+    for (auto& s : m->shard) { if (s) kzg_srs_free(s); s = nullptr; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t kzg_multi_create(const int32_t* device_ids, int32_t n_devices, kzg_multi** out) {
+    if (!out || !device_ids || n_devices <= 0 || n_devices > 64) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    kzg_multi* m = new (std::nothrow) kzg_multi();
+    if (!m) return KZG_ERR_INVALID_ARG;
+    for (int32_t i = 0; i < n_devices; ++i) {
+        kzg_ctx* c = nullptr;
+        int32_t rc = kzg_ctx_create(device_ids[i], &c);
+        if (rc != KZG_OK) { for (auto* x : m->ctx) kzg_ctx_destroy(x); delete m; return rc; }
+        m->ctx.push_back(c);
+    }
+    m->shard.assign((size_t)n_devices, nullptr);
+    *out = m;
+    return KZG_OK;
+}
+
+void kzg_multi_destroy(kzg_multi* m) {
+    if (!m) return;
+    drop_shards(m);
+    for (auto* c : m->ctx) kzg_ctx_destroy(c);
+    delete m;
+}
+
+int32_t kzg_multi_device_count(const kzg_multi* m) { return m ? (int32_t)m->ctx.size() : 0; }
+size_t kzg_multi_srs_len(const kzg_multi* m) { return m ? m->n_total : 0; }
+
+int32_t kzg_multi_srs_upload(kzg_multi* m, const uint64_t* g1_xy_mont, size_t n_points) {
+    if (!m || (n_points && !g1_xy_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    drop_shards(m);
+    set_bounds(m, n_points);
+    return for_each_device(m, [&](size_t g) {
+        return kzg_srs_upload(m->ctx[g], g1_xy_mont + 8 * m->lo[g], m->lo[g + 1] - m->lo[g], &m->shard[g]);
+    });
+}
+
+int32_t kzg_multi_srs_generate(kzg_multi* m, const uint64_t tau_mont[4], size_t n_points) {
+    if (!m || !tau_mont) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    drop_shards(m);
+    set_bounds(m, n_points);
+    return for_each_device(m, [&](size_t g) {
+        return kzg_srs_generate(m->ctx[g], tau_mont, (uint64_t)m->lo[g], m->lo[g + 1] - m->lo[g], &m->shard[g]);
+    });
+}
+
+static int32_t fold(const std::vector<uint64_t>& parts, size_t G, uint64_t out_xy[8], uint8_t* out_inf) {
+    return kzg_g1_fold_partials(parts.data(), G, out_xy, out_inf);
+}
+
+int32_t kzg_multi_commit_coeff_form(kzg_multi* m, const uint64_t* coeffs_mont, size_t n, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!m || !out_xy_mont || (n && !coeffs_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (n > m->n_total) return KZG_ERR_POLY_LENGTH;                                  // kzg.rs:112-116
+    const size_t G = m->ctx.size();
+    std::vector<uint64_t> parts(16 * G, 0);
+    int32_t rc = for_each_device(m, [&](size_t g) -> int32_t {
+        const size_t lo = m->lo[g], hi = std::min(m->lo[g + 1], n);
+        if (lo >= hi) return KZG_OK;                                                 // identity partial (zeros)
+        return kzg_msm_g1_srs_partial(m->ctx[g], m->shard[g], 0, coeffs_mont + 4 * lo, hi - lo, parts.data() + 16 * g);
+    });
+    if (rc != KZG_OK) return rc;
+    return fold(parts, G, out_xy_mont, out_is_infinity);
+}
+
+int32_t kzg_multi_commit_eval_form(kzg_multi* m, const uint64_t* evals_mont, size_t n, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!m || !out_xy_mont || (n && !evals_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (n > m->n_total) return KZG_ERR_SRS_CAPACITY_EXCEEDED;                        // kzg.rs:89-94
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
+    const size_t G = m->ctx.size();
+    std::vector<uint64_t> parts(16 * G, 0);
+    int32_t rc = for_each_device(m, [&](size_t g) -> int32_t {
+        if (m->lo[g] >= n || m->lo[g + 1] == m->lo[g]) return KZG_OK;
+        return kzg_commit_eval_form_partial(m->ctx[g], m->shard[g], m->lo[g], evals_mont, n, parts.data() + 16 * g);
+    });
+    if (rc != KZG_OK) return rc;
+    return fold(parts, G, out_xy_mont, out_is_infinity);
+}
+
+int32_t kzg_multi_compute_proof(kzg_multi* m, const uint64_t* evals_mont, size_t n, size_t n_roots, const uint64_t z_mont[4],
+                                uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont) {
+    if (!m || !out_xy_mont || !z_mont || (n && !evals_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (n != n_roots) return KZG_ERR_ROOTS_LENGTH;                                   // kzg.rs:135-139
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;
+    if (n > m->n_total) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
+    const size_t G = m->ctx.size();
+    std::vector<uint64_t> parts(16 * G, 0), ys(4 * G, 0);
+    int32_t rc = for_each_device(m, [&](size_t g) -> int32_t {
+        if (g != 0 && (m->lo[g] >= n || m->lo[g + 1] == m->lo[g])) return KZG_OK;   // device 0 always runs: it reports y
+        return kzg_compute_proof_partial(m->ctx[g], m->shard[g], m->lo[g], evals_mont, n, nullptr, n_roots, z_mont, parts.data() + 16 * g,
+                                         ys.data() + 4 * g);
+    });
+    if (rc != KZG_OK) return rc;
+    if (out_y_mont) memcpy(out_y_mont, ys.data(), 32);
+    return fold(parts, G, out_xy_mont, out_is_infinity);
+}
+
+}  // extern "C"

@@ -254,3 +254,63 @@ class ShardedKzg:
             raise ValueError(_lib.status_message(rc))
         proof = self._finish(part)
         return (proof, y) if want_y else proof
+
+
+class MultiKzg:
+    """Several GPUs behind one handle in ONE process (`kzg_multi_*`): device g holds the SRS powers [g N / G, (g+1) N / G) and one
+    host thread of the library drives it; partial sums are folded on the host.  No torch, no collective: what a Rust host binds
+    to get the 8-GPU split of SURVEY.md 8e.  `device_ids` may repeat an id (several contexts on one GPU)."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = _lib.load().kzg_multi_create(ids, len(device_ids), C.byref(h))
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+        self.handle = h
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+
+    def srs_upload(self, g1_points):
+        pts = _lib.as_u64(g1_points, 8).reshape(-1, 8)
+        self._check(_lib.load().kzg_multi_srs_upload(self.handle, _lib.ptr(pts), pts.shape[0]))
+
+    def srs_generate(self, tau: int, n: int):
+        from .fr import fr_from_int
+        self._check(_lib.load().kzg_multi_srs_generate(self.handle, _lib.ptr(fr_from_int(tau)), n))
+
+    def __len__(self):
+        return _lib.load().kzg_multi_srs_len(self.handle)
+
+    def commit_coeff_form(self, coeffs):
+        c = _lib.as_u64(coeffs, 4).reshape(-1, 4)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
+        self._check(_lib.load().kzg_multi_commit_coeff_form(self.handle, _lib.ptr(c), len(c), _lib.ptr(out), C.byref(inf)))
+        return out
+
+    def commit_eval_form(self, evals):
+        e = _lib.as_u64(evals, 4).reshape(-1, 4)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
+        self._check(_lib.load().kzg_multi_commit_eval_form(self.handle, _lib.ptr(e), len(e), _lib.ptr(out), C.byref(inf)))
+        return out
+
+    def compute_proof(self, evals, z_fr, n_roots=None):
+        e = _lib.as_u64(evals, 4).reshape(-1, 4)
+        z = np.ascontiguousarray(_lib.as_u64(z_fr, 0).reshape(4))
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0); y = np.zeros(4, dtype=np.uint64)
+        self._check(_lib.load().kzg_multi_compute_proof(self.handle, _lib.ptr(e), len(e), len(e) if n_roots is None else n_roots, _lib.ptr(z),
+                                                        _lib.ptr(out), C.byref(inf), _lib.ptr(y)))
+        return out, y
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().kzg_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

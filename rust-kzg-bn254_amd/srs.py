@@ -78,6 +78,28 @@ class SRS:
     def __len__(self):
         return self._n
 
+    def cache_lagrange(self, n: int):
+        """Compute KZG::g1_ifft(n) once and keep it on the device (`kzg_srs_cache_lagrange`): `commit_eval_form` of exactly n
+        evaluations then is one MSM over it, as in the reference (kzg.rs:98-100), instead of IFFT + MSM."""
+        rc = _lib.load().kzg_srs_cache_lagrange(self.ctx.handle, self.handle, n)
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
+
+    def drop_lagrange(self):
+        _lib.load().kzg_srs_drop_lagrange(self.ctx.handle, self.handle)
+
+    def lagrange(self, n: int) -> "SRS":
+        """The Lagrange basis of the first n points as an SRS of its own (`kzg_srs_lagrange`)."""
+        h = C.c_void_p()
+        rc = _lib.load().kzg_srs_lagrange(self.ctx.handle, self.handle, n, C.byref(h))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
+        out = SRS.__new__(SRS)
+        out.ctx, out.order, out.handle, out._n = self.ctx, n, h, n
+        return out
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.load().kzg_srs_free(self.handle)

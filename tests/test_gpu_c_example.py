@@ -18,3 +18,14 @@ def test_c_example_builds_and_runs(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
     assert "proof verifies" in res.stdout and "4 / 4" in res.stdout
+
+
+def test_multi_device_c_example(tmp_path):
+    """examples/multi_commit.c: kzg_multi_* from plain C, three contexts on GPU 0, folded commitment == single-device commitment."""
+    exe = str(tmp_path / "multi_commit")
+    libdir = os.path.join(ROOT, "rust-kzg-bn254_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "multi_commit.c"),
+                           "-L" + libdir, "-lkzg_bn254_mi355x", "-Wl,-rpath," + libdir, "-o", exe])
+    res = subprocess.run([exe, "0", "0", "0"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+    assert "3 device context(s)" in res.stdout and "== the single-device one" in res.stdout

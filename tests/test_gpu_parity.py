@@ -907,3 +907,96 @@ def test_msm_batch_of_64_small_msms(k, test_srs_wire):
     got = k.helpers.g1_lincomb_batch(pts, scs)
     for g, p, s_ in zip(got, pts, scs):
         assert np.array_equal(g, orc.msm_pippenger(p, s_))
+
+
+def test_g1_ifft_paths_and_lagrange_cache(k, tau_srs, ref_srs, test_srs_wire):
+    """g1_ifft beyond the fixture: the high-radix direct stages (n <= 2^14) and the radix-2 butterflies (forced with
+    KZG_G1FFT_RADIX_BITS=0, and n = 2^15 by default) against the oracle at n = 1024 and against each other; the Lagrange basis
+    kept on the device (kzg_srs_cache_lagrange / kzg_srs_lagrange): commit_eval_form over it == IFFT + MSM == oracle."""
+    kzg = k.KZG.new()
+    rc, want = orc.g1_ifft(test_srs_wire, 1024)
+    assert rc == 0
+    got = kzg.g1_ifft(1024, ref_srs)
+    assert np.array_equal(got, want)
+    for n in (4, 32, 512, 2048):
+        a = kzg.g1_ifft(n, ref_srs)
+        os.environ["KZG_G1FFT_RADIX_BITS"] = "0"
+        try:
+            b = kzg.g1_ifft(n, ref_srs)
+        finally:
+            del os.environ["KZG_G1FFT_RADIX_BITS"]
+        assert np.array_equal(a, b), n
+        os.environ["KZG_G1FFT_RADIX_BITS"] = "2"
+        try:
+            c = kzg.g1_ifft(n, ref_srs)
+        finally:
+            del os.environ["KZG_G1FFT_RADIX_BITS"]
+        assert np.array_equal(a, c), n
+    # known tau: L_i = l_i(tau) G with l_i the Lagrange polynomial of the domain, checked at a few i for n = 2^15
+    n = 1 << 15
+    L = kzg.g1_ifft(n, tau_srs)
+    w = pyref.root_of_unity(15)
+    zn = (pow(TAU, n, R_) - 1) * pow(n, -1, R_) % R_
+    for i in (0, 1, 2, 12345, n - 1):
+        wi = pow(w, i, R_)
+        li = zn * wi % R_ * pow(TAU - wi, -1, R_) % R_
+        assert pyref.point_from_wire(L[i]) == pyref.ec_mul(li, (1, 2)), i
+    # cached Lagrange basis: same commitments as the IFFT path and the oracle's literal form
+    rnd = random.Random(77)
+    for n, srs, wire in ((256, ref_srs, test_srs_wire), (2048, ref_srs, test_srs_wire), (1 << 14, tau_srs, None)):
+        poly = k.PolynomialEvalForm(pyref.frs_to_mont([rnd.randrange(R_) for _ in range(n)]))
+        via_ifft = kzg.commit_eval_form(poly, srs)
+        srs.cache_lagrange(n)
+        try:
+            via_cache = kzg.commit_eval_form(poly, srs)
+            other = kzg.commit_eval_form(k.PolynomialEvalForm(poly.evaluations()[:n // 2]), srs)     # another length: IFFT path
+        finally:
+            srs.drop_lagrange()
+        assert np.array_equal(via_cache, via_ifft), n
+        lag = srs.lagrange(n)
+        assert np.array_equal(msm_srs(k, lag, poly.evaluations()), via_ifft)
+        assert np.array_equal(lag.g1, kzg.g1_ifft(n, srs))
+        lag.close()
+        if wire is not None and n <= 256:
+            rc, lit = orc.commit_eval_form(wire, poly.evaluations(), literal=True)
+            assert rc == 0 and np.array_equal(via_cache, lit)
+        assert other.shape == (8,)
+    with pytest.raises(k.errors.GenericError):
+        ref_srs.cache_lagrange(48)
+
+
+def test_multi_device_handle_three_contexts_on_one_gpu(k, test_srs_wire, tau_srs):
+    """kzg_multi_*: the multi-GPU split behind the C-ABI (one context + one host thread per entry), here three contexts on GPU 0:
+    uploaded SRS (3000 reference points, uneven shards) against the oracle, generated known-tau SRS against big-integer values."""
+    from rust_kzg_bn254_amd.sharding import MultiKzg
+    m = MultiKzg([0, 0, 0])
+    m.srs_upload(test_srs_wire)
+    assert len(m) == 3000
+    for n in (1, 999, 1000, 1001, 2048, 3000):
+        sc = rand_scalars(n, 40 + n)
+        assert np.array_equal(m.commit_coeff_form(sc), orc.msm_pippenger(test_srs_wire[:n], sc)), n
+    with pytest.raises(ValueError, match="polynomial length is not correct"):
+        m.commit_coeff_form(rand_scalars(3001, 1))
+    ev = rand_scalars(2048, 4048)
+    rc, want = orc.commit_eval_form(test_srs_wire, ev, literal=False)
+    assert rc == 0 and np.array_equal(m.commit_eval_form(ev), want)
+    rc, roots = orc.calculate_roots_of_unity(2048 * 32)
+    z = pyref.fr_to_mont(987654321)
+    rc, wantp, wanty = orc.compute_proof(test_srs_wire, ev, roots, z, literal=False)
+    gp, gy = m.compute_proof(ev, z)
+    assert rc == 0 and np.array_equal(gp, wantp) and np.array_equal(gy, wanty)
+    zon = roots[5]                                                            # on-domain point
+    rc, wantp, wanty = orc.compute_proof(test_srs_wire, ev, roots, zon, literal=False)
+    gp, gy = m.compute_proof(ev, zon)
+    assert np.array_equal(gp, wantp) and np.array_equal(gy, wanty)
+    with pytest.raises(ValueError, match="inconsistent length"):
+        m.compute_proof(ev, z, n_roots=1024)
+    m.close()
+    m = MultiKzg([0, 0, 0, 0, 0])
+    n = 1 << 16
+    m.srs_generate(TAU, n)
+    rnd = random.Random(5)
+    vals = [rnd.randrange(R_) for _ in range(n)]
+    ptau = sum(v * pow(TAU, i, R_) for i, v in enumerate(vals)) % R_
+    assert pyref.point_from_wire(m.commit_coeff_form(pyref.frs_to_mont(vals))) == pyref.ec_mul(ptau, (1, 2))
+    m.close()
