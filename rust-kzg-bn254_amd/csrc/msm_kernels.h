@@ -19,6 +19,15 @@
 
 namespace kzg {
 
+// The latency-bound kernels of one MSM (sort, bucket sums, reductions) usually run BESIDE the accumulate kernel of the other MSM
+// in flight: raised wave priority lets their dependent chains issue ahead of the accumulate waves they share a SIMD with (the
+// accumulate kernel is throughput bound and loses nothing but those slots).  -DKZG_NO_SETPRIO: A/B switch.
+__device__ __forceinline__ void latency_bound_kernel() {
+#if !defined(KZG_NO_SETPRIO)
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 constexpr uint32_t DIGIT_NONE = 0xFFFFFFFFu;
 constexpr int RED_T = 512;          // chunks (= threads of the per-window scan block) per window
 
@@ -29,6 +38,7 @@ constexpr int RED_T = 512;          // chunks (= threads of the per-window scan 
 // `n_total` scalars = batch * n; scalar j belongs to MSM j / n, whose digit rows are (j / n) * W + w.
 __global__ void __launch_bounds__(256)
 k_msm_digits(const uint4* __restrict__ scalars, uint32_t n_total, uint32_t n, int c, int W, uint32_t* __restrict__ digits) {
+    latency_bound_kernel();
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_total) return;
     const uint32_t msm = j / n, i = j - msm * n;
@@ -82,6 +92,7 @@ constexpr int SCAN1_THREADS = 1024;
 constexpr uint32_t SCAN1_MAX = 1u << 17;
 __global__ void __launch_bounds__(SCAN1_THREADS)
 k_scan_counts_1wg(const uint32_t* __restrict__ count, uint32_t G, uint32_t* __restrict__ offs /* G + 1 */) {
+    latency_bound_kernel();
     __shared__ uint32_t lds[SCAN1_THREADS];
     const uint32_t t = threadIdx.x;
     // thread t owns the 4-aligned chunk [lo, hi): 16-byte loads, a few per thread
@@ -157,6 +168,7 @@ k_scan_final(const uint32_t* __restrict__ count, uint32_t G, const uint32_t* __r
 __global__ void __launch_bounds__(256)
 k_sort_hist(const uint32_t* __restrict__ digits, uint32_t set_len, uint32_t tile_len, uint32_t tiles_per_set, uint32_t B,
             uint32_t* __restrict__ count, uint32_t* __restrict__ blockbase) {
+    latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
     const uint32_t set = blockIdx.x / tiles_per_set, tile = blockIdx.x % tiles_per_set;
     const uint32_t lo = tile * tile_len;
@@ -182,6 +194,7 @@ __global__ void __launch_bounds__(256)
 k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len, uint32_t tile_len, uint32_t tiles_per_set, uint32_t B,
                const uint32_t* __restrict__ offs, const uint32_t* __restrict__ blockbase, uint32_t table_stride,
                uint32_t windows_per_msm, uint32_t* __restrict__ sorted) {
+    latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
     const uint32_t set = blockIdx.x / tiles_per_set, tile = blockIdx.x % tiles_per_set;
     const uint32_t base_idx = table_stride ? 0u : (set / windows_per_msm) * n;      // batched MSMs: bases are concatenated
@@ -207,6 +220,7 @@ k_sort_scatter(const uint32_t* __restrict__ digits, uint32_t n, uint32_t set_len
 // take microseconds.  One thread per entry; the order inside a bucket is arbitrary (the bucket sum does not depend on it).
 __global__ void __launch_bounds__(256)
 k_sort_small_hist(const uint32_t* __restrict__ digits, uint32_t n_entries, uint32_t set_len, uint32_t B, uint32_t* __restrict__ count) {
+    latency_bound_kernel();
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) return;
     const uint32_t v = digits[e];
@@ -216,6 +230,7 @@ __global__ void __launch_bounds__(256)
 k_sort_small_scatter(const uint32_t* __restrict__ digits, uint32_t n_entries, uint32_t n, uint32_t set_len, uint32_t B,
                      const uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor /* G zeros */, uint32_t table_stride,
                      uint32_t windows_per_msm, uint32_t* __restrict__ sorted) {
+    latency_bound_kernel();
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) return;
     const uint32_t v = digits[e];
@@ -247,6 +262,7 @@ constexpr uint32_t SORT2_MAX_BINS = 512;
 __global__ void __launch_bounds__(256)
 k_sort2_hist1(const uint32_t* __restrict__ digits, uint32_t E, uint32_t tile_len, uint32_t Hb,
               uint32_t* __restrict__ ccount, uint32_t* __restrict__ blockbase1) {
+    latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
     const uint32_t lo = blockIdx.x * tile_len;
     const uint32_t hi = (E - lo < tile_len) ? E : lo + tile_len;
@@ -267,6 +283,7 @@ k_sort2_hist1(const uint32_t* __restrict__ digits, uint32_t E, uint32_t tile_len
 __global__ void __launch_bounds__(512)
 k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restrict__ cstart, uint32_t* __restrict__ tstart,
              uint32_t* __restrict__ tile_bin) {
+    latency_bound_kernel();
     __shared__ uint32_t a[512], b[512];
     const uint32_t t = threadIdx.x;
     uint32_t c = t < Hb ? ccount[t] : 0u;
@@ -289,6 +306,7 @@ __global__ void __launch_bounds__(256)
 k_sort2_scatter1(const uint32_t* __restrict__ digits, uint32_t n, uint32_t E, uint32_t tile_len, uint32_t Hb,
                  const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ blockbase1, uint32_t table_stride,
                  uint32_t* __restrict__ tmp1) {
+    latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
     const uint32_t lo = blockIdx.x * tile_len;
     const uint32_t hi = (E - lo < tile_len) ? E : lo + tile_len;
@@ -307,6 +325,7 @@ k_sort2_scatter1(const uint32_t* __restrict__ digits, uint32_t n, uint32_t E, ui
 __global__ void __launch_bounds__(256)
 k_sort2_hist2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
               const uint32_t* __restrict__ tile_bin, uint32_t Hb, uint32_t* __restrict__ count, uint32_t* __restrict__ blockbase2) {
+    latency_bound_kernel();
     __shared__ uint32_t hist[SORT2_LO];
     const uint32_t tile = blockIdx.x;
     if (tile >= tstart[Hb]) return;
@@ -326,6 +345,7 @@ __global__ void __launch_bounds__(256)
 k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
                  const uint32_t* __restrict__ tile_bin, uint32_t Hb, const uint32_t* __restrict__ offs,
                  const uint32_t* __restrict__ blockbase2, uint32_t* __restrict__ sorted) {
+    latency_bound_kernel();
     __shared__ uint32_t cur[SORT2_LO];
     const uint32_t tile = blockIdx.x;
     if (tile >= tstart[Hb]) return;
@@ -620,6 +640,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 k_msm_bucket_fin(const uint32_t* __restrict__ offs, uint32_t G, uint32_t nl, uint32_t m, uint32_t n_chunks,
                  const int32_t* __restrict__ head, size_t head_stride, const int32_t* __restrict__ cont, size_t cont_stride,
                  int32_t* __restrict__ bucket, size_t bucket_stride) {
+    latency_bound_kernel();
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const uint32_t L = acc_seg_len(offs[G], nl);
     BucketSpan s;
@@ -764,6 +785,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 k_msm_bucket_bits1(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
                    const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
                    uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
+    latency_bound_kernel();
     const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (g >= G1) return;                               // wave-uniform
     const uint32_t L = acc_seg_len(offs[B], nl);
@@ -784,6 +806,7 @@ k_msm_bucket_bits1(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, c
 //   wave >= 6 G1p : out[6 G1p + role * G1p + g2], role 0..6, zeta transform of the totals X1[6][g2 * 64 .. +64)  (bits 6..11, totals)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
+    latency_bound_kernel();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= 7u * G1p) return;
     const bool sum_job = wave < 6u * G1p;

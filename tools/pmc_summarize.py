@@ -6,7 +6,7 @@ Units / gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZ
 coalesced 16 B/lane STREAMING reads; k_msm_accumulate's reads are 64-byte random gathers (one 64 B point per lane,
 4 x dwordx4), calibrated here against the known byte count of the gather (entries x 64 B + entries x 4 B):
 the counter reads 1.2x that minimum, i.e. it is NOT halved for this pattern, so no doubling is applied.
-Usage: python tools/pmc_summarize.py <fetch_csv> <write_csv> <out_json>"""
+Usage: python tools/pmc_summarize.py <fetch_csv> <write_csv> <out_json> [log_n]"""
 import collections
 import csv
 import json
@@ -25,6 +25,7 @@ def main():
     out = {"units": "KB per dispatch (average)", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         out["kernels"][k] = {"FETCH_SIZE_KB": fetch.get(k), "WRITE_SIZE_KB": write.get(k)}
+    out["log_n"] = int(sys.argv[4]) if len(sys.argv) > 4 else 20          # workload the passes were collected on (bench.py checks it)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     acc = out["kernels"].get("k_msm_accumulate")
     if acc:
