@@ -330,6 +330,17 @@ def main():
             stream_proof(2)
             t = time.perf_counter(); stream_proof(6); pr_stream_ms = (time.perf_counter() - t) / 6 * 1e3
             assert np.array_equal(o8, want_proof), "streamed proof differs"
+            # KZG::compute_blob_proof end to end (kzg.rs:288-309): bytes in, Fiat-Shamir challenge (SHA-256 over 32 MiB on a host
+            # thread) and proof out; and commit + proof of the same blob in one call (the hash runs beside the GPU commitment)
+            ob = np.zeros(8, np.uint64); oz = np.zeros(4, np.uint64); oy = np.zeros(4, np.uint64); oc = np.zeros(8, np.uint64); oci = C.c_uint8(0)
+            assert lib.kzg_commit_blob(ctx.handle, srs.handle, blob_bytes.ctypes.data_as(u8p), blob_bytes.size, _lib.ptr(oc), C.byref(oci)) == 0
+            bp_ms = avg_ms(lambda: lib.kzg_compute_blob_proof(ctx.handle, srs.handle, blob_bytes.ctypes.data_as(u8p), blob_bytes.size, n, _lib.ptr(oc),
+                                                              _lib.ptr(ob), C.byref(oi), _lib.ptr(oz), _lib.ptr(oy)), reps=4, warm=1)
+            oc2 = np.zeros(8, np.uint64); ob2 = np.zeros(8, np.uint64)
+            cp_ms = avg_ms(lambda: lib.kzg_commit_and_prove_blob(ctx.handle, srs.handle, blob_bytes.ctypes.data_as(u8p), blob_bytes.size, n, _lib.ptr(oc2),
+                                                                 C.byref(oci), _lib.ptr(ob2), C.byref(oi), _lib.ptr(oz), _lib.ptr(oy)), reps=4, warm=1)
+            assert np.array_equal(oc2, oc) and np.array_equal(ob2, ob), "commit + proof in one call differs from the two calls"
+            ch_ms = avg_ms(lambda: lib.kzg_compute_challenge(blob_bytes.ctypes.data_as(u8p), blob_bytes.size, _lib.ptr(oc), _lib.ptr(oz)), reps=3, warm=1)
             # config 5 shape: verify_kzg_proof_batch core at n = 4096 (three 4096-point MSMs batched on the GPU + host pairing check)
             nb = 4096
             g1w = np.zeros((nb, 8), dtype=np.uint64)
@@ -352,6 +363,8 @@ def main():
             out["secondary"] = {
                 "host_buffers_commit_coeff_streamed_ms": cc_stream_ms,
                 "commit_blob_from_host_bytes_ms": cb_ms, "commit_blob_from_host_bytes_streamed_ms": cb_stream_ms,
+                "compute_blob_proof_from_host_bytes_ms": bp_ms, "commit_and_prove_blob_from_host_bytes_ms": cp_ms,
+                "compute_challenge_host_sha256_ms": ch_ms,
                 "batch_verify_4096_core_ms": bv_ms, "batch_verify_4096_three_msms_ms": m3_ms,
                 "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,

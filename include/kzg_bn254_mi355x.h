@@ -117,7 +117,9 @@ int32_t kzg_msm_g1_srs_partial_device(kzg_ctx* ctx, const kzg_srs* srs, size_t o
                                       const void* d_scalars_mont, size_t n, uint64_t out_xyzz_mont[16]);
 int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
                                const uint64_t* scalars_mont, size_t n, uint64_t out_xyzz_mont[16]);
+#ifndef KZG_NUM_SLOTS
 #define KZG_NUM_SLOTS 4
+#endif
 /* Asynchronous form for streams of commitments (software pipelining): `begin` enqueues the whole kernel sequence of one
  * MSM over srs[offset .. offset + n) on the stream of `slot` (0 .. KZG_NUM_SLOTS-1; each slot has its own stream and workspace) and
  * returns without waiting; `end` waits for that slot, runs the O(1) host epilogue and writes the affine point
@@ -268,7 +270,12 @@ int32_t kzg_g2_mul_generator(const uint64_t scalar_mont[4], uint64_t out_g2_mont
 int32_t kzg_pairings_verify(const uint64_t a1_xy_mont[8], const uint64_t a2_g2_mont[16],
                             const uint64_t b1_xy_mont[8], const uint64_t b2_g2_mont[16], int32_t* out_ok);
 /* verify::verify_proof (verifier/src/verify.rs:10-72).  Off-curve commitment/proof -> KZG_ERR_G1_NOT_ON_CURVE;
- * [tau - z]G2 == identity -> KZG_ERR_TAU_EQUALS_Z.  Host-only. */
+ * [tau - z]G2 == identity -> KZG_ERR_TAU_EQUALS_Z.  Host-only.
+ * g2_tau (here and in kzg_verify_kzg_proof_batch): NULL = consts::G2_TAU; a caller-supplied point is only checked to be ON THE
+ * CURVE, exactly as the reference does (verify.rs:29-33, batch.rs:212-214) -- its membership in the order-r subgroup of the twist
+ * is NOT checked, and outside that subgroup the Tate pairing used here and arkworks' optimal ate pairing may disagree: pass
+ * subgroup points (any [s]G2).  The Fiat-Shamir transcripts of the batch verifier (compute_r_powers, verifier/src/batch.rs:76-168)
+ * stay with the caller, who passes r_powers. */
 int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t proof_xy_mont[8],
                          const uint64_t value_mont[4], const uint64_t z_mont[4],
                          const uint64_t* g2_tau_mont, int32_t* out_ok);

@@ -32,7 +32,7 @@ ERR_ZERO_LENGTH = -13
 ERR_SRS_LENGTH = -14
 ERR_DESERIALIZE = -15
 ERR_NOT_ON_CURVE = -16
-NUM_SLOTS = 4          # KZG_NUM_SLOTS of the header
+NUM_SLOTS = int(os.environ.get("KZG_NUM_SLOTS", "4"))          # KZG_NUM_SLOTS of the header (env: variant builds with more slots)
 ERR_G1_NOT_ON_CURVE = -17
 ERR_G2_TAU_NOT_ON_CURVE = -18
 ERR_TAU_EQUALS_Z = -19

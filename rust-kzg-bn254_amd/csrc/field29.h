@@ -94,14 +94,15 @@ KZG_HD void fe_opaque_limbs(int32_t (&o)[NL], const Fe<F>& a) {
     for (int j = 0; j < NL; ++j) o[j] = fe_opaque(a.l[j]);
 }
 
-// One multiply-accumulate step of a column sum.  The empty asm on the accumulator keeps the additions in SOURCE order: LLVM's
-// reassociation sorts the operands of a long integer sum by rank, which moves the carry of the previous column (the latest
-// value) to the END of the chain -- where it can no longer be the addend of a v_mad_i64_i32 and costs one 64-bit add per
-// column (146 v_lshl_add_u64 per mixed addition, 6.5 % of its instructions).  With the barrier every column is ONE chain of
-// mads that starts from the carry.  -DKZG_NO_CHAIN: A/B switch.
+// One multiply-accumulate step of a column sum.  LLVM's reassociation sorts the operands of a long integer sum by rank, which
+// moves the carry of the previous column (the latest value) to the END of the chain -- where it can no longer be the addend of a
+// v_mad_i64_i32 and costs one 64-bit add per column (146 v_lshl_add_u64 per mixed addition, 6.5 % of its instructions).  An empty
+// asm on the accumulator (-DKZG_CHAIN) keeps the additions in source order and removes those adds -- but hipcc pads every asm
+// statement with an s_nop (1 215 per mixed addition), and the same-box A/B says the nops cost more than the adds:
+// k_msm_accumulate 1.17-1.19 ms with the barrier, 1.10-1.11 ms without.  So the barrier is OFF by default.
 KZG_HD void fe_mac(int64_t& acc, int32_t a, int32_t b) {
     acc += (int64_t)a * (int64_t)b;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_CHAIN)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(KZG_CHAIN)
     asm("" : "+v"(acc));
 #endif
 }
