@@ -144,6 +144,100 @@ KZG_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
     for (int j = 0; j < NL; ++j) r.l[j] = out[j];
 }
 
+// ---------------------------------------------------------------------------------------------
+// TWO independent Montgomery products with their column sums interleaved statement by statement (used by xyzz_madd, curve.h):
+// with the chain barrier of fe_mac on BOTH accumulators every column is one chain of mads that starts from the carry (no 64-bit
+// join add), and the instruction after a barrier belongs to the OTHER product, so hipcc's one-state pad behind an asm statement
+// is not needed.
+// ---------------------------------------------------------------------------------------------
+KZG_HD void fe_mac_b(int64_t& acc, int32_t a, int32_t b) {
+    acc += (int64_t)a * (int64_t)b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(acc));
+#endif
+}
+template <class F>
+KZG_HD void fe_mul2(Fe<F>& r1, const Fe<F>& a1, const Fe<F>& b1, Fe<F>& r2, const Fe<F>& a2, const Fe<F>& b2) {
+    KZG_CHECK_MUL(a1, b1, "fe_mul2");
+    KZG_CHECK_MUL(a2, b2, "fe_mul2");
+    int64_t acc1 = 0, acc2 = 0;
+    int32_t m1[NL], m2[NL], o1[NL], o2[NL];
+    int32_t al1[NL], bl1[NL], al2[NL], bl2[NL];
+    fe_opaque_limbs(al1, a1); fe_opaque_limbs(bl1, b1);
+    fe_opaque_limbs(al2, a2); fe_opaque_limbs(bl2, b2);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+#pragma unroll
+        for (int j = 0; j <= k; ++j) { fe_mac_b(acc1, al1[j], bl1[k - j]); fe_mac_b(acc2, al2[j], bl2[k - j]); }
+#pragma unroll
+        for (int j = 0; j < k; ++j) { fe_mac_b(acc1, m1[j], (int32_t)F::P[k - j]); fe_mac_b(acc2, m2[j], (int32_t)F::P[k - j]); }
+        m1[k] = (int32_t)(((uint32_t)acc1 * F::INV) & LMASK);
+        m2[k] = (int32_t)(((uint32_t)acc2 * F::INV) & LMASK);
+        fe_mac_b(acc1, m1[k], (int32_t)F::P[0]);
+        fe_mac_b(acc2, m2[k], (int32_t)F::P[0]);
+        acc1 >>= LB;
+        acc2 >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) { fe_mac_b(acc1, al1[j], bl1[k - j]); fe_mac_b(acc2, al2[j], bl2[k - j]); }
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) { fe_mac_b(acc1, m1[j], (int32_t)F::P[k - j]); fe_mac_b(acc2, m2[j], (int32_t)F::P[k - j]); }
+        o1[k - NL] = (int32_t)((uint32_t)acc1 & LMASK);
+        o2[k - NL] = (int32_t)((uint32_t)acc2 & LMASK);
+        acc1 >>= LB;
+        acc2 >>= LB;
+    }
+    o1[NL - 1] = (int32_t)acc1;
+    o2[NL - 1] = (int32_t)acc2;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { r1.l[j] = o1[j]; r2.l[j] = o2[j]; }
+}
+
+template <class F>
+KZG_HD void fe_sqr2(Fe<F>& r1, const Fe<F>& a1, Fe<F>& r2, const Fe<F>& a2) {
+    KZG_CHECK_MUL(a1, a1, "fe_sqr2");
+    KZG_CHECK_MUL(a2, a2, "fe_sqr2");
+    int64_t acc1 = 0, acc2 = 0;
+    int32_t m1[NL], m2[NL], o1[NL], o2[NL];
+    int32_t d1[NL], d2[NL], al1[NL], al2[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { d1[j] = fe_opaque(a1.l[j] * 2); d2[j] = fe_opaque(a2.l[j] * 2); }
+    fe_opaque_limbs(al1, a1);
+    fe_opaque_limbs(al2, a2);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+#pragma unroll
+        for (int j = 0; 2 * j < k; ++j) { fe_mac_b(acc1, d1[j], al1[k - j]); fe_mac_b(acc2, d2[j], al2[k - j]); }
+        if ((k & 1) == 0) { fe_mac_b(acc1, al1[k / 2], al1[k / 2]); fe_mac_b(acc2, al2[k / 2], al2[k / 2]); }
+#pragma unroll
+        for (int j = 0; j < k; ++j) { fe_mac_b(acc1, m1[j], (int32_t)F::P[k - j]); fe_mac_b(acc2, m2[j], (int32_t)F::P[k - j]); }
+        m1[k] = (int32_t)(((uint32_t)acc1 * F::INV) & LMASK);
+        m2[k] = (int32_t)(((uint32_t)acc2 * F::INV) & LMASK);
+        fe_mac_b(acc1, m1[k], (int32_t)F::P[0]);
+        fe_mac_b(acc2, m2[k], (int32_t)F::P[0]);
+        acc1 >>= LB;
+        acc2 >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+        for (int j = k - NL + 1; 2 * j < k; ++j) { fe_mac_b(acc1, d1[j], al1[k - j]); fe_mac_b(acc2, d2[j], al2[k - j]); }
+        if ((k & 1) == 0) { fe_mac_b(acc1, al1[k / 2], al1[k / 2]); fe_mac_b(acc2, al2[k / 2], al2[k / 2]); }
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) { fe_mac_b(acc1, m1[j], (int32_t)F::P[k - j]); fe_mac_b(acc2, m2[j], (int32_t)F::P[k - j]); }
+        o1[k - NL] = (int32_t)((uint32_t)acc1 & LMASK);
+        o2[k - NL] = (int32_t)((uint32_t)acc2 & LMASK);
+        acc1 >>= LB;
+        acc2 >>= LB;
+    }
+    o1[NL - 1] = (int32_t)acc1;
+    o2[NL - 1] = (int32_t)acc2;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { r1.l[j] = o1[j]; r2.l[j] = o2[j]; }
+}
+
 // Fused (a*b - c*d) * 2^-261 mod m with ONE Montgomery reduction (saves 81 mads + 9 mul_lo against two fe_mul and a
 // subtraction).  Needs all four operands' limbs within +-2^29 (27 * 2^58 < 2^63 per column) and |a*b| + |c*d| < 2^261 m.
 // Result normalised, in (-m, 2m).
