@@ -1,25 +1,27 @@
-// ntt.hip — radix-2^K Stockham NTT / inverse NTT over BN254 Fr, LDS-tiled.
+// ntt.hip — radix-2^K Stockham NTT / inverse NTT over BN254 Fr, LDS-tiled (round 2: two passes at 2^20).
 //
 // Replaces `GeneralEvaluationDomain::<Fr>::new(n).fft(..)` / `.ifft(..)` at
 // primitives/src/polynomial.rs:131-135 and :242-246: natural order in and out on the domain
 // {w^i}, w = 5^((r-1)/n) (= PRIMITIVE_ROOTS_OF_UNITY[log2 n], primitives/src/consts.rs:22-52); the
 // inverse uses w^-1 and scales by n^-1.
 //
-// Algorithm (decimation in time, Stockham autosort, P = ceil(log n / 7) passes):
+// Algorithm (decimation in time, Stockham autosort, P = ceil(log n / 10) passes: 10 + 10 at n = 2^20):
 //   pass with radix R = 2^K brings the sub-transform length from n_cur/R to n_cur (stride s = N / n_cur):
 //     y[u + j * N/R] = sum_j'  w_{n_cur}^(p j') x[q + s (R p + j')] * w_R^(j j'),   u = q + s p
-//   Each workgroup owns a tile of C = 2048 / R consecutive units u: it gathers the R x C elements
-//   (contiguous runs in global memory), applies the inter-pass twiddles, runs the K radix-2 butterfly
-//   stages in LDS (9 limb planes, padded rows; per-tile twiddle table w_R^t in LDS), and scatters rows
-//   back.  Data stay in the wire residue class (a * 2^256) throughout: the transform is linear and the
-//   twiddles are in internal Montgomery form, so no domain conversion is needed.  Intermediate passes
-//   keep elements as 9 signed 29-bit limb planes (lazy, |v| < 16 m); the last pass reduces, scales and
-//   packs canonical 256-bit words.
-//   Algorithmic traffic: 64 B per element (32 B read + 32 B written); this implementation moves
-//   P x (read + write) with 36 B planes in between.
+//   A workgroup (512 threads, one per CU: 129 KB of LDS) owns tiles of C = 2048 / R consecutive units u.  Per tile: the R x C
+//   elements come from global memory as canonical 256-bit words (runs of C x 32 B), go through the K radix-2 butterfly stages in
+//   LDS (9 limb planes, padded rows; radix-4 steps in registers, their multiplies in independent PAIRS: fe_mul2), and leave as
+//   256-bit words again.  The inter-pass twiddle w_{n_cur'}^(p' j') of the NEXT pass is applied at the STORE of this pass (the
+//   multiply that brings the lazy value back into (-m, 2m) anyway), so later passes load, unpack and go.  Data stay in the wire
+//   residue class (a * 2^256) throughout: the transform is linear and the twiddles are in internal Montgomery form.
+//   Round 1 ran three passes (7 + 6 + 7) with 36-byte limb planes in between: SQ counters showed its VALU work fully issued
+//   (27 of 45 us per pass) and the rest spent in the un-overlapped load and store phases of a single round of tiles.  Here a
+//   workgroup walks several tiles and fetches the NEXT tile's words into registers while it computes the current one.
+//   Algorithmic traffic: 64 B per element; this implementation moves P x 64 B.
 #include "engine.h"
 #include "field29.h"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -28,14 +30,12 @@ namespace kzg {
 
 constexpr int NTT_TILE_LOG = 11;
 constexpr int NTT_TILE = 1 << NTT_TILE_LOG;       // elements per workgroup tile
-constexpr int NTT_KMAX = 7;
+constexpr int NTT_KMAX = 10;
 constexpr int NTT_PL = NTT_TILE + (1 << NTT_KMAX); // plane length with one pad element per row
-#ifndef KZG_NTT_THREADS
-#define KZG_NTT_THREADS 512
-#endif
-constexpr int NTT_THREADS = KZG_NTT_THREADS;
+constexpr int NTT_THREADS = 512;
+constexpr int NTT_EPT = NTT_TILE / NTT_THREADS;    // elements per thread in the load / store phases
 constexpr int NTT_LO_BITS = 10;
-constexpr int NTT_TW = 96;                         // LDS twiddle entries: R/2 local + R row entries must fit (2 tiles per CU)
+constexpr int NTT_TW = 1 << (NTT_KMAX - 1);        // per-tile twiddles w_R^t, t < R/2
 
 // ---- twiddle tables: planes[9][len] of w^(t * step), internal Montgomery form -----------------------
 __device__ __forceinline__ void fr_pow_root(Fr& out, int log_n, bool inverse, uint32_t e) {
@@ -63,17 +63,6 @@ k_ntt_build_table(int32_t* __restrict__ planes, uint32_t len, int log_n, int inv
     for (int j = 0; j < NL; ++j) planes[(size_t)j * len + t] = w.l[j];
 }
 
-// last-pass separable twiddles: sep[uu * R + j] = w_N^(uu * j), uu < C = 2048 / R, j < R = 2^K (tile-independent)
-__global__ void __launch_bounds__(256)
-k_ntt_build_sep(int32_t* __restrict__ planes, int log_n, int inverse, int K) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint32_t)NTT_TILE) return;
-    Fr w;
-    fr_pow_root(w, log_n, inverse != 0, (t >> K) * (t & ((1u << K) - 1)));
-#pragma unroll
-    for (int j = 0; j < NL; ++j) planes[(size_t)j * NTT_TILE + t] = w.l[j];
-}
-
 __device__ __forceinline__ void load_planes(Fr& v, const int32_t* __restrict__ planes, size_t stride, size_t i) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) v.l[j] = planes[(size_t)j * stride + i];
@@ -90,216 +79,257 @@ __device__ __forceinline__ void twiddle(Fr& w, const int32_t* __restrict__ lo, u
     }
 }
 
-// One Stockham pass.  in_wire / out_wire (canonical 256-bit words) are used by the first / last pass,
-// the planes otherwise.
-__global__ void __launch_bounds__(NTT_THREADS)
-k_ntt_pass(const uint4* __restrict__ in_wire, const int32_t* __restrict__ in_planes,
-           uint4* __restrict__ out_wire, int32_t* __restrict__ out_planes,
-           int log_n, int K, int log_s,
-           const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
-           int first, int last, int scale_log_n /* >= 0: multiply by (2^scale_log_n)^-1 at the end */,
-           const int32_t* __restrict__ sep /* last pass (s = 1): w_N^(uu j) table, or nullptr */) {
-    __shared__ int32_t lds[NL * NTT_PL];
-    // twiddle scratch: entries [0, R/2) = per-tile w_R^t; entries [64, 64 + R) = inter-pass row (only when R <= 32...64 fits)
-    __shared__ int32_t twl[NL * NTT_TW];
+// LDS position of (row i, column uu) of a tile.  C >= 16 columns: row-major with one pad word per row (consecutive lanes =
+// consecutive columns = consecutive banks).  C <= 8 (K >= 8, e.g. the 1024 x 2 tiles of a 2^20 transform): a half-wave touches
+// 32 / C different rows, so the layout is column-major with a column stride = R + 32 / C (column uu starts 32 / C banks further) and
+// the row index is XOR-swizzled, pos = i ^ (((i >> 2) ^ (i >> 6)) & (32 / C - 1)): the rows of one access differ in bits {2..5}
+// (first radix-4 step), {0,1,4,5} (second), {0..3} (later steps, final store) or the top bits (bit-reversed fill), and this map is
+// injective on each of these sets -- without it the 1024 x 2 tile ran at 70-77 % LDS bank-conflict cycles (SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ uint32_t ntt_lds_pos(uint32_t i, uint32_t uu, int log_c, int K) {
+    if (log_c >= 4) return i * ((1u << log_c) + 1u) + uu;
+    const uint32_t spread = 32u >> log_c;                       // rows per half-wave
+    const uint32_t cs = (1u << K) + spread;
+    return uu * cs + (i ^ (((i >> 2) ^ (i >> 6)) & (spread - 1u)));
+}
 
-    const uint32_t N = 1u << log_n;
-    const uint32_t R = 1u << K;
+// inter-pass twiddles of one pass boundary for every element index: tw[idx] = w_N^((p' j') << log_s') as canonical words
+__global__ void __launch_bounds__(256)
+k_ntt_build_pass_twiddles(uint4* __restrict__ tw, int log_n, int next_K, int next_log_s,
+                          const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len);
+
+struct NttPassArgs {
+    int log_n, K, log_s;          // this pass
+    int next_K, next_log_s;       // the pass after it (next_K = 0: this is the last pass)
+    int scale_log_n;              // last pass: >= 0 multiplies by (2^scale_log_n)^-1
+    uint32_t n_tiles;
+};
+
+// global word index of element (uu, j) of tile `tile` on the INPUT side of the pass
+__device__ __forceinline__ size_t ntt_in_index(const NttPassArgs& a, uint32_t tile, uint32_t t, uint32_t& uu, uint32_t& j, bool& valid) {
+    const int log_c = NTT_TILE_LOG - a.K;
+    const uint32_t C = 1u << log_c, R = 1u << a.K, s = 1u << a.log_s;
+    if (s >= C) { uu = t & (C - 1); j = t >> log_c; }
+    else { const uint32_t q = t & (s - 1); j = (t >> a.log_s) & (R - 1); uu = ((t >> (a.log_s + a.K)) << a.log_s) | q; }
+    const uint32_t u = (tile << log_c) + uu;
+    valid = u < ((1u << a.log_n) >> a.K);
+    const uint32_t q = u & (s - 1), p = u >> a.log_s;
+    return (size_t)q + ((size_t)(R * p + j) << a.log_s);
+}
+
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, NttPassArgs a,
+           const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
+           const uint4* __restrict__ next_tw /* or nullptr: w_N^(E(idx)) of the next pass for every output index, canonical words of the internal form */) {
+    __shared__ int32_t lds[NL * NTT_PL];
+    __shared__ int32_t twl[NL * NTT_TW];
+    const int K = a.K, log_n = a.log_n;
+    const uint32_t N = 1u << log_n, R = 1u << K;
     const int log_c = NTT_TILE_LOG - K;
-    const uint32_t C = 1u << log_c, Cp = C + 1;
-    const uint32_t s = 1u << log_s;
+    const uint32_t C = 1u << log_c;
     const uint32_t n_units = N >> K;
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile_u0 = blockIdx.x << log_c;
+    const bool last = a.next_K == 0;
 
-    // per-tile local twiddles w_R^t = w_N^(t * N/R), t < R/2
+    // per-workgroup local twiddles w_R^t = w_N^(t * N/R), t < R/2 (the same for every tile of the pass)
     if (tid < (R >> 1)) {
         Fr w;
         twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, tid << (log_n - K));
-        if (R == 1) fe_set_one(w);
 #pragma unroll
         for (int j = 0; j < NL; ++j) twl[j * NTT_TW + tid] = w.l[j];
     }
-
-    // every unit of the tile has the same p = tile_u0 >> log_s, and the row fits behind the local twiddles
-    const bool row_tw = !first && s >= C && (R >> 1) + R <= (uint32_t)NTT_TW;
-    if (row_tw && tid < R) {
-        const uint32_t p = tile_u0 >> log_s;
-        Fr w;
-        twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, (p * tid) << log_s);
+    if (R == 1 && tid == 0) {
+        Fr w; fe_set_one(w);
 #pragma unroll
-        for (int j = 0; j < NL; ++j) twl[j * NTT_TW + (R >> 1) + tid] = w.l[j];
+        for (int j = 0; j < NL; ++j) twl[j * NTT_TW] = w.l[j];
     }
-    if (row_tw) __syncthreads();
 
-    // Last pass (s = 1): every unit of the tile has its own p = tile_u0 + uu, so the inter-pass twiddle w_N^(p j) differs per
-    // element.  A two-level table lookup per element was 18 scattered 4-byte loads (the slowest part of the pass: +29 us at
-    // 2^20).  w_N^(p j) = w_N^(tile_u0 j) * w_N^(uu j): the first factor depends only on j, which is FIXED per thread here
-    // (j = t mod R, NTT_THREADS a multiple of R) -> one lookup per thread, kept in registers; the second is a tile-independent
-    // 2048-entry table read with consecutive lanes on consecutive entries.
-    const bool sep_tw = !first && s == 1 && sep != nullptr;
-    Fr tw_a;
-    fe_set_one(tw_a);
-    if (sep_tw && tile_u0 != 0) twiddle(tw_a, tlo, lo_len, lo_bits, thi, hi_len, tile_u0 * (tid & (R - 1)));
-
-    // ---- gather -------------------------------------------------------------------------------
-    for (uint32_t t = tid; t < (uint32_t)NTT_TILE; t += NTT_THREADS) {
-        uint32_t uu, j;
-        if (s >= C) { uu = t & (C - 1); j = t >> log_c; }
-        else { uint32_t q = t & (s - 1); j = (t >> log_s) & (R - 1); uu = ((t >> (log_s + K)) << log_s) | q; }
-        uint32_t u = tile_u0 + uu;
-        Fr v;
-        fe_set_zero(v);
-        if (u < n_units) {
-            uint32_t q = u & (s - 1), p = u >> log_s;
-            size_t idx = (size_t)q + ((size_t)(R * p + j) << log_s);
-            if (first) {
-                uint4 a = in_wire[2 * idx], b = in_wire[2 * idx + 1];
-                uint32_t w32[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                fe_unpack(v, w32);
-            } else {
-                load_planes(v, in_planes, N, idx);
-                if (sep_tw) {
-                    if (p != 0 && j != 0) {
-                        Fr w;
-                        load_planes(w, sep, NTT_TILE, (size_t)uu * R + j);
-                        if (tile_u0 != 0) fe_mul(w, w, tw_a);
-                        fe_mul(v, v, w);
-                    }
-                } else if (p != 0 && j != 0) {
-                    Fr w;
-                    if (row_tw) {
+    // words of the first tile
+    uint4 pre[NTT_EPT][2];
+    {
+        const uint32_t tile = blockIdx.x;
 #pragma unroll
-                        for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + (R >> 1) + j];
-                    } else {
-                        twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, (p * j) << log_s);   // w_{n_cur}^(p j) = w_N^(p j s)
-                    }
-                    fe_mul(v, v, w);                                                  // |v| < 16 m, |w| < 2 m
+        for (int k = 0; k < NTT_EPT; ++k) {
+            uint32_t uu, j; bool valid;
+            const size_t idx = ntt_in_index(a, tile, tid + k * NTT_THREADS, uu, j, valid);
+            if (valid) { pre[k][0] = in_words[2 * idx]; pre[k][1] = in_words[2 * idx + 1]; }
+            else { pre[k][0] = make_uint4(0, 0, 0, 0); pre[k][1] = make_uint4(0, 0, 0, 0); }
+        }
+    }
+    for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const uint32_t tile_u0 = tile << log_c;
+        // ---- registers -> LDS (bit-reversed rows) ----------------------------------------------
+#pragma unroll
+        for (int k = 0; k < NTT_EPT; ++k) {
+            uint32_t uu, j; bool valid;
+            (void)ntt_in_index(a, tile, tid + k * NTT_THREADS, uu, j, valid);
+            const uint32_t w32[8] = {pre[k][0].x, pre[k][0].y, pre[k][0].z, pre[k][0].w, pre[k][1].x, pre[k][1].y, pre[k][1].z, pre[k][1].w};
+            Fr v;
+            fe_unpack(v, w32);                          // canonical, or < 3 m from the previous pass: both fine for the lazy stages
+            uint32_t jr = K ? (__brev(j) >> (32 - K)) : 0;
+            const uint32_t e = ntt_lds_pos(jr, uu, log_c, K);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) lds[l * NTT_PL + e] = v.l[l];
+        }
+        __syncthreads();
+        // ---- prefetch the next tile's words: in flight during the butterfly stages ---------------
+        {
+            const uint32_t nt = tile + gridDim.x;
+            if (nt < a.n_tiles) {
+#pragma unroll
+                for (int k = 0; k < NTT_EPT; ++k) {
+                    uint32_t uu, j; bool valid;
+                    const size_t idx = ntt_in_index(a, nt, tid + k * NTT_THREADS, uu, j, valid);
+                    if (valid) { pre[k][0] = in_words[2 * idx]; pre[k][1] = in_words[2 * idx + 1]; }
+                    else { pre[k][0] = make_uint4(0, 0, 0, 0); pre[k][1] = make_uint4(0, 0, 0, 0); }
                 }
             }
         }
-        uint32_t jr = __brev(j) >> (32 - K);
-        if (K == 0) jr = 0;
-        uint32_t e = jr * Cp + uu;
+        // ---- K DIT stages in LDS: pairs of stages as radix-4 steps in registers, a last radix-2 stage when K is odd ------
+        // Radix-4 step over half-sizes h and 2h on rows i0, i0+h, i0+2h, i0+3h (same butterflies and twiddles as two radix-2
+        // stages, so the results are identical): one LDS round trip, one barrier and four limb normalisations per four elements.
+        uint32_t log_h = 0;
+        for (; log_h + 1 < (uint32_t)K; log_h += 2) {
+            const uint32_t h = 1u << log_h;
+            for (uint32_t gt = tid; gt < (uint32_t)(NTT_TILE / 4); gt += NTT_THREADS) {
+                const uint32_t g = gt >> log_c, uu = gt & (C - 1);
+                const uint32_t lowb = g & (h - 1);
+                const uint32_t i0 = ((g >> log_h) << (log_h + 2)) | lowb;
+                const uint32_t e0 = ntt_lds_pos(i0, uu, log_c, K), e1 = ntt_lds_pos(i0 + h, uu, log_c, K),
+                               e2 = ntt_lds_pos(i0 + 2 * h, uu, log_c, K), e3 = ntt_lds_pos(i0 + 3 * h, uu, log_c, K);
+                const uint32_t t1 = lowb << (K - 1 - log_h);                 // stage h:  w_R^(lowb R / 2h)
+                const uint32_t t2 = lowb << (K - 2 - log_h);                 // stage 2h: w_R^(lowb R / 4h), rows i0 / i0+2h
+                const uint32_t t3 = (lowb + h) << (K - 2 - log_h);           //           w_R^((lowb+h) R / 4h), rows i0+h / i0+3h
+                Fr a0, a1, a2, a3, w, w3;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) lds[l * NTT_PL + e] = v.l[l];
-    }
-    __syncthreads();
-
-    // ---- K DIT stages in LDS: pairs of stages as radix-4 steps in registers, a last radix-2 stage when K is odd ---------
-    // Radix-4 step over half-sizes h and 2h on rows i0, i0+h, i0+2h, i0+3h (same butterflies and twiddles as two radix-2 stages,
-    // so the results are identical): one LDS round trip, one barrier and four limb normalisations per four elements instead of
-    // two, eight and eight.  The intermediate values are multiplied un-normalised (limbs < 2^30 against twiddle limbs < 2^29).
-    uint32_t log_h = 0;
-    for (; log_h + 1 < (uint32_t)K; log_h += 2) {
-        const uint32_t h = 1u << log_h;
-        for (uint32_t gt = tid; gt < (uint32_t)(NTT_TILE / 4); gt += NTT_THREADS) {
-            const uint32_t g = gt >> log_c, uu = gt & (C - 1);
-            const uint32_t lowb = g & (h - 1);
-            const uint32_t i0 = ((g >> log_h) << (log_h + 2)) | lowb;
-            const uint32_t e0 = i0 * Cp + uu, e1 = e0 + h * Cp, e2 = e1 + h * Cp, e3 = e2 + h * Cp;
-            const uint32_t t1 = lowb << (K - 1 - log_h);                 // stage h:  w_R^(lowb R / 2h)
-            const uint32_t t2 = lowb << (K - 2 - log_h);                 // stage 2h: w_R^(lowb R / 4h), rows i0 / i0+2h
-            const uint32_t t3 = (lowb + h) << (K - 2 - log_h);           //           w_R^((lowb+h) R / 4h), rows i0+h / i0+3h
-            Fr a0, a1, a2, a3, w;
+                for (int l = 0; l < NL; ++l) {
+                    a0.l[l] = lds[l * NTT_PL + e0];
+                    a1.l[l] = lds[l * NTT_PL + e1];
+                    a2.l[l] = lds[l * NTT_PL + e2];
+                    a3.l[l] = lds[l * NTT_PL + e3];
+                }
+                Fr p, q;
+                if (h == 1) { p = a1; q = a3; }                              // first stage: every twiddle is 1
+                else {
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                a0.l[l] = lds[l * NTT_PL + e0];
-                a1.l[l] = lds[l * NTT_PL + e1];
-                a2.l[l] = lds[l * NTT_PL + e2];
-                a3.l[l] = lds[l * NTT_PL + e3];
+                    for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + t1];
+                    fe_mul2(p, a1, w, q, a3, w);
+                }
+                Fr b0, b1, b2, b3;
+                fe_add(b0, a0, p); fe_sub(b1, a0, p);
+                fe_add(b2, a2, q); fe_sub(b3, a2, q);
+                Fr u, v;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) { w.l[l] = twl[l * NTT_TW + t2]; w3.l[l] = twl[l * NTT_TW + t3]; }
+                fe_mul2(u, b2, w, v, b3, w3);
+                Fr c0, c1, c2, c3;
+                fe_add(c0, b0, u); fe_norm(c0);
+                fe_sub(c2, b0, u); fe_norm(c2);
+                fe_add(c1, b1, v); fe_norm(c1);
+                fe_sub(c3, b1, v); fe_norm(c3);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    lds[l * NTT_PL + e0] = c0.l[l];
+                    lds[l * NTT_PL + e1] = c1.l[l];
+                    lds[l * NTT_PL + e2] = c2.l[l];
+                    lds[l * NTT_PL + e3] = c3.l[l];
+                }
             }
-            Fr p, q;
-            if (h == 1) { p = a1; q = a3; }                              // first stage: every twiddle is 1
-            else {
-#pragma unroll
-                for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + t1];
-                fe_mul(p, a1, w);
-                fe_mul(q, a3, w);
-            }
-            Fr b0, b1, b2, b3;
-            fe_add(b0, a0, p); fe_sub(b1, a0, p);
-            fe_add(b2, a2, q); fe_sub(b3, a2, q);
-            Fr u, v;
-#pragma unroll
-            for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + t2];
-            fe_mul(u, b2, w);
-#pragma unroll
-            for (int l = 0; l < NL; ++l) w.l[l] = twl[l * NTT_TW + t3];
-            fe_mul(v, b3, w);
-            Fr c0, c1, c2, c3;
-            fe_add(c0, b0, u); fe_norm(c0);
-            fe_sub(c2, b0, u); fe_norm(c2);
-            fe_add(c1, b1, v); fe_norm(c1);
-            fe_sub(c3, b1, v); fe_norm(c3);
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                lds[l * NTT_PL + e0] = c0.l[l];
-                lds[l * NTT_PL + e1] = c1.l[l];
-                lds[l * NTT_PL + e2] = c2.l[l];
-                lds[l * NTT_PL + e3] = c3.l[l];
-            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (log_h < (uint32_t)K) {
-        const uint32_t h = 1u << log_h;
-        for (uint32_t bt = tid; bt < (uint32_t)(NTT_TILE / 2); bt += NTT_THREADS) {
-            uint32_t b = bt >> log_c, uu = bt & (C - 1);
-            uint32_t lowb = b & (h - 1);
-            uint32_t i0 = ((b >> log_h) << (log_h + 1)) | lowb;
-            uint32_t e0 = i0 * Cp + uu, e1 = (i0 + h) * Cp + uu;
-            uint32_t tw_idx = lowb << (K - 1 - log_h);                 // (b mod h) * R / (2h)
-            Fr a, x, w, t;
+        if (log_h < (uint32_t)K) {
+            const uint32_t h = 1u << log_h;
+            for (uint32_t bt = tid; bt < (uint32_t)(NTT_TILE / 2); bt += NTT_THREADS) {
+                uint32_t b = bt >> log_c, uu = bt & (C - 1);
+                uint32_t lowb = b & (h - 1);
+                uint32_t i0 = ((b >> log_h) << (log_h + 1)) | lowb;
+                uint32_t e0 = ntt_lds_pos(i0, uu, log_c, K), e1 = ntt_lds_pos(i0 + h, uu, log_c, K);
+                uint32_t tw_idx = lowb << (K - 1 - log_h);                 // (b mod h) * R / (2h)
+                Fr x0, x, w, t;
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                a.l[l] = lds[l * NTT_PL + e0];
-                x.l[l] = lds[l * NTT_PL + e1];
-                w.l[l] = twl[l * NTT_TW + tw_idx];
-            }
-            if (h == 1) t = x;                         // stage 1: every twiddle is w_R^0 = 1
-            else fe_mul(t, x, w);
-            Fr y0, y1;
-            fe_add(y0, a, t); fe_norm(y0);
-            fe_sub(y1, a, t); fe_norm(y1);
+                for (int l = 0; l < NL; ++l) {
+                    x0.l[l] = lds[l * NTT_PL + e0];
+                    x.l[l] = lds[l * NTT_PL + e1];
+                    w.l[l] = twl[l * NTT_TW + tw_idx];
+                }
+                if (h == 1) t = x;                         // stage 1: every twiddle is w_R^0 = 1
+                else fe_mul(t, x, w);
+                Fr y0, y1;
+                fe_add(y0, x0, t); fe_norm(y0);
+                fe_sub(y1, x0, t); fe_norm(y1);
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                lds[l * NTT_PL + e0] = y0.l[l];
-                lds[l * NTT_PL + e1] = y1.l[l];
+                for (int l = 0; l < NL; ++l) {
+                    lds[l * NTT_PL + e0] = y0.l[l];
+                    lds[l * NTT_PL + e1] = y1.l[l];
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-
-    // ---- scatter ------------------------------------------------------------------------------------
-    for (uint32_t t = tid; t < (uint32_t)NTT_TILE; t += NTT_THREADS) {
-        uint32_t uu = t & (C - 1), j = t >> log_c;
-        uint32_t u = tile_u0 + uu;
-        if (u >= n_units) continue;
-        size_t idx = (size_t)u + ((size_t)j << (log_n - K));
-        uint32_t e = j * Cp + uu;
-        Fr v;
+        // ---- LDS -> global: rows j, C consecutive units each -------------------------------------------------
 #pragma unroll
-        for (int l = 0; l < NL; ++l) v.l[l] = lds[l * NTT_PL + e];
-        if (last) {
-            Fr k;
-            if (scale_log_n >= 0) {
+        for (int k = 0; k < NTT_EPT; ++k) {
+            const uint32_t t = tid + k * NTT_THREADS;
+            const uint32_t uu = t & (C - 1), j = t >> log_c;
+            const uint32_t u = tile_u0 + uu;
+            if (u >= n_units) continue;
+            const size_t idx = (size_t)u + ((size_t)j << (log_n - K));
+            const uint32_t e = ntt_lds_pos(j, uu, log_c, K);
+            Fr v;
 #pragma unroll
-                for (int l = 0; l < NL; ++l) k.l[l] = (int32_t)FrParams::NINV[scale_log_n * NL + l];
-            } else {
-                fe_set_one(k);
-            }
-            fe_mul(v, v, k);          // reduce to (-m, 2m) (and scale by n^-1 for the inverse transform)
-            fe_canon(v);
+            for (int l = 0; l < NL; ++l) v.l[l] = lds[l * NTT_PL + e];
             uint32_t w32[8];
-            fe_pack(w32, v);
-            out_wire[2 * idx] = make_uint4(w32[0], w32[1], w32[2], w32[3]);
-            out_wire[2 * idx + 1] = make_uint4(w32[4], w32[5], w32[6], w32[7]);
-        } else {
+            if (last) {
+                Fr kk;
+                if (a.scale_log_n >= 0) {
 #pragma unroll
-            for (int l = 0; l < NL; ++l) out_planes[(size_t)l * N + idx] = v.l[l];
+                    for (int l = 0; l < NL; ++l) kk.l[l] = (int32_t)FrParams::NINV[a.scale_log_n * NL + l];
+                } else {
+                    fe_set_one(kk);
+                }
+                fe_mul(v, v, kk);          // reduce to (-m, 2m) (and scale by n^-1 for the inverse transform)
+                fe_canon(v);
+                fe_pack(w32, v);
+            } else {
+                // the next pass reads x[q' + s' (R' p' + j')] and needs it times w_{n_cur'}^(p' j') = w_N^(p' j' s'): applied here
+                const uint32_t tt = (uint32_t)(idx >> a.next_log_s);
+                const uint32_t jn = tt & ((1u << a.next_K) - 1), pn = tt >> a.next_K;
+                const uint32_t E = (uint32_t)(((unsigned long long)pn * jn) << a.next_log_s) & (N - 1);
+                Fr w;
+                if (next_tw) {             // one coalesced 32-byte read (same access pattern as the data) instead of a two-level lookup + multiply
+                    const uint4 ta = next_tw[2 * idx], tb2 = next_tw[2 * idx + 1];
+                    const uint32_t tw32[8] = {ta.x, ta.y, ta.z, ta.w, tb2.x, tb2.y, tb2.z, tb2.w};
+                    fe_unpack(w, tw32);
+                } else if (E != 0) twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, E);
+                else fe_set_one(w);
+                fe_mul(v, v, w);           // (-m, 2m)
+#pragma unroll
+                for (int l = 0; l < NL; ++l) v.l[l] += (int32_t)FrParams::P[l];      // (0, 3m) < 2^256: a non-negative 256-bit word
+                fe_norm(v);
+                fe_pack(w32, v);
+            }
+            out_words[2 * idx] = make_uint4(w32[0], w32[1], w32[2], w32[3]);
+            out_words[2 * idx + 1] = make_uint4(w32[4], w32[5], w32[6], w32[7]);
         }
+        __syncthreads();                   // the tile's rows are read before the next tile overwrites them
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_ntt_build_pass_twiddles(uint4* __restrict__ tw, int log_n, int next_K, int next_log_s,
+                          const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t N = 1u << log_n;
+    if (idx >= N) return;
+    const uint32_t tt = (uint32_t)(idx >> next_log_s);
+    const uint32_t jn = tt & ((1u << next_K) - 1), pn = tt >> next_K;
+    const uint32_t E = (uint32_t)(((unsigned long long)pn * jn) << next_log_s) & (N - 1);
+    Fr w;
+    if (E != 0) twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, E);
+    else fe_set_one(w);
+    fe_canon(w);
+    uint32_t o[8];
+    fe_pack(o, w);
+    tw[2 * idx] = make_uint4(o[0], o[1], o[2], o[3]);
+    tw[2 * idx + 1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -328,19 +358,25 @@ int32_t ntt_get_tables(kzg_ctx* ctx, int log_n, bool inverse, NttTables* out) {
     return KZG_OK;
 }
 
-struct SepKey { int dev, log_n, inverse, K; bool operator<(const SepKey& o) const { return std::tie(dev, log_n, inverse, K) < std::tie(o.dev, o.log_n, o.inverse, o.K); } };
-static std::map<SepKey, int32_t*> g_sep;
-static int32_t ntt_get_sep(kzg_ctx* ctx, int log_n, bool inverse, int K, const int32_t** out) {
+// HBM capacity spent to remove work (like the MSM window tables): the inter-pass twiddle of every element as one 32-byte word,
+// 32 MiB per pass boundary at 2^20; kept per (device, log n, direction, boundary) for transforms of up to 2^22 elements.
+constexpr int NTT_FULL_TW_MAX_LOG = 22;
+struct PassTwKey { int dev, log_n, inverse, next_K, next_log_s; bool operator<(const PassTwKey& o) const { return std::tie(dev, log_n, inverse, next_K, next_log_s) < std::tie(o.dev, o.log_n, o.inverse, o.next_K, o.next_log_s); } };
+static std::map<PassTwKey, uint4*> g_pass_tw;
+static int32_t ntt_get_pass_twiddles(kzg_ctx* ctx, int log_n, bool inverse, int next_K, int next_log_s, const NttTables& tb, int lo_bits, const uint4** out) {
     std::lock_guard<std::mutex> lk(g_tables_mu);
-    SepKey key{ctx->device, log_n, inverse ? 1 : 0, K};
-    auto it = g_sep.find(key);
-    if (it != g_sep.end()) { *out = it->second; return KZG_OK; }
-    int32_t* p = nullptr;
-    KZG_HIP_TRY(ctx, hipMalloc(&p, (size_t)NTT_TILE * NL * 4));
-    hipLaunchKernelGGL(k_ntt_build_sep, dim3(NTT_TILE / 256), dim3(256), 0, ctx->stream, p, log_n, inverse ? 1 : 0, K);
+    PassTwKey key{ctx->device, log_n, inverse ? 1 : 0, next_K, next_log_s};
+    auto it = g_pass_tw.find(key);
+    if (it != g_pass_tw.end()) { *out = it->second; return KZG_OK; }
+    const size_t n = (size_t)1 << log_n;
+    uint4* p = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * 32);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return KZG_OK; }     // no memory: the kernel looks the twiddles up itself
+    hipLaunchKernelGGL(k_ntt_build_pass_twiddles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, log_n, next_K, next_log_s,
+                       tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // built once; afterwards read from any stream of the device
-    g_sep[key] = p;
+    g_pass_tw[key] = p;
     *out = p;
     return KZG_OK;
 }
@@ -358,39 +394,39 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
     if (rc != KZG_OK) return rc;
     int lo_bits = log_n < NTT_LO_BITS ? log_n : NTT_LO_BITS;
 
-    int P = (log_n + NTT_KMAX - 1) / NTT_KMAX;
-    int base = log_n / P, extra = log_n % P;
-    if (P > 1) {
-        KZG_HIP_TRY(ctx, ws->data.reserve(n * NL * 4));
-        if (P > 2) KZG_HIP_TRY(ctx, ws->tmp.reserve(n * NL * 4));
-    }
-    int32_t* bufs[2] = {ws->data.as<int32_t>(), ws->tmp.as<int32_t>()};
-    int Ks[8];
-    for (int pi = 0; pi < P; ++pi) Ks[pi] = base;
-    {
-        int order[8], no = 0;
-        order[no++] = 0;
-        if (P > 1) order[no++] = P - 1;
-        for (int pi = 1; pi + 1 < P; ++pi) order[no++] = pi;
-        for (int e = 0; e < extra; ++e) Ks[order[e]] += 1;
-    }
-    const int32_t* sep = nullptr;
-    if (P > 1) { rc = ntt_get_sep(ctx, log_n, inverse, Ks[P - 1], &sep); if (rc != KZG_OK) return rc; }
+    const int P = (log_n + NTT_KMAX - 1) / NTT_KMAX;
+    int Ks[4];
+    for (int pi = 0; pi < P; ++pi) Ks[pi] = log_n / P + (pi < log_n % P ? 1 : 0);
+    // buffers: data -> A -> (B ->) data; a single pass works in place (one tile holds the whole transform)
+    if (P > 1) KZG_HIP_TRY(ctx, ws->data.reserve(n * 32));
+    if (P > 2) KZG_HIP_TRY(ctx, ws->tmp.reserve(n * 32));
+    uint4* bufs[2] = {ws->data.as<uint4>(), ws->tmp.as<uint4>()};
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     int log_ncur = 0;
     for (int pi = 0; pi < P; ++pi) {
-        int K = Ks[pi];
-        log_ncur += K;
-        int log_s = log_n - log_ncur;
-        bool first = pi == 0, last = pi == P - 1;
-        const int32_t* in_planes = first ? nullptr : bufs[(pi - 1) & 1];
-        int32_t* out_planes = last ? nullptr : bufs[pi & 1];
-        uint32_t n_units = (uint32_t)(n >> K);
-        uint32_t C = 1u << (NTT_TILE_LOG - K);
-        uint32_t tiles = (n_units + C - 1) / C;
-        hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(NTT_THREADS), 0, st,
-                           reinterpret_cast<const uint4*>(d_data), in_planes, reinterpret_cast<uint4*>(d_data), out_planes,
-                           log_n, K, log_s, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len,
-                           first ? 1 : 0, last ? 1 : 0, (last && inverse) ? log_n : -1, (last && !first) ? sep : nullptr);
+        NttPassArgs a;
+        a.log_n = log_n;
+        a.K = Ks[pi];
+        log_ncur += a.K;
+        a.log_s = log_n - log_ncur;
+        const bool last = pi == P - 1;
+        a.next_K = last ? 0 : Ks[pi + 1];
+        a.next_log_s = last ? 0 : log_n - (log_ncur + Ks[pi + 1]);
+        a.scale_log_n = (last && inverse) ? log_n : -1;
+        const uint32_t n_units = (uint32_t)(n >> a.K);
+        const uint32_t C = 1u << (NTT_TILE_LOG - a.K);
+        a.n_tiles = (n_units + C - 1) / C;
+        const uint4* src = pi == 0 ? reinterpret_cast<const uint4*>(d_data) : bufs[(pi - 1) & 1];
+        uint4* dst = last ? reinterpret_cast<uint4*>(d_data) : bufs[pi & 1];
+        // one workgroup per CU (129 KB of LDS); it walks its tiles with the next one's words prefetched
+        const uint32_t grid = std::min<uint32_t>(a.n_tiles, (uint32_t)cus);
+        const uint4* next_tw = nullptr;
+        if (!last && log_n <= NTT_FULL_TW_MAX_LOG) {
+            rc = ntt_get_pass_twiddles(ctx, log_n, inverse, a.next_K, a.next_log_s, tb, lo_bits, &next_tw);
+            if (rc != KZG_OK) return rc;
+        }
+        hipLaunchKernelGGL(k_ntt_pass, dim3(grid), dim3(NTT_THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
     }
     KZG_HIP_TRY(ctx, hipGetLastError());
     return KZG_OK;

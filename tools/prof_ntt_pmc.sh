@@ -28,7 +28,7 @@ for d in ("sq", "sq2"):
                 agg[(r["Counter_Name"])].append(float(r["Counter_Value"]))
         for c, v in sorted(agg.items()):
             # three passes per transform: report per pass position
-            per = [sum(v[i::3]) / len(v[i::3]) for i in range(3)]
+            per = [sum(v[i::2]) / len(v[i::2]) for i in range(2)] + [0]
             print("%-24s pass1=%.4g pass2=%.4g pass3=%.4g" % (c, per[0], per[1], per[2]))
 for f in glob.glob("$O/kt/**/*kernel_stats.csv", recursive=True):
     for ln in open(f):
