@@ -226,7 +226,8 @@ def main():
         achieved = BYTES_PER_PAIR * units_per_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic_bytes(LOG_N) if world == 1 else (None, "PMC passes are single-GPU")
         plan = {"window_bits": 17, "windows": 15} if sh.len == (1 << 20) else None
-        phase_names = ["digits", "sort_histograms_scan", "scatter", "unused", "accumulate", "bucket_sums_reduce1", "reduce2", "device_total"]
+        # table mode (two-level sort from the scalars): coarse histogram | scan + pass 1 | pass 2; other modes: digits | histogram + scan | scatter
+        phase_names = ["digits_or_coarse_hist", "sort_pass1", "sort_pass2", "unused", "accumulate", "bucket_sums_reduce1", "reduce2", "device_total"]
         out = {
             "metric": "G1-MSM (scalar,point) pairs/s = 2^%d x KZG coeff-form commitments/s, 2^%d-point SRS" % (LOG_N, LOG_N),
             "value": pairs_per_s,

@@ -115,8 +115,8 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         p.sort2 = !p.sort_small && can2 && ((want && entries >= ((size_t)1 << 23)) || !lds_fits);
         if (!p.sort2 && !lds_fits) p.sort_small = true;                    // (slow but correct: a forced odd configuration)
         p.Hb = p.sort2 ? (p.B >> SORT2_LO_BITS) : 0;
-        p.tile1 = 32768;
-        p.tiles1 = (uint32_t)((entries + p.tile1 - 1) / p.tile1);
+        p.tile1 = n >= ((size_t)1 << 19) ? 2048 : 1024;                    // SCALARS per pass-1 tile (W entries each)
+        p.tiles1 = (uint32_t)((n + p.tile1 - 1) / p.tile1);
         p.tiles2cap = (uint32_t)(entries / SORT2_CHUNK + p.Hb + 1);
     }
     p.T = std::min<uint32_t>(p.B, RED_T);
@@ -149,7 +149,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
     if (p.tables && G1 > 1 && 13 * G1p > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
 
-    KZG_HIP_TRY(ctx, ws.digits.reserve(entries * 4));
+    if (!p.sort2) KZG_HIP_TRY(ctx, ws.digits.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.sorted.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.count.reserve((size_t)p.G * 4 + 16));
     if (p.sort2) {
@@ -204,49 +204,55 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     };
 
     KZG_MARK(0);
-    KZG_HIP_TRY(ctx, hipMemsetAsync(ws.count.p, 0, (size_t)p.G * 4, st));
     const uint32_t n_total = p.n * batch;
     const uint32_t gn = (n_total + 255) / 256;
-    hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, n_total, p.n, p.c, p.W, ws.digits.as<uint32_t>());
-    KZG_MARK(1);
     const size_t lds_bytes = (size_t)p.B * 4;
     if (p.sort2) {
+        // two-level sort straight from the scalars (no digit array)
         uint32_t* small = ws.sort_small.as<uint32_t>();
         uint32_t* ccount = small;                       // Hb
         uint32_t* cstart = small + (p.Hb + 1);          // Hb + 1
         uint32_t* tstart = small + 2 * (p.Hb + 1);      // Hb + 1
         uint32_t* tile_bin = small + 3 * (p.Hb + 1);    // tiles2cap
         KZG_HIP_TRY(ctx, hipMemsetAsync(ccount, 0, (size_t)p.Hb * 4, st));
-        hipLaunchKernelGGL(k_sort2_hist1, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.tile1, p.Hb,
-                           ccount, ws.blockbase.as<uint32_t>());
-        hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart, tile_bin);
-        hipLaunchKernelGGL(k_sort2_scatter1, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, ws.digits.as<uint32_t>(), p.n, (uint32_t)entries, p.tile1,
-                           p.Hb, cstart, ws.blockbase.as<uint32_t>(), bases.table_stride, ws.sort_tmp.as<uint32_t>());
+        hipLaunchKernelGGL(k_sort2_scalars<false>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
+                           ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, bases.table_stride, (uint32_t*)nullptr);
+        KZG_MARK(1);
+        hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart, tile_bin, ws.count.as<uint32_t>());
+        hipLaunchKernelGGL(k_sort2_scalars<true>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
+                           ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, bases.table_stride, ws.sort_tmp.as<uint32_t>());
+        KZG_MARK(2);
         hipLaunchKernelGGL(k_sort2_hist2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
                            ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
-        scan_counts();
-        KZG_MARK(2);
+        hipLaunchKernelGGL(k_sort2_bin, dim3(p.Hb), dim3(SORT2_BIN_THREADS), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, p.Hb, ws.count.as<uint32_t>(),
+                           d_offs, ws.sorted.as<uint32_t>());
         hipLaunchKernelGGL(k_sort2_scatter2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
                            d_offs, ws.blockbase.as<uint32_t>(), ws.sorted.as<uint32_t>());
-    } else if (p.sort_small) {
-        const uint32_t ge = (uint32_t)((entries + 255) / 256);
-        KZG_HIP_TRY(ctx, hipMemsetAsync(ws.blockbase.p, 0, (size_t)p.G * 4, st));
-        hipLaunchKernelGGL(k_sort_small_hist, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.set_len, p.B,
-                           ws.count.as<uint32_t>());
-        scan_counts();
-        KZG_MARK(2);
-        hipLaunchKernelGGL(k_sort_small_scatter, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.n, p.set_len, p.B,
-                           d_offs, ws.blockbase.as<uint32_t>(), bases.table_stride, (uint32_t)p.W, ws.sorted.as<uint32_t>());
+        KZG_MARK(3);
     } else {
-        hipLaunchKernelGGL(k_sort_hist, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.set_len, p.tile_len,
-                           p.tiles_per_set, p.B, ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
-        scan_counts();
-        KZG_MARK(2);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.n, p.set_len, p.tile_len,
-                           p.tiles_per_set, p.B, d_offs, ws.blockbase.as<uint32_t>(), bases.table_stride,
-                           (uint32_t)p.W, ws.sorted.as<uint32_t>());
+        KZG_HIP_TRY(ctx, hipMemsetAsync(ws.count.p, 0, (size_t)p.G * 4, st));
+        hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(256), 0, st, d_scalars, n_total, p.n, p.c, p.W, ws.digits.as<uint32_t>());
+        KZG_MARK(1);
+        if (p.sort_small) {
+            const uint32_t ge = (uint32_t)((entries + 255) / 256);
+            KZG_HIP_TRY(ctx, hipMemsetAsync(ws.blockbase.p, 0, (size_t)p.G * 4, st));
+            hipLaunchKernelGGL(k_sort_small_hist, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.set_len, p.B,
+                               ws.count.as<uint32_t>());
+            scan_counts();
+            KZG_MARK(2);
+            hipLaunchKernelGGL(k_sort_small_scatter, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.n, p.set_len, p.B,
+                               d_offs, ws.blockbase.as<uint32_t>(), bases.table_stride, (uint32_t)p.W, ws.sorted.as<uint32_t>());
+        } else {
+            hipLaunchKernelGGL(k_sort_hist, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.set_len, p.tile_len,
+                               p.tiles_per_set, p.B, ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
+            scan_counts();
+            KZG_MARK(2);
+            hipLaunchKernelGGL(k_sort_scatter, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.n, p.set_len, p.tile_len,
+                               p.tiles_per_set, p.B, d_offs, ws.blockbase.as<uint32_t>(), bases.table_stride,
+                               (uint32_t)p.W, ws.sorted.as<uint32_t>());
+        }
+        KZG_MARK(3);
     }
-    KZG_MARK(3);
     KZG_MARK(4);
     // (64- and 128-thread workgroups measured the same as 256)
     hipLaunchKernelGGL(k_msm_accumulate, dim3(p.nl / 256), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.G,

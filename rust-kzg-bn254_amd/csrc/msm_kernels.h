@@ -252,42 +252,76 @@ k_sort_small_scatter(const uint32_t* __restrict__ digits, uint32_t n_entries, ui
 // groups entries by the high key bits (<= 512 bins: every tile writes runs of >= 256 B per bin), pass 2 sorts each
 // bin's entries by the low 7 key bits (runs of ~512 B per bucket): up to 2^16 buckets (c = 17).  Between the passes an
 // entry is one u32: sign << 31 | low key << 24 | point index (< 2^24).
+//   k_sort2_scalars<false>  scalars -> digits -> coarse histogram per tile      k_sort2_scan     bin starts, large-bin tiles
+//   k_sort2_scalars<true>   scalars -> digits -> entries grouped by bin (tmp1)  k_sort2_bin      per bin: fine sort + bucket offsets
+//   k_sort2_hist2 / k_sort2_scatter2: the tiled pass 2 for LARGE bins only (their grids exit at once otherwise)
 constexpr int SORT2_LO_BITS = 7;
 constexpr uint32_t SORT2_LO = 1u << SORT2_LO_BITS;
 constexpr int SORT2_IDX_BITS = 24;
 constexpr uint32_t SORT2_IDX_MASK = (1u << SORT2_IDX_BITS) - 1u;
-constexpr uint32_t SORT2_CHUNK = 16384;         // entries per pass-2 tile
+constexpr uint32_t SORT2_CHUNK = 4096;          // entries per pass-2 tile of a LARGE bin
 constexpr uint32_t SORT2_MAX_BINS = 512;
 
+// Pass 1 works straight from the scalars: a tile is `tile_s` scalars (W entries each), and both kernels recompute the signed
+// digits instead of going through a W*n digit array (round 2 first half: digits kernel + hist1 + scatter1 moved 284 MB for the
+// 2^20 commitment; these two move 127 MB and drop one launch).
+//   SCATTER = false : coarse histogram of the tile -> ccount (global) and the tile's base inside every bin (blockbase1)
+//   SCATTER = true  : entries -> tmp1, grouped by coarse bin
+template <bool SCATTER>
 __global__ void __launch_bounds__(256)
-k_sort2_hist1(const uint32_t* __restrict__ digits, uint32_t E, uint32_t tile_len, uint32_t Hb,
-              uint32_t* __restrict__ ccount, uint32_t* __restrict__ blockbase1) {
+k_sort2_scalars(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32_t tile_s, uint32_t Hb, uint32_t* __restrict__ ccount,
+                uint32_t* __restrict__ blockbase1, const uint32_t* __restrict__ cstart, uint32_t table_stride, uint32_t* __restrict__ tmp1) {
     latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
-    const uint32_t lo = blockIdx.x * tile_len;
-    const uint32_t hi = (E - lo < tile_len) ? E : lo + tile_len;
-    for (uint32_t b = threadIdx.x; b < Hb; b += blockDim.x) lds_u32[b] = 0;
+    const uint32_t lo = blockIdx.x * tile_s;
+    const uint32_t hi = (n - lo < tile_s) ? n : lo + tile_s;
+    for (uint32_t b = threadIdx.x; b < Hb; b += blockDim.x) lds_u32[b] = SCATTER ? cstart[b] + blockbase1[(size_t)blockIdx.x * Hb + b] : 0u;
     __syncthreads();
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-        uint32_t v = digits[e];
-        if (v != DIGIT_NONE) atomicAdd(&lds_u32[(v & 0x7FFFFFFFu) >> SORT2_LO_BITS], 1u);
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint4 s_lo = scalars[2 * (size_t)i], s_hi = scalars[2 * (size_t)i + 1];
+        uint32_t w32[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
+        uint32_t k[8];
+        fe_wire_to_canonical_words<FrParams>(k, w32);
+        uint32_t carry = 0, idx = i;
+        for (int w = 0; w < W; ++w, idx += table_stride) {
+            const uint32_t raw = (k[0] & mask) + carry;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) k[j] = (k[j] >> c) | (k[j + 1] << (32 - c));
+            k[7] >>= c;
+            const uint32_t neg = raw > half;
+            const uint32_t mag = neg ? (1u << c) - raw : raw;
+            carry = neg;
+            if (mag == 0) continue;
+            const uint32_t key = mag - 1;
+            if (SCATTER) {
+                const uint32_t pos = atomicAdd(&lds_u32[key >> SORT2_LO_BITS], 1u);
+                tmp1[pos] = (neg << 31) | ((key & (SORT2_LO - 1)) << SORT2_IDX_BITS) | idx;
+            } else {
+                atomicAdd(&lds_u32[key >> SORT2_LO_BITS], 1u);
+            }
+        }
     }
+    if (SCATTER) return;
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < Hb; b += blockDim.x) {
-        uint32_t h = lds_u32[b];
+        const uint32_t h = lds_u32[b];
         blockbase1[(size_t)blockIdx.x * Hb + b] = h ? atomicAdd(&ccount[b], h) : 0u;
     }
 }
-// single block: cstart[h] = exclusive scan of the coarse counts, tstart[h] = exclusive scan of ceil(count / CHUNK), and the
-// pass-2 tile -> coarse bin map (tile_bin), which used to be a launch of its own
+// single block: cstart[h] = exclusive scan of the coarse counts.  Bins of more than SORT2_BIN_CAP entries (skewed scalars, the
+// short top window) are LARGE: they are cut into tiles of SORT2_CHUNK entries for the tiled pass-2 kernels (tstart = exclusive
+// scan of their tile counts, tile_bin = tile -> bin), and their fine counters are zeroed here; all other bins are sorted by one
+// workgroup each in k_sort2_bin.
+constexpr uint32_t SORT2_BIN_CAP = 65536;
 __global__ void __launch_bounds__(512)
 k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restrict__ cstart, uint32_t* __restrict__ tstart,
-             uint32_t* __restrict__ tile_bin) {
+             uint32_t* __restrict__ tile_bin, uint32_t* __restrict__ count) {
     latency_bound_kernel();
     __shared__ uint32_t a[512], b[512];
     const uint32_t t = threadIdx.x;
     uint32_t c = t < Hb ? ccount[t] : 0u;
-    uint32_t k = (c + SORT2_CHUNK - 1) / SORT2_CHUNK;
+    uint32_t k = c > SORT2_BIN_CAP ? (c + SORT2_CHUNK - 1) / SORT2_CHUNK : 0u;
     a[t] = c; b[t] = k;
     __syncthreads();
     for (uint32_t d = 1; d < 512; d <<= 1) {
@@ -299,28 +333,9 @@ k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restr
     if (t < Hb) {
         cstart[t] = a[t] - c; tstart[t] = b[t] - k;
         for (uint32_t q = b[t] - k; q < b[t]; ++q) tile_bin[q] = t;
+        if (k) for (uint32_t q = 0; q < SORT2_LO; ++q) count[(size_t)t * SORT2_LO + q] = 0u;
     }
     if (t == Hb - 1) { cstart[Hb] = a[t]; tstart[Hb] = b[t]; }
-}
-__global__ void __launch_bounds__(256)
-k_sort2_scatter1(const uint32_t* __restrict__ digits, uint32_t n, uint32_t E, uint32_t tile_len, uint32_t Hb,
-                 const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ blockbase1, uint32_t table_stride,
-                 uint32_t* __restrict__ tmp1) {
-    latency_bound_kernel();
-    extern __shared__ uint32_t lds_u32[];
-    const uint32_t lo = blockIdx.x * tile_len;
-    const uint32_t hi = (E - lo < tile_len) ? E : lo + tile_len;
-    for (uint32_t b = threadIdx.x; b < Hb; b += blockDim.x) lds_u32[b] = cstart[b] + blockbase1[(size_t)blockIdx.x * Hb + b];
-    __syncthreads();
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-        uint32_t v = digits[e];
-        if (v == DIGIT_NONE) continue;
-        uint32_t key = v & 0x7FFFFFFFu;
-        uint32_t pos = atomicAdd(&lds_u32[key >> SORT2_LO_BITS], 1u);
-        uint32_t w = e / n;
-        uint32_t idx = w * table_stride + (e - w * n);
-        tmp1[pos] = (v & 0x80000000u) | ((key & (SORT2_LO - 1)) << SORT2_IDX_BITS) | idx;
-    }
 }
 __global__ void __launch_bounds__(256)
 k_sort2_hist2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
@@ -359,6 +374,82 @@ k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__
         uint32_t v = tmp1[e];
         uint32_t pos = atomicAdd(&cur[(v >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
         sorted[pos] = v & (0x80000000u | SORT2_IDX_MASK);
+    }
+}
+
+// Pass 2 for every bin of at most SORT2_BIN_CAP entries, ONE workgroup per bin: fine histogram (LDS), its scan, the bucket
+// offsets offs[h * 128 + k] (bins are contiguous in tmp1, so no global scan is needed) and the scatter into `sorted`.  It replaced
+// three launches (tiled histogram, global scan of all bucket counts, tiled scatter).  For a LARGE bin the workgroup only turns
+// the fine counts that k_sort2_hist2 gathered into offsets; k_sort2_scatter2 then moves its entries.
+// The scatter goes through LDS: a chunk of SORT2_BIN_CHUNK entries is counting-sorted inside the workgroup first, so that a wave
+// writes runs of consecutive positions (lane-per-entry stores of 4 bytes to 64 different lines ran at 2 TB/s of requests).
+constexpr int SORT2_BIN_THREADS = 1024;
+constexpr int SORT2_BIN_PER = 8;                                        // entries per thread and chunk
+constexpr uint32_t SORT2_BIN_CHUNK = SORT2_BIN_THREADS * SORT2_BIN_PER;
+__global__ void __launch_bounds__(SORT2_BIN_THREADS)
+k_sort2_bin(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, uint32_t Hb, const uint32_t* __restrict__ count,
+            uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+    latency_bound_kernel();
+    __shared__ uint32_t hist[SORT2_LO], gpos[SORT2_LO], lstart[SORT2_LO], buf[SORT2_BIN_CHUNK];
+    const uint32_t h = blockIdx.x, t = threadIdx.x;
+    const uint32_t lo = cstart[h], hi = cstart[h + 1];
+    const bool large = hi - lo > SORT2_BIN_CAP;
+    if (t < SORT2_LO) hist[t] = large ? count[(size_t)h * SORT2_LO + t] : 0u;
+    __syncthreads();
+    if (!large) {
+        uint32_t e = lo + t;
+        for (; e + 3 * SORT2_BIN_THREADS < hi; e += 4 * SORT2_BIN_THREADS) {
+            const uint32_t v0 = tmp1[e], v1 = tmp1[e + SORT2_BIN_THREADS], v2 = tmp1[e + 2 * SORT2_BIN_THREADS], v3 = tmp1[e + 3 * SORT2_BIN_THREADS];
+            atomicAdd(&hist[(v0 >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+            atomicAdd(&hist[(v1 >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+            atomicAdd(&hist[(v2 >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+            atomicAdd(&hist[(v3 >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+        }
+        for (; e < hi; e += SORT2_BIN_THREADS) atomicAdd(&hist[(tmp1[e] >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+        __syncthreads();
+    }
+    // exclusive scan of the SORT2_LO fine counts by wave 0 (two counters per lane)
+    static_assert(SORT2_LO == 128, "two counters per lane of one wave");
+    if (t < 64) {
+        const uint32_t c0 = hist[2 * t], c1 = hist[2 * t + 1];
+        uint32_t incl = c0 + c1;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)t >= d) incl += x; }
+        const uint32_t start = lo + incl - (c0 + c1);
+        gpos[2 * t] = start; gpos[2 * t + 1] = start + c0;
+        offs[(size_t)h * SORT2_LO + 2 * t] = start;
+        offs[(size_t)h * SORT2_LO + 2 * t + 1] = start + c0;
+    }
+    if (h == Hb - 1 && t == 0) offs[(size_t)Hb * SORT2_LO] = cstart[Hb];
+    if (large) return;
+    for (uint32_t base = lo; base < hi; base += SORT2_BIN_CHUNK) {
+        const uint32_t cn = hi - base < SORT2_BIN_CHUNK ? hi - base : SORT2_BIN_CHUNK;
+        __syncthreads();                                           // (gpos of the previous chunk updated, buf free)
+        if (t < SORT2_LO) hist[t] = 0;
+        __syncthreads();
+        uint32_t v[SORT2_BIN_PER], r[SORT2_BIN_PER];
+#pragma unroll
+        for (int j = 0; j < SORT2_BIN_PER; ++j) { const uint32_t i = j * SORT2_BIN_THREADS + t; v[j] = i < cn ? tmp1[base + i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < SORT2_BIN_PER; ++j)
+            if (j * SORT2_BIN_THREADS + t < cn) r[j] = atomicAdd(&hist[(v[j] >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+        __syncthreads();
+        if (t < 64) {
+            const uint32_t c0 = hist[2 * t], c1 = hist[2 * t + 1];
+            uint32_t incl = c0 + c1;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)t >= d) incl += x; }
+            lstart[2 * t] = incl - (c0 + c1); lstart[2 * t + 1] = incl - c1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SORT2_BIN_PER; ++j)
+            if (j * SORT2_BIN_THREADS + t < cn) buf[lstart[(v[j] >> SORT2_IDX_BITS) & (SORT2_LO - 1)] + r[j]] = v[j];
+        __syncthreads();
+        for (uint32_t i = t; i < cn; i += SORT2_BIN_THREADS) {
+            const uint32_t x = buf[i], k = (x >> SORT2_IDX_BITS) & (SORT2_LO - 1);
+            sorted[gpos[k] + (i - lstart[k])] = x & (0x80000000u | SORT2_IDX_MASK);
+        }
+        __syncthreads();
+        if (t < SORT2_LO) gpos[t] += hist[t];
     }
 }
 
