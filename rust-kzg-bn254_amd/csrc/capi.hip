@@ -239,6 +239,7 @@ void kzg_srs_free(kzg_srs* srs) {
     for (auto& kv : srs->lagrange) kzg_srs_free(kv.second);
     srs->lagrange.clear();
     if (srs->d_points) { (void)hipSetDevice(srs->ctx->device); (void)hipFree(srs->d_points); }
+    if (srs->d_small) { (void)hipSetDevice(srs->ctx->device); (void)hipFree(srs->d_small); }
     delete srs;
 }
 
@@ -358,7 +359,7 @@ static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, c
         int32_t rc = stage_scalars(ctx, static_cast<const uint64_t*>(scalars), n, &d_scalars);
         if (rc != KZG_OK) return rc;
     }
-    return msm_run(ctx, srs_bases(srs, offset, ctx->msm_c_override == 0), d_scalars, n, out_xy, out_inf, out_xyzz);
+    return msm_run(ctx, srs_bases(srs, offset, n, ctx->msm_c_override == 0), d_scalars, n, out_xy, out_inf, out_xyzz);
 }
 
 int32_t kzg_msm_g1_srs(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const uint64_t* scalars_mont, size_t n,
@@ -387,7 +388,7 @@ int32_t kzg_msm_g1_srs_device_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t off
     if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return msm_begin(ctx, slot, srs_bases(srs, offset, ctx->msm_c_override == 0), d_scalars_mont, n);
+    return msm_begin(ctx, slot, srs_bases(srs, offset, n, ctx->msm_c_override == 0), d_scalars_mont, n);
 }
 int32_t kzg_msm_g1_srs_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const uint64_t* scalars_mont, size_t n, int32_t slot) {
     if (!ctx || !srs || srs->ctx->device != ctx->device || !scalars_mont || slot < 0 || slot >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
@@ -401,7 +402,7 @@ int32_t kzg_msm_g1_srs_begin(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, co
     MsmWorkspace& ws = ctx->slot_msm(slot);
     KZG_HIP_TRY(ctx, ws.scalars.reserve(n * 32 + 32));
     if (n) KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, st));
-    return msm_begin(ctx, slot, srs_bases(srs, offset, ctx->msm_c_override == 0), ws.scalars.p, n);
+    return msm_begin(ctx, slot, srs_bases(srs, offset, n, ctx->msm_c_override == 0), ws.scalars.p, n);
 }
 int32_t kzg_msm_g1_srs_end(kzg_ctx* ctx, int32_t slot, uint64_t* out_xy_mont, uint8_t* out_is_infinity, uint64_t* out_xyzz_mont) {
     if (!ctx || (!out_xy_mont && !out_xyzz_mont)) return KZG_ERR_INVALID_ARG;
@@ -564,10 +565,10 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
     auto cached = srs->lagrange.find(n);
     if (cached != srs->lagrange.end())                                   // the reference's literal form: MSM over the Lagrange basis (kzg.rs:98-100)
-        return msm_run(ctx, srs_bases(cached->second, 0, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
+        return msm_run(ctx, srs_bases(cached->second, 0, n, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
     int32_t rc = ntt_run(ctx, ctx->poly[0].a.p, n, true);               // coefficients = IFFT(evaluations)
     if (rc != KZG_OK) return rc;
-    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
+    return msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
 }
 
 // ---- multi-GPU forms: this rank's SRS shard holds the powers [shard_lo, shard_lo + len(srs_shard)) -----------------------
@@ -584,7 +585,7 @@ int32_t kzg_commit_eval_form_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, siz
     if (rc != KZG_OK) return rc;
     if (shard_lo >= n) { KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); memset(out_xyzz_mont, 0, 128); return KZG_OK; }
     const size_t len = std::min(srs_shard->n, n - shard_lo);
-    return msm_run(ctx, srs_bases(srs_shard, 0, ctx->msm_c_override == 0), ctx->poly[0].a.as<uint4>() + 2 * shard_lo, len, nullptr, nullptr, out_xyzz_mont);
+    return msm_run(ctx, srs_bases(srs_shard, 0, len, ctx->msm_c_override == 0), ctx->poly[0].a.as<uint4>() + 2 * shard_lo, len, nullptr, nullptr, out_xyzz_mont);
 }
 
 int32_t kzg_compute_proof_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo, const uint64_t* evals_mont, size_t n,
@@ -633,7 +634,7 @@ int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_by
     if (rc != KZG_OK) return rc;
     rc = ntt_run(ctx, d, n, true);                                                   // commit_eval_form: IFFT ...
     if (rc != KZG_OK) return rc;
-    return msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), d, n, out_xy_mont, out_is_infinity, nullptr);   // ... + MSM
+    return msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), d, n, out_xy_mont, out_is_infinity, nullptr);   // ... + MSM
 }
 
 // asynchronous forms of commit_eval_form / commit_blob: the whole chain (H2D, bytes -> Fr, IFFT, MSM) goes onto the slot's stream
@@ -664,7 +665,7 @@ static int32_t commit_begin_common(kzg_ctx* ctx, const kzg_srs* srs, const uint6
     if (n > 1) { rc = ntt_get_tables(ctx, log_n, true, &tb); if (rc != KZG_OK) return rc; }
     rc = ntt_run(ctx, d, n, true, st, &ctx->slot_ntt(slot));
     if (rc != KZG_OK) return rc;
-    return msm_begin(ctx, slot, srs_bases(srs, 0, ctx->msm_c_override == 0), d, n);
+    return msm_begin(ctx, slot, srs_bases(srs, 0, n, ctx->msm_c_override == 0), d, n);
 }
 int32_t kzg_commit_eval_form_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals_mont, size_t n, int32_t slot) {
     if (!ctx || !srs || srs->ctx->device != ctx->device || !evals_mont) return KZG_ERR_INVALID_ARG;
@@ -840,7 +841,7 @@ static int32_t blob_proof_common(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t
         rc = ntt_run(ctx, ctx->msm.scalars.p, n, true);
         if (rc != KZG_OK) return rc;
         uint64_t cxy[8]; uint8_t cinf = 0;
-        rc = msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), ctx->msm.scalars.p, n, cxy, &cinf, nullptr);
+        rc = msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), ctx->msm.scalars.p, n, cxy, &cinf, nullptr);
         if (rc != KZG_OK) return rc;
         commitment = kzg_host::g1_from_wire(cxy);
         if (out_commitment_xy) memcpy(out_commitment_xy, cxy, 64);

@@ -93,6 +93,10 @@ struct kzg_srs {
     size_t n = 0;
     int pre_c = 0;
     int pre_W = 0;
+    // second table set with narrower windows (small_c < pre_c) for MSMs of at most SRS_SMALL_MAX pairs (srs.hip); may be absent
+    uint4* d_small = nullptr;
+    int small_c = 0;
+    int small_W = 0;
     // Lagrange-basis copies of the first m points (KZG::g1_ifft(m), kzg.rs:263-285), built by kzg_srs_cache_lagrange and used by
     // the eval-form commitments of exactly m evaluations instead of IFFT + MSM over the monomial basis; owned by this SRS
     std::map<size_t, kzg_srs*> lagrange;
@@ -109,10 +113,16 @@ struct MsmBases {
     int c = 0;
     int W = 0;
 };
-inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, bool allow_tables) {
+constexpr int SRS_SMALL_C = 15;                       // window bits of the second table set
+constexpr size_t SRS_SMALL_MAX = (size_t)1 << 13;     // MSMs of up to this many pairs use it
+// bases of an MSM of n pairs over srs[offset .. offset + n)
+inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, size_t n, bool allow_tables) {
     MsmBases b;
     b.points = srs->d_points + 4 * offset;
-    if (allow_tables && srs->pre_W > 0) { b.table_stride = (uint32_t)srs->n; b.c = srs->pre_c; b.W = srs->pre_W; }
+    if (allow_tables && srs->pre_W > 0) {
+        b.table_stride = (uint32_t)srs->n; b.c = srs->pre_c; b.W = srs->pre_W;
+        if (srs->d_small && n <= SRS_SMALL_MAX) { b.points = srs->d_small + 4 * offset; b.c = srs->small_c; b.W = srs->small_W; }
+    }
     return b;
 }
 

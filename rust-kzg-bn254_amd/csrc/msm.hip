@@ -111,8 +111,9 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         p.sort_small = entries < ((size_t)1 << 18);
         const bool can2 = p.tables && p.c - 1 > SORT2_LO_BITS && (p.B >> SORT2_LO_BITS) <= SORT2_MAX_BINS &&
                           (size_t)p.W * bases.table_stride <= ((size_t)1 << SORT2_IDX_BITS);
-        // ~0.05 ms of extra launches: pays on large sorts, and is the only LDS sort for 2^16 buckets
-        p.sort2 = !p.sort_small && can2 && ((want && entries >= ((size_t)1 << 23)) || !lds_fits);
+        int min_log = 18;                                                  // (was 2^23: the scalar-tile pass 1 and the per-bin pass 2 win from the first size the single-pass sort is not "small" for)
+        { const char* e2 = getenv("KZG_SORT2_MIN_LOG"); if (e2 && atoi(e2) >= 18 && atoi(e2) <= 30) min_log = atoi(e2); }
+        p.sort2 = !p.sort_small && can2 && ((want && entries >= ((size_t)1 << min_log)) || !lds_fits);
         if (!p.sort2 && !lds_fits) p.sort_small = true;                    // (slow but correct: a forced odd configuration)
         p.Hb = p.sort2 ? (p.B >> SORT2_LO_BITS) : 0;
         p.tile1 = n >= ((size_t)1 << 19) ? 2048 : 1024;                    // SCALARS per pass-1 tile (W entries each)

@@ -406,7 +406,7 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
         return KZG_OK;
     }
     const size_t len = std::min(srs->n, n - coeff_lo);
-    rc = msm_run(ctx, srs_bases(srs, 0, ctx->msm_c_override == 0), set.c.as<uint4>() + 2 * coeff_lo, len, out_xy, out_inf, out_xyzz);
+    rc = msm_run(ctx, srs_bases(srs, 0, len, ctx->msm_c_override == 0), set.c.as<uint4>() + 2 * coeff_lo, len, out_xy, out_inf, out_xyzz);
     if (rc == KZG_OK && out_y) proof_read_y(set, out_y);      // msm_run has synchronised the stream
     return rc;
 }
@@ -420,7 +420,7 @@ int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, siz
     PolySet& set = ctx->poly[slot];
     rc = proof_enqueue(ctx, set, st, &ctx->slot_ntt(slot), evals, n, z, true);
     if (rc != KZG_OK) { (void)hipStreamSynchronize(st); return rc; }
-    return msm_begin(ctx, slot, srs_bases(srs, 0, ctx->msm_c_override == 0), set.c.p, n);
+    return msm_begin(ctx, slot, srs_bases(srs, 0, n, ctx->msm_c_override == 0), set.c.p, n);
 }
 int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y) {
     int32_t rc = msm_end(ctx, slot, out_xy, out_inf, nullptr);

@@ -284,27 +284,52 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
     if (n < 128) return KZG_OK;
     int lg = 0;
     while ((n >> (lg + 1)) != 0) ++lg;
-    // window bits: about log2(n) - 4 keeps the bucket reduction small against the n * ceil(255 / c) additions; at 2^20 points
-    // c = 17 (15 windows, 2^16 buckets) has 6 % fewer additions than c = 16 and the same reduction latency (one wave per SIMD)
-    int c = lg - 4;
-    if (c < 7) c = 7;
-    if (c > 16) c = 16;
-    if (lg == 20) c = 17;
+    // window bits, measured with the equal-split accumulate and the two-level sort (tools/sweep_shard_c.py, tools/time_small.py):
+    // the bucket reduction costs about the same ~0.17 ms for 2^12..2^16 buckets (one wave per 64 buckets, all resident), so the
+    // window count decides: c = 17 (15 windows) from 2^18 points, c = 15 (17 windows) for 2^14..2^17 (2^17 pairs, three in
+    // flight: 0.248 ms at c = 15, 0.284 at c = 17, 0.294 at c = 13), c = 13 below (narrow windows on a small SRS mean few, heavy
+    // buckets, which the reduction sums one after the other: 2^12 points at c = 8 took 2.6 ms, 0.35 ms at c = 13).  Above 2^20
+    // points the 24-bit index of the two-level sort no longer holds W * n, and the single-pass sort needs c <= 16.
+    int c = 13;
+    if (lg >= 14) c = 15;
+    if (lg >= 18) c = 17;
+    if (lg > 20) c = 16;
     const char* envc = getenv("KZG_TABLE_C");
     if (envc && atoi(envc) >= 7 && atoi(envc) <= 17) c = atoi(envc);
-    const int W = (255 + c - 1) / c;
-    const size_t bytes = (size_t)W * n * 64;
-    if (bytes > ((size_t)48 << 30) || (size_t)W * n >= ((size_t)1 << 31)) return KZG_OK;
+    // tables T_w = 2^(cw) * SRS, w < W, as one allocation (table 0 = a copy of the SRS); nullptr when they do not fit
+    auto build = [&](int cw, uint4** out, int* out_W) -> int32_t {
+        *out = nullptr;
+        const int W = (255 + cw - 1) / cw;
+        const size_t bytes = (size_t)W * n * 64;
+        if (bytes > ((size_t)48 << 30) || (size_t)W * n >= ((size_t)1 << 31)) return KZG_OK;
+        uint4* table = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&table), bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return KZG_OK; }      // not enough memory: stay without
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(table, srs->d_points, n * 64, hipMemcpyDeviceToDevice, ctx->stream));
+        for (int w = 1; w < W; ++w) {
+            hipLaunchKernelGGL(k_srs_window_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               table + 4 * (size_t)(w - 1) * n, table + 4 * (size_t)w * n, n, cw);
+        }
+        KZG_HIP_TRY(ctx, hipGetLastError());
+        KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *out = table; *out_W = W;
+        return KZG_OK;
+    };
     uint4* table = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&table), bytes);
-    if (e != hipSuccess) { (void)hipGetLastError(); return KZG_OK; }      // not enough memory: stay in generic mode
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(table, srs->d_points, n * 64, hipMemcpyDeviceToDevice, ctx->stream));
-    for (int w = 1; w < W; ++w) {
-        hipLaunchKernelGGL(k_srs_window_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           table + 4 * (size_t)(w - 1) * n, table + 4 * (size_t)w * n, n, c);
+    int W = 0;
+    { int32_t rc = build(c, &table, &W); if (rc != KZG_OK) return rc; }
+    if (!table) return KZG_OK;                                                // generic mode
+    // A second, narrower table set for SMALL MSMs over this SRS: every launch pays for all 2^(c-1) buckets (scan, empty-bucket
+    // walks, 2^(c-7) reduction waves), which a 2^11..2^13-coefficient commitment does not amortise -- 0.36..0.42 ms on the c = 17
+    // tables of a 2^20-point SRS, 0.27..0.31 ms on c = 15 ones (tools/time_commit_sizes.py).  HBM is plentiful (another 1.06 GiB
+    // at 2^20 points), so both are kept and srs_bases() picks per launch.  KZG_NO_SMALL_TABLES=1: only the main set.
+    const char* env_small = getenv("KZG_NO_SMALL_TABLES");
+    if (c > SRS_SMALL_C && !(env_small && atoi(env_small) != 0)) {
+        uint4* t2 = nullptr; int W2 = 0;
+        int32_t rc = build(SRS_SMALL_C, &t2, &W2);
+        if (rc != KZG_OK) { (void)hipFree(table); return rc; }
+        if (t2) { srs->d_small = t2; srs->small_c = SRS_SMALL_C; srs->small_W = W2; }
     }
-    KZG_HIP_TRY(ctx, hipGetLastError());
-    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     KZG_HIP_TRY(ctx, hipFree(srs->d_points));
     srs->d_points = table;
     srs->pre_c = c;

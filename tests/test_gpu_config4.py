@@ -253,3 +253,30 @@ def test_blob_proof_2_20_known_tau(k, srs, dom):
     assert pyref.fr_from_mont(y) == yi
     assert pyref.point_from_wire(proof) == expect_point(proof_scalar(ftau, yi, zi))
     assert np.array_equal(kz.compute_blob_proof(blob, com, srs), proof)
+
+
+def test_small_and_mid_commitments_on_the_2_20_srs(k, srs):
+    """One loaded 2^20-point SRS carries two window-table sets (srs.hip: c = 17, and c = 15 for MSMs of <= 2^13 pairs): coefficient-form
+    commitments on either side of that limit, and MSMs over an SRS slice that does not start at 0, against p(tau) * G1 by big integers
+    (prover/src/kzg.rs:107-124: the commitment uses the first len(poly) SRS points)."""
+    lib = k._lib.load()
+    ctx = k.default_context()
+    rnd = random.Random(0x5A11)
+    kz = k.KZG.new()
+    for n in (1, 100, 2048, 8192, 8193, 40_000):
+        coeffs = [rnd.randrange(R_) for _ in range(n)]
+        want = 0
+        for cf in reversed(coeffs):
+            want = (want * TAU + cf) % R_
+        got = kz.commit_coeff_form(k.PolynomialCoeffForm(ints_to_mont(coeffs)), srs)
+        assert pyref.point_from_wire(got) == expect_point(want), n
+    for offset, n in ((12_345, 4096), (777_000, 8192), (1_000_000, 20_000)):
+        sc = [rnd.randrange(R_) for _ in range(n)]
+        want, tp = 0, pow(TAU, offset, R_)
+        for s_ in sc:
+            want = (want + s_ * tp) % R_
+            tp = tp * TAU % R_
+        out = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+        wire = ints_to_mont(sc)
+        assert lib.kzg_msm_g1_srs(ctx.handle, srs.handle, offset, k._lib.ptr(wire), n, k._lib.ptr(out), C.byref(inf)) == 0
+        assert pyref.point_from_wire(out) == expect_point(want), (offset, n)

@@ -10,7 +10,7 @@ from rust_kzg_bn254_amd import _lib
 lib = _lib.load(); ctx = k.Context(0)
 tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") %% bench.FR
 out = np.zeros(16, np.uint64)
-for log_n in (17, 18, 19):
+for log_n in [int(x) for x in os.environ.get("SHARD_LOGS", "17,18,19").split(",")]:
     n = 1 << log_n
     srs = k.SRS.generate(tau, n, ctx=ctx)
     d = torch.from_numpy(bench.blob_like_scalars(n, 123).view(np.int64)).cuda(); torch.cuda.synchronize()
@@ -25,11 +25,11 @@ for log_n in (17, 18, 19):
     from rust_kzg_bn254_amd.sharding import ShardedMsm
     sh = ShardedMsm(ctx, n)
     res = []
-    for depth in (2, 4):
+    for depth in (3, 4):
         list(sh.commit_stream(srs, [d.data_ptr()] * 8, depth=depth))
         t0 = time.perf_counter(); list(sh.commit_stream(srs, [d.data_ptr()] * 80, depth=depth)); dt = time.perf_counter() - t0
         res.append(dt / 80 * 1e3)
-    print("c=%%s n=2^%%d pipelined depth2 %%.3f depth4 %%.3f ms/MSM" %% (os.environ.get("KZG_TABLE_C", "auto"), log_n, res[0], res[1]), flush=True)
+    print("c=%%s n=2^%%d pipelined depth3 %%.3f depth4 %%.3f ms/MSM" %% (os.environ.get("KZG_TABLE_C", "auto"), log_n, res[0], res[1]), flush=True)
     srs.close()
 ''' % ROOT
 for c in os.environ.get("SWEEP_C", "auto,11,12,13,14,15,16").split(","):

@@ -11,7 +11,7 @@ from rust_kzg_bn254_amd import _lib
 lib = _lib.load()
 ctxs = [k.Context(0) for _ in range(3)]
 tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % bench.FR
-for log_n in (17, 18, 19, 20):
+for log_n in [int(x) for x in os.environ.get("SHARD_LOGS", "17,18,19,20").split(",")]:
     n = 1 << log_n
     srs = k.SRS.generate(tau, n, ctx=ctxs[0])
     sc = bench.blob_like_scalars(n, 123)

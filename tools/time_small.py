@@ -9,7 +9,7 @@ from rust_kzg_bn254_amd import _lib
 lib = _lib.load(); ctx = k.Context(0)
 tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % bench.FR
 rng = np.random.default_rng(5)
-names = ["digits", "hist+scan", "scatter", "segments", "accumulate", "bucket_fin", "reduce", "device_total"]
+names = ["digits|hist1", "sort1", "sort2", "-", "accumulate", "bucket_sums+bits1", "bits2|reduce", "device_total"]
 for log_n in [int(x) for x in os.environ.get("SMALL_LOGS", "10,12,14,16,18").split(",")]:
     n = 1 << log_n
     uni = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); uni[:, 3] &= np.uint64((1 << 60) - 1)
