@@ -183,6 +183,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     if (!ctx->lds_attr_set) {
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort2_scatter1_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)((3 * SORT2_MAX_BINS + SORT2_P1_THREADS * 31) * 4)));
         ctx->lds_attr_set = true;
     }
 
@@ -220,8 +222,15 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
                            ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, bases.table_stride, (uint32_t*)nullptr);
         KZG_MARK(1);
         hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart, tile_bin, ws.count.as<uint32_t>());
-        hipLaunchKernelGGL(k_sort2_scalars<true>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
-                           ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, bases.table_stride, ws.sort_tmp.as<uint32_t>());
+        static const bool direct_scatter = []() { const char* e = getenv("KZG_SORT2_DIRECT"); return e && atoi(e) != 0; }();   // A/B: pass 1 without the LDS staging
+        if (direct_scatter || p.W > 31) {
+            hipLaunchKernelGGL(k_sort2_scalars<true>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
+                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, bases.table_stride, ws.sort_tmp.as<uint32_t>());
+        } else {
+            const size_t lds1 = ((size_t)3 * p.Hb + (size_t)SORT2_P1_THREADS * p.W) * 4;
+            hipLaunchKernelGGL(k_sort2_scatter1_lds, dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb,
+                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, bases.table_stride, ws.sort_tmp.as<uint32_t>());
+        }
         KZG_MARK(2);
         hipLaunchKernelGGL(k_sort2_hist2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
                            ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());

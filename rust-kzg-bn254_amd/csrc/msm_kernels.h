@@ -329,6 +329,92 @@ k_sort2_scalars(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uin
         blockbase1[(size_t)blockIdx.x * Hb + b] = h ? atomicAdd(&ccount[b], h) : 0u;
     }
 }
+// Pass-1 scatter through LDS: the tile is walked in chunks of SORT2_P1_THREADS scalars (one per thread); a chunk's entries are
+// counted per bin, placed bin by bin in an LDS buffer and written out from there, so that the lanes of a wave store runs of
+// consecutive words (~15 entries per bin and chunk) instead of 64 single words to 64 different lines.  The digits are computed
+// twice (count, place) rather than kept: W values per thread would not stay in registers.
+// LDS entry: bin << 22 | low key << 15 | sign << 14 | window << 9 | scalar index inside the chunk.
+constexpr int SORT2_P1_THREADS = 512;
+static_assert(SORT2_MAX_BINS <= 512 && SORT2_LO_BITS == 7, "LDS entry layout of k_sort2_scatter1_lds");
+template <class F>
+__device__ __forceinline__ void sort2_for_digits(uint32_t k[8], int c, int W, F&& f) {
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) {
+        const uint32_t raw = (k[0] & mask) + carry;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) k[j] = (k[j] >> c) | (k[j + 1] << (32 - c));
+        k[7] >>= c;
+        const uint32_t neg = raw > half;
+        const uint32_t mag = neg ? (1u << c) - raw : raw;
+        carry = neg;
+        if (mag != 0) f((uint32_t)w, mag - 1, neg);
+    }
+}
+__global__ void __launch_bounds__(SORT2_P1_THREADS)
+k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32_t tile_s, uint32_t Hb, const uint32_t* __restrict__ blockbase1,
+                     const uint32_t* __restrict__ cstart, uint32_t table_stride, uint32_t* __restrict__ tmp1) {
+    latency_bound_kernel();
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* gpos = lds_u32;                 // Hb: next global position of the tile in every bin
+    uint32_t* hist = gpos + Hb;               // Hb: entries of the chunk per bin, then the placement cursor
+    uint32_t* lstart = hist + Hb;             // Hb: first buffer slot of every bin
+    uint32_t* buf = lstart + Hb;              // SORT2_P1_THREADS * W
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint32_t lo = blockIdx.x * tile_s;
+    const uint32_t hi = (n - lo < tile_s) ? n : lo + tile_s;
+    for (uint32_t b = t; b < Hb; b += SORT2_P1_THREADS) gpos[b] = cstart[b] + blockbase1[(size_t)blockIdx.x * Hb + b];
+    const uint32_t per_lane = (Hb + 63) / 64;           // bins per lane of wave 0 in the scan (<= 8)
+    for (uint32_t base = lo; base < hi; base += SORT2_P1_THREADS) {
+        __syncthreads();                                 // gpos ready / updated, buf and hist free
+        for (uint32_t b = t; b < Hb; b += SORT2_P1_THREADS) hist[b] = 0;
+        __syncthreads();
+        const uint32_t i = base + t;
+        const bool have = i < hi;
+        uint32_t kk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (have) {
+            const uint4 s_lo = scalars[2 * (size_t)i], s_hi = scalars[2 * (size_t)i + 1];
+            const uint32_t w32[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
+            fe_wire_to_canonical_words<FrParams>(kk, w32);
+            uint32_t k[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) k[j] = kk[j];
+            sort2_for_digits(k, c, W, [&](uint32_t, uint32_t key, uint32_t) { atomicAdd(&hist[key >> SORT2_LO_BITS], 1u); });
+        }
+        __syncthreads();
+        if (t < 64) {                                    // exclusive scan of the Hb counts: per_lane consecutive bins per lane
+            uint32_t sum = 0;
+            for (uint32_t q = 0; q < per_lane; ++q) { const uint32_t b = lane * per_lane + q; if (b < Hb) sum += hist[b]; }
+            uint32_t incl = sum;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += x; }
+            uint32_t run = incl - sum;
+            for (uint32_t q = 0; q < per_lane; ++q) {
+                const uint32_t b = lane * per_lane + q;
+                if (b < Hb) { lstart[b] = run; run += hist[b]; }
+            }
+        }
+        __syncthreads();
+        const uint32_t cn = lstart[Hb - 1] + hist[Hb - 1];   // entries of this chunk
+        __syncthreads();                                 // (everyone has read hist before it becomes the cursor)
+        for (uint32_t b = t; b < Hb; b += SORT2_P1_THREADS) hist[b] = 0;
+        __syncthreads();
+        if (have) {
+            sort2_for_digits(kk, c, W, [&](uint32_t w, uint32_t key, uint32_t neg) {
+                const uint32_t bin = key >> SORT2_LO_BITS;
+                const uint32_t slot = lstart[bin] + atomicAdd(&hist[bin], 1u);
+                buf[slot] = (bin << 22) | ((key & (SORT2_LO - 1)) << 15) | (neg << 14) | (w << 9) | t;
+            });
+        }
+        __syncthreads();
+        for (uint32_t q = t; q < cn; q += SORT2_P1_THREADS) {
+            const uint32_t x = buf[q], bin = x >> 22;
+            const uint32_t idx = ((x >> 9) & 31u) * table_stride + base + (x & 511u);
+            tmp1[gpos[bin] + (q - lstart[bin])] = ((x >> 14) & 1u) << 31 | ((x >> 15) & (SORT2_LO - 1)) << SORT2_IDX_BITS | idx;
+        }
+        __syncthreads();
+        for (uint32_t b = t; b < Hb; b += SORT2_P1_THREADS) gpos[b] += hist[b];
+    }
+}
 // single block: cstart[h] = exclusive scan of the coarse counts.  Bins of more than SORT2_BIN_CAP entries (skewed scalars, the
 // short top window) are LARGE: they are cut into tiles of SORT2_CHUNK entries for the tiled pass-2 kernels (tstart = exclusive
 // scan of their tile counts, tile_bin = tile -> bin), and their fine counters are zeroed here; all other bins are sorted by one
