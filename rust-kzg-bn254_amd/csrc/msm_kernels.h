@@ -3,9 +3,10 @@
 // that backs `G1Projective::msm` at prover/src/kzg.rs:100,121 and primitives/src/helpers.rs:332.
 //
 // Pipeline (Pippenger, signed c-bit windows, sort-by-bucket):
-//   k_msm_digits      scalars (wire) -> canonical integer -> W signed digits; bucket histogram
+//   k_msm_digits      scalars (wire) -> canonical integer -> W signed digits     (generic mode and small MSMs)
 //   k_scan_*          exclusive scan of the bucket counts                        (one single-workgroup kernel)
-//   k_sort*           entries (point index | sign) grouped by bucket             (counting sort, one or two levels)
+//   k_sort*           entries (point index | sign) grouped by bucket             (counting sort; the two-level k_sort2_* path of
+//                     table mode works straight from the scalars and produces the bucket offsets itself)
 //   k_msm_accumulate  equal split of the sorted entries over the lanes: XYZZ mixed adds of 64-byte affine points
 //   k_msm_bucket_*    lane partials -> bucket sums (fused with the first reduction level in table mode)
 //   k_red_*           sum_k (k+1) * B_k: zeta transform over shuffles (table mode) / chunked running sums (generic mode)
