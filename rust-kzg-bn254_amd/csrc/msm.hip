@@ -49,6 +49,9 @@ struct Plan {
     bool sort_small;     // global-atomic sort (few entries)
     uint32_t Hb, tile1, tiles1, tiles2cap;
     uint32_t T, m;       // generic-mode reduction: chunks per window, buckets per chunk
+    // table mode: a sorted entry holds window * idx_stride + i.  idx_stride = the table stride, or (compact form, SRS of more than
+    // 2^20 points) the next power of two >= n, 2^idx_log, with the accumulate kernel adding window * stride_adj
+    uint32_t idx_stride, idx_log, stride_adj;
 };
 
 // Window bits of the generic mode for `batch` MSMs of n pairs: W * batch window sums leave the device (<= MSM_MAX_OUT).
@@ -96,6 +99,14 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         p.nl = (uint32_t)std::min<size_t>(lanes, (size_t)1 << 24);
     }
     p.set_len = (uint32_t)(p.tables ? entries : n);
+    p.idx_stride = bases.table_stride; p.idx_log = 31; p.stride_adj = 0;
+    if (p.tables && (size_t)p.W * bases.table_stride > ((size_t)1 << SORT2_IDX_BITS)) {
+        int lg = ilog2_floor(n);
+        if (((size_t)1 << lg) < n) ++lg;
+        if (((size_t)p.W << lg) <= ((size_t)1 << SORT2_IDX_BITS) && ((size_t)1 << lg) <= bases.table_stride) {
+            p.idx_log = (uint32_t)lg; p.idx_stride = 1u << lg; p.stride_adj = bases.table_stride - p.idx_stride;
+        }
+    }
     // single-pass sort tiles: large against the bucket count (one contiguous flush of B counters per tile), and not too many
     size_t mult = 2;
     { const char* env = getenv("KZG_SORT_TILE_MULT"); if (env && atoi(env) > 0) mult = (size_t)atoi(env); }
@@ -110,7 +121,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         const bool lds_fits = (size_t)p.B * 4 <= SORT1_MAX_LDS;            // single-pass sort: one LDS counter per bucket
         p.sort_small = entries < ((size_t)1 << 18);
         const bool can2 = p.tables && p.c - 1 > SORT2_LO_BITS && (p.B >> SORT2_LO_BITS) <= SORT2_MAX_BINS &&
-                          (size_t)p.W * bases.table_stride <= ((size_t)1 << SORT2_IDX_BITS);
+                          (size_t)p.W * p.idx_stride <= ((size_t)1 << SORT2_IDX_BITS);
         int min_log = 18;                                                  // (was 2^23: the scalar-tile pass 1 and the per-bin pass 2 win from the first size the single-pass sort is not "small" for)
         { const char* e2 = getenv("KZG_SORT2_MIN_LOG"); if (e2 && atoi(e2) >= 18 && atoi(e2) <= 30) min_log = atoi(e2); }
         p.sort2 = !p.sort_small && can2 && ((want && entries >= ((size_t)1 << min_log)) || !lds_fits);
@@ -134,11 +145,21 @@ struct Pending {
     uint32_t n_out = 0;
     uint32_t batch = 1;
     size_t n = 0;
+    uint32_t out_off = 0;    // first point of this launch's results in the pinned result buffer
+    bool profiled = true;    // the workspace's phase events belong to this launch (the last one enqueued)
+};
+// One asynchronous MSM = up to MSM_MAX_PARTS launches back to back on the slot's stream, sharing its workspace (stream order keeps
+// them apart); each copies its O(200) result points to its own MSM_PART_OUT-point window of the pinned buffer.
+constexpr uint32_t MSM_MAX_PARTS = 16;
+constexpr uint32_t MSM_PART_OUT = MSM_MAX_OUT / MSM_MAX_PARTS;
+struct MsmPending {
+    Pending part[MSM_MAX_PARTS];
+    uint32_t n_parts = 0;
 };
 
 // Enqueue every kernel of one MSM (or batch) plus the D2H copy of its O(100) result points on `st`, using `ws`.
 static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
-                           uint32_t batch, Pending* pend) {
+                           uint32_t batch, Pending* pend, uint32_t out_off = 0) {
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
     const Plan p = make_plan(ctx, n, bases, batch);
     const size_t entries = (size_t)p.W * n * batch;
@@ -219,17 +240,17 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         uint32_t* tile_bin = small + 3 * (p.Hb + 1);    // tiles2cap
         KZG_HIP_TRY(ctx, hipMemsetAsync(ccount, 0, (size_t)p.Hb * 4, st));
         hipLaunchKernelGGL(k_sort2_scalars<false>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
-                           ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, bases.table_stride, (uint32_t*)nullptr);
+                           ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, p.idx_stride, (uint32_t*)nullptr);
         KZG_MARK(1);
         hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart, tile_bin, ws.count.as<uint32_t>());
         static const bool direct_scatter = []() { const char* e = getenv("KZG_SORT2_DIRECT"); return e && atoi(e) != 0; }();   // A/B: pass 1 without the LDS staging
         if (direct_scatter || p.W > 31) {
             hipLaunchKernelGGL(k_sort2_scalars<true>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
-                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, bases.table_stride, ws.sort_tmp.as<uint32_t>());
+                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>());
         } else {
             const size_t lds1 = ((size_t)3 * p.Hb + (size_t)SORT2_P1_THREADS * p.W) * 4;
             hipLaunchKernelGGL(k_sort2_scatter1_lds, dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb,
-                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, bases.table_stride, ws.sort_tmp.as<uint32_t>());
+                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>());
         }
         KZG_MARK(2);
         hipLaunchKernelGGL(k_sort2_hist2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
@@ -251,14 +272,14 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
             scan_counts();
             KZG_MARK(2);
             hipLaunchKernelGGL(k_sort_small_scatter, dim3(ge), dim3(256), 0, st, ws.digits.as<uint32_t>(), (uint32_t)entries, p.n, p.set_len, p.B,
-                               d_offs, ws.blockbase.as<uint32_t>(), bases.table_stride, (uint32_t)p.W, ws.sorted.as<uint32_t>());
+                               d_offs, ws.blockbase.as<uint32_t>(), p.idx_stride, (uint32_t)p.W, ws.sorted.as<uint32_t>());
         } else {
             hipLaunchKernelGGL(k_sort_hist, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.set_len, p.tile_len,
                                p.tiles_per_set, p.B, ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
             scan_counts();
             KZG_MARK(2);
             hipLaunchKernelGGL(k_sort_scatter, dim3(p.tiles), dim3(256), lds_bytes, st, ws.digits.as<uint32_t>(), p.n, p.set_len, p.tile_len,
-                               p.tiles_per_set, p.B, d_offs, ws.blockbase.as<uint32_t>(), bases.table_stride,
+                               p.tiles_per_set, p.B, d_offs, ws.blockbase.as<uint32_t>(), p.idx_stride,
                                (uint32_t)p.W, ws.sorted.as<uint32_t>());
         }
         KZG_MARK(3);
@@ -266,7 +287,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     KZG_MARK(4);
     // (64- and 128-thread workgroups measured the same as 256)
     hipLaunchKernelGGL(k_msm_accumulate, dim3(p.nl / 256), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.G,
-                       ws.head.as<int32_t>(), (size_t)p.G, ws.cont.as<int32_t>(), (size_t)p.nl);
+                       ws.head.as<int32_t>(), (size_t)p.G, ws.cont.as<int32_t>(), (size_t)p.nl, p.idx_log, p.stride_adj);
     KZG_MARK(5);
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
@@ -299,7 +320,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     }
     KZG_MARK(7);
     KZG_HIP_TRY(ctx, hipGetLastError());
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.pinned_out, ws.out_wire.p, (size_t)n_out * 128, hipMemcpyDeviceToHost, st));
+    if (out_off + n_out > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ws.pinned_out) + (size_t)out_off * 128, ws.out_wire.p, (size_t)n_out * 128, hipMemcpyDeviceToHost, st));
     if (!ws.ev_done) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
     KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_done, st));        // msm_finish waits for THIS launch, not for the stream: a later MSM may already be queued behind it
 #undef KZG_MARK
@@ -307,6 +329,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     pend->n_out = n_out;
     pend->batch = batch;
     pend->n = n;
+    pend->out_off = out_off;
+    pend->profiled = true;
     return KZG_OK;
 }
 
@@ -316,7 +340,7 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
     (void)st;
     KZG_HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
-    if (ctx->profiling && ws.ev_ready) {
+    if (ctx->profiling && ws.ev_ready && pend.profiled) {
         for (int i = 0; i < 7; ++i) {
             float ms = 0;
             KZG_HIP_TRY(ctx, hipEventElapsedTime(&ms, ws.ev[i], ws.ev[i + 1]));
@@ -334,7 +358,7 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     static thread_local std::vector<Xyzz> vals_store;
     if (vals_store.size() < n_out) vals_store.resize(n_out);
     Xyzz* vals = vals_store.data();
-    const uint64_t* w = reinterpret_cast<const uint64_t*>(ws.pinned_out);
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(ws.pinned_out) + 16 * (size_t)pend.out_off;
     for (uint32_t i = 0; i < n_out; ++i) memcpy(&vals[i], w + 16 * i, 128);
     if (!p.tables) {
         for (uint32_t b = 0; b < batch; ++b)
@@ -374,7 +398,43 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
 }
 
 // ---- two-slot asynchronous form: begin enqueues, end waits and runs the host epilogue ---------------------------------
-struct MsmPending : Pending {};
+// Pairs per launch of an MSM over `bases`.  Tables more than 2^24 / W points apart (an SRS beyond 2^20 points at c = 17) are walked
+// in power-of-two chunks whose COMPACT indices fit the two-level sort (make_plan): a 2^22-point commitment is four 2^20 launches.
+static size_t msm_launch_len(const MsmBases& bases) {
+    if (bases.table_stride != 0 && (size_t)bases.W * bases.table_stride > ((size_t)1 << SORT2_IDX_BITS)) {
+        size_t cpow = 1;
+        while (((size_t)bases.W * cpow * 2) <= ((size_t)1 << SORT2_IDX_BITS)) cpow *= 2;
+        if (cpow >= ((size_t)1 << 16)) return cpow;
+    }
+    return MSM_MAX_LAUNCH;
+}
+// all launches of one MSM of n <= MSM_MAX_LAUNCH pairs on `st` / `ws`
+static int32_t msm_enqueue_parts(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
+                                 MsmPending* mp) {
+    const size_t chunk = msm_launch_len(bases);
+    const size_t parts = (n + chunk - 1) / chunk;
+    if (parts > MSM_MAX_PARTS) return KZG_ERR_TOO_LARGE;
+    mp->n_parts = 0;
+    for (size_t k = 0, off = 0; off < n; off += chunk, ++k) {
+        MsmBases b = bases;
+        b.points = bases.points + 4 * off;
+        int32_t rc = msm_enqueue(ctx, ws, st, b, d_scalars + 2 * off, std::min(chunk, n - off), 1, &mp->part[k], parts > 1 ? (uint32_t)k * MSM_PART_OUT : 0u);
+        if (rc != KZG_OK) { if (k) (void)hipStreamSynchronize(st); return rc; }
+        if (k) mp->part[k - 1].profiled = false;
+        mp->n_parts = (uint32_t)k + 1;
+    }
+    return KZG_OK;
+}
+static int32_t msm_finish_parts(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmPending& mp, kzg_host::Xyzz* total) {
+    *total = kzg_host::xyzz_inf();
+    for (uint32_t k = 0; k < mp.n_parts; ++k) {
+        kzg_host::Xyzz part;
+        int32_t rc = msm_finish(ctx, ws, st, mp.part[k], &part);
+        if (rc != KZG_OK) return rc;
+        *total = k ? kzg_host::xyzz_add(*total, part) : part;
+    }
+    return KZG_OK;
+}
 
 int32_t msm_slot_stream(kzg_ctx* ctx, int slot, hipStream_t* out) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
@@ -396,8 +456,7 @@ int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_s
     { int32_t rc0 = msm_slot_stream(ctx, slot, &st); if (rc0 != KZG_OK) return rc0; }
     MsmPending* pend = new (std::nothrow) MsmPending();
     if (!pend) return KZG_ERR_DEVICE;
-    int32_t rc = msm_enqueue(ctx, ctx->slot_msm(slot), st, bases,
-                             reinterpret_cast<const uint4*>(d_scalars), n, 1, pend);
+    int32_t rc = msm_enqueue_parts(ctx, ctx->slot_msm(slot), st, bases, reinterpret_cast<const uint4*>(d_scalars), n, pend);
     if (rc != KZG_OK) { delete pend; return rc; }
     ctx->slot_pending[slot] = pend;
     return KZG_OK;
@@ -410,7 +469,7 @@ int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, ui
     kzg_host::Xyzz total;
     hipStream_t st = nullptr;
     (void)msm_slot_stream(ctx, slot, &st);
-    int32_t rc = msm_finish(ctx, ctx->slot_msm(slot), st, *pend, &total);
+    int32_t rc = msm_finish_parts(ctx, ctx->slot_msm(slot), st, *pend, &total);
     delete pend;
     if (rc != KZG_OK) return rc;
     if (out_xyzz) memcpy(out_xyzz, &total, 128);
@@ -451,16 +510,16 @@ int32_t msm_run(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size
     }
     kzg_host::Xyzz total = kzg_host::xyzz_inf();
     const uint4* sc = reinterpret_cast<const uint4*>(d_scalars);
+    static thread_local MsmPending mp;
     for (size_t off = 0; off < n; off += MSM_MAX_LAUNCH) {
-        size_t len = std::min(MSM_MAX_LAUNCH, n - off);
-        kzg_host::Xyzz part;
+        const size_t len = std::min(MSM_MAX_LAUNCH, n - off);
         MsmBases b = bases;
         b.points = bases.points + 4 * off;
-        Pending pend;
-        int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, b, sc + 2 * off, len, 1, &pend);
-        if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, &part);
+        kzg_host::Xyzz part;
+        int32_t rc = msm_enqueue_parts(ctx, ctx->msm, ctx->stream, b, sc + 2 * off, len, &mp);
+        if (rc == KZG_OK) rc = msm_finish_parts(ctx, ctx->msm, ctx->stream, mp, &part);
         if (rc != KZG_OK) return rc;
-        total = kzg_host::xyzz_add(total, part);
+        total = off ? kzg_host::xyzz_add(total, part) : part;
     }
     if (out_xyzz) memcpy(out_xyzz, &total, 128);
     if (out_xy) kzg_host::xyzz_to_affine(total, out_xy, out_inf);

@@ -596,12 +596,19 @@ __device__ __forceinline__ uint32_t acc_seg_len(uint32_t E, uint32_t nl) { retur
 #else
 #define KZG_ACC_IDX(v) ((v) & 0x7FFFFFFFu)
 #endif
+// A sorted entry holds window * 2^idx_log + i (COMPACT index: SRS of more than 2^20 points, whose tables are table_stride >
+// 2^idx_log points apart and would not fit the 24 index bits of the two-level sort): the point is at entry + window * stride_adj.
+// Plain indices come with idx_log = 31 (window part = 0).
+__device__ __forceinline__ size_t acc_point_index(uint32_t ix, uint32_t idx_log, uint32_t stride_adj) {
+    return (size_t)ix + (size_t)(ix >> idx_log) * stride_adj;
+}
 #ifndef KZG_ACC_WAVES
 #define KZG_ACC_WAVES 3        // waves per SIMD (<= 168 VGPRs); 4 (128 VGPRs, more spills) measured equal in round 1
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KZG_ACC_WAVES, KZG_ACC_WAVES)))
 k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs, uint32_t G,
-                 int32_t* __restrict__ head, size_t head_stride, int32_t* __restrict__ cont, size_t cont_stride) {
+                 int32_t* __restrict__ head, size_t head_stride, int32_t* __restrict__ cont, size_t cont_stride,
+                 uint32_t idx_log, uint32_t stride_adj) {
     const uint32_t nl = gridDim.x * blockDim.x;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
@@ -670,7 +677,7 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
         const uint32_t last = end - 1;
         uint32_t v = sorted[begin];
         uint32_t v1 = sorted[begin + 1 < end ? begin + 1 : last];
-        const uint4* src = points + 4 * (size_t)(KZG_ACC_IDX(v));
+        const uint4* src = points + 4 * acc_point_index(KZG_ACC_IDX(v), idx_log, stride_adj);
         uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
         for (uint32_t e = begin; e < end; ++e) {
 #ifdef KZG_ACC_STAMPS
@@ -696,7 +703,7 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
             fe_unpack(p.x, wx);
             fe_unpack(p.y, wy);
             v = v1;                                    // entry e + 1 (the last iteration re-reads entry `last`: unused)
-            src = points + 4 * (size_t)(KZG_ACC_IDX(v));
+            src = points + 4 * acc_point_index(KZG_ACC_IDX(v), idx_log, stride_adj);
             q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
             v1 = sorted[e + 2 < end ? e + 2 : last];
             if (any == 0) continue;                                                       // identity base

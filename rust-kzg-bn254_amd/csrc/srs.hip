@@ -289,11 +289,11 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
     // window count decides: c = 17 (15 windows) from 2^18 points, c = 15 (17 windows) for 2^14..2^17 (2^17 pairs, three in
     // flight: 0.248 ms at c = 15, 0.284 at c = 17, 0.294 at c = 13), c = 13 below (narrow windows on a small SRS mean few, heavy
     // buckets, which the reduction sums one after the other: 2^12 points at c = 8 took 2.6 ms, 0.35 ms at c = 13).  Above 2^20
-    // points the 24-bit index of the two-level sort no longer holds W * n, and the single-pass sort needs c <= 16.
+    // points the 24-bit index of the two-level sort no longer holds W * n: those MSMs run as chunks of 2^20 pairs with compact
+    // indices (msm.hip msm_run).
     int c = 13;
     if (lg >= 14) c = 15;
     if (lg >= 18) c = 17;
-    if (lg > 20) c = 16;
     const char* envc = getenv("KZG_TABLE_C");
     if (envc && atoi(envc) >= 7 && atoi(envc) <= 17) c = atoi(envc);
     // tables T_w = 2^(cw) * SRS, w < W, as one allocation (table 0 = a copy of the SRS); nullptr when they do not fit
