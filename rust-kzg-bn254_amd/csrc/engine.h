@@ -73,6 +73,7 @@ struct kzg_ctx {
     int msm_seg_override = 0;
     bool profiling = false;
     bool lds_attr_set = false;
+    bool poly_lds_attr_set = false;
     uint32_t acc_wave_slots = 3 * 1024;   // resident waves of the accumulate kernel on this device: 3 per SIMD x 4 SIMDs x CUs (set at kzg_ctx_create)
     kzg::MsmWorkspace msm;
     kzg::MsmWorkspace msm_x[KZG_NUM_SLOTS - 1];   // workspaces of slots 1.. of the asynchronous calls

@@ -3,9 +3,15 @@
 //   q_i = (f_i - y) / (w^i - z)   kzg.rs:151-174
 //   q_m = sum_{i != m} (f_i - y) w^i / (z (z - w^i))   when z = w^m, kzg.rs:237-260
 // then the quotient is committed as MSM(srs, IFFT(q)) (see kzg_commit_eval_form).
-// The reference performs one field inversion per division (2n-3n serial inversions); here all
-// denominators w^i - z share one batch inversion (Montgomery's trick: per-lane prefix products, one
-// Fermat inversion per lane, back-substitution).  Results are identical field elements.
+// The reference performs one field inversion per division (2n-3n serial inversions); here all denominators w^i - z
+// share ONE inversion, done on the host: the domain is a group, so the product of the denominators over a coset
+// {j + k n/m : k < m} is known in closed form,
+//     prod_k (w^(j + k n/m) - z) = (-1)^(m+1) (W^j - z^m),   W = w^m  (the m-th roots of W^j are exactly those w^..),
+// i.e. it is again a denominator of the SAME problem on the m-times smaller domain at the point z^m.  Montgomery's trick needs
+// the inverse of each group's product: that is the smaller problem's answer.  The recursion ends at 1 / (1 - z^n), which the
+// host computes while it enqueues (one 254-bit exponentiation, ~15 us); the device only multiplies: ~3 products per element
+// and level.  (Round 1 / first half of round 2: one Fermat inversion per lane, 381 dependent multiplies = 213 us on the
+// critical path of every proof, whatever n.)  Results are identical field elements.
 // Also: helpers::calculate_roots_of_unity (helpers.rs:553-589) as a kernel.
 #include "engine.h"
 #include "field29.h"
@@ -13,6 +19,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace kzg {
 
@@ -94,54 +101,195 @@ struct ProofScalars {        // device-resident small state of one proof computa
     uint32_t y_wire[8];
 };
 
-// ---- K1: denominators, batch inversion, barycentric partial sums -------------------------------------
-// lane t owns elements i = k * T + t.  inv[i] = 1 / (w^i - z)  (1 for the on-domain index).
+// ---- K0: the inverses 1 / (W^j - Z) on a small domain, one workgroup ----------------------------------------------
+// out[j] = 1 / (w^(j e) - z^e), j < N = 2^log_ns <= 4096, e = n / N; zt[a] = z^(2^a) (wire), zt[log_n + 1] = 1 / (1 - z^n).
+// Level by level from the single value 1 / (1 - z^n), size s -> 2 s, in place in LDS: lane t < s owns the pair {t, t + s} of the
+// 2s-point domain, whose elements are +-W^t:  d0 = W^t - Z, d1 = -W^t - Z, d0 d1 = -(W^2t - Z^2), so with g = the value of the
+// coarser level  1/d0 = -g d1,  1/d1 = -g d0: two independent multiplies per level and lane, log2 N levels.
+// A zero denominator (z on the domain) gets the inverse 1, as the callers expect, and its partner is inverted by Fermat; the
+// value that lane read from the coarser level was never valid and is not used.
+constexpr int POLY_SMALL_THREADS = 1024;
+constexpr uint32_t POLY_SMALL_MAX_LOG = 12;
+constexpr uint32_t POLY_SMALL_MAX = 1u << POLY_SMALL_MAX_LOG;
+__global__ void __launch_bounds__(POLY_SMALL_THREADS)
+k_poly_inv_small(const uint4* __restrict__ zt, int log_n, int log_ns, NttTables tb, int32_t* __restrict__ out /* planes, stride 2^log_ns */) {
+    extern __shared__ int32_t lds_inv[];                      // NL planes of 2^log_ns
+    __shared__ int32_t zl[(POLY_SMALL_MAX_LOG + 1) * NL];     // canonical z^(2^log_e) of every level
+    const uint32_t t0 = threadIdx.x, N = 1u << log_ns;
+    if (t0 == 0) {
+        Fr top;
+        wire_load(top, zt, (size_t)log_n + 1);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) lds_inv[(size_t)j * N] = top.l[j];
+    }
+    if ((int)t0 < log_ns) {                                   // level log_s = t0 works on the 2^(t0+1)-point domain
+        Fr z;
+        wire_load(z, zt, (size_t)(log_n - (int)t0 - 1));
+        fe_canon(z);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) zl[t0 * NL + j] = z.l[j];
+    }
+    __syncthreads();
+    for (int log_s = 0; log_s < log_ns; ++log_s) {
+        const uint32_t s = 1u << log_s;
+        const int log_e = log_n - log_s - 1;                   // the 2s-point domain: generator w^(2^log_e), point z^(2^log_e)
+        // part A, independent of the coarser level: the two denominators of each of this thread's lanes (at most two lanes)
+        Fr d0[2], d1[2];
+        Fr z;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) z.l[j] = zl[log_s * NL + j];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t t = t0 + q * POLY_SMALL_THREADS;
+            if (t >= s) break;
+            Fr w;
+            domain_elem(w, tb, t << log_e);
+            fe_canon(w);
+            fe_sub(d0[q], w, z);                               // W^t - Z
+            fe_neg(d1[q], w);
+            fe_norm(d1[q]);
+            fe_canon(d1[q]);                                   // -W^t, canonical
+            fe_sub(d1[q], d1[q], z);
+        }
+        // part B
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t t = t0 + q * POLY_SMALL_THREADS;
+            if (t >= s) break;
+            Fr g, i0, i1;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) g.l[j] = -lds_inv[(size_t)j * N + t];
+            fe_norm(g);
+            const bool z0 = fe_is_literal_zero(d0[q]), z1 = fe_is_literal_zero(d1[q]);
+            if (__builtin_expect(z0 || z1, 0)) {
+                fe_set_one(i0); fe_set_one(i1);
+                if (!z0) fr_inverse(i0, d0[q]);
+                if (!z1) fr_inverse(i1, d1[q]);
+            } else {
+                fe_mul2(i0, g, d1[q], i1, g, d0[q]);
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { lds_inv[(size_t)j * N + t] = i0.l[j]; lds_inv[(size_t)j * N + t + s] = i1.l[j]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = t0; i < N; i += POLY_SMALL_THREADS)
+#pragma unroll
+        for (int j = 0; j < NL; ++j) out[(size_t)j * N + i] = lds_inv[(size_t)j * N + i];
+}
+
+// The four inverses of the coset {t + k T : k < 4} of the 4T-point domain (generator w^(2^log_e), point Z = z^(2^log_e), canonical):
+// its elements are W^t times the fourth roots of unity 1, i, -1, -i (i = w^(n/4)), and d0 d1 d2 d3 = -(W^4t - Z^4), so with
+// G = -next[t]:  1/d0 = G d1 (d2 d3),  1/d1 = G d0 (d2 d3),  1/d2 = G (d0 d1) d3,  1/d3 = G (d0 d1) d2.
+// Returns the index k of a zero denominator (z on the domain; its inverse is set to 1), or 4.
+__device__ __forceinline__ uint32_t inv4_group(Fr inv[4], const NttTables& tb, int log_n, int log_e, uint32_t t, const Fr& z,
+                                               const int32_t* __restrict__ next, size_t next_stride) {
+    Fr w0, w1, qi, d[4];
+    domain_elem(w0, tb, t << log_e);
+    domain_elem(qi, tb, 1u << (log_n - 2));                    // w^(n/4): the primitive fourth root
+    fe_mul(w1, w0, qi);
+    fe_canon(w0);
+    fe_canon(w1);
+    fe_sub(d[0], w0, z);
+    fe_sub(d[1], w1, z);
+    Fr n0, n1;
+    fe_neg(n0, w0); fe_norm(n0); fe_canon(n0);
+    fe_neg(n1, w1); fe_norm(n1); fe_canon(n1);
+    fe_sub(d[2], n0, z);
+    fe_sub(d[3], n1, z);
+    uint32_t zero_k = 4;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) if (fe_is_literal_zero(d[k])) { zero_k = k; fe_set_one(d[k]); }
+    Fr p01, p23, G;
+    fe_mul2(p01, d[0], d[1], p23, d[2], d[3]);
+    if (__builtin_expect(zero_k != 4, 0)) {
+        Fr P;
+        fe_mul(P, p01, p23);
+        fr_inverse(G, P);
+    } else {
+        pl_load(G, next, next_stride, t);
+        fe_neg(G, G);
+        fe_norm(G);
+    }
+    Fr a, b;
+    fe_mul2(a, G, p23, b, G, p01);
+    fe_mul2(inv[0], a, d[1], inv[1], a, d[0]);
+    fe_mul2(inv[2], b, d[3], inv[3], b, d[2]);
+    return zero_k;
+}
+
+// ---- K0b: one x4 level for domains too large for K0 --------------------------------------------------------------------
+// out[j] = 1 / (w^(j e) - z^e), j < N = 2^log_nl, e = n / N, from next[t] = 1 / (w^(4 t e) - z^(4 e)), t < N / 4
 __global__ void __launch_bounds__(POLY_THREADS)
-k_poly_inverses(const uint4* __restrict__ evals, uint32_t n, NttTables tb, const uint4* __restrict__ z_wire,
-                int32_t* __restrict__ inv, int32_t* __restrict__ dvals, int32_t* __restrict__ partial /* NL x gridDim */,
+k_poly_inv_level(const uint4* __restrict__ zt, int log_n, int log_nl, NttTables tb, const int32_t* __restrict__ next, int32_t* __restrict__ out) {
+    const uint32_t N = 1u << log_nl, T = N >> 2, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int log_e = log_n - log_nl;
+    Fr z, inv[4];
+    wire_load(z, zt, (size_t)log_e);
+    fe_canon(z);
+    inv4_group(inv, tb, log_n, log_e, t, z, next, T);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) pl_store(out, N, t + k * T, inv[k]);
+}
+
+// ---- K1: the last level (inverses of all n denominators) + barycentric partial sums ---------------------------------------
+// lane t owns elements i = k * T + t.  inv[i] = 1 / (w^i - z)  (1 for the on-domain index).
+//   direct != 0: next[i] already is that inverse (n <= 4096: K0 produced all of them); any number of lanes
+//   direct == 0: T = n / 4 lanes and next[t] = 1 / (w^(4 t) - z^4) (inv4_group)
+__global__ void __launch_bounds__(POLY_THREADS)
+k_poly_inverses(const uint4* __restrict__ evals, uint32_t n, int log_n, NttTables tb, const uint4* __restrict__ z_wire,
+                const int32_t* __restrict__ next, int direct, int32_t* __restrict__ inv, int32_t* __restrict__ partial /* NL x gridDim */,
                 ProofScalars* __restrict__ ps) {
     __shared__ int32_t lds[NL * POLY_THREADS];
     const uint32_t T = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     Fr z;
     wire_load(z, z_wire, 0);
     fe_canon(z);
-    Fr run;
-    fe_set_one(run);
-    // forward: prefix products
-    for (uint32_t i = t; i < n; i += T) {
-        Fr w, d;
-        domain_elem(w, tb, i);
-        fe_canon(w);
-        fe_sub(d, w, z);                          // canonical - canonical: in (-m, m), limbs within +-2^29
-        bool zero = fe_is_literal_zero(d);
-        if (zero) { ps->on_domain_index = i; fe_set_one(d); }
-        pl_store(dvals, n, i, d);
-        pl_store(inv, n, i, run);                 // product of this lane's earlier denominators
-        fe_mul(run, run, d);
-    }
-    Fr rinv;
-    fr_inverse(rinv, run);
-    // backward: inv_i = rinv * prefix_i ; rinv *= d_i
-    const uint32_t cnt = (n > t) ? (n - 1 - t) / T + 1 : 0;
     Fr sum;
     fe_set_zero(sum);
-    for (uint32_t k = cnt; k-- > 0;) {
-        const uint32_t i = t + k * T;
-        Fr pre, d, iv;
-        pl_load(pre, inv, n, i);
-        pl_load(d, dvals, n, i);
-        fe_mul(iv, rinv, pre);
-        fe_mul(rinv, rinv, d);
-        pl_store(inv, n, i, iv);
-        // barycentric term f_i w^i / (z - w^i) = -(f_i w^i inv_i)
-        Fr f, w, term;
-        wire_load(f, evals, i);
-        domain_elem(w, tb, i);
-        fe_mul(term, f, w);
-        fe_mul(term, term, iv);
-        fe_sub(sum, sum, term);
-        fe_norm(sum);                             // |sum| grows by 2m per term
-        if ((k & 31u) == 0) fe_reduce(sum);
+    if (direct) {
+        uint32_t cnt = 0;
+        for (uint32_t i = t; i < n; i += T, ++cnt) {
+            Fr w, wc, d, iv, f, term;
+            domain_elem(w, tb, i);
+            wc = w;
+            fe_canon(wc);
+            fe_sub(d, wc, z);
+            if (fe_is_literal_zero(d)) ps->on_domain_index = i;
+            pl_load(iv, next, n, i);
+            if (next != inv) pl_store(inv, n, i, iv);
+            wire_load(f, evals, i);
+            fe_mul(term, f, w);
+            fe_mul(term, term, iv);
+            fe_sub(sum, sum, term);                   // barycentric term f_i w^i / (z - w^i) = -(f_i w^i inv_i)
+            fe_norm(sum);                             // |sum| grows by 2m per term
+            if ((cnt & 31u) == 31u) fe_reduce(sum);
+        }
+    } else if (t < (n >> 2)) {
+        const uint32_t Tq = n >> 2;
+        Fr iv[4], f[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) wire_load(f[k], evals, t + k * Tq);          // in flight during the inversion arithmetic
+        const uint32_t zero_k = inv4_group(iv, tb, log_n, 0, t, z, next, Tq);
+        if (zero_k != 4) ps->on_domain_index = t + zero_k * Tq;
+        Fr w0, w1, qi;
+        domain_elem(w0, tb, t);
+        domain_elem(qi, tb, 1u << (log_n - 2));
+        fe_mul(w1, w0, qi);
+        Fr fw[4];
+        fe_mul2(fw[0], f[0], w0, fw[2], f[2], w0);                                     // w^(t + 2 Tq) = -w^t
+        fe_mul2(fw[1], f[1], w1, fw[3], f[3], w1);
+        Fr tm[4];
+        fe_mul2(tm[0], fw[0], iv[0], tm[2], fw[2], iv[2]);
+        fe_mul2(tm[1], fw[1], iv[1], tm[3], fw[3], iv[3]);
+        // sum = -(tm0 + tm1) + (tm2 + tm3): elements 2 and 3 carry the factor -1 of their root
+        fe_sub(sum, tm[2], tm[0]);
+        fe_add(sum, sum, tm[3]);
+        fe_sub(sum, sum, tm[1]);
+        fe_norm(sum);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) pl_store(inv, n, t + k * Tq, iv[k]);
     }
     fe_reduce(sum);
     block_sum(sum, lds);
@@ -328,6 +476,57 @@ int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_
     return KZG_OK;
 }
 
+// ---- host Fr arithmetic on wire words (Montgomery, R = 2^256) for the one inversion of a proof -------------------------
+namespace {
+typedef unsigned __int128 hu128;
+const uint64_t H_FR[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+const uint64_t H_FR_NINV = 0xc2e1f593efffffffULL;          // -r^-1 mod 2^64
+const uint64_t H_FR_R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};   // 2^512 mod r
+bool h_geq_r(const uint64_t t[4]) {
+    for (int i = 3; i >= 0; --i) if (t[i] != H_FR[i]) return t[i] > H_FR[i];
+    return true;
+}
+void h_sub_r(uint64_t t[4]) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; ++i) { hu128 d = (hu128)t[i] - H_FR[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+}
+void h_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    uint64_t t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        hu128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (hu128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        hu128 top = (hu128)t[4] + (uint64_t)c;
+        const uint64_t m = t[0] * H_FR_NINV;
+        c = ((hu128)m * H_FR[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) { c += (hu128)m * H_FR[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        top += (uint64_t)c;
+        t[3] = (uint64_t)top; t[4] = (uint64_t)(top >> 64);
+    }
+    if (t[4] || h_geq_r(t)) h_sub_r(t);
+    memcpy(out, t, 32);
+}
+// out = a - b mod r (both < r)
+void h_fr_sub(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    uint64_t t[4], br = 0;
+    for (int i = 0; i < 4; ++i) { hu128 d = (hu128)a[i] - b[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+    if (br) { hu128 c = 0; for (int i = 0; i < 4; ++i) { c += (hu128)t[i] + H_FR[i]; t[i] = (uint64_t)c; c >>= 64; } }
+    memcpy(out, t, 32);
+}
+// a^(r-2), wire in / wire out
+void h_fr_inv(const uint64_t a[4], uint64_t out[4]) {
+    uint64_t e[4] = {H_FR[0] - 2, H_FR[1], H_FR[2], H_FR[3]};
+    uint64_t acc[4], base[4];
+    const uint64_t one_int[4] = {1, 0, 0, 0};
+    h_fr_mul(H_FR_R2, one_int, acc);                         // 1 in wire form
+    memcpy(base, a, 32);
+    for (int i = 0; i < 254; ++i) {
+        if ((e[i >> 6] >> (i & 63)) & 1) h_fr_mul(acc, base, acc);
+        h_fr_mul(base, base, base);
+    }
+    memcpy(out, acc, 32);
+}
+}  // namespace
+
 // Enqueue the O(n) part of a proof on `st` with the buffers of `ps_set`, without waiting: upload, denominators + batch
 // inversion, y, quotient (+ on-domain entry), IFFT of the quotient.  y is copied back into ps_set.pinned + 2048 (valid once the
 // stream has been synchronised); the quotient's coefficients are left in ps_set.c.
@@ -338,35 +537,76 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     int32_t rc = ntt_get_tables(ctx, log_n, false, &tb);
     if (rc != KZG_OK) return rc;
     if (want_proof && n > 1) { NttTables tbi; rc = ntt_get_tables(ctx, log_n, true, &tbi); if (rc != KZG_OK) return rc; }
-    // lanes: about `per_lane` elements each, at least one block.  Every lane pays one Fermat inversion (~380 dependent multiplies,
-    // the latency floor of this kernel), so fewer elements per lane shorten the serial part until the extra waves cost more.
-    static int per_lane = 0;
-    if (per_lane == 0) { const char* env = getenv("KZG_POLY_PER_LANE"); per_lane = env && atoi(env) > 0 ? atoi(env) : 16; }   // measured at 2^20: 32 -> 3.42 ms, 16 -> 3.32 ms, 8 -> 3.41 ms per proof
+    // lanes of the last level: 4 elements each (one coset), at least one block
+    const int per_lane = 4;           // = the coset size of the last inversion level (k_poly_inverses)
     uint32_t blocks = (uint32_t)((n + (size_t)POLY_THREADS * per_lane - 1) / ((size_t)POLY_THREADS * per_lane));
     if (blocks == 0) blocks = 1;
     KZG_HIP_TRY(ctx, set.a.reserve(n * 32));                 // evaluations (wire)
-    KZG_HIP_TRY(ctx, set.b.reserve(n * NL * 4 * 2));         // inverses | denominators (planes)
+    // inverses (planes) | level scratch: the smaller domains' inverses, two ping-pong plane sets of the small kernel
+    const size_t n1 = n > POLY_SMALL_MAX ? n / 4 : 0;        // the level above the last one (0: the small kernel gives all n inverses)
+    const size_t lvl_words = n1 ? (n1 + n1 / 2) * NL + 64 : 0;          // sum over n/4, n/16, ... < n1 * 4/3
+    KZG_HIP_TRY(ctx, set.b.reserve((n * NL + lvl_words) * 4));
     KZG_HIP_TRY(ctx, set.c.reserve(n * 32));                 // quotient (wire)
     KZG_HIP_TRY(ctx, set.small.reserve(4096 + (size_t)blocks * NL * 4 * 2));
     if (!set.pinned) KZG_HIP_TRY(ctx, hipHostMalloc(&set.pinned, 4096, hipHostMallocDefault));
     uint8_t* small = set.small.as<uint8_t>();
     ProofScalars* ps = reinterpret_cast<ProofScalars*>(small);
-    uint4* d_z = reinterpret_cast<uint4*>(small + 1024);
+    uint4* d_zt = reinterpret_cast<uint4*>(small + 1024);    // zt[a] = z^(2^a), a <= log_n; zt[log_n + 1] = 1 / (1 - z^n)
+    uint4* d_z = d_zt;
     int32_t* partial = reinterpret_cast<int32_t*>(small + 4096);
     int32_t* d_inv = set.b.as<int32_t>();
-    int32_t* d_den = d_inv + n * NL;
+    int32_t* d_lvl = d_inv + n * NL;
 
-    uint8_t* pin = static_cast<uint8_t*>(set.pinned);       // [0, 1024): init image, [1024, 1056): z, [2048, ..): y readback
+    uint8_t* pin = static_cast<uint8_t*>(set.pinned);       // [0, 1024): init image, [1024, 2048): z powers + top inverse, [2048, ..): y readback
     ProofScalars* init = reinterpret_cast<ProofScalars*>(pin);
     memset(init, 0, sizeof *init);
     init->on_domain_index = NO_INDEX;
-    memcpy(pin + 1024, z, 32);
+    {
+        uint64_t* zt = reinterpret_cast<uint64_t*>(pin + 1024);
+        memcpy(zt, z, 32);
+        for (int a = 1; a <= log_n; ++a) h_fr_mul(zt + 4 * (a - 1), zt + 4 * (a - 1), zt + 4 * a);
+        const uint64_t one_int[4] = {1, 0, 0, 0};
+        uint64_t one_w[4], den[4];
+        h_fr_mul(H_FR_R2, one_int, one_w);
+        h_fr_sub(one_w, zt + 4 * log_n, den);                // 1 - z^n (zero: z is on the domain, the device inverts what it needs itself)
+        uint64_t* top = zt + 4 * (log_n + 1);
+        if ((den[0] | den[1] | den[2] | den[3]) == 0) memset(top, 0, 32); else h_fr_inv(den, top);
+    }
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_z, pin + 1024, 32, hipMemcpyHostToDevice, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zt, pin + 1024, (size_t)(log_n + 2) * 32, hipMemcpyHostToDevice, st));
     if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));   // nullptr: set.a already holds the n evaluations (blob proofs)
 
-    hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, d_z,
-                       d_inv, d_den, partial, ps);
+    // the chain of smaller domains, coarsest first: small kernel (<= 4096 points, in LDS), then x4 levels, then the last level
+    const int32_t* next = nullptr;
+    int direct = 0;
+    if (!ctx->poly_lds_attr_set) {
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_poly_inv_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(NL * POLY_SMALL_MAX * 4)));
+        ctx->poly_lds_attr_set = true;
+    }
+    if (n <= POLY_SMALL_MAX) {
+        hipLaunchKernelGGL(k_poly_inv_small, dim3(1), dim3(POLY_SMALL_THREADS), (size_t)NL * n * 4, st, d_zt, log_n, log_n, tb, d_inv);
+        next = d_inv; direct = 1;
+    } else {
+        int log_l = log_n - 2;                               // sizes n/4, n/16, .. down to the first one <= 4096
+        std::vector<int> logs;
+        while (log_l > (int)POLY_SMALL_MAX_LOG) { logs.push_back(log_l); log_l -= 2; }
+        std::vector<int32_t*> bufs;                          // level buffers inside d_lvl: size 2^logs[0] first
+        int32_t* cursor = d_lvl;
+        for (int l : logs) { bufs.push_back(cursor); cursor += ((size_t)NL << l); }
+        int32_t* small_out = cursor;                         // 2^log_l <= 4096 entries
+        hipLaunchKernelGGL(k_poly_inv_small, dim3(1), dim3(POLY_SMALL_THREADS), ((size_t)NL << log_l) * 4, st, d_zt, log_n, log_l, tb, small_out);
+        const int32_t* prev = small_out;
+        for (int q = (int)logs.size() - 1; q >= 0; --q) {
+            const uint32_t T = 1u << (logs[q] - 2);
+            hipLaunchKernelGGL(k_poly_inv_level, dim3((T + POLY_THREADS - 1) / POLY_THREADS), dim3(POLY_THREADS), 0, st, d_zt, log_n, logs[q], tb,
+                               prev, bufs[q]);
+            prev = bufs[q];
+        }
+        next = prev;
+    }
+    hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, tb, d_z,
+                       next, direct, d_inv, partial, ps);
     hipLaunchKernelGGL(k_poly_finish_y, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, d_z,
                        partial, blocks, ps);
     KZG_HIP_TRY(ctx, hipGetLastError());
