@@ -54,25 +54,6 @@ __device__ __forceinline__ void wire_store(uint4* __restrict__ dst, size_t i, co
     dst[2 * i] = make_uint4(w32[0], w32[1], w32[2], w32[3]);
     dst[2 * i + 1] = make_uint4(w32[4], w32[5], w32[6], w32[7]);
 }
-// a^(r-2) by square-and-multiply over the modulus words (Fermat)
-__device__ __noinline__ void fr_inverse(Fr& out, const Fr& a) {
-    Fr acc, base = a;
-    fe_set_one(acc);
-    uint32_t e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = FrParams::P32[j];
-    e[0] -= 2u;                                   // r - 2 (no borrow: low word of r is 0xf0000001)
-    for (int w = 0; w < 8; ++w) {
-        uint32_t bits = e[w];
-        for (int b = 0; b < 32; ++b) {
-            if (w == 7 && b >= 30) break;        // r < 2^254
-            if (bits & 1u) fe_mul(acc, acc, base);
-            fe_sqr(base, base);
-            bits >>= 1;
-        }
-    }
-    out = acc;
-}
 // block-wide sum of one Fr per thread (values in (-m, 2m)); result (reduced) valid in thread 0
 __device__ __forceinline__ void block_sum(Fr& v, int32_t* lds /* NL * POLY_THREADS */) {
     const int t = threadIdx.x;
@@ -106,8 +87,10 @@ struct ProofScalars {        // device-resident small state of one proof computa
 // Level by level from the single value 1 / (1 - z^n), size s -> 2 s, in place in LDS: lane t < s owns the pair {t, t + s} of the
 // 2s-point domain, whose elements are +-W^t:  d0 = W^t - Z, d1 = -W^t - Z, d0 d1 = -(W^2t - Z^2), so with g = the value of the
 // coarser level  1/d0 = -g d1,  1/d1 = -g d0: two independent multiplies per level and lane, log2 N levels.
-// A zero denominator (z on the domain) gets the inverse 1, as the callers expect, and its partner is inverted by Fermat; the
-// value that lane read from the coarser level was never valid and is not used.
+// A zero denominator (z on the domain, the case of compute_proof_with_known_z_fr_index) gets the inverse 1, as the callers expect;
+// the other denominators of its group are Z (rho - 1) for the roots of unity rho != 1 of the group, so their inverses are Z^-1 times
+// constants: the host supplies z^-(2^a) and 1/(i-1), -1/2, 1/(-i-1) with the other scalars (zt[log_n+2 ..]).  The value such a lane
+// read from the coarser level was never valid and is not used.
 constexpr int POLY_SMALL_THREADS = 1024;
 constexpr uint32_t POLY_SMALL_MAX_LOG = 12;
 constexpr uint32_t POLY_SMALL_MAX = 1u << POLY_SMALL_MAX_LOG;
@@ -138,10 +121,9 @@ k_poly_inv_small(const uint4* __restrict__ zt, int log_n, int log_ns, NttTables 
         Fr z;
 #pragma unroll
         for (int j = 0; j < NL; ++j) z.l[j] = zl[log_s * NL + j];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        auto part_a = [&](int q) {
             const uint32_t t = t0 + q * POLY_SMALL_THREADS;
-            if (t >= s) break;
+            if (t >= s) return;
             Fr w;
             domain_elem(w, tb, t << log_e);
             fe_canon(w);
@@ -150,27 +132,34 @@ k_poly_inv_small(const uint4* __restrict__ zt, int log_n, int log_ns, NttTables 
             fe_norm(d1[q]);
             fe_canon(d1[q]);                                   // -W^t, canonical
             fe_sub(d1[q], d1[q], z);
-        }
+        };
+        part_a(0);
+        part_a(1);
         // part B
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        auto part_b = [&](int q) {
             const uint32_t t = t0 + q * POLY_SMALL_THREADS;
-            if (t >= s) break;
+            if (t >= s) return;
             Fr g, i0, i1;
 #pragma unroll
             for (int j = 0; j < NL; ++j) g.l[j] = -lds_inv[(size_t)j * N + t];
             fe_norm(g);
             const bool z0 = fe_is_literal_zero(d0[q]), z1 = fe_is_literal_zero(d1[q]);
-            if (__builtin_expect(z0 || z1, 0)) {
+            if (__builtin_expect(z0 || z1, 0)) {               // +-W^t = Z: the other denominator is -2 Z, its inverse (-1/2) Z^-1 from the host's table
+                Fr zi, c2, other;
+                wire_load(zi, zt, (size_t)(log_n + 2 + log_e));
+                wire_load(c2, zt, (size_t)(2 * log_n + 3 + 1));
+                fe_mul(other, zi, c2);
                 fe_set_one(i0); fe_set_one(i1);
-                if (!z0) fr_inverse(i0, d0[q]);
-                if (!z1) fr_inverse(i1, d1[q]);
+                if (!z0) i0 = other;
+                if (!z1) i1 = other;
             } else {
                 fe_mul2(i0, g, d1[q], i1, g, d0[q]);
             }
 #pragma unroll
             for (int j = 0; j < NL; ++j) { lds_inv[(size_t)j * N + t] = i0.l[j]; lds_inv[(size_t)j * N + t + s] = i1.l[j]; }
-        }
+        };
+        part_b(0);
+        part_b(1);
         __syncthreads();
     }
     for (uint32_t i = t0; i < N; i += POLY_SMALL_THREADS)
@@ -182,7 +171,7 @@ k_poly_inv_small(const uint4* __restrict__ zt, int log_n, int log_ns, NttTables 
 // its elements are W^t times the fourth roots of unity 1, i, -1, -i (i = w^(n/4)), and d0 d1 d2 d3 = -(W^4t - Z^4), so with
 // G = -next[t]:  1/d0 = G d1 (d2 d3),  1/d1 = G d0 (d2 d3),  1/d2 = G (d0 d1) d3,  1/d3 = G (d0 d1) d2.
 // Returns the index k of a zero denominator (z on the domain; its inverse is set to 1), or 4.
-__device__ __forceinline__ uint32_t inv4_group(Fr inv[4], const NttTables& tb, int log_n, int log_e, uint32_t t, const Fr& z,
+__device__ __forceinline__ uint32_t inv4_group(Fr inv[4], const NttTables& tb, const uint4* __restrict__ zt, int log_n, int log_e, uint32_t t, const Fr& z,
                                                const int32_t* __restrict__ next, size_t next_stride) {
     Fr w0, w1, qi, d[4];
     domain_elem(w0, tb, t << log_e);
@@ -200,17 +189,24 @@ __device__ __forceinline__ uint32_t inv4_group(Fr inv[4], const NttTables& tb, i
     uint32_t zero_k = 4;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) if (fe_is_literal_zero(d[k])) { zero_k = k; fe_set_one(d[k]); }
+    if (__builtin_expect(zero_k != 4, 0)) {                    // d_k = Z (i^(k - k0) - 1): inverses = Z^-1 times the host's constants
+        Fr zi;
+        wire_load(zi, zt, (size_t)(log_n + 2 + log_e));
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t r = (k - zero_k) & 3u;
+            if (r == 0) { fe_set_one(inv[k]); continue; }
+            Fr c;
+            wire_load(c, zt, (size_t)(2 * log_n + 3 + (r - 1)));
+            fe_mul(inv[k], zi, c);
+        }
+        return zero_k;
+    }
     Fr p01, p23, G;
     fe_mul2(p01, d[0], d[1], p23, d[2], d[3]);
-    if (__builtin_expect(zero_k != 4, 0)) {
-        Fr P;
-        fe_mul(P, p01, p23);
-        fr_inverse(G, P);
-    } else {
-        pl_load(G, next, next_stride, t);
-        fe_neg(G, G);
-        fe_norm(G);
-    }
+    pl_load(G, next, next_stride, t);
+    fe_neg(G, G);
+    fe_norm(G);
     Fr a, b;
     fe_mul2(a, G, p23, b, G, p01);
     fe_mul2(inv[0], a, d[1], inv[1], a, d[0]);
@@ -228,7 +224,7 @@ k_poly_inv_level(const uint4* __restrict__ zt, int log_n, int log_nl, NttTables 
     Fr z, inv[4];
     wire_load(z, zt, (size_t)log_e);
     fe_canon(z);
-    inv4_group(inv, tb, log_n, log_e, t, z, next, T);
+    inv4_group(inv, tb, zt, log_n, log_e, t, z, next, T);
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) pl_store(out, N, t + k * T, inv[k]);
 }
@@ -271,7 +267,7 @@ k_poly_inverses(const uint4* __restrict__ evals, uint32_t n, int log_n, NttTable
         Fr iv[4], f[4];
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) wire_load(f[k], evals, t + k * Tq);          // in flight during the inversion arithmetic
-        const uint32_t zero_k = inv4_group(iv, tb, log_n, 0, t, z, next, Tq);
+        const uint32_t zero_k = inv4_group(iv, tb, z_wire, log_n, 0, t, z, next, Tq);
         if (zero_k != 4) ps->on_domain_index = t + zero_k * Tq;
         Fr w0, w1, qi;
         domain_elem(w0, tb, t);
@@ -525,6 +521,31 @@ void h_fr_inv(const uint64_t a[4], uint64_t out[4]) {
     }
     memcpy(out, acc, 32);
 }
+// 1/(i - 1), -1/2, 1/(-i - 1) in wire form, i = 5^((r-1)/4) (= w_n^(n/4) for every n >= 4: arkworks' roots are powers of 5^((r-1)/2^28))
+const uint64_t* h_on_domain_constants() {
+    static const struct Init {
+        uint64_t c[12];
+        Init() {
+            const uint64_t one_int[4] = {1, 0, 0, 0}, five_int[4] = {5, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
+            uint64_t one_w[4], five_w[4], two_w[4], qi[4], acc[4], base[4], t[4];
+            h_fr_mul(H_FR_R2, one_int, one_w);
+            h_fr_mul(H_FR_R2, five_int, five_w);
+            uint64_t e[4] = {H_FR[0] - 1, H_FR[1], H_FR[2], H_FR[3]};            // (r - 1) / 4
+            for (int i = 0; i < 4; ++i) e[i] = (e[i] >> 2) | (i < 3 ? e[i + 1] << 62 : 0);
+            memcpy(acc, one_w, 32); memcpy(base, five_w, 32);
+            for (int i = 0; i < 254; ++i) {
+                if ((e[i >> 6] >> (i & 63)) & 1) h_fr_mul(acc, base, acc);
+                h_fr_mul(base, base, base);
+            }
+            memcpy(qi, acc, 32);
+            h_fr_sub(qi, one_w, t); h_fr_inv(t, c);                             // 1 / (i - 1)
+            h_fr_sub(zero, one_w, two_w); h_fr_sub(two_w, one_w, two_w);         // -2
+            h_fr_inv(two_w, c + 4);                                             // -1/2
+            h_fr_sub(zero, qi, t); h_fr_sub(t, one_w, t); h_fr_inv(t, c + 8);   // 1 / (-i - 1)
+        }
+    } init;
+    return init.c;
+}
 }  // namespace
 
 // Enqueue the O(n) part of a proof on `st` with the buffers of `ps_set`, without waiting: upload, denominators + batch
@@ -551,13 +572,13 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     if (!set.pinned) KZG_HIP_TRY(ctx, hipHostMalloc(&set.pinned, 4096, hipHostMallocDefault));
     uint8_t* small = set.small.as<uint8_t>();
     ProofScalars* ps = reinterpret_cast<ProofScalars*>(small);
-    uint4* d_zt = reinterpret_cast<uint4*>(small + 1024);    // zt[a] = z^(2^a), a <= log_n; zt[log_n + 1] = 1 / (1 - z^n)
+    uint4* d_zt = reinterpret_cast<uint4*>(small + 1024);    // zt[a] = z^(2^a), a <= log_n; zt[log_n + 1] = 1 / (1 - z^n); then z^-(2^a) and three constants (on-domain z)
     uint4* d_z = d_zt;
     int32_t* partial = reinterpret_cast<int32_t*>(small + 4096);
     int32_t* d_inv = set.b.as<int32_t>();
     int32_t* d_lvl = d_inv + n * NL;
 
-    uint8_t* pin = static_cast<uint8_t*>(set.pinned);       // [0, 1024): init image, [1024, 2048): z powers + top inverse, [2048, ..): y readback
+    uint8_t* pin = static_cast<uint8_t*>(set.pinned);       // [0, 1024): init image, [1024, 3072): the scalars of the inversion chain (zt), [3072, ..): y readback
     ProofScalars* init = reinterpret_cast<ProofScalars*>(pin);
     memset(init, 0, sizeof *init);
     init->on_domain_index = NO_INDEX;
@@ -570,10 +591,20 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         h_fr_mul(H_FR_R2, one_int, one_w);
         h_fr_sub(one_w, zt + 4 * log_n, den);                // 1 - z^n (zero: z is on the domain, the device inverts what it needs itself)
         uint64_t* top = zt + 4 * (log_n + 1);
-        if ((den[0] | den[1] | den[2] | den[3]) == 0) memset(top, 0, 32); else h_fr_inv(den, top);
+        uint64_t* zit = zt + 4 * (log_n + 2);                // z^-(2^a), a <= log_n: only read when z is on the domain
+        uint64_t* cst = zt + 4 * (2 * log_n + 3);            // 1/(i - 1), -1/2, 1/(-i - 1), i = w^(n/4) = 5^((r-1)/4)
+        if ((den[0] | den[1] | den[2] | den[3]) == 0) {
+            memset(top, 0, 32);
+            h_fr_inv(zt, zit);
+            for (int a = 1; a <= log_n; ++a) h_fr_mul(zit + 4 * (a - 1), zit + 4 * (a - 1), zit + 4 * a);
+        } else {
+            h_fr_inv(den, top);
+            memset(zit, 0, (size_t)(log_n + 1) * 32);
+        }
+        memcpy(cst, h_on_domain_constants(), 96);
     }
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zt, pin + 1024, (size_t)(log_n + 2) * 32, hipMemcpyHostToDevice, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zt, pin + 1024, (size_t)(2 * log_n + 6) * 32, hipMemcpyHostToDevice, st));
     if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));   // nullptr: set.a already holds the n evaluations (blob proofs)
 
     // the chain of smaller domains, coarsest first: small kernel (<= 4096 points, in LDS), then x4 levels, then the last level
@@ -610,7 +641,7 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     hipLaunchKernelGGL(k_poly_finish_y, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, d_z,
                        partial, blocks, ps);
     KZG_HIP_TRY(ctx, hipGetLastError());
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + 2048, ps, sizeof(ProofScalars), hipMemcpyDeviceToHost, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + 3072, ps, sizeof(ProofScalars), hipMemcpyDeviceToHost, st));
     if (!want_proof) return KZG_OK;
     hipLaunchKernelGGL(k_poly_quotient, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, d_inv,
                        ps, set.c.as<uint4>(), partial);
@@ -621,7 +652,7 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     return ntt_run(ctx, set.c.p, n, true, st, nttws);
 }
 static void proof_read_y(const PolySet& set, uint64_t* out_y) {
-    const ProofScalars* host = reinterpret_cast<const ProofScalars*>(static_cast<const uint8_t*>(set.pinned) + 2048);
+    const ProofScalars* host = reinterpret_cast<const ProofScalars*>(static_cast<const uint8_t*>(set.pinned) + 3072);
     memcpy(out_y, host->y_wire, 32);
 }
 
