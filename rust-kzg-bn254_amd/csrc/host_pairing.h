@@ -112,7 +112,11 @@ inline Fq2 mul(const Fq2& a, const Fq2& b) {
     Fq t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1);
     return {sub(t0, t1), sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), t0), t1)};
 }
-inline Fq2 sqr(const Fq2& a) { return mul(a, a); }
+inline Fq2 sqr(const Fq2& a) {                    // (c0 + c1)(c0 - c1) + 2 c0 c1 u
+    Fq t = mul(a.c0, a.c1);
+    return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), add(t, t)};
+}
+inline Fq2 mul_fq(const Fq2& a, const Fq& k) { return {mul(a.c0, k), mul(a.c1, k)}; }
 inline bool is_zero(const Fq2& a) { return is_zero(a.c0) && is_zero(a.c1); }
 inline bool eq(const Fq2& a, const Fq2& b) { return eq(a.c0, b.c0) && eq(a.c1, b.c1); }
 inline Fq2 inv(const Fq2& a) {                    // (c0 - c1 u) / (c0^2 + c1^2)
@@ -256,6 +260,29 @@ inline Fq12 mul(const Fq12& a, const Fq12& b) {
     }
     Fq12 r; fq12_reduce(t, r); return r;
 }
+// Squaring: the same Karatsuba split with three 6-coefficient SQUARINGS (21 multiplications each: 63 instead of 108)
+inline void poly6_sqr(const Fq* a, Fq out[11]) {
+    for (int i = 0; i < 11; ++i) out[i] = fq_zero();
+    for (int i = 0; i < 6; ++i) {
+        out[2 * i] = add(out[2 * i], sqr(a[i]));
+        for (int j = i + 1; j < 6; ++j) out[i + j] = add(out[i + j], dbl(mul(a[i], a[j])));
+    }
+}
+inline Fq12 sqr(const Fq12& a) {
+    Fq sa[6], lo[11], hi[11], mid[11];
+    for (int i = 0; i < 6; ++i) sa[i] = add(a.c[i], a.c[i + 6]);
+    poly6_sqr(a.c, lo);
+    poly6_sqr(a.c + 6, hi);
+    poly6_sqr(sa, mid);
+    Fq t[23];
+    for (int i = 0; i < 23; ++i) t[i] = fq_zero();
+    for (int i = 0; i < 11; ++i) {
+        t[i] = add(t[i], lo[i]);
+        t[i + 12] = add(t[i + 12], hi[i]);
+        t[i + 6] = add(t[i + 6], sub(sub(mid[i], lo[i]), hi[i]));
+    }
+    Fq12 r; fq12_reduce(t, r); return r;
+}
 inline Fq12 fq12_pow(const Fq12& a, const uint64_t* e, int words) {
     Fq12 acc = fq12_one();
     bool started = false;
@@ -348,7 +375,7 @@ inline Fq12 miller_tate_product(const G1* ps, const G2* qs, int count) {
     int top = 255;
     while (!((FR_MODULUS_WORDS[top >> 6] >> (top & 63)) & 1)) --top;
     for (int i = top - 1; i >= 0; --i) {
-        f = mul(f, f);
+        f = sqr(f);
         for (int k = 0; k < m; ++k) {
             MillerPoint& t = pts[k];
             if (t.done) continue;
@@ -457,7 +484,7 @@ inline Fq12 final_exponentiation_fast(const Fq12& f) {
     Fq12 acc = fq12_one();
     bool started = false;
     for (int i = 255; i >= 0; --i) {
-        if (started) acc = mul(acc, acc);
+        if (started) acc = sqr(acc);
         int msk = 0;
         for (int d = 0; d < 4; ++d) msk |= (int)((HARD_EXP_DIGITS[d][i >> 6] >> (i & 63)) & 1) << d;
         if (msk) { acc = started ? mul(acc, tab[msk]) : tab[msk]; started = true; }
@@ -465,11 +492,179 @@ inline Fq12 final_exponentiation_fast(const Fq12& f) {
     return acc;
 }
 
+// The same value with the hard part (p^4 - p^2 + 1)/r = l0 + l1 p + l2 p^2 + p^3 written in the BN parameter x = 4965661367192848881
+// (l2 = 6x^2 + 1, l1 = -36x^3 - 18x^2 - 12x + 1, l0 = -36x^3 - 30x^2 - 18x - 2; Scott, Benger, Charlemagne, Dominguez Perez, Kachisa,
+// "On the final exponentiation for calculating pairings on ordinary elliptic curves", 2009): three exponentiations by the 63-bit x
+// (62 squarings + 27 multiplications each) and a 13-step vector addition chain, instead of 254 squarings + ~240 multiplications.
+// After the easy part g lies in the cyclotomic subgroup, where the inverse is the conjugation w -> -w.
+static const uint64_t BN_X = 0x44e992b44a6909f1ULL;
+inline Fq12 fq12_pow_x(const Fq12& a) {
+    Fq12 acc = a;
+    for (int i = 61; i >= 0; --i) {                            // bit 62 is the top bit of x
+        acc = sqr(acc);
+        if ((BN_X >> i) & 1) acc = mul(acc, a);
+    }
+    return acc;
+}
+inline Fq12 final_exponentiation_x(const Fq12& f) {
+    Fq12 fi;
+    if (!fq12_inverse(f, fi)) return f;                         // f = 0 cannot occur for valid inputs
+    Fq12 g = mul(conjugate_p6(f), fi);                          // f^(p^6 - 1)
+    g = mul(frobenius(g, 2), g);                                // ^(p^2 + 1)
+    const Fq12 fx = fq12_pow_x(g), fx2 = fq12_pow_x(fx), fx3 = fq12_pow_x(fx2);
+    const Fq12 y0 = mul(mul(frobenius(g, 1), frobenius(g, 2)), frobenius(g, 3));
+    const Fq12 y1 = conjugate_p6(g);
+    const Fq12 y2 = frobenius(fx2, 2);
+    const Fq12 y3 = conjugate_p6(frobenius(fx, 1));
+    const Fq12 y4 = conjugate_p6(mul(fx, frobenius(fx2, 1)));
+    const Fq12 y5 = conjugate_p6(fx2);
+    const Fq12 y6 = conjugate_p6(mul(fx3, frobenius(fx3, 1)));
+    // y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36
+    Fq12 t0 = sqr(y6);
+    t0 = mul(t0, y4);
+    t0 = mul(t0, y5);
+    Fq12 t1 = mul(y3, y5);
+    t1 = mul(t1, t0);
+    t0 = mul(t0, y2);
+    t1 = sqr(t1);
+    t1 = mul(t1, t0);
+    t1 = sqr(t1);
+    t0 = mul(t1, y1);
+    t1 = mul(t1, y0);
+    t0 = sqr(t0);
+    return mul(t0, t1);
+}
+
+// ---- optimal ate pairing (what arkworks' Bn254::multi_pairing computes up to the representation of GT) --------------------------------
+// e(P, Q) = ( f_{6x+2, Q}(P) * l_{[6x+2]Q, pi(Q)}(P) * l_{[6x+2]Q + pi(Q), -pi^2(Q)}(P) )^((p^12 - 1)/r)
+// The loop runs over the 65-bit 6x + 2 (signed digits: 22 non-zero of 66) on the G2 point, in Jacobian coordinates on the twist
+// E': y^2 = x^3 + 3/(9+u) over Fq2, four times shorter than the Tate loop over r above.  With the untwist (x', y') -> (x' w^2, y' w^3)
+// the line through T with slope lambda, evaluated at P = (xP, yP) in G1, is  yP - lambda xP w + (lambda xT - yT) w^3  with Fq2
+// coefficients; scaling a line by an element of Fq2 does not change the pairing (the final exponentiation kills Fq6), which removes
+// every inversion:
+//   tangent at T = (X, Y, Z):  (Z3 Z^2) yP - (3X^2 Z^2) xP w + (3X^3 - 2Y^2) w^3,          Z3 = 2YZ
+//   chord through T and Q:     Z3 yP - r xP w + (r xQ - Z3 yQ) w^3,   H = xQ Z^2 - X, r = yQ Z^3 - Y, Z3 = HZ
+// An Fq2 coefficient c0 + c1 u sits at w^k as (c0 - 9 c1) w^k + c1 w^(k+6)  (u = w^6 - 9).
+// Formulas checked against a big-integer model (bilinearity, order r, pi(Q) = [p]Q) before they were written here, and by
+// tests/hostcheck/pairingcheck.cpp against the Tate construction above.
+struct AteLine { Fq2 a, b, c; };                                // a + b w + c w^3
+inline void ate_dbl_step(G2Jac& T, const G1& P, AteLine& l) {
+    const Fq2 A = sqr(T.X), B = sqr(T.Y), C = sqr(B);
+    const Fq2 D = dbl2(sub(sub(sqr(add(T.X, B)), A), C));
+    const Fq2 E = add(dbl2(A), A), Z2 = sqr(T.Z);
+    const Fq2 X3 = sub(sqr(E), dbl2(D));
+    const Fq2 Y3 = sub(mul(E, sub(D, X3)), dbl2(dbl2(dbl2(C))));
+    const Fq2 Z3 = dbl2(mul(T.Y, T.Z));
+    l.a = mul_fq(mul(Z3, Z2), P.y);
+    l.b = neg(mul_fq(mul(E, Z2), P.x));
+    l.c = sub(mul(E, T.X), dbl2(B));
+    T.X = X3; T.Y = Y3; T.Z = Z3;
+}
+inline void ate_add_step(G2Jac& T, const G2& Q, const G1& P, AteLine& l) {
+    const Fq2 Z2 = sqr(T.Z);
+    const Fq2 H = sub(mul(Q.x, Z2), T.X);
+    const Fq2 r = sub(mul(Q.y, mul(Z2, T.Z)), T.Y);
+    const Fq2 Z3 = mul(T.Z, H);
+    l.a = mul_fq(Z3, P.y);
+    l.b = neg(mul_fq(r, P.x));
+    l.c = sub(mul(r, Q.x), mul(Z3, Q.y));
+    const Fq2 HH = sqr(H), HHH = mul(H, HH), V = mul(T.X, HH);
+    const Fq2 X3 = sub(sub(sqr(r), HHH), dbl2(V));
+    T.Y = sub(mul(r, sub(V, X3)), mul(T.Y, HHH));
+    T.X = X3; T.Z = Z3;
+}
+// f * (a + b w + c w^3): f is read as six Fq2 coefficients g_i of w^i (g_i = (c_i + 9 c_{i+6}) + c_{i+6} u), w^6 = xi = 9 + u
+inline Fq2 mul_xi(const Fq2& a) {                               // (9 + u)(a0 + a1 u)
+    Fq n0 = add(dbl(dbl(dbl(a.c0))), a.c0), n1 = add(dbl(dbl(dbl(a.c1))), a.c1);
+    return {sub(n0, a.c1), add(n1, a.c0)};
+}
+inline Fq12 mul_by_line(const Fq12& f, const AteLine& l) {
+    Fq2 g[6], h[6];
+    for (int i = 0; i < 6; ++i) {
+        const Fq nine = add(dbl(dbl(dbl(f.c[i + 6]))), f.c[i + 6]);
+        g[i] = {add(f.c[i], nine), f.c[i + 6]};
+    }
+    for (int k = 0; k < 6; ++k) {
+        Fq2 t = mul(l.a, g[k]);
+        const Fq2 gb = k >= 1 ? g[k - 1] : mul_xi(g[5]);          // g_{k-1} w^(k-1) * w, wrapping through w^6 = xi
+        const Fq2 gc = k >= 3 ? g[k - 3] : mul_xi(g[k + 3]);
+        t = add(t, mul(l.b, gb));
+        t = add(t, mul(l.c, gc));
+        h[k] = t;
+    }
+    Fq12 r;
+    for (int i = 0; i < 6; ++i) {
+        const Fq nine = add(dbl(dbl(dbl(h[i].c1))), h[i].c1);
+        r.c[i] = sub(h[i].c0, nine);
+        r.c[i + 6] = h[i].c1;
+    }
+    return r;
+}
+inline Fq2 conj(const Fq2& a) { return {a.c0, neg(a.c1)}; }
+inline G2 g2_frobenius(const G2& q) {                           // pi on the twist
+    G2 r; r.inf = q.inf;
+    r.x = mul(conj(q.x), Fq2{TWIST_FROB_X0, TWIST_FROB_X1});
+    r.y = mul(conj(q.y), Fq2{TWIST_FROB_Y0, TWIST_FROB_Y1});
+    return r;
+}
+inline G2 g2_frobenius2_neg(const G2& q) {                      // -pi^2: (x GX2, y)   (pi^2 negates y)
+    G2 r; r.inf = q.inf;
+    r.x = mul_fq(q.x, TWIST_FROB2_X);
+    r.y = q.y;
+    return r;
+}
+struct AteNaf {
+    int8_t d[66]; int len;
+    AteNaf() {
+        unsigned __int128 s = (unsigned __int128)BN_X * 6 + 2;
+        len = 0;
+        while (s) {
+            int z = 0;
+            if (s & 1) { z = 2 - (int)(s & 3); s -= (unsigned __int128)(__int128)z; }
+            d[len++] = (int8_t)z;
+            s >>= 1;
+        }
+    }
+};
+inline const AteNaf& ate_naf() { static const AteNaf n; return n; }
+// product over the pairs of the optimal-ate Miller functions (pairs with an identity point contribute 1)
+inline Fq12 miller_ate_product(const G1* ps, const G2* qs, int count) {
+    struct Pt { G2Jac T; G2 q, nq; G1 p; } pts[4];
+    int m = 0;
+    for (int k = 0; k < count && m < 4; ++k) {
+        if (ps[k].inf || qs[k].inf) continue;
+        pts[m].q = qs[k]; pts[m].nq = g2_neg(qs[k]); pts[m].p = ps[k];
+        pts[m].T.X = qs[k].x; pts[m].T.Y = qs[k].y; pts[m].T.Z = {FQ_ONE, fq_zero()}; pts[m].T.inf = false;
+        ++m;
+    }
+    Fq12 f = fq12_one();
+    if (m == 0) return f;
+    const AteNaf& naf = ate_naf();
+    AteLine l;
+    for (int i = naf.len - 2; i >= 0; --i) {
+        f = sqr(f);
+        for (int k = 0; k < m; ++k) { ate_dbl_step(pts[k].T, pts[k].p, l); f = mul_by_line(f, l); }
+        if (naf.d[i]) for (int k = 0; k < m; ++k) { ate_add_step(pts[k].T, naf.d[i] > 0 ? pts[k].q : pts[k].nq, pts[k].p, l); f = mul_by_line(f, l); }
+    }
+    for (int k = 0; k < m; ++k) {
+        ate_add_step(pts[k].T, g2_frobenius(pts[k].q), pts[k].p, l); f = mul_by_line(f, l);
+        ate_add_step(pts[k].T, g2_frobenius2_neg(pts[k].q), pts[k].p, l); f = mul_by_line(f, l);
+    }
+    return f;
+}
+inline Fq12 pairing_ate(const G1& p, const G2& q) { return final_exponentiation_x(miller_ate_product(&p, &q, 1)); }
+
 // helpers::pairings_verify(a1, a2, b1, b2): e(a1, a2) * e(-b1, b2) == 1   (helpers.rs:392-398)
 inline bool pairings_verify(const G1& a1, const G2& a2, const G1& b1, const G2& b2) {
     G1 ps[2] = {a1, g1_neg(b1)};
     G2 qs[2] = {a2, b2};
-    return fq12_is_one(final_exponentiation_fast(miller_tate_product(ps, qs, 2)));
+    return fq12_is_one(final_exponentiation_x(miller_ate_product(ps, qs, 2)));
+}
+// the same predicate through the Tate construction (self-check builds compare the two)
+inline bool pairings_verify_tate(const G1& a1, const G2& a2, const G1& b1, const G2& b2) {
+    G1 ps[2] = {a1, g1_neg(b1)};
+    G2 qs[2] = {a2, b2};
+    return fq12_is_one(final_exponentiation_x(miller_tate_product(ps, qs, 2)));
 }
 // the straightforward construction (affine Miller loops, generic final exponentiation), kept as the cross-check of the fast path
 inline bool pairings_verify_reference(const G1& a1, const G2& a2, const G1& b1, const G2& b2) {

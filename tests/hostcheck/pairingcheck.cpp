@@ -38,12 +38,26 @@ int main() {
         Fq12 fast = final_exponentiation_fast(miller_tate_product(one_p, one_q, 1));
         printf("fast_equals_literal %d\n", (int)fq12_eq(fast, pairing(pa, qb)));
         printf("final_exp_fast_equals_generic %d\n", (int)fq12_eq(final_exponentiation_fast(miller_tate(pa, qb)), final_exponentiation(miller_tate(pa, qb))));
+        printf("final_exp_x_equals_straus %d\n", (int)fq12_eq(final_exponentiation_x(miller_tate(pa, qb)), final_exponentiation_fast(miller_tate(pa, qb))));
+        printf("fq12_sqr_equals_mul %d\n", (int)(fq12_eq(sqr(e), mul(e, e)) && fq12_eq(sqr(miller_tate(pa, qb)), mul(miller_tate(pa, qb), miller_tate(pa, qb)))));
         Fq12 fi; bool okinv = fq12_inverse(e, fi);
         printf("fq12_inverse %d\n", (int)(okinv && fq12_is_one(mul(e, fi))));
         printf("frobenius %d\n", (int)fq12_eq(frobenius(e, 1), fq12_pow(e, FQ_MODULUS_WORDS, 4)));
         printf("frobenius3 %d\n", (int)fq12_eq(frobenius(e, 3), frobenius(frobenius(frobenius(e, 1), 1), 1)));
         printf("reference_verify_true %d\n", (int)pairings_verify_reference(pa, qb, pb, qa));
         printf("reference_verify_false %d\n", (int)!pairings_verify_reference(pa, qb, pb, h));
+        // optimal ate construction: a pairing of its own (different value from the Tate one), so its properties are checked directly
+        {
+            Fq12 ea = pairing_ate(g, h);
+            printf("ate_nondegenerate %d\n", (int)!fq12_is_one(ea));
+            printf("ate_order_r %d\n", (int)fq12_is_one(fq12_pow(ea, r, 4)));
+            printf("ate_bilinear %d\n", (int)fq12_eq(pairing_ate(pa, qb), fq12_pow(fq12_pow(ea, a, 4), b, 4)));
+            printf("ate_bilinear_left %d\n", (int)fq12_eq(pairing_ate(pa, h), fq12_pow(ea, a, 4)));
+            printf("ate_bilinear_right %d\n", (int)fq12_eq(pairing_ate(g, qb), fq12_pow(ea, b, 4)));
+            printf("ate_frobenius_is_p %d\n", (int)(eq(g2_frobenius(h).x, g2_mul(h, FQ_MODULUS_WORDS).x) && eq(g2_frobenius(h).y, g2_mul(h, FQ_MODULUS_WORDS).y)));
+            printf("tate_verify_true %d\n", (int)pairings_verify_tate(pa, qb, pb, qa));
+            printf("tate_verify_false %d\n", (int)!pairings_verify_tate(pa, qb, pb, h));
+        }
         auto t2 = std::chrono::steady_clock::now();
         bool okv = pairings_verify(pa, qb, pb, qa);
         auto t3 = std::chrono::steady_clock::now();
