@@ -149,11 +149,18 @@ int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* 
 }
 
 // ---- SRS ------------------------------------------------------------------------------------------
-static int32_t upload_points(kzg_ctx* ctx, const uint64_t* xy, size_t n, uint4* d_out, DeviceBuffer& staging) {
-    KZG_HIP_TRY(ctx, staging.reserve(n * 64));
+// off_curve != nullptr: the points are also validated on the device (y^2 == x^3 + 3 or identity); *off_curve = 1 if one fails
+static int32_t upload_points(kzg_ctx* ctx, const uint64_t* xy, size_t n, uint4* d_out, DeviceBuffer& staging, uint32_t* off_curve = nullptr) {
+    KZG_HIP_TRY(ctx, staging.reserve(n * 64 + 64));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(staging.p, xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
-    int32_t rc = points_wire_to_device(ctx, staging.as<uint4>(), d_out, n);
+    uint32_t* d_flag = nullptr;
+    if (off_curve) {
+        d_flag = reinterpret_cast<uint32_t*>(static_cast<char*>(staging.p) + n * 64);
+        KZG_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+    }
+    int32_t rc = points_wire_to_device(ctx, staging.as<uint4>(), d_out, n, d_flag);
     if (rc != KZG_OK) return rc;
+    if (off_curve) KZG_HIP_TRY(ctx, hipMemcpyAsync(off_curve, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KZG_OK;
 }
@@ -326,24 +333,30 @@ int32_t kzg_msm_g1(kzg_ctx* ctx, const uint64_t* bases_xy_mont, size_t n_bases, 
     return msm_run(ctx, b, d_scalars, n_bases, out_xy_mont, out_is_infinity, nullptr);
 }
 
-int32_t kzg_msm_g1_batch(kzg_ctx* ctx, const uint64_t* bases_xy_mont, const uint64_t* scalars_mont, size_t n, size_t batch,
-                         uint64_t* out_xy_mont, uint8_t* out_is_infinity) {
+static int32_t msm_g1_batch_impl(kzg_ctx* ctx, const uint64_t* bases_xy_mont, const uint64_t* scalars_mont, size_t n, size_t batch,
+                                 uint64_t* out_xy_mont, uint8_t* out_is_infinity, uint32_t* off_curve) {
     if (!ctx || !out_xy_mont || batch == 0 || batch > 64) return KZG_ERR_INVALID_ARG;
     if (n && (!bases_xy_mont || !scalars_mont)) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (off_curve) *off_curve = 0;
     if (n == 0) {
         for (size_t i = 0; i < batch; ++i) write_identity(out_xy_mont + 8 * i, out_is_infinity ? out_is_infinity + i : nullptr, nullptr);
         return KZG_OK;
     }
     const size_t total = n * batch;
     KZG_HIP_TRY(ctx, ctx->msm.bases.reserve(total * 64));
-    int32_t rc = upload_points(ctx, bases_xy_mont, total, ctx->msm.bases.as<uint4>(), ctx->msm.bases_wire);
+    int32_t rc = upload_points(ctx, bases_xy_mont, total, ctx->msm.bases.as<uint4>(), ctx->msm.bases_wire, off_curve);
     if (rc != KZG_OK) return rc;
+    if (off_curve && *off_curve) return KZG_OK;              // the caller reports the invalid point; no MSM over it
     const void* d_scalars;
     rc = stage_scalars(ctx, scalars_mont, total, &d_scalars);
     if (rc != KZG_OK) return rc;
     return msm_run_batch(ctx, ctx->msm.bases.as<uint4>(), d_scalars, n, (uint32_t)batch, out_xy_mont, out_is_infinity);
+}
+int32_t kzg_msm_g1_batch(kzg_ctx* ctx, const uint64_t* bases_xy_mont, const uint64_t* scalars_mont, size_t n, size_t batch,
+                         uint64_t* out_xy_mont, uint8_t* out_is_infinity) {
+    return msm_g1_batch_impl(ctx, bases_xy_mont, scalars_mont, n, batch, out_xy_mont, out_is_infinity, nullptr);
 }
 
 static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
@@ -484,11 +497,11 @@ int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_
     if (!ctx || !out_ok) return KZG_ERR_INVALID_ARG;
     if (n && (!commitments_xy_mont || !zs_mont || !ys_mont || !proofs_xy_mont || !r_powers_mont)) return KZG_ERR_INVALID_ARG;
     using namespace kzg_host;
-    for (size_t i = 0; i < n; ++i)                                                         // batch.rs:203-210
-        if (!g1_on_curve(g1_from_wire(commitments_xy_mont + 8 * i)) || !g1_on_curve(g1_from_wire(proofs_xy_mont + 8 * i)))
-            return KZG_ERR_G1_NOT_ON_CURVE;
+    // batch.rs:203-210 (every commitment and proof on the curve) is checked on the GPU, on the points the MSM uploads anyway
+    // (k_points_wire_to_device_checked: 2n curve equations cost the host 0.5 ms at n = 4096); the error order of the reference is
+    // kept: a point off the curve is reported before a bad g2_tau (batch.rs:214-216).
     G2 g2_tau;
-    if (!load_g2_tau(g2_tau_mont, &g2_tau)) return KZG_ERR_G2_TAU_NOT_ON_CURVE;            // batch.rs:214-216
+    const bool g2_ok = load_g2_tau(g2_tau_mont, &g2_tau);
     // scalars of the three linear combinations (batch.rs:228, :245, :246).  sum_i r^i (C_i - [y_i]G) is evaluated as
     // sum_i r^i C_i - [sum_i r^i y_i] G: the same group element with one fixed-base product instead of n.
     std::vector<uint64_t> bases(3 * n * 8), scalars(3 * n * 4);
@@ -508,8 +521,11 @@ int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_
     }
     uint64_t sums[3 * 8];
     uint8_t infs[3];
-    int32_t rc = kzg_msm_g1_batch(ctx, bases.data(), scalars.data(), n, 3, sums, infs);
+    uint32_t off_curve = 0;
+    int32_t rc = msm_g1_batch_impl(ctx, bases.data(), scalars.data(), n, 3, sums, infs, &off_curve);
     if (rc != KZG_OK) return rc;
+    if (off_curve) return KZG_ERR_G1_NOT_ON_CURVE;
+    if (!g2_ok) return KZG_ERR_G2_TAU_NOT_ON_CURVE;
     G1 proof_lincomb = g1_from_wire(sums), proof_z_lincomb = g1_from_wire(sums + 8), c_lincomb = g1_from_wire(sums + 16);
     uint64_t s_int[4];
     fr_wire_to_canonical(s, s_int);

@@ -143,7 +143,8 @@ int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars
 int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs);
 
 // wire affine points (device memory) -> device affine format (curve.h), asynchronous on ctx->stream
-int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, size_t n);
+// d_off_curve_flag != nullptr: also check y^2 == x^3 + 3 of every non-identity point, *flag |= 1 on a violation (device word, zeroed by the caller)
+int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, size_t n, uint32_t* d_off_curve_flag = nullptr);
 
 // Two-level twiddle table of one domain: w^t (t < lo_len) and w^(t * lo_len) (t < hi_len), 9 limb planes each,
 // internal Montgomery form.  Cached per (device, log n, direction).

@@ -491,9 +491,10 @@ void msm_drop_slots(kzg_ctx* ctx) {
     for (int s = 0; s < KZG_NUM_SLOTS; ++s) { delete ctx->slot_pending[s]; ctx->slot_pending[s] = nullptr; }
 }
 
-int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, size_t n) {
+int32_t points_wire_to_device(kzg_ctx* ctx, const uint4* d_wire, uint4* d_out, size_t n, uint32_t* d_off_curve_flag) {
     if (n == 0) return KZG_OK;
-    hipLaunchKernelGGL(k_points_wire_to_device, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_wire, d_out, n);
+    if (d_off_curve_flag) hipLaunchKernelGGL(k_points_wire_to_device_checked, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_wire, d_out, n, d_off_curve_flag);
+    else hipLaunchKernelGGL(k_points_wire_to_device, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_wire, d_out, n);
     KZG_HIP_TRY(ctx, hipGetLastError());
     return KZG_OK;
 }

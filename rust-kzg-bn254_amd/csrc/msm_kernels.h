@@ -1047,4 +1047,37 @@ k_points_wire_to_device(const uint4* __restrict__ in, uint4* __restrict__ out, s
     out[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
 }
 
+// the same conversion with the curve check y^2 == x^3 + 3 of every point that is not the identity (batch verification validates its
+// 2n inputs, verifier/src/batch.rs:203-210: done here on the points the MSM uploads anyway); *flag |= 1 for a point off the curve
+__global__ void __launch_bounds__(256)
+k_points_wire_to_device_checked(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, uint32_t* __restrict__ flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 a = in[4 * i], b = in[4 * i + 1], c = in[4 * i + 2], d = in[4 * i + 3];
+    uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t o[16];
+    affine_wire_to_device(o, w);
+    out[4 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+    out[4 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    out[4 * i + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+    out[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) any |= o[j];
+    if (any == 0) return;                                     // identity
+    Fq x, y, t, y2, b3;
+    fe_unpack(x, o);
+    fe_unpack(y, o + 8);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) b3.l[j] = (int32_t)FqParams::B3[j];
+    fe_sqr(t, x);
+    fe_mul(t, t, x);
+    fe_add(t, t, b3);
+    fe_norm(t);                                               // x^3 + 3, |.| < 4m
+    fe_sqr(y2, y);
+    fe_sub(t, y2, t);
+    fe_reduce(t);
+    if (!fe_is_zero_mod(t)) atomicOr(flag, 1u);
+}
+
 }  // namespace kzg
