@@ -497,11 +497,53 @@ inline Fq12 final_exponentiation_fast(const Fq12& f) {
 // "On the final exponentiation for calculating pairings on ordinary elliptic curves", 2009): three exponentiations by the 63-bit x
 // (62 squarings + 27 multiplications each) and a 13-step vector addition chain, instead of 254 squarings + ~240 multiplications.
 // After the easy part g lies in the cyclotomic subgroup, where the inverse is the conjugation w -> -w.
+inline Fq2 mul_xi(const Fq2& a) {                               // (9 + u)(a0 + a1 u)
+    Fq n0 = add(dbl(dbl(dbl(a.c0))), a.c0), n1 = add(dbl(dbl(dbl(a.c1))), a.c1);
+    return {sub(n0, a.c1), add(n1, a.c0)};
+}
+// Squaring in the cyclotomic subgroup (where the easy part of the final exponentiation lands): Granger-Scott, "Faster squaring in
+// the cyclotomic subgroup of sixth degree extensions" -- three squarings in Fq4 = Fq2[s]/(s^2 - xi), i.e. nine Fq2 squarings = 18
+// multiplications in Fq instead of 63.  The element is read as six Fq2 coefficients g_i of w^i (as in mul_by_line); in the tower
+// Fq12 = Fq6[w]/(w^2 - v), Fq6 = Fq2[v]/(v^3 - xi), v = w^2 they are c0 = (g0, g2, g4), c1 = (g1, g3, g5).
+inline void fq4_sqr(const Fq2& a, const Fq2& b, Fq2& c0, Fq2& c1) {       // (a + b s)^2 = (a^2 + xi b^2) + 2ab s
+    const Fq2 t0 = sqr(a), t1 = sqr(b);
+    c0 = add(mul_xi(t1), t0);
+    c1 = sub(sub(sqr(add(a, b)), t0), t1);
+}
+inline Fq12 cyclotomic_sqr(const Fq12& f) {
+    Fq2 g[6];
+    for (int i = 0; i < 6; ++i) {
+        const Fq nine = add(dbl(dbl(dbl(f.c[i + 6]))), f.c[i + 6]);
+        g[i] = {add(f.c[i], nine), f.c[i + 6]};
+    }
+    // z0 = c0.c0 = g0, z4 = c0.c1 = g2, z3 = c0.c2 = g4, z2 = c1.c0 = g1, z1 = c1.c1 = g3, z5 = c1.c2 = g5
+    const Fq2 z0 = g[0], z4 = g[2], z3 = g[4], z2 = g[1], z1 = g[3], z5 = g[5];
+    Fq2 t0, t1, t2, t3, t4, t5;
+    fq4_sqr(z0, z1, t0, t1);
+    fq4_sqr(z2, z3, t2, t3);
+    fq4_sqr(z4, z5, t4, t5);
+    auto three_minus_two = [](const Fq2& t, const Fq2& z) { return add(dbl2(sub(t, z)), t); };      // 3t - 2z
+    auto three_plus_two = [](const Fq2& t, const Fq2& z) { return add(dbl2(add(t, z)), t); };        // 3t + 2z
+    Fq2 h[6];
+    h[0] = three_minus_two(t0, z0);                // z0
+    h[3] = three_plus_two(t1, z1);                 // z1
+    h[1] = three_plus_two(mul_xi(t5), z2);         // z2
+    h[4] = three_minus_two(t4, z3);                // z3
+    h[2] = three_minus_two(t2, z4);                // z4
+    h[5] = three_plus_two(t3, z5);                 // z5
+    Fq12 r;
+    for (int i = 0; i < 6; ++i) {
+        const Fq nine = add(dbl(dbl(dbl(h[i].c1))), h[i].c1);
+        r.c[i] = sub(h[i].c0, nine);
+        r.c[i + 6] = h[i].c1;
+    }
+    return r;
+}
 static const uint64_t BN_X = 0x44e992b44a6909f1ULL;
 inline Fq12 fq12_pow_x(const Fq12& a) {
     Fq12 acc = a;
-    for (int i = 61; i >= 0; --i) {                            // bit 62 is the top bit of x
-        acc = sqr(acc);
+    for (int i = 61; i >= 0; --i) {                            // bit 62 is the top bit of x; `a` is in the cyclotomic subgroup
+        acc = cyclotomic_sqr(acc);
         if ((BN_X >> i) & 1) acc = mul(acc, a);
     }
     return acc;
@@ -574,10 +616,6 @@ inline void ate_add_step(G2Jac& T, const G2& Q, const G1& P, AteLine& l) {
     T.X = X3; T.Z = Z3;
 }
 // f * (a + b w + c w^3): f is read as six Fq2 coefficients g_i of w^i (g_i = (c_i + 9 c_{i+6}) + c_{i+6} u), w^6 = xi = 9 + u
-inline Fq2 mul_xi(const Fq2& a) {                               // (9 + u)(a0 + a1 u)
-    Fq n0 = add(dbl(dbl(dbl(a.c0))), a.c0), n1 = add(dbl(dbl(dbl(a.c1))), a.c1);
-    return {sub(n0, a.c1), add(n1, a.c0)};
-}
 inline Fq12 mul_by_line(const Fq12& f, const AteLine& l) {
     Fq2 g[6], h[6];
     for (int i = 0; i < 6; ++i) {

@@ -40,6 +40,10 @@ int main() {
         printf("final_exp_fast_equals_generic %d\n", (int)fq12_eq(final_exponentiation_fast(miller_tate(pa, qb)), final_exponentiation(miller_tate(pa, qb))));
         printf("final_exp_x_equals_straus %d\n", (int)fq12_eq(final_exponentiation_x(miller_tate(pa, qb)), final_exponentiation_fast(miller_tate(pa, qb))));
         printf("fq12_sqr_equals_mul %d\n", (int)(fq12_eq(sqr(e), mul(e, e)) && fq12_eq(sqr(miller_tate(pa, qb)), mul(miller_tate(pa, qb), miller_tate(pa, qb)))));
+        {   // cyclotomic squaring == squaring on elements of the cyclotomic subgroup (pairing values are such elements)
+            Fq12 c = fq12_pow(e, a, 4);
+            printf("cyclotomic_sqr %d\n", (int)(fq12_eq(cyclotomic_sqr(e), sqr(e)) && fq12_eq(cyclotomic_sqr(c), sqr(c))));
+        }
         Fq12 fi; bool okinv = fq12_inverse(e, fi);
         printf("fq12_inverse %d\n", (int)(okinv && fq12_is_one(mul(e, fi))));
         printf("frobenius %d\n", (int)fq12_eq(frobenius(e, 1), fq12_pow(e, FQ_MODULUS_WORDS, 4)));
