@@ -45,21 +45,122 @@ __device__ __forceinline__ void fe_inverse_fermat(Fe<F>& out, const Fe<F>& a) {
     out = acc;
 }
 
-// r = [k] * p, k canonical 256-bit words (MSB-first double-and-add from the top set bit)
-__device__ __forceinline__ void xyzz_scalar_mul(Xyzz& r, const Xyzz& p, const uint32_t k[8]) {
+// ---- GLV: k P = k1 P + k2 phi(P), phi(x, y) = (beta x, y) = [lambda] P on BN254 G1, |k1|, |k2| < 2^127 ---------------------------
+// beta, lambda: the cube roots of unity of Fq / Fr with phi(G) = [lambda] G (checked with big integers: tools note in DESIGN.md 9);
+// lattice basis of {(x, y): x + y lambda = 0 mod r} from the extended Euclid on (r, lambda):
+//   (a1, b1) = (9931322734385697763, -147946756881789319000765030803803410728), (a2, b2) = (147946756881789319010696353538189108491, a1),
+// a1 b2 - a2 b1 = r.  c1 = floor(k g1 / 2^256), c2 = floor(k g2 / 2^256) with g1 = round(2^256 b2 / r), g2 = round(2^256 (-b1) / r);
+// k1 = k - c1 a1 - c2 a2, k2 = c1 |b1| - c2 b2  (2 10^5 random k and the edge values: both below 2^127 in magnitude).
+// Little-endian 32-bit words.
+__device__ const uint32_t GLV_G1[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x00000002u};
+__device__ const uint32_t GLV_G2[5] = {0x391eb18eu, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x00000002u};
+__device__ const uint32_t GLV_A1[2] = {0x94d213e3u, 0x89d32568u};                                   // = b2
+__device__ const uint32_t GLV_B1M[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u};        // -b1
+__device__ const uint32_t GLV_A2[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+__device__ const uint32_t GLV_BETA[8] = {0x77fffffeu, 0x57634731u, 0xacdb5c4fu, 0xd4f263f1u, 0xa0d48bacu, 0x59e26bceu, 0u, 0u};   // plain integer
+
+// out[0 .. na+nb) = a * b (schoolbook, 32-bit words)
+template <int NA, int NB>
+__device__ __forceinline__ void glv_mul_words(uint32_t* out, const uint32_t* a, const uint32_t* b) {
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) out[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+            out[i + j] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        out[i + NB] = (uint32_t)carry;
+    }
+}
+// 256-bit two's complement helpers
+__device__ __forceinline__ void glv_sub8(uint32_t* r, const uint32_t* a, const uint32_t* b, int nb) {   // r = a - b (b has nb <= 8 words)
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t bi = i < nb ? b[i] : 0u;
+        const uint64_t t = (uint64_t)a[i] - bi - borrow;
+        r[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1u;
+    }
+}
+__device__ __forceinline__ uint32_t glv_abs8(uint32_t* v) {                                             // v = |v|, returns the sign
+    const uint32_t neg = v[7] >> 31;
+    if (neg) {
+        uint64_t carry = 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const uint64_t t = (uint64_t)(~v[i]) + carry; v[i] = (uint32_t)t; carry = t >> 32; }
+    }
+    return neg;
+}
+// k (canonical, < r) -> kk[0..3] = |k1|, kk[4..7] = |k2|, their signs in bit 31 of kk[3] / kk[7]
+__device__ __forceinline__ void glv_decompose(uint32_t kk[8], const uint32_t k[8]) {
+    uint32_t p1[11], p2[13];
+    glv_mul_words<8, 3>(p1, k, GLV_G1);
+    glv_mul_words<8, 5>(p2, k, GLV_G2);
+    const uint32_t c1[2] = {p1[8], p1[9]};                          // < 2^64  (p1[10] = 0: k g1 < 2^320)
+    const uint32_t c2[4] = {p2[8], p2[9], p2[10], p2[11]};          // < 2^128 (p2[12] = 0)
+    uint32_t t1[4], t2[8], t3[6], t4[6];
+    glv_mul_words<2, 2>(t1, c1, GLV_A1);
+    glv_mul_words<4, 4>(t2, c2, GLV_A2);
+    glv_mul_words<2, 4>(t3, c1, GLV_B1M);
+    glv_mul_words<4, 2>(t4, c2, GLV_A1);
+    uint32_t k1[8], k2[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    glv_sub8(k1, k, t1, 4);
+    glv_sub8(k1, k1, t2, 8);
+    uint32_t t3w[8] = {t3[0], t3[1], t3[2], t3[3], t3[4], t3[5], 0, 0};
+    (void)z;
+    glv_sub8(k2, t3w, t4, 6);
+    const uint32_t s1 = glv_abs8(k1), s2 = glv_abs8(k2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { kk[i] = k1[i]; kk[4 + i] = k2[i]; }
+    kk[3] |= s1 << 31;
+    kk[7] |= s2 << 31;
+}
+
+// r = [k] * p with k given as its GLV halves (glv_decompose): 127 doublings, each followed by ONE addition of +-P, +-phi(P) or their
+// sum selected per lane (a wave executes the addition whenever any of its lanes has a bit set, i.e. always: the plain
+// double-and-add paid 254 doublings AND 254 additions per wave)
+__device__ __forceinline__ void xyzz_scalar_mul(Xyzz& r, const Xyzz& p, const uint32_t kk[8]) {
+    if (p.inf) { xyzz_set_inf(r); return; }
+    const uint32_t s1 = kk[3] >> 31, s2 = kk[7] >> 31;
+    Fq beta, kin, bx, y1, y2;
+    {
+        uint32_t bw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bw[j] = GLV_BETA[j];
+        fe_unpack(beta, bw);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) kin.l[j] = (int32_t)FqParams::K_PLAIN_IN[j];
+        fe_mul(beta, beta, kin);                                   // plain integer -> internal form
+    }
+    fe_mul(bx, p.x, beta);
+    fe_cneg(y1, p.y, s1);
+    fe_cneg(y2, p.y, s2);
+    Xyzz P1 = p, P2 = p, S;
+    P1.y = y1;
+    P2.x = bx; P2.y = y2;
+    xyzz_add<true>(S, P1, P2);
     Xyzz acc;
     xyzz_set_inf(acc);
-    for (int w = 7; w >= 0; --w) {
-        const uint32_t bits = k[w];
-        for (int b = 31; b >= 0; --b) {
-            Xyzz t;
-            xyzz_dbl_impl(t, acc);
-            acc = t;
-            if ((bits >> b) & 1u) {
-                xyzz_add<true>(t, acc, p);
-                acc = t;
-            }
-        }
+#pragma unroll 1
+    for (int i = 126; i >= 0; --i) {
+        Xyzz t;
+        xyzz_dbl_impl(t, acc);
+        acc = t;
+        const uint32_t b1 = (kk[i >> 5] >> (i & 31)) & 1u, b2 = (kk[4 + (i >> 5)] >> (i & 31)) & 1u;
+        Xyzz op;
+        const bool both = b1 & b2;
+        fe_select(op.x, both, S.x, b1 ? P1.x : P2.x);
+        fe_select(op.y, both, S.y, b1 ? P1.y : P2.y);
+        fe_select(op.zz, both, S.zz, p.zz);
+        fe_select(op.zzz, both, S.zzz, p.zzz);
+        op.inf = both ? S.inf : !(b1 | b2);
+        xyzz_add<true>(t, acc, op);
+        acc = t;
     }
     r = acc;
 }
@@ -76,7 +177,7 @@ __device__ __forceinline__ void tw_load(Fr& w, const NttTables& tb, uint32_t E) 
     }
 }
 
-// scal[e] = canonical integer of w^-e (plain = 1) or of w^-e / n (plain = 0), e < n: the scalars of every stage
+// scal[e] = the GLV halves (glv_decompose) of the canonical integer of w^-e, or of w^-e / n (scaled != 0), e < n: the scalars of every stage
 __global__ void __launch_bounds__(256)
 k_g1fft_scalars(uint4* __restrict__ scal, uint32_t n, int log_n, NttTables tb_inv, int scaled) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,8 +195,9 @@ k_g1fft_scalars(uint4* __restrict__ scal, uint32_t n, int log_n, NttTables tb_in
     one_plain.l[0] = 1;
     fe_mul(c, w, one_plain);                       // internal Montgomery form -> plain integer
     fe_canon(c);
-    uint32_t k[8];
-    fe_pack(k, c);
+    uint32_t kc[8], k[8];
+    fe_pack(kc, c);
+    glv_decompose(k, kc);
     scal[2 * (size_t)e] = make_uint4(k[0], k[1], k[2], k[3]);
     scal[2 * (size_t)e + 1] = make_uint4(k[4], k[5], k[6], k[7]);
 }
