@@ -46,6 +46,11 @@ int main() {
         }
         Fq12 fi; bool okinv = fq12_inverse(e, fi);
         printf("fq12_inverse %d\n", (int)(okinv && fq12_is_one(mul(e, fi))));
+        {
+            Fq12 m = miller_tate(pa, qb), i1, i2;               // a generic element (not in any subgroup)
+            const bool ok1 = fq12_inverse(m, i1), ok2 = fq12_inverse_norm(m, i2);
+            printf("fq12_inverse_norm %d\n", (int)(ok1 && ok2 && fq12_eq(i1, i2) && fq12_is_one(mul(m, i2))));
+        }
         printf("frobenius %d\n", (int)fq12_eq(frobenius(e, 1), fq12_pow(e, FQ_MODULUS_WORDS, 4)));
         printf("frobenius3 %d\n", (int)fq12_eq(frobenius(e, 3), frobenius(frobenius(frobenius(e, 1), 1), 1)));
         printf("reference_verify_true %d\n", (int)pairings_verify_reference(pa, qb, pb, qa));
