@@ -456,7 +456,7 @@ int32_t kzg_g2_mul_generator(const uint64_t scalar_mont[4], uint64_t out_g2_mont
     if (!scalar_mont || !out_g2_mont) return KZG_ERR_INVALID_ARG;
     uint64_t k[4];
     kzg_host::fr_wire_to_canonical(scalar_mont, k);
-    kzg_host::g2_to_wire(kzg_host::g2_mul(kzg_host::g2_generator(), k), out_g2_mont);
+    kzg_host::g2_to_wire(kzg_host::g2_mul_generator(k), out_g2_mont);
     return KZG_OK;
 }
 
@@ -483,9 +483,8 @@ int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t pr
     uint64_t y[4], z[4];
     fr_wire_to_canonical(value_mont, y);
     fr_wire_to_canonical(z_mont, z);
-    G1 gen; gen.x = FQ_ONE; gen.y = FQ_TWO; gen.inf = false;
-    G1 commit_minus_value = g1_add(commitment, g1_neg(g1_mul(gen, y)));                    // verify.rs:37-42
-    G2 x_minus_z = g2_add(g2_tau, g2_neg(g2_mul(g2_generator(), z)));                      // verify.rs:46-51
+    G1 commit_minus_value = g1_add(commitment, g1_neg(g1_mul_generator(y)));               // verify.rs:37-42 (fixed-base tables)
+    G2 x_minus_z = g2_add(g2_tau, g2_neg(g2_mul_generator(z)));                            // verify.rs:46-51
     if (x_minus_z.inf) return KZG_ERR_TAU_EQUALS_Z;                                        // verify.rs:56-60
     *out_ok = pairings_verify(commit_minus_value, g2_generator(), proof, x_minus_z) ? 1 : 0;   // verify.rs:66-71
     return KZG_OK;
@@ -529,8 +528,7 @@ int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_
     G1 proof_lincomb = g1_from_wire(sums), proof_z_lincomb = g1_from_wire(sums + 8), c_lincomb = g1_from_wire(sums + 16);
     uint64_t s_int[4];
     fr_wire_to_canonical(s, s_int);
-    G1 gen; gen.x = FQ_ONE; gen.y = FQ_TWO; gen.inf = false;
-    G1 rhs = g1_add(g1_add(c_lincomb, g1_neg(g1_mul(gen, s_int))), proof_z_lincomb);       // batch.rs:249
+    G1 rhs = g1_add(g1_add(c_lincomb, g1_neg(g1_mul_generator(s_int))), proof_z_lincomb);   // batch.rs:249
     *out_ok = pairings_verify(proof_lincomb, g2_tau, rhs, g2_generator()) ? 1 : 0;         // batch.rs:253-254
     return KZG_OK;
 }

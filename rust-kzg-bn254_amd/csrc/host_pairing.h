@@ -203,6 +203,100 @@ inline G2 g2_mul(const G2& p, const uint64_t k[4]) {
     return r;
 }
 
+// ---- fixed-base multiplication of the two generators (verify.rs:37-51: [y] G1 and [z] G2 in every verification) --------------------
+// 64 windows of 4 bits: k G = sum_w T_w[d_w], T_w[d] = d 2^(4w) G as affine points, so a multiplication is at most 64 mixed additions
+// and no doubling (a 254-step double-and-add was 0.25 ms for G2, a fifth of verify_proof).  Tables are built on first use:
+// Jacobian / XYZZ sums, normalised with ONE inversion each (Montgomery's trick).
+struct FixedBaseTables {
+    G1 g1[64][15];
+    G2 g2[64][15];
+    FixedBaseTables() {
+        // G1
+        {
+            static Xyzz pts[64 * 15];
+            Xyzz base; base.x = FQ_ONE; base.y = FQ_TWO; base.zz = FQ_ONE; base.zzz = FQ_ONE;
+            for (int w = 0; w < 64; ++w) {
+                Xyzz acc = base;
+                for (int d = 0; d < 15; ++d) { pts[w * 15 + d] = acc; acc = xyzz_add(acc, base); }
+                base = acc;                                          // 16 * base
+            }
+            // batch inversion of zz * zzz: 1/zz = zzz * inv, 1/zzz = zz * inv  (all points are finite: d 2^(4w) < r)
+            static Fq pre[64 * 15];
+            Fq run = FQ_ONE;
+            for (int i = 0; i < 64 * 15; ++i) { pre[i] = run; run = mul(run, mul(pts[i].zz, pts[i].zzz)); }
+            Fq iv = inv(run);
+            for (int i = 64 * 15 - 1; i >= 0; --i) {
+                const Fq zi = mul(iv, pre[i]);                       // 1 / (zz zzz)
+                iv = mul(iv, mul(pts[i].zz, pts[i].zzz));
+                G1& o = g1[i / 15][i % 15];
+                o.x = mul(pts[i].x, mul(zi, pts[i].zzz));
+                o.y = mul(pts[i].y, mul(zi, pts[i].zz));
+                o.inf = false;
+            }
+        }
+        // G2
+        {
+            static G2Jac pts[64 * 15];
+            const G2 gen = g2_generator();
+            G2Jac base; base.X = gen.x; base.Y = gen.y; base.Z = {FQ_ONE, fq_zero()}; base.inf = false;
+            for (int w = 0; w < 64; ++w) {
+                // affine copy of the window base for the mixed additions below
+                const Fq2 zi = inv(base.Z), zi2 = sqr(zi);
+                G2 b; b.inf = false; b.x = mul(base.X, zi2); b.y = mul(base.Y, mul(zi2, zi));
+                G2Jac acc; acc.X = b.x; acc.Y = b.y; acc.Z = {FQ_ONE, fq_zero()}; acc.inf = false;
+                for (int d = 0; d < 15; ++d) { pts[w * 15 + d] = acc; acc = g2j_madd(acc, b); }
+                base = acc;
+            }
+            static Fq2 pre[64 * 15];
+            Fq2 run = {FQ_ONE, fq_zero()};
+            for (int i = 0; i < 64 * 15; ++i) { pre[i] = run; run = mul(run, pts[i].Z); }
+            Fq2 iv = inv(run);
+            for (int i = 64 * 15 - 1; i >= 0; --i) {
+                const Fq2 zi = mul(iv, pre[i]), zi2 = sqr(zi);
+                iv = mul(iv, pts[i].Z);
+                G2& o = g2[i / 15][i % 15];
+                o.x = mul(pts[i].X, zi2);
+                o.y = mul(pts[i].Y, mul(zi2, zi));
+                o.inf = false;
+            }
+        }
+    }
+};
+inline const FixedBaseTables& fixed_base_tables() { static const FixedBaseTables t; return t; }
+// k in canonical integer words, any value below 2^256 (the windows cover 256 bits; multiples of r come out as the identity through the group law)
+inline G1 g1_mul_generator(const uint64_t k[4]) {
+    const FixedBaseTables& t = fixed_base_tables();
+    Xyzz acc = xyzz_inf();
+    for (int w = 0; w < 64; ++w) {
+        const int d = (int)((k[w >> 4] >> ((w & 15) * 4)) & 15);
+        if (!d) continue;
+        const G1& p = t.g1[w][d - 1];
+        Xyzz q; q.x = p.x; q.y = p.y; q.zz = FQ_ONE; q.zzz = FQ_ONE;
+        acc = xyzz_add(acc, q);
+    }
+    G1 out; out.x = fq_zero(); out.y = fq_zero(); out.inf = true;
+    if (is_inf(acc)) return out;
+    const Fq iz = inv(mul(acc.zz, acc.zzz));
+    out.x = mul(acc.x, mul(iz, acc.zzz));
+    out.y = mul(acc.y, mul(iz, acc.zz));
+    out.inf = false;
+    return out;
+}
+inline G2 g2_mul_generator(const uint64_t k[4]) {
+    const FixedBaseTables& t = fixed_base_tables();
+    G2Jac acc; acc.inf = true; acc.X = {fq_zero(), fq_zero()}; acc.Y = acc.X; acc.Z = acc.X;
+    for (int w = 0; w < 64; ++w) {
+        const int d = (int)((k[w >> 4] >> ((w & 15) * 4)) & 15);
+        if (d) acc = g2j_madd(acc, t.g2[w][d - 1]);
+    }
+    if (acc.inf) return g2_inf();
+    const Fq2 zi = inv(acc.Z), zi2 = sqr(zi);
+    G2 r; r.inf = false;
+    r.x = mul(acc.X, zi2);
+    r.y = mul(acc.Y, mul(zi2, zi));
+    return r;
+}
+
 // ---- Fq12 = Fq[w] / (w^12 - 18 w^6 + 82) ----------------------------------------------------------------------------------------
 struct Fq12 { Fq c[12]; };
 inline Fq12 fq12_one() { Fq12 r; memset(&r, 0, sizeof r); r.c[0] = FQ_ONE; return r; }

@@ -44,6 +44,20 @@ int main() {
             Fq12 c = fq12_pow(e, a, 4);
             printf("cyclotomic_sqr %d\n", (int)(fq12_eq(cyclotomic_sqr(e), sqr(e)) && fq12_eq(cyclotomic_sqr(c), sqr(c))));
         }
+        {   // fixed-base tables against the generic double-and-add, incl. 0, 1, r - 1, r and a full-width value
+            uint64_t zero[4] = {0, 0, 0, 0}, one[4] = {1, 0, 0, 0}, rm1[4], full[4] = {~0ULL, ~0ULL, ~0ULL, ~0ULL};
+            memcpy(rm1, r, 32); rm1[0] -= 1;
+            const uint64_t* ks[6] = {zero, one, rm1, r, a, full};
+            bool ok1 = true, ok2 = true;
+            for (int i = 0; i < 6; ++i) {
+                G1 x1 = g1_mul_generator(ks[i]), y1 = g1_mul(g, ks[i]);
+                ok1 = ok1 && x1.inf == y1.inf && (x1.inf || (eq(x1.x, y1.x) && eq(x1.y, y1.y)));
+                G2 x2 = g2_mul_generator(ks[i]), y2 = g2_mul(h, ks[i]);
+                ok2 = ok2 && x2.inf == y2.inf && (x2.inf || (eq(x2.x, y2.x) && eq(x2.y, y2.y)));
+            }
+            printf("fixed_base_g1 %d\n", (int)ok1);
+            printf("fixed_base_g2 %d\n", (int)ok2);
+        }
         Fq12 fi; bool okinv = fq12_inverse(e, fi);
         printf("fq12_inverse %d\n", (int)(okinv && fq12_is_one(mul(e, fi))));
         {
