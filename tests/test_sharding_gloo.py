@@ -80,8 +80,10 @@ def _worker(rank, world, port, n, q):
 
     fake = Fake(None, n, rank, world, gather_device=None)
     fake.inflight = {}
-    outs = list(fake.commit_stream(None, range(len(sets))))
-    ok = ok and len(outs) == len(sets) and all(np.array_equal(o, orc.msm_pippenger(srs, sets[j], threads=1)) for j, o in enumerate(outs))
+    wants = [orc.msm_pippenger(srs, sets[j], threads=1) for j in range(len(sets))]
+    for depth, bucket in ((None, None), (2, 1), (3, 2), (1, 3), (4, 8)):       # default: depth 3, eight steps per exchange (one flush of 7 here)
+        outs = list(fake.commit_stream(None, range(len(sets)), depth=depth, bucket=bucket))
+        ok = ok and len(outs) == len(sets) and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs)) and not fake.inflight
     ok = ok and list(fake.commit_stream(None, [])) == [] and not fake.inflight
     q.put((rank, ok, gathered.shape))
     dist.destroy_process_group()
