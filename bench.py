@@ -192,7 +192,8 @@ def main():
     # above with the GPU idle; the clock needs ~30 steps to settle (per-step times 1.45 -> 1.15 ms).
     # The same step count on every rank (the exchange is a collective); none of this is timed, the W warm-up steps follow.
     barrier()
-    run_steps(int(os.environ.get("KZG_BENCH_SPINUP_STEPS", str(min(48 * world, 384)))), d_scalars.data_ptr(), depth_used)
+    spinup_steps = int(os.environ.get("KZG_BENCH_SPINUP_STEPS", str(min(48 * world, 384))))
+    run_steps(spinup_steps, d_scalars.data_ptr(), depth_used)
     run_steps(args.warmup, d_scalars.data_ptr(), depth_used)            # the W untimed warm-up steps
     elapsed, result = timed(args.steps, d_scalars.data_ptr(), depth_used)            # THE timed region: exactly --steps steps
     if world > 1:
@@ -263,6 +264,7 @@ def main():
             "config": {"workload": "G1 MSM 2^%d scalars (KZG::commit_coeff_form), scalars resident in HBM" % LOG_N,
                        "sharding": "by scalar index over %d GPU(s); all-gather of XYZZ partials + host fold" % world,
                        "pipeline_depth": depth_used,
+                       "untimed_before_warmup": "set-up: %d steps (workspaces), the first device-wide synchronisation, %d steps (clock ramp); then the %d warm-up steps" % (depth_used, spinup_steps, args.warmup),
                        "latency_ms_is": "one commitment at a time (depth 1), %d steps" % side_steps,
                        "bit_exact_vs_oracle": exact,
                        "bit_exact_check": "folded commitment == (sum_i c_i tau^i mod r) * G1 by big-integer arithmetic + one affine scalar "
