@@ -368,6 +368,55 @@ def test_random_blob_commit_and_proof_2_12(k, tau_srs):
     assert pyref.point_from_wire(proof) == pyref.ec_mul(qtau, (1, 2))
 
 
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 11, 12, 13, 14, 15])
+def test_proofs_every_inversion_chain_shape(k, tau_srs, log_n):
+    """compute_proof_impl (kzg.rs:128-178, :237-260) on domains of 1 .. 2^15 points: the batch inversion of the denominators is a
+    chain of levels whose shape depends on n (small kernel only / + the fused x4 last level / + x4 middle levels), off the domain
+    and ON it (first, middle, last index: the zero denominator sits in a different lane and level each time).  Expected values by
+    big integers on the known-tau SRS: y = f^(z), proof = ((f^(tau) - y) / (tau - z)) G1 with f^ from the barycentric formula."""
+    n = 1 << log_n
+    rnd = random.Random(0xC0DE + log_n)
+    evals = [rnd.randrange(R_) for _ in range(n)]
+    w = pyref.root_of_unity(log_n) if log_n else 1
+    roots, cur = [], 1
+    for _ in range(n):
+        roots.append(cur)
+        cur = cur * w % R_
+
+    def bary(x):
+        if n == 1:
+            return evals[0]
+        dens = [(x - r) % R_ for r in roots]
+        pre, acc = [], 1
+        for d in dens:
+            pre.append(acc)
+            acc = acc * d % R_
+        inv = pow(acc, -1, R_)
+        tot = 0
+        for i in range(n - 1, -1, -1):
+            tot += evals[i] * roots[i] % R_ * (inv * pre[i] % R_)
+            inv = inv * dens[i] % R_
+        return tot % R_ * (pow(x, n, R_) - 1) % R_ * pow(n, -1, R_) % R_
+
+    ftau = bary(TAU)
+    poly = k.PolynomialEvalForm(pyref.frs_to_mont(evals))
+    kzg = k.KZG.new(); kzg.calculate_and_store_roots_of_unity(n * 32)
+    z_off = rnd.randrange(R_)
+    cases = [(z_off, bary(z_off))] + [(roots[m], evals[m]) for m in sorted({0, n // 2, n - 1})]
+    for z, y_want in cases:
+        proof, y = kzg._compute_proof_impl(poly, pyref.fr_to_mont(z), tau_srs, want_y=True)
+        assert pyref.fr_from_mont(y) == y_want, (log_n, z == z_off)
+        if z == TAU % R_:
+            continue
+        if n == 1:
+            want_pt = None                                          # the quotient of a constant is zero
+        else:
+            want_pt = pyref.ec_mul((ftau - y_want) * pow(TAU - z, -1, R_) % R_, (1, 2))
+            if (ftau - y_want) % R_ == 0:
+                want_pt = None
+        assert pyref.point_from_wire(proof) == want_pt, (log_n, z == z_off)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # g1_ifft (kzg.rs:263-285)
 # ---------------------------------------------------------------------------------------------------------
