@@ -959,88 +959,16 @@ k_red_window_sum(int32_t* __restrict__ a, size_t stride, uint32_t T, uint32_t* _
 // Superset-sum ("zeta") transform over the 64 lanes of a wave: after the 6 steps lane x holds the sum of the values
 // of all lanes l with (l & x) == x.  Lane 0 = total T; lane 2^k = S_k (sum over the lanes whose index has bit k set):
 // all seven sums the bucket reduction needs from a group of 64 buckets come out of 6 wave-wide additions.
-__device__ __forceinline__ void fe_shfl_xor(Fq& r, const Fq& v, int mask) {
-#pragma unroll
-    for (int j = 0; j < NL; ++j) r.l[j] = __shfl_xor(v.l[j], mask, 64);
-}
-// One step of the transform, v[l] += v[l + d] for the lanes l with bit log2(d) clear, as ONE addition done by BOTH lanes of the pair
-// (l, l + d): the upper lane would idle, and the wave is bound by the instructions it issues, so the 14 products of add-2008-s
-// are split 8 / 8 over the pair in four rounds of two products (the same instruction stream for both lanes, operands selected
-// per lane) with 54 limb exchanges over the xor shuffle: ~5.7 us instead of 8.7 us per step.
-//   round 1   A: U1 = X1 ZZ2, S1 = Y1 ZZZ2          B: U2 = X2 ZZ1, S2 = Y2 ZZZ1          -> both: P = U2 - U1, R = S2 - S1
-//   round 2   A: PP = P^2,  RR = R^2                 B: T1 = ZZ1 ZZ2, T2 = ZZZ1 ZZZ2       -> B gets PP
-//   round 3   A: PPP = P PP, Q = U1 PP               B: ZZ3 = T1 PP                        -> B gets PPP
-//   round 4   A: R (Q - X3), S1 PPP  (X3 = RR - PPP - 2Q)   B: ZZZ3 = T2 PPP               -> A gets ZZ3, ZZZ3
-// An identity operand or P1 = +-P2 (PP = 0) anywhere in the wave sends the whole wave through the one-lane addition for this step
-// (xyzz_add resolves identities by selection and handles doubling / cancellation).
-__device__ __forceinline__ void zeta_step_one_lane(Xyzz& v, uint32_t lane, int k) {
-    Xyzz u;
-    xyzz_shfl_down(u, v, 1 << k);
-    if (((lane >> k) & 1u) == 0) {
-        Xyzz r;
-        xyzz_add<true>(r, v, u);
-        v = r;
-    }
-}
-__device__ __forceinline__ void zeta_step_pair(Xyzz& v, uint32_t lane, int k) {
-    const int d = 1 << k;
-    const bool isA = ((lane >> k) & 1u) == 0;
-    // an identity operand anywhere in the wave (empty buckets of a small MSM): the one-lane step resolves it by selection
-    if (__any(v.inf)) { zeta_step_one_lane(v, lane, k); return; }
-    Fq o_zz, o_zzz, m1, m2, t;
-    // round 1: own X * partner's ZZ and own Y * partner's ZZZ are U1, S1 on the lower lane and U2, S2 on the upper one
-    fe_shfl_xor(o_zz, v.zz, d);
-    fe_shfl_xor(o_zzz, v.zzz, d);
-    Fq u_own, s_own;
-    fe_mul2(u_own, v.x, o_zz, s_own, v.y, o_zzz);
-    Fq P, R;
-    fe_shfl_xor(t, u_own, d); fe_sub(P, t, u_own); fe_cneg(P, P, isA ? 0u : 1u);        // U2 - U1 on both lanes
-    fe_shfl_xor(t, s_own, d); fe_sub(R, t, s_own); fe_cneg(R, R, isA ? 0u : 1u);        // S2 - S1
-    // round 2
-    {
-        Fq a1, b1, a2, b2;
-        fe_select(a1, isA, P, v.zz); fe_select(b1, isA, P, o_zz);
-        fe_select(a2, isA, R, v.zzz); fe_select(b2, isA, R, o_zzz);
-        fe_mul2(m1, a1, b1, m2, a2, b2);                            // A: PP, RR;  B: T1 = ZZ1 ZZ2, T2 = ZZZ1 ZZZ2
-    }
-    Fq pp;
-    fe_shfl_xor(t, m1, d); fe_select(pp, isA, m1, t);
-    if (__builtin_expect(__any(fe_is_zero_mod(pp)), 0)) {           // P1 = +-P2 somewhere in the wave: doubling / cancellation live in xyzz_add
-        zeta_step_one_lane(v, lane, k);
-        return;
-    }
-    const Fq rr_or_t2 = m2;                                         // A: RR, B: T2
-    // round 3: A: PPP = P PP, Q = U1 PP;  B: ZZ3 = T1 PP (second product unused)
-    Fq a3;
-    fe_select(a3, isA, P, m1);
-    Fq r3a, q;
-    fe_mul2(r3a, a3, pp, q, u_own, pp);
-    Fq ppp, zz3;
-    fe_shfl_xor(t, r3a, d); fe_select(ppp, isA, r3a, t); zz3 = t;    // zz3 is meaningful on A (the partner's ZZ3)
-    // round 4: A: R (Q - X3), S1 PPP;  B: ZZZ3 = T2 PPP (second product unused)
-    Fq x3, w;
-    fe_sub(x3, rr_or_t2, ppp); fe_sub(x3, x3, q); fe_sub(x3, x3, q); fe_norm(x3);      // A: RR - PPP - 2Q in (-6m, 5m)
-    fe_sub(w, q, x3);
-    Fq a4, b4, r4a, r4b;
-    fe_select(a4, isA, R, rr_or_t2); fe_select(b4, isA, w, ppp);
-    fe_mul2(r4a, a4, b4, r4b, s_own, ppp);
-    Fq zzz3;
-    fe_shfl_xor(zzz3, r4a, d);
-    if (isA) {
-        v.x = x3;
-        fe_sub(v.y, r4a, r4b); fe_norm(v.y);                        // (-3m, 3m)
-        v.zz = zz3;
-        v.zzz = zzz3;
-    }
-}
 __device__ __forceinline__ void wave_zeta(Xyzz& v, uint32_t lane) {
 #pragma unroll 1
     for (int k = 0; k < 6; ++k) {
-#if defined(KZG_ZETA_ONE_LANE)
-        zeta_step_one_lane(v, lane, k);
-#else
-        zeta_step_pair(v, lane, k);
-#endif
+        Xyzz u;
+        xyzz_shfl_down(u, v, 1 << k);
+        if (((lane >> k) & 1u) == 0) {
+            Xyzz r;
+            xyzz_add<true>(r, v, u);
+            v = r;
+        }
     }
 }
 __device__ __forceinline__ int zeta_role(uint32_t lane) {       // lane 0 -> role 6 (total), lane 2^k -> role k, else -1
@@ -1081,7 +1009,7 @@ k_msm_bucket_bits1(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, c
 // level 2 (one launch, two kinds of job), results straight to wire words: with G1p = ceil(G1 / 64)
 //   wave <  6 G1p : out[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                                  (a < 6: finishes bits 0..5)
 //   wave >= 6 G1p : out[6 G1p + role * G1p + g2], role 0..6, zeta transform of the totals X1[6][g2 * 64 .. +64)  (bits 6..11, totals)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
     latency_bound_kernel();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
