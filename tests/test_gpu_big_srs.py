@@ -105,3 +105,15 @@ def test_two_level_sort_with_skewed_and_ragged_inputs(log_srs):
             assert got == want, (log_srs, offset, len(sc))
     finally:
         srs.close()
+
+
+def test_randomised_soak_of_the_srs_msm_entry_points():
+    """tools/soak_msm.py for a few seconds with a fixed seed: random lengths (incl. the tile / chunk / table-set boundaries), offsets,
+    scalar shapes and call forms against big-integer values (a 90-second run of it with random seeds is part of the round's checks)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOAK_SECONDS="6", SOAK_SEED="20260102", SOAK_SRS_LOG="18")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_msm.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-400:] + r.stderr[-400:]
