@@ -38,6 +38,10 @@ BYTES_PER_PAIR = 96            # 64 B packed affine point + 32
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 MADS_PER_MIXED_ADD = 1467      # v_mad_i64_i32 per xyzz_madd (8 x 162 + 2 x 126 - 81 for the fused Y3)
 MAD_NS_PER_WAVE_INSTR_PER_SIMD = 2.0   # measured v_mad_u64_u32 issue rate on MI355X (profiles/r01_valu_rates_mi355x.txt)
+# The whole instruction stream of one mixed addition in the accumulate loop (ISA of the loop body, tools/ubench/acc_variants.hip V4 built
+# with the out-of-line slow path: 2 564 instructions) priced at the issue rates measured with FOUR waves per SIMD (the kernel runs three):
+# (count, ns per wave-instruction per SIMD) -- mads, v_mul_lo_u32, 64-bit shifts, v_and, other 32-bit VALU, s_nop (asm barriers of the paired multiplies)
+VALU_MIX_PER_MIXED_ADD = ((1467, 2.13), (81, 2.03), (144 + 18, 1.85), (187, 1.24), (255, 1.24), (290, 0.42))
 N_SIMDS = 1024
 
 
@@ -283,8 +287,14 @@ def main():
             # VALU roofline of the same kernel: multiply-adds it must issue / the measured v_mad_i64_i32 issue rate of the chip
             entries = plan["windows"] * units_per_launch
             floor_ms = entries / 64.0 * MADS_PER_MIXED_ADD * MAD_NS_PER_WAVE_INSTR_PER_SIMD / N_SIMDS * 1e-6
+            mix_ns = sum(c * r for c, r in VALU_MIX_PER_MIXED_ADD)
+            mix_floor_ms = entries / 64.0 * mix_ns / N_SIMDS * 1e-6
             out["roofline"]["valu"] = {"mixed_adds_per_launch": entries, "mads_per_mixed_add": MADS_PER_MIXED_ADD,
                                        "mad_issue_floor_ms": floor_ms, "frac_of_mad_issue_floor": floor_ms / acc_ms,
+                                       "instruction_issue_floor_ms": mix_floor_ms, "frac_of_instruction_issue_floor": mix_floor_ms / acc_ms,
+                                       "instruction_issue_floor_is": "all %d instructions of one mixed addition at their measured issue rates (4 waves per SIMD): "
+                                                                     "what this instruction stream costs on a saturated SIMD; only removing instructions goes below it"
+                                                                     % sum(c for c, _ in VALU_MIX_PER_MIXED_ADD),
                                        "peak": "v_mad_i64_i32: %.1f ns per wave-instruction per SIMD, %d SIMDs (measured)" % (MAD_NS_PER_WAVE_INSTR_PER_SIMD, N_SIMDS)}
         if world == 1 and not args.no_secondary:
             # secondary figures of the same run (outside the timed region; BASELINE configs 3 and 4 on one GPU)
