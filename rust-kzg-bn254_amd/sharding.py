@@ -6,10 +6,36 @@ every rank then folds them on the host (G - 1 point additions + one inversion, k
 """
 import collections
 import ctypes as C
+import datetime
+import os
+import time
 
 import numpy as np
 
 from . import _lib
+
+# A rank whose MSM could not be enqueued still takes part in every collective (the other ranks have already issued theirs, or
+# will): it sends this partial instead.  All-ones words are >= the field modulus, so no real XYZZ partial looks like it.
+POISON = np.full(16, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+
+
+class ShardError(RuntimeError):
+    """One or more ranks failed at step `step` of a sharded stream; raised by EVERY rank at that step."""
+
+    def __init__(self, step, ranks, cause=None):
+        self.step, self.ranks = step, list(ranks)
+        msg = "sharded MSM: rank(s) %s failed at step %d" % (self.ranks, step)
+        if cause is not None:
+            msg += ": %s" % (cause,)
+        super().__init__(msg)
+
+
+class ExchangeTimeout(RuntimeError):
+    """The all-gather of the partials did not complete within the time-out (a peer is gone or hung)."""
+
+
+def exchange_timeout_s():
+    return float(os.environ.get("KZG_EXCHANGE_TIMEOUT_S", "60"))
 
 
 def shard_bounds(n: int, rank: int, world: int):
@@ -49,6 +75,8 @@ class PartialGatherer:
         self.world, self.device = world, device
         self.torch = torch
         self._count = 0
+        self._work = None
+        self._busy = False
         if device is not None:
             m = self.MAX_BUCKET * 16
             self.pin_in = torch.empty(m, dtype=torch.int64).pin_memory()
@@ -73,12 +101,14 @@ class PartialGatherer:
         count = partials.shape[0]
         if count < 1 or count > self.MAX_BUCKET:
             raise ValueError("1 .. %d partials per exchange" % self.MAX_BUCKET)
+        if self._busy:
+            raise RuntimeError("PartialGatherer: finish() the exchange in flight before starting another")
         self._count = count
+        self._busy = True
         if self.device is None:
             t = torch.from_numpy(partials.view(np.int64).reshape(-1).copy())
-            outs = [torch.empty(count * 16, dtype=torch.int64) for _ in range(self.world)]
-            dist.all_gather(outs, t)
-            self._cpu_result = torch.stack(outs).numpy().view(np.uint64).reshape(self.world, count, 16)
+            self._cpu_outs = [torch.empty(count * 16, dtype=torch.int64) for _ in range(self.world)]
+            self._work = dist.all_gather(self._cpu_outs, t, async_op=True)
             return
         m = count * 16
         self.pin_in.numpy()[:m] = partials.view(np.int64).reshape(-1)
@@ -86,13 +116,42 @@ class PartialGatherer:
             self.dev_in[:m].copy_(self.pin_in[:m], non_blocking=True)
             dist.all_gather_into_tensor(self.dev_out[:self.world * m], self.dev_in[:m])
             self.pin_out[:self.world * m].copy_(self.dev_out[:self.world * m], non_blocking=True)
+            self._done = torch.cuda.Event()
+            self._done.record(self.stream)
 
-    def finish(self):
+    def finish(self, timeout_s=None):
+        """Result of the exchange in flight, (world, count, 16).  Waits at most `timeout_s` (default KZG_EXCHANGE_TIMEOUT_S = 60 s):
+        a peer that died or never issued its collective would otherwise block this rank for ever; ExchangeTimeout then tells the
+        caller to exit non-zero (the communicator is unusable after it)."""
+        if not self._busy:
+            raise RuntimeError("PartialGatherer: no exchange in flight")
+        timeout_s = exchange_timeout_s() if timeout_s is None else float(timeout_s)
         if self.device is None:
-            return self._cpu_result
-        self.stream.synchronize()
+            try:
+                ok = self._work.wait(datetime.timedelta(seconds=timeout_s))
+            except RuntimeError as e:                   # gloo raises on time-out / peer loss
+                raise ExchangeTimeout("all-gather of the partials failed: %s" % (e,)) from e
+            finally:
+                self._busy = False
+            if ok is False:
+                raise ExchangeTimeout("all-gather of the partials timed out after %.0f s" % timeout_s)
+            return self.torch.stack(self._cpu_outs).numpy().view(np.uint64).reshape(self.world, self._count, 16)
+        deadline = time.monotonic() + timeout_s
+        spins = 0
+        while not self._done.query():
+            spins += 1
+            if spins > 2000:                            # ~first 100 us busy, then yield the core
+                time.sleep(50e-6)
+            if time.monotonic() > deadline:
+                self._busy = False
+                raise ExchangeTimeout("all-gather of the partials timed out after %.0f s (a peer rank is gone or hung)" % timeout_s)
+        self._busy = False
         m = self._count * 16
         return self.pin_out.numpy()[:self.world * m].view(np.uint64).reshape(self.world, self._count, 16).copy()
+
+    @property
+    def busy(self):
+        return self._busy
 
 
 def fold_partials(parts):
@@ -184,7 +243,11 @@ class ShardedMsm:
         host comes to collect them: measured over a one-rank communicator, three MSMs in flight (tools/time_exchange_bucket.py),
         2^19 pairs per step 0.640 ms without exchange, 0.765 / 0.723 / 0.704 / 0.676 ms with 1 / 2 / 4 / 8 steps per exchange;
         2^17 pairs 0.249 against 0.269 / - / 0.251 / 0.250 ms.  The bucket size is fixed (not adaptive): every rank must issue
-        collectives of the same size, and must see the same number of items.  Yields the commitments in order."""
+        collectives of the same size, and must see the same number of items.  Yields the commitments in order.
+        Failures with world > 1: a rank whose begin() / end() fails keeps issuing its collectives with a POISON partial for that step
+        and does no more GPU work; every rank (the failing one included) raises ShardError at that step, after the same number of
+        collectives, so nobody is left blocked in an all-gather.  A peer that dies outright shows up as ExchangeTimeout
+        (KZG_EXCHANGE_TIMEOUT_S, default 60 s): exit non-zero on it, the communicator cannot be used again."""
         if depth is None:
             depth = 2 if self.len >= (1 << 20) else 3
         depth = max(1, min(int(depth), _lib.NUM_SLOTS))
@@ -197,24 +260,46 @@ class ShardedMsm:
             if self._gatherer is None:
                 self._gatherer = PartialGatherer(self.world, self.gather_device)
             g = self._gatherer
+            if g.busy:                                  # left over by a stream that was abandoned: every rank issued it
+                g.finish()
         exchanging = False
         pending = []                                   # partials of finished MSMs not yet sent
+        sent_first = 0                                 # step index of the first partial of the exchange in flight
+        next_step = 0                                  # step index of the next partial to enter `pending`
+        failure = None                                 # this rank's first failure (world > 1: reported through the exchange)
 
         def collect():
-            """results of the exchange in flight, in step order"""
+            """results of the exchange in flight, in step order; ShardError on EVERY rank if any rank sent POISON"""
             got = g.finish()                           # (world, count, 16)
-            return [fold_partials(got[:, j, :]) for j in range(got.shape[1])]
+            outs = []
+            for j in range(got.shape[1]):
+                bad = [r for r in range(self.world) if np.array_equal(got[r, j], POISON)]
+                if bad:
+                    raise ShardError(sent_first + j, bad, failure if self.rank in bad else None)
+                outs.append(fold_partials(got[:, j, :]))
+            return outs
 
         def retire(flush=False):
-            nonlocal exchanging
+            nonlocal exchanging, sent_first, next_step, failure
             slot = inflight.popleft()
             if g is None:
                 return [self.end(slot)]
-            pending.append(self._end_partial(slot))
+            if slot is None:
+                part = POISON
+            else:
+                try:
+                    part = self._end_partial(slot)
+                except Exception as e:                  # noqa: BLE001 -- reported to every rank through the exchange
+                    failure = failure or e
+                    part = POISON
+            pending.append(part)
+            next_step += 1
             out = []
             if len(pending) == bucket or (flush and not inflight):
                 if exchanging:
+                    exchanging = False
                     out = collect()
+                sent_first = next_step - len(pending)
                 g.start(np.stack(pending))
                 pending.clear()
                 exchanging = True
@@ -225,7 +310,16 @@ class ShardedMsm:
                 if len(inflight) == depth:
                     yield from retire()
                 slot = k % depth
-                self.begin(srs_shard, ptr, slot)
+                if g is None:
+                    self.begin(srs_shard, ptr, slot)
+                elif failure is not None:
+                    slot = None                         # after a failure this rank only keeps the collectives matched
+                else:
+                    try:
+                        self.begin(srs_shard, ptr, slot)
+                    except Exception as e:              # noqa: BLE001
+                        failure = e
+                        slot = None
                 inflight.append(slot)
             while inflight:
                 yield from retire(flush=True)
@@ -236,10 +330,17 @@ class ShardedMsm:
             # a failed begin() or a consumer that stops early must not leave slots (or an exchange) in flight
             while inflight:
                 slot = inflight.popleft()
-                part = np.zeros(16, dtype=np.uint64)
-                _lib.load().kzg_msm_g1_srs_end(self.ctx.handle, slot, None, None, _lib.ptr(part))
-            if exchanging and g is not None and self.world == 1:
-                g.finish()
+                if slot is None:
+                    continue
+                try:
+                    self._end_partial(slot)
+                except Exception:                       # noqa: BLE001 -- draining: the slot is free again either way
+                    pass
+            if exchanging and g is not None and g.busy:
+                try:
+                    g.finish()                          # every rank issued this collective: only a wait
+                except ExchangeTimeout:
+                    pass
 
 
 class ShardedKzg:

@@ -85,6 +85,56 @@ def _worker(rank, world, port, n, q):
         outs = list(fake.commit_stream(None, range(len(sets)), depth=depth, bucket=bucket))
         ok = ok and len(outs) == len(sets) and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs)) and not fake.inflight
     ok = ok and list(fake.commit_stream(None, [])) == [] and not fake.inflight
+
+    # the consumer stops early on every rank while an exchange is in flight (the clean-up must wait for it at any
+    # world size), then runs a second stream over the same gatherer: results must not be mixed up with the abandoned exchange
+    gen = fake.commit_stream(None, range(len(sets)), depth=2, bucket=2)
+    first = next(gen)
+    ok = ok and np.array_equal(first, wants[0])
+    gen.close()
+    ok = ok and not fake.inflight and not fake._gatherer.busy
+    outs = list(fake.commit_stream(None, range(len(sets)), depth=2, bucket=2))
+    ok = ok and len(outs) == len(sets) and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs))
+
+    # a mid-stream failure on ONE rank (begin() of step 3 raises on rank 1 only): every rank must raise ShardError for step 3
+    # after yielding steps 0..2, nobody may hang in a collective, and the next stream must work
+    class Failing(Fake):
+        def begin(self, srs_shard, ptr, slot):
+            if ptr == 3 and self.rank == 1:
+                raise ValueError("injected failure")
+            super().begin(srs_shard, ptr, slot)
+
+    for depth, bucket in ((3, 8), (2, 1), (1, 2)):
+        bad = Failing(None, n, rank, world, gather_device=None)
+        bad.inflight = {}
+        outs, err = [], None
+        try:
+            for o in bad.commit_stream(None, range(len(sets)), depth=depth, bucket=bucket):
+                outs.append(o)
+        except sharding.ShardError as e:
+            err = e
+        ok = ok and err is not None and err.step == 3 and err.ranks == [1] and not bad.inflight
+        ok = ok and len(outs) <= 3 and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs))
+        ok = ok and (("injected failure" in str(err)) == (rank == 1))
+        outs = list(bad.commit_stream(None, [0, 1, 2], depth=depth, bucket=bucket))
+        ok = ok and len(outs) == 3 and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs))
+
+    # an end() that fails on one rank is reported the same way
+    class FailingEnd(Fake):
+        def _end_partial(self, slot):
+            j = self.inflight[slot]
+            if j == 2 and self.rank == 0:
+                self.inflight.pop(slot)
+                raise ValueError("injected end failure")
+            return super()._end_partial(slot)
+
+    bad = FailingEnd(None, n, rank, world, gather_device=None)
+    bad.inflight = {}
+    try:
+        list(bad.commit_stream(None, range(5), depth=2, bucket=2))
+        ok = False
+    except sharding.ShardError as e:
+        ok = ok and e.step == 2 and e.ranks == [0]
     q.put((rank, ok, gathered.shape))
     dist.destroy_process_group()
 
