@@ -126,7 +126,8 @@ int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
  * (out_xy_mont / out_is_infinity) and/or the unconverted partial sum (out_xyzz_mont, 16 u64); either may be NULL.
  * With begin(k+1) issued before end(k), the sort / bucket-reduction phases of one MSM run beside the accumulation of the
  * other and the host epilogue leaves the critical path.  d_scalars_mont must be complete before `begin` and stay
- * untouched until `end`.  1 <= n <= 2^24; a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG.
+ * untouched until `end`.  1 <= n <= 2^24 (and at most 16 launches: over an SRS of more than 2^20 points, whose MSMs run as launches
+ * of 2^20 pairs, that is n <= 2^24 as well; the synchronous calls have no such cap); a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG.
  * The synchronous MSM / commit / proof calls use slot 0's workspace: while slot 0 is in flight they return
  * KZG_ERR_INVALID_ARG (text in kzg_ctx_last_error); the other slots may be in flight beside them.  Two slots hide the latency-bound
  * phases of a 2^20-pair MSM; shard-sized MSMs (2^17 .. 2^18 pairs per GPU) keep gaining up to four. */
@@ -260,9 +261,9 @@ int32_t kzg_calculate_roots_of_unity(kzg_ctx* ctx, uint64_t length_of_data_after
 
 /* ---- verifier surface ------------------------------------------------------------
  * G2 wire format: 16 u64 = x.c0 | x.c1 | y.c0 | y.c1, each a 4 x u64 Montgomery Fq (arkworks' Fq2{c0,c1} in memory);
- * identity = all zeros.  The pairing itself is O(1) per verification and runs on the host (reduced Tate pairing:
- * it decides `multi_pairing(..).is_zero()` exactly as arkworks' optimal ate does); the n-point linear combinations of
- * batch verification run on the GPU.  g2_tau_mont = NULL selects consts::G2_TAU (primitives/src/consts.rs:55-64). */
+ * identity = all zeros.  The pairing itself is O(1) per verification and runs on the host (optimal ate Miller loop + final
+ * exponentiation, the construction arkworks computes; csrc/host_pairing.h); the n-point linear combinations and the n barycentric
+ * evaluations of batch verification run on the GPU.  g2_tau_mont = NULL selects consts::G2_TAU (primitives/src/consts.rs:55-64). */
 int32_t kzg_g2_generator(uint64_t out_g2_mont[16]);                  /* G2Affine::generator() */
 int32_t kzg_g2_tau_mainnet(uint64_t out_g2_mont[16]);                /* consts::G2_TAU */
 int32_t kzg_g2_mul_generator(const uint64_t scalar_mont[4], uint64_t out_g2_mont[16]);   /* [s]G2 (tests / custom setups) */
@@ -273,9 +274,8 @@ int32_t kzg_pairings_verify(const uint64_t a1_xy_mont[8], const uint64_t a2_g2_m
  * [tau - z]G2 == identity -> KZG_ERR_TAU_EQUALS_Z.  Host-only.
  * g2_tau (here and in kzg_verify_kzg_proof_batch): NULL = consts::G2_TAU; a caller-supplied point is only checked to be ON THE
  * CURVE, exactly as the reference does (verify.rs:29-33, batch.rs:212-214) -- its membership in the order-r subgroup of the twist
- * is NOT checked, and outside that subgroup the Tate pairing used here and arkworks' optimal ate pairing may disagree: pass
- * subgroup points (any [s]G2).  The Fiat-Shamir transcripts of the batch verifier (compute_r_powers, verifier/src/batch.rs:76-168)
- * stay with the caller, who passes r_powers. */
+ * is NOT checked; outside that subgroup a pairing value is not defined by the reference either (a degenerate Miller-loop step,
+ * T = +-Q, makes this library answer "not equal"): pass subgroup points (any [s]G2). */
 int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t proof_xy_mont[8],
                          const uint64_t value_mont[4], const uint64_t z_mont[4],
                          const uint64_t* g2_tau_mont, int32_t* out_ok);
@@ -286,6 +286,33 @@ int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_
                                    const uint64_t* ys_mont, const uint64_t* proofs_xy_mont,
                                    const uint64_t* r_powers_mont, size_t n,
                                    const uint64_t* g2_tau_mont, int32_t* out_ok);
+/* batch::compute_r_powers (verifier/src/batch.rs:76-168): r = SHA-256("EIGENDA_RCKZGBATCH___V1_" || 8 zero bytes || u64be(n) ||
+ * n x u64be(blobs_as_field_elements_length[i]) || n x (C_i || z_i || y_i || proof_i)) mod r with the points ark-compressed and z, y
+ * canonical big-endian; out = [r^0 .. r^(n-1)] (helpers::compute_powers, helpers.rs:298-313).  Host only (rows serialised on a
+ * thread pool). */
+int32_t kzg_compute_r_powers(const uint64_t* commitments_xy_mont, const uint64_t* zs_mont, const uint64_t* ys_mont,
+                             const uint64_t* proofs_xy_mont, const uint64_t* blobs_as_field_elements_length, size_t n,
+                             uint64_t* out_r_powers_mont);
+/* helpers::compute_challenges_and_evaluate_polynomial (primitives/src/helpers.rs:613-662) for n blobs in ONE call:
+ * out_zs[i] = compute_challenge(blob_i, commitment_i) (helpers.rs:411-472), out_ys[i] = p_i(z_i) (helpers.rs:475-535).
+ * blobs[i] / blob_lens[i] = the padded bytes of blob i (Blob::data()).  The n transcripts are hashed on a pool of host threads
+ * (KZG_HOST_THREADS, default: all cores up to 32); the n barycentric evaluations run as one batched GPU launch for blobs of up to
+ * 4096 field elements (one workgroup per blob, one inversion per blob) and through the single-polynomial path beyond.  Errors, for
+ * the first failing blob in order: KZG_ERR_TOO_LARGE (polynomial.rs:42-46), KZG_ERR_G1_NOT_ON_CURVE (helpers.rs:413),
+ * KZG_ERR_ZERO_LENGTH (empty blob: helpers.rs:554-558). */
+int32_t kzg_compute_challenges_and_evaluate_polynomial(kzg_ctx* ctx, const uint8_t* const* blobs, const size_t* blob_lens,
+                                                       const uint64_t* commitments_xy_mont, size_t n,
+                                                       uint64_t* out_zs_mont, uint64_t* out_ys_mont);
+/* The evaluation half of the call above with the points given: out_ys[i] = p_i(zs[i]) for n blobs (helpers.rs:475-535 each, incl.
+ * the early return for z on the domain, helpers.rs:497-504), one batched GPU launch.  KZG_ERR_TOO_LARGE / KZG_ERR_ZERO_LENGTH as above. */
+int32_t kzg_evaluate_blobs_in_evaluation_form_batch(kzg_ctx* ctx, const uint8_t* const* blobs, const size_t* blob_lens,
+                                                    const uint64_t* zs_mont, size_t n, uint64_t* out_ys_mont);
+/* batch::verify_blob_kzg_proof_batch (verifier/src/batch.rs:16-69) end to end -- BASELINE config 5 in one call: validation of the
+ * 2n points (KZG_ERR_G1_NOT_ON_CURVE), the n challenges and evaluations (above), compute_r_powers, then verify_kzg_proof_batch
+ * (three batched GPU MSMs + the host 2-pairing check).  *out_ok = 1 iff every proof verifies.  n = 0 -> *out_ok = 1. */
+int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blobs, const size_t* blob_lens,
+                                        const uint64_t* commitments_xy_mont, const uint64_t* proofs_xy_mont, size_t n,
+                                        const uint64_t* g2_tau_mont, int32_t* out_ok);
 
 #ifdef __cplusplus
 }

@@ -644,3 +644,51 @@ EXPORT int orc_compute_challenge(const uint8_t *blob, size_t blob_len, const uin
     fe_from_be_bytes_mod_order(&FR, (fe *)z_out, dg, 32);
     free(el); free(buf); return 0;
 }
+
+/* helpers.rs:613-662 compute_challenges_and_evaluate_polynomial: for every blob i (already padded bytes, Blob::data()),
+ * z_i = compute_challenge(blob_i, commitment_i) and y_i = evaluate_polynomial_in_evaluation_form(blob_i.to_polynomial_eval_form(), z_i).
+ * blobs = the blobs' bytes back to back, lens[i] = byte length of blob i.  zs / ys: n x 4 u64 each. */
+EXPORT int orc_compute_challenges_and_evaluate_polynomial(const uint8_t *blobs, const uint64_t *lens, const uint64_t *commitments_xy,
+                                                          size_t n, uint64_t *zs, uint64_t *ys) {
+    oracle_init();
+    size_t off = 0;
+    for (size_t i = 0; i < n; ++i) {
+        size_t len = (size_t)lens[i], k = (len + 31) / 32, m = next_pow2(k);
+        if (k == 0) return -1;
+        orc_compute_challenge(blobs + off, len, commitments_xy + 8 * i, zs + 4 * i);
+        fe *el = (fe *)calloc(m, sizeof(fe));                         /* polynomial.rs:49-51: zero-padded to a power of two */
+        orc_to_fr_array(blobs + off, len, (uint64_t *)el);
+        int rc = orc_evaluate_polynomial_in_evaluation_form((const uint64_t *)el, m, zs + 4 * i, ys + 4 * i);
+        free(el);
+        if (rc) return rc;
+        off += len;
+    }
+    return 0;
+}
+
+/* verifier/src/batch.rs:76-168 compute_r_powers:
+ *   data = "EIGENDA_RCKZGBATCH___V1_" (24 B) || 8 zero bytes || u64be(n) || n x u64be(len_i) || n x (C_i || z_i || y_i || proof_i)
+ * with C_i / proof_i ark-compressed (32 B), z_i / y_i canonical big-endian (32 B); r = SHA-256(data) mod r (hash_to_field_element,
+ * helpers.rs:382-390); out = [r^0 .. r^(n-1)] (compute_powers, helpers.rs:298-313). */
+EXPORT int orc_compute_r_powers(const uint64_t *commitments_xy, const uint64_t *zs, const uint64_t *ys, const uint64_t *proofs_xy,
+                                const uint64_t *lens, size_t n, uint64_t *out) {
+    oracle_init();
+    size_t total = 40 + n * 8 + n * 128;
+    uint8_t *buf = (uint8_t *)calloc(total, 1);
+    memcpy(buf, "EIGENDA_RCKZGBATCH___V1_", 24);
+    for (int b = 0; b < 8; ++b) buf[32 + 7 - b] = (uint8_t)((uint64_t)n >> (8 * b));
+    for (size_t i = 0; i < n; ++i)
+        for (int b = 0; b < 8; ++b) buf[40 + 8 * i + 7 - b] = (uint8_t)(lens[i] >> (8 * b));
+    uint8_t *p = buf + 40 + 8 * n;
+    for (size_t i = 0; i < n; ++i, p += 128) {
+        orc_g1_serialize_compressed_ark(commitments_xy + 8 * i, p);
+        fe_to_be_bytes(&FR, p + 32, (const fe *)(zs + 4 * i));
+        fe_to_be_bytes(&FR, p + 64, (const fe *)(ys + 4 * i));
+        orc_g1_serialize_compressed_ark(proofs_xy + 8 * i, p + 96);
+    }
+    uint8_t dg[32]; orc_sha256(buf, total, dg);
+    fe r; fe_from_be_bytes_mod_order(&FR, &r, dg, 32);
+    fe cur = FR.one;
+    for (size_t i = 0; i < n; ++i) { memcpy(out + 4 * i, &cur, 32); fe_mul(&FR, &cur, &cur, &r); }
+    free(buf); return 0;
+}

@@ -106,6 +106,10 @@ PROTOTYPES = {
     "kzg_pairings_verify": (i32, [u64p, u64p, u64p, u64p, C.POINTER(i32)]),
     "kzg_verify_proof": (i32, [u64p, u64p, u64p, u64p, u64p, C.POINTER(i32)]),
     "kzg_verify_kzg_proof_batch": (i32, [vp, u64p, u64p, u64p, u64p, u64p, sz, u64p, C.POINTER(i32)]),
+    "kzg_compute_r_powers": (i32, [u64p, u64p, u64p, u64p, u64p, sz, u64p]),
+    "kzg_compute_challenges_and_evaluate_polynomial": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, sz, u64p, u64p]),
+    "kzg_evaluate_blobs_in_evaluation_form_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, sz, u64p]),
+    "kzg_verify_blob_kzg_proof_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, u64p, sz, u64p, C.POINTER(i32)]),
 }
 
 _lib = None
@@ -139,6 +143,16 @@ def as_u64(a, cols):
 
 def ptr(a):
     return a.ctypes.data_as(u64p)
+
+
+def blob_args(blobs):
+    """(char* array, size_t array, keep-alive) for the `const uint8_t* const* blobs, const size_t* blob_lens` arguments of the batch
+    verification calls; `blobs` = objects with .data() (Blob) or bytes."""
+    datas = [b.data() if hasattr(b, "data") else bytes(b) for b in blobs]
+    n = len(datas)
+    ptrs = (C.c_char_p * max(n, 1))(*datas)
+    lens = (sz * max(n, 1))(*[len(d) for d in datas])
+    return ptrs, lens, datas
 
 
 class Context:

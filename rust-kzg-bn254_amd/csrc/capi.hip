@@ -5,9 +5,11 @@
 #include "host_sha256.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <thread>
 #include <vector>
@@ -30,6 +32,8 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
 int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot);
 int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
+int32_t vb_evaluate_run(kzg_ctx* ctx, const uint8_t* packed, size_t packed_len, const void* meta_host, size_t nb, const uint64_t* zs,
+                        uint64_t* ys_out, uint8_t* fallback_out);
 int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out,
                        hipStream_t st = nullptr, DeviceBuffer* d_bytes = nullptr, DeviceBuffer* d_elems = nullptr);
 
@@ -105,6 +109,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     ctx->ntt.release();
     for (auto& w : ctx->ntt_x) w.release();
     for (auto& ps : ctx->poly) ps.release();
+    if (ctx->vb_pinned) { (void)hipHostFree(ctx->vb_pinned); ctx->vb_pinned = nullptr; ctx->vb_pinned_bytes = 0; }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -490,11 +495,9 @@ int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t pr
     return KZG_OK;
 }
 
-int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_mont, const uint64_t* zs_mont, const uint64_t* ys_mont,
-                                   const uint64_t* proofs_xy_mont, const uint64_t* r_powers_mont, size_t n,
-                                   const uint64_t* g2_tau_mont, int32_t* out_ok) {
-    if (!ctx || !out_ok) return KZG_ERR_INVALID_ARG;
-    if (n && (!commitments_xy_mont || !zs_mont || !ys_mont || !proofs_xy_mont || !r_powers_mont)) return KZG_ERR_INVALID_ARG;
+static int32_t verify_batch_core(kzg_ctx* ctx, const uint64_t* commitments_xy_mont, const uint64_t* zs_mont, const uint64_t* ys_mont,
+                                 const uint64_t* proofs_xy_mont, const uint64_t* r_powers_mont, size_t n,
+                                 const uint64_t* g2_tau_mont, int32_t* out_ok) {
     using namespace kzg_host;
     // batch.rs:203-210 (every commitment and proof on the curve) is checked on the GPU, on the points the MSM uploads anyway
     // (k_points_wire_to_device_checked: 2n curve equations cost the host 0.5 ms at n = 4096); the error order of the reference is
@@ -531,6 +534,14 @@ int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_
     G1 rhs = g1_add(g1_add(c_lincomb, g1_neg(g1_mul_generator(s_int))), proof_z_lincomb);   // batch.rs:249
     *out_ok = pairings_verify(proof_lincomb, g2_tau, rhs, g2_generator()) ? 1 : 0;         // batch.rs:253-254
     return KZG_OK;
+}
+
+int32_t kzg_verify_kzg_proof_batch(kzg_ctx* ctx, const uint64_t* commitments_xy_mont, const uint64_t* zs_mont, const uint64_t* ys_mont,
+                                   const uint64_t* proofs_xy_mont, const uint64_t* r_powers_mont, size_t n,
+                                   const uint64_t* g2_tau_mont, int32_t* out_ok) {
+    if (!ctx || !out_ok) return KZG_ERR_INVALID_ARG;
+    if (n && (!commitments_xy_mont || !zs_mont || !ys_mont || !proofs_xy_mont || !r_powers_mont)) return KZG_ERR_INVALID_ARG;
+    return verify_batch_core(ctx, commitments_xy_mont, zs_mont, ys_mont, proofs_xy_mont, r_powers_mont, n, g2_tau_mont, out_ok);
 }
 
 // ---- NTT ------------------------------------------------------------------------------------------
@@ -907,6 +918,207 @@ int32_t kzg_calculate_roots_of_unity(kzg_ctx* ctx, uint64_t length_of_data_after
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return roots_run(ctx, out_mont, n);
+}
+
+// ---- batch verification end to end (verifier/src/batch.rs:16-69, :76-168; primitives/src/helpers.rs:613-662) ---------------------
+namespace {
+
+const char RC_BATCH_DOMAIN[] = "EIGENDA_RCKZGBATCH___V1_";     // primitives/src/consts.rs:11 (24 bytes)
+constexpr size_t VB_GROUP_BYTES = (size_t)256 << 20;           // packed blob bytes per GPU round
+constexpr uint32_t VB_BATCH_MAX_LOG = 12;                      // = VB_MAX_LOG of poly.hip: larger blobs take the single-polynomial path
+struct VbMeta { uint64_t off; uint32_t len; uint32_t log_n; }; // = VbBlob of poly.hip
+
+void fr_wire_to_be_bytes(const uint64_t wire[4], uint8_t out[32]) {
+    uint64_t k[4];
+    kzg_host::fr_wire_to_canonical(wire, k);
+    for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) out[8 * i + b] = (uint8_t)(k[3 - i] >> (8 * (7 - b)));
+}
+void digest_to_fr_wire(const uint8_t dig[32], uint64_t out[4]) {            // hash_to_field_element (helpers.rs:382-390)
+    uint64_t w[4];
+    for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int b = 0; b < 8; ++b) v = (v << 8) | dig[8 * (3 - i) + b]; w[i] = v; }
+    while (kzg_host::fr_geq_r(w)) kzg_host::fr_sub_r(w);
+    kzg_host::fr_mul(w, FR_R2_WORDS, out);
+}
+unsigned host_threads(size_t jobs) {
+    unsigned t = std::thread::hardware_concurrency();
+    if (t == 0) t = 4;
+    { const char* env = getenv("KZG_HOST_THREADS"); if (env && atoi(env) > 0) t = (unsigned)atoi(env); }
+    if (t > 32) t = 32;
+    if ((size_t)t > jobs) t = (unsigned)jobs;
+    return t ? t : 1;
+}
+// run job(i) for i in [0, n) on a pool of host threads (the calling thread included)
+void parallel_for(size_t n, const std::function<void(size_t)>& job) {
+    const unsigned T = host_threads(n);
+    if (T <= 1) { for (size_t i = 0; i < n; ++i) job(i); return; }
+    std::atomic<size_t> next{0};
+    auto body = [&] { for (;;) { const size_t i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) return; job(i); } };
+    std::vector<std::thread> pool;
+    pool.reserve(T - 1);
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back(body);
+    body();
+    for (auto& th : pool) th.join();
+}
+
+// The data-parallel front end of verify_blob_kzg_proof_batch: z_i = compute_challenge(blob_i, C_i), y_i = p_i(z_i) for all n blobs.
+// Transcripts: n independent SHA-256 streams on a pool of host threads (each also packs its blob into the pinned staging buffer);
+// evaluations: two GPU launches for all blobs of up to 4096 elements (poly.hip k_vb_prep / k_vb_eval), the single-polynomial path
+// for the rest.  `validated` = the caller has already checked every commitment (batch.rs:29-37); otherwise compute_challenge's own
+// validate_g1_point (helpers.rs:413) is reported in blob order.
+// commitments == nullptr: zs are INPUTS (kzg_evaluate_blobs_in_evaluation_form_batch), nothing is hashed.
+int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, const size_t* lens, const uint64_t* commitments, size_t n,
+                                   bool validated, uint64_t* zs, uint64_t* ys) {
+    using namespace kzg_host;
+    // per-blob guards in the reference's order (helpers.rs:634-645): to_polynomial_eval_form (TOO_LARGE), compute_challenge
+    // (validate_g1_point), evaluate_polynomial_in_evaluation_form -> calculate_roots_of_unity (ZERO_LENGTH)
+    std::vector<int32_t> status(n, KZG_OK);
+    std::vector<VbMeta> meta(n);
+    std::vector<size_t> group_end;                            // blob index where each GPU round ends
+    size_t off = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t elems = (lens[i] + 31) / 32;
+        if (lens[i] && !blobs[i]) return KZG_ERR_INVALID_ARG;
+        if (elems > ((size_t)1 << 28)) { status[i] = KZG_ERR_TOO_LARGE; meta[i] = VbMeta{0, 0, 99}; continue; }
+        size_t np = 1; uint32_t lg = 0;
+        while (np < elems) { np <<= 1; ++lg; }
+        const bool batched = lens[i] != 0 && lg <= VB_BATCH_MAX_LOG;
+        const size_t span = batched ? elems * 32 : 0;
+        if (off && off + span > VB_GROUP_BYTES) { group_end.push_back(i); off = 0; }
+        meta[i] = VbMeta{(uint64_t)off, (uint32_t)(batched ? lens[i] : 0), batched ? lg : 99u};
+        off += span;
+    }
+    group_end.push_back(n);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->slot_pending[0]) { ctx->last_error = "a kzg_*_begin on slot 0 is still in flight: call its end first"; return KZG_ERR_INVALID_ARG; }
+    std::vector<uint8_t> fallback(n, 0);
+    size_t g0 = 0;
+    for (size_t g1 : group_end) {
+        size_t bytes = 0;
+        for (size_t i = g0; i < g1; ++i) if (meta[i].log_n != 99u) bytes = std::max(bytes, (size_t)meta[i].off + ((size_t)meta[i].len + 31) / 32 * 32);
+        if (bytes > ctx->vb_pinned_bytes) {
+            if (ctx->vb_pinned) { (void)hipHostFree(ctx->vb_pinned); ctx->vb_pinned = nullptr; ctx->vb_pinned_bytes = 0; }
+            const size_t cap = bytes + bytes / 4 + 4096;
+            KZG_HIP_TRY(ctx, hipHostMalloc(&ctx->vb_pinned, cap, hipHostMallocDefault));
+            ctx->vb_pinned_bytes = cap;
+        }
+        uint8_t* stage = static_cast<uint8_t*>(ctx->vb_pinned);
+        parallel_for(g1 - g0, [&](size_t k) {
+            const size_t i = g0 + k;
+            if (status[i] != KZG_OK) return;
+            G1 c;
+            if (commitments) {
+                c = g1_from_wire(commitments + 8 * i);
+                if (!validated && !g1_on_curve(c)) { status[i] = KZG_ERR_G1_NOT_ON_CURVE; return; }
+            }
+            if (lens[i] == 0) { status[i] = KZG_ERR_ZERO_LENGTH; return; }
+            const uint8_t* src = blobs[i];
+            if (meta[i].log_n != 99u) {                       // pack (zero-filled to the 32-byte chunk) and hash the packed copy
+                uint8_t* dst = stage + meta[i].off;
+                const size_t span = (lens[i] + 31) / 32 * 32;
+                memcpy(dst, blobs[i], lens[i]);
+                if (span > lens[i]) memset(dst + lens[i], 0, span - lens[i]);
+                src = dst;
+            }
+            if (!commitments) return;
+            Sha256 sh;
+            sha256_init(sh);
+            challenge_absorb_prefix(sh, src, lens[i], blob_padded_len(lens[i]));
+            challenge_finish(sh, c, zs + 4 * i);
+        });
+        for (size_t i = g0; i < g1; ++i) if (status[i] != KZG_OK) return status[i];      // the first failing blob, in order
+        int32_t rc = vb_evaluate_run(ctx, stage, bytes, meta.data() + g0, g1 - g0, zs + 4 * g0, ys + 4 * g0, fallback.data() + g0);
+        if (rc != KZG_OK) return rc;
+        g0 = g1;
+    }
+    for (size_t i = 0; i < n; ++i) {                          // z on the domain, or more than 4096 elements: one polynomial at a time
+        if (!fallback[i]) continue;
+        const size_t np = blob_padded_len(lens[i]);
+        PolySet& set = ctx->poly[0];
+        void* d_evals = nullptr;
+        int32_t rc = blob_to_fr_run(ctx, blobs[i], lens[i], np, &d_evals, ctx->stream, &set.c, &set.a);
+        if (rc == KZG_OK) rc = proof_run(ctx, nullptr, nullptr, np, zs + 4 * i, nullptr, nullptr, ys + 4 * i, false, 0, nullptr);
+        if (rc != KZG_OK) return rc;
+    }
+    return KZG_OK;
+}
+
+// batch.rs:76-168 on the host: 40 + 8 n + 128 n transcript bytes, one SHA-256, n - 1 field multiplications
+void r_powers_host(const uint64_t* commitments, const uint64_t* zs, const uint64_t* ys, const uint64_t* proofs, const uint64_t* lens_elems,
+                   size_t n, uint64_t* out) {
+    using namespace kzg_host;
+    std::vector<uint8_t> data(40 + n * 8 + n * 128, 0);
+    memcpy(data.data(), RC_BATCH_DOMAIN, 24);                                          // bytes 24..31 stay zero (batch.rs:107-112)
+    for (int b = 0; b < 8; ++b) data[32 + b] = (uint8_t)((uint64_t)n >> (8 * (7 - b)));
+    for (size_t i = 0; i < n; ++i) for (int b = 0; b < 8; ++b) data[40 + 8 * i + b] = (uint8_t)(lens_elems[i] >> (8 * (7 - b)));
+    uint8_t* rows = data.data() + 40 + 8 * n;
+    parallel_for(n, [&](size_t i) {
+        uint8_t* p = rows + 128 * i;
+        g1_serialize_compressed_ark(g1_from_wire(commitments + 8 * i), p);
+        fr_wire_to_be_bytes(zs + 4 * i, p + 32);
+        fr_wire_to_be_bytes(ys + 4 * i, p + 64);
+        g1_serialize_compressed_ark(g1_from_wire(proofs + 8 * i), p + 96);
+    });
+    Sha256 sh;
+    sha256_init(sh);
+    sha256_update(sh, data.data(), data.size());
+    uint8_t dig[32];
+    sha256_final(sh, dig);
+    uint64_t r[4], cur[4];
+    digest_to_fr_wire(dig, r);
+    const uint64_t one_int[4] = {1, 0, 0, 0};
+    fr_mul(FR_R2_WORDS, one_int, cur);                                                 // 1 in wire form
+    for (size_t i = 0; i < n; ++i) { memcpy(out + 4 * i, cur, 32); fr_mul(cur, r, cur); }   // compute_powers (helpers.rs:298-313)
+}
+
+}  // namespace
+
+int32_t kzg_compute_challenges_and_evaluate_polynomial(kzg_ctx* ctx, const uint8_t* const* blobs, const size_t* blob_lens,
+                                                       const uint64_t* commitments_xy_mont, size_t n, uint64_t* out_zs_mont, uint64_t* out_ys_mont) {
+    if (!ctx) return KZG_ERR_INVALID_ARG;
+    if (n == 0) return KZG_OK;
+    if (!blobs || !blob_lens || !commitments_xy_mont || !out_zs_mont || !out_ys_mont) return KZG_ERR_INVALID_ARG;
+    return challenges_and_evaluations(ctx, blobs, blob_lens, commitments_xy_mont, n, false, out_zs_mont, out_ys_mont);
+}
+
+int32_t kzg_evaluate_blobs_in_evaluation_form_batch(kzg_ctx* ctx, const uint8_t* const* blobs, const size_t* blob_lens, const uint64_t* zs_mont,
+                                                    size_t n, uint64_t* out_ys_mont) {
+    if (!ctx) return KZG_ERR_INVALID_ARG;
+    if (n == 0) return KZG_OK;
+    if (!blobs || !blob_lens || !zs_mont || !out_ys_mont) return KZG_ERR_INVALID_ARG;
+    return challenges_and_evaluations(ctx, blobs, blob_lens, nullptr, n, true, const_cast<uint64_t*>(zs_mont), out_ys_mont);
+}
+
+int32_t kzg_compute_r_powers(const uint64_t* commitments_xy_mont, const uint64_t* zs_mont, const uint64_t* ys_mont, const uint64_t* proofs_xy_mont,
+                             const uint64_t* blobs_as_field_elements_length, size_t n, uint64_t* out_r_powers_mont) {
+    if (n == 0) return KZG_OK;
+    if (!commitments_xy_mont || !zs_mont || !ys_mont || !proofs_xy_mont || !blobs_as_field_elements_length || !out_r_powers_mont) return KZG_ERR_INVALID_ARG;
+    r_powers_host(commitments_xy_mont, zs_mont, ys_mont, proofs_xy_mont, blobs_as_field_elements_length, n, out_r_powers_mont);
+    return KZG_OK;
+}
+
+int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blobs, const size_t* blob_lens, const uint64_t* commitments_xy_mont,
+                                        const uint64_t* proofs_xy_mont, size_t n, const uint64_t* g2_tau_mont, int32_t* out_ok) {
+    if (!ctx || !out_ok) return KZG_ERR_INVALID_ARG;
+    if (n && (!blobs || !blob_lens || !commitments_xy_mont || !proofs_xy_mont)) return KZG_ERR_INVALID_ARG;
+    using namespace kzg_host;
+    // batch.rs:29-37: every commitment, then every proof, on the curve (cofactor 1: no subgroup check to make) -- before anything else
+    {
+        std::atomic<int> bad{0};
+        parallel_for(2 * n, [&](size_t k) {
+            const uint64_t* p = k < n ? commitments_xy_mont + 8 * k : proofs_xy_mont + 8 * (k - n);
+            if (!g1_on_curve(g1_from_wire(p))) bad.store(1, std::memory_order_relaxed);
+        });
+        if (bad.load()) return KZG_ERR_G1_NOT_ON_CURVE;
+    }
+    std::vector<uint64_t> zs(4 * n), ys(4 * n), rp(4 * n), lens_elems(n);
+    if (n) {
+        int32_t rc = challenges_and_evaluations(ctx, blobs, blob_lens, commitments_xy_mont, n, true, zs.data(), ys.data());   // batch.rs:43-44
+        if (rc != KZG_OK) return rc;
+        for (size_t i = 0; i < n; ++i) lens_elems[i] = (uint64_t)blob_padded_len(blob_lens[i]);                              // batch.rs:48-54
+        r_powers_host(commitments_xy_mont, zs.data(), ys.data(), proofs_xy_mont, lens_elems.data(), n, rp.data());           // batch.rs:222
+    }
+    return verify_batch_core(ctx, commitments_xy_mont, zs.data(), ys.data(), proofs_xy_mont, rp.data(), n, g2_tau_mont, out_ok);   // batch.rs:62-68
 }
 
 }  // extern "C"

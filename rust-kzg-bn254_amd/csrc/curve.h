@@ -115,7 +115,7 @@ KZG_HD void xyzz_madd(Xyzz& acc, const Affine& p, uint32_t neg) {
     if (acc.inf) { xyzz_from_affine(acc, p, neg); return; }
     Fq y2s, u2, s2, pp_, rr_, P, R, ppp, q, t, v;
     fe_cneg(y2s, p.y, neg);
-#if defined(KZG_MADD_PAIRED) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(KZG_MADD_PAIRED)
     fe_mul2(u2, p.x, acc.zz, s2, y2s, acc.zzz);
 #else
     fe_mul(u2, p.x, acc.zz);                   // U2 = x2 ZZ1
@@ -123,14 +123,14 @@ KZG_HD void xyzz_madd(Xyzz& acc, const Affine& p, uint32_t neg) {
 #endif
     fe_sub(P, u2, acc.x);                      // P in (-6m, 9m), limbs within +-2^29
     fe_sub(R, s2, acc.y);                      // R in (-4m, 5m)
-#if defined(KZG_MADD_PAIRED) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(KZG_MADD_PAIRED)
     fe_sqr2(pp_, P, rr_, R);
 #else
     fe_sqr(pp_, P);                            // 81 m^2 < 169 m^2
     fe_sqr(rr_, R);
 #endif
     if (__builtin_expect(fe_is_zero_mod(pp_), 0)) { xyzz_madd_exceptional<INLINE_SLOW>(acc, p.x, y2s, rr_); return; }
-#if defined(KZG_MADD_PAIRED) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(KZG_MADD_PAIRED)
     fe_mul2(ppp, P, pp_, q, acc.x, pp_);
 #else
     fe_mul(ppp, P, pp_);                       // 9m * 2m
@@ -140,7 +140,7 @@ KZG_HD void xyzz_madd(Xyzz& acc, const Affine& p, uint32_t neg) {
     fe_sub(t, q, v);                           // (-6m, 9m), limbs within +-2^29
     fe_mulsub(acc.y, R, t, acc.y, ppp);        // Y3 = R (Q - X3) - Y1 PPP: 45 m^2 + 6 m^2, one reduction -> (-m, 2m)
     acc.x = v;
-#if defined(KZG_MADD_PAIRED) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(KZG_MADD_PAIRED)
     { Fq z2, z3; fe_mul2(z2, acc.zz, pp_, z3, acc.zzz, ppp); acc.zz = z2; acc.zzz = z3; }
 #else
     fe_mul(acc.zz, acc.zz, pp_);

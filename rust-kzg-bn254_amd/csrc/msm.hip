@@ -159,7 +159,7 @@ struct MsmPending {
 
 // Enqueue every kernel of one MSM (or batch) plus the D2H copy of its O(100) result points on `st`, using `ws`.
 static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
-                           uint32_t batch, Pending* pend, uint32_t out_off = 0) {
+                           uint32_t batch, Pending* pend, uint32_t out_off = 0, uint32_t out_cap = MSM_MAX_OUT) {
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
     const Plan p = make_plan(ctx, n, bases, batch);
     const size_t entries = (size_t)p.W * n * batch;
@@ -320,7 +320,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     }
     KZG_MARK(7);
     KZG_HIP_TRY(ctx, hipGetLastError());
-    if (out_off + n_out > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
+    // this launch owns [out_off, out_off + out_cap) of the pinned result buffer (one MSM_PART_OUT window per part of a multi-part MSM)
+    if (n_out > out_cap || out_off + n_out > MSM_MAX_OUT) {
+        (void)hipStreamSynchronize(st);
+        ctx->last_error = "MSM result points exceed this launch's window of the result buffer";
+        return KZG_ERR_INVALID_ARG;
+    }
     KZG_HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ws.pinned_out) + (size_t)out_off * 128, ws.out_wire.p, (size_t)n_out * 128, hipMemcpyDeviceToHost, st));
     if (!ws.ev_done) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
     KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_done, st));        // msm_finish waits for THIS launch, not for the stream: a later MSM may already be queued behind it
@@ -418,7 +423,8 @@ static int32_t msm_enqueue_parts(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st,
     for (size_t k = 0, off = 0; off < n; off += chunk, ++k) {
         MsmBases b = bases;
         b.points = bases.points + 4 * off;
-        int32_t rc = msm_enqueue(ctx, ws, st, b, d_scalars + 2 * off, std::min(chunk, n - off), 1, &mp->part[k], parts > 1 ? (uint32_t)k * MSM_PART_OUT : 0u);
+        int32_t rc = msm_enqueue(ctx, ws, st, b, d_scalars + 2 * off, std::min(chunk, n - off), 1, &mp->part[k], parts > 1 ? (uint32_t)k * MSM_PART_OUT : 0u,
+                                 parts > 1 ? MSM_PART_OUT : MSM_MAX_OUT);
         if (rc != KZG_OK) { if (k) (void)hipStreamSynchronize(st); return rc; }
         if (k) mp->part[k - 1].profiled = false;
         mp->n_parts = (uint32_t)k + 1;

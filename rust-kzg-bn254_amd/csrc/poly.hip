@@ -438,6 +438,199 @@ k_poly_roots(uint4* __restrict__ out, uint32_t n, NttTables tb) {
     wire_store(out, i, w);
 }
 
+// ---- batch verification front end: all n barycentric evaluations of verify_blob_kzg_proof_batch in two launches ---------------
+// verifier/src/batch.rs:16-69 -> primitives/src/helpers.rs:613-662 evaluates y_i = p_i(z_i) blob after blob (n_i inversions each).
+// Here blob i (2^log_n <= 2^VB_MAX_LOG evaluations, read straight from its big-endian bytes) is one workgroup:
+//   k_vb_prep   one LANE per blob: z^n by squarings and the ONE inversion of the blob, 1 / (z^n - 1) = 1 / prod_j (z - w^j) (Fermat)
+//   k_vb_eval   one WORKGROUP per blob: lane t owns the denominators d_j = z - w^j, j = t + k Lf; a product tree over the lanes
+//               in LDS (up-sweep), seeded at the root with the inverse from k_vb_prep and walked down (inverse of a node =
+//               inverse of its parent x product of its sibling) leaves every lane the inverse of its own product; Montgomery's
+//               trick inside the lane; then sum_j f_j w^j / (z - w^j) and y = (z^n - 1) / n times that sum (helpers.rs:507-532).
+// z on the domain (1 - z^n == 0; the early return of helpers.rs:497-504) and blobs beyond 2^VB_MAX_LOG elements are flagged and evaluated by
+// the single-polynomial path (proof_run) on the host's request.
+constexpr int VB_MAX_LOG = 12;
+constexpr int VB_THREADS = 1024;
+struct VbBlob { uint64_t off; uint32_t len; uint32_t log_n; };          // byte offset (32-byte aligned, zero-filled to the next chunk), byte length, log2(padded elements)
+struct VbPrep { int32_t z[NL]; int32_t znm1[NL]; int32_t tinv[NL]; uint32_t fallback; };
+
+__global__ void __launch_bounds__(64)
+k_vb_prep(const uint4* __restrict__ zs_wire, const VbBlob* __restrict__ meta, uint32_t nb, VbPrep* __restrict__ prep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int log_n = (int)meta[i].log_n;
+    Fr z, zn, one, den;
+    wire_load(z, zs_wire, i);
+    zn = z;
+    for (int a = 0; a < log_n; ++a) fe_sqr(zn, zn);
+    fe_set_one(one);
+    fe_sub(den, zn, one);
+    fe_reduce(den);                                        // z^n - 1 in (-m, 2m)
+    Fr dc = den;
+    fe_canon(dc);
+    VbPrep& o = prep[i];
+    o.fallback = (fe_is_literal_zero(dc) || log_n > VB_MAX_LOG) ? 1u : 0u;
+    fe_canon(z);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { o.z[j] = z.l[j]; o.znm1[j] = den.l[j]; }
+    if (o.fallback) return;
+    // den^(r - 2): exponent = the modulus with its lowest limb reduced by two (P[0] = 0x10000001: no borrow)
+    Fr acc = den;
+#pragma unroll 1
+    for (int bit = 252; bit >= 0; --bit) {
+        fe_sqr(acc, acc);
+        const uint32_t limb = FrParams::P[bit / LB] - (bit / LB == 0 ? 2u : 0u);
+        if ((limb >> (bit % LB)) & 1u) fe_mul(acc, acc, den);
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) o.tinv[j] = acc.l[j];
+}
+
+// raw big-endian chunk j of a packed blob as a plain integer < 2^256 in limbs (zero beyond the blob's elements)
+__device__ __forceinline__ void vb_load_raw(Fr& x, const uint8_t* __restrict__ base, uint32_t j, uint32_t n_elems) {
+    uint32_t w32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (j < n_elems) {
+        const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)j * 32);
+        const uint4 hi = p[0], lo = p[1];                  // bytes 0..15 (most significant), 16..31
+        w32[7] = __builtin_bswap32(hi.x); w32[6] = __builtin_bswap32(hi.y); w32[5] = __builtin_bswap32(hi.z); w32[4] = __builtin_bswap32(hi.w);
+        w32[3] = __builtin_bswap32(lo.x); w32[2] = __builtin_bswap32(lo.y); w32[1] = __builtin_bswap32(lo.z); w32[0] = __builtin_bswap32(lo.w);
+    }
+    fe_unpack(x, w32);
+}
+
+// lane t of a blob's workgroup: its M denominators, their product into the tree leaf (phase 1), and after the tree walk the M
+// barycentric terms (phase 2).  M = n / Lf in {1, 2, 4}: a template parameter so that d[] / pre[] stay in registers.
+template <int M>
+struct VbLane {
+    Fr d[M], pre[M];
+    __device__ __forceinline__ void denominators(Fr& p, const Fr& z, const NttTables& tb, uint32_t t, uint32_t Lf, int sh) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            Fr w;
+            domain_elem(w, tb, (t + (uint32_t)k * Lf) << sh);
+            fe_canon(w);
+            fe_sub(d[k], z, w);                            // canonical - canonical: limbs within +-2^29, |d| < m
+            if (k == 0) p = d[0];
+            else { pre[k] = p; fe_mul(p, p, d[k]); }
+        }
+    }
+    __device__ __forceinline__ void terms(Fr& sum, Fr inv_all, const NttTables& tb, const uint8_t* __restrict__ base, uint32_t n_elems, uint32_t t, uint32_t Lf, int sh) {
+#pragma unroll
+        for (int k = M - 1; k >= 0; --k) {
+            Fr inv;
+            if (k > 0) { fe_mul(inv, inv_all, pre[k]); fe_mul(inv_all, inv_all, d[k]); }
+            else inv = inv_all;
+            const uint32_t jdx = t + (uint32_t)k * Lf;
+            Fr x, w, term;
+            vb_load_raw(x, base, jdx, n_elems);
+            domain_elem(w, tb, jdx << sh);
+            fe_mul(term, x, w);                            // plain integer x internal form = plain residue f_j w^j
+            fe_mul(term, term, inv);
+            fe_add(sum, sum, term);
+        }
+        fe_norm(sum);                                      // <= 4 terms of (-m, 2m)
+        fe_reduce(sum);
+    }
+};
+
+template <int M>
+__device__ __forceinline__ void vb_eval_body(int32_t* __restrict__ tree, const uint8_t* __restrict__ bytes, const VbBlob& b, const VbPrep& pr,
+                                             const NttTables& tb, uint4* __restrict__ ys_wire) {
+    const int log_n = (int)b.log_n;
+    const uint32_t n = 1u << log_n, Lf = n / (uint32_t)M, S = 2 * Lf;
+    const uint32_t t = threadIdx.x, n_elems = (b.len + 31) / 32;
+    const int sh = VB_MAX_LOG - log_n;                     // w_n^j = w_4096^(j << sh)
+    Fr z;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) z.l[j] = pr.z[j];
+    VbLane<M> lane;
+    if (t < Lf) {
+        Fr p;
+        lane.denominators(p, z, tb, t, Lf, sh);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) tree[j * S + Lf + t] = p.l[j];
+    }
+    __syncthreads();
+    for (uint32_t s = Lf >> 1; s >= 1; s >>= 1) {          // up-sweep: node = product of its two children
+        if (t < s) {
+            const uint32_t node = s + t;
+            Fr a, c, r;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { a.l[j] = tree[j * S + 2 * node]; c.l[j] = tree[j * S + 2 * node + 1]; }
+            fe_mul(r, a, c);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) tree[j * S + node] = r.l[j];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) tree[j * S + 1] = pr.tinv[j];                   // 1 / prod_j (z - w^j) = 1 / (z^n - 1)
+    }
+    __syncthreads();
+    for (uint32_t s = 1; s < Lf; s <<= 1) {                // down-sweep: inverse of a child = inverse of the node x its sibling
+        if (t < s) {
+            const uint32_t node = s + t;
+            Fr g, a, c, ia, ic;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { g.l[j] = tree[j * S + node]; a.l[j] = tree[j * S + 2 * node]; c.l[j] = tree[j * S + 2 * node + 1]; }
+            fe_mul2(ia, g, c, ic, g, a);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { tree[j * S + 2 * node] = ia.l[j]; tree[j * S + 2 * node + 1] = ic.l[j]; }
+        }
+        __syncthreads();
+    }
+    Fr sum;
+    fe_set_zero(sum);
+    if (t < Lf) {
+        Fr inv_all;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) inv_all.l[j] = tree[j * S + Lf + t];
+        lane.terms(sum, inv_all, tb, bytes + b.off, n_elems, t, Lf, sh);
+    }
+    __syncthreads();                                       // the tree is dead: its planes carry the block sum
+    int level = 0;
+    for (uint32_t dd = VB_THREADS / 2; dd >= 1; dd >>= 1, ++level) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) tree[j * VB_THREADS + t] = sum.l[j];
+        __syncthreads();
+        if (t < dd) {
+            Fr u;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) u.l[j] = tree[j * VB_THREADS + t + dd];
+            fe_add(sum, sum, u);
+            fe_norm(sum);
+            if (level % 4 == 3) fe_reduce(sum);            // 16 terms of (-m, 2m) since the last reduction
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    fe_reduce(sum);
+    Fr y, znm1, ninv, kraw;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { znm1.l[j] = pr.znm1[j]; ninv.l[j] = (int32_t)FrParams::NINV[log_n * NL + j]; kraw.l[j] = (int32_t)FrParams::K_RAW[j]; }
+    fe_mul(y, sum, znm1);
+    fe_mul(y, y, ninv);                                    // helpers.rs:529-532; y is a PLAIN residue here (the raw f_j carried no Montgomery factor)
+    fe_mul(y, y, kraw);                                    // -> wire form y 2^256
+    fe_canon(y);
+    uint32_t o[8];
+    fe_pack(o, y);
+    ys_wire[2 * (size_t)blockIdx.x] = make_uint4(o[0], o[1], o[2], o[3]);
+    ys_wire[2 * (size_t)blockIdx.x + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+__global__ void __launch_bounds__(VB_THREADS)
+k_vb_eval(const uint8_t* __restrict__ bytes, const VbBlob* __restrict__ meta, const VbPrep* __restrict__ prep, NttTables tb /* 2^VB_MAX_LOG domain */,
+          uint4* __restrict__ ys_wire) {
+    extern __shared__ int32_t tree[];                      // NL planes of 2 Lf nodes (heap order: root 1, leaves Lf + t)
+    const VbBlob b = meta[blockIdx.x];
+    const VbPrep& pr = prep[blockIdx.x];
+    if (pr.fallback) return;                               // uniform across the workgroup
+    const uint32_t n = 1u << b.log_n;
+    if (n <= (uint32_t)VB_THREADS) vb_eval_body<1>(tree, bytes, b, pr, tb, ys_wire);
+    else if (n == 2u * VB_THREADS) vb_eval_body<2>(tree, bytes, b, pr, tb, ys_wire);
+    else vb_eval_body<4>(tree, bytes, b, pr, tb, ys_wire);
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------
 static int ilog2_exact(size_t n) { int k = 0; while (((size_t)1 << k) < n) ++k; return k; }
 
@@ -697,6 +890,48 @@ int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, 
     int32_t rc = msm_end(ctx, slot, out_xy, out_inf, nullptr);
     if (rc == KZG_OK && out_y) proof_read_y(ctx->poly[slot], out_y);
     return rc;
+}
+
+// Batched y_i = p_i(z_i) for `nb` blobs whose bytes sit packed in host memory `packed` (blob i at meta[i].off, 32-byte aligned,
+// zero-filled up to the next 32-byte chunk; `packed_len` bytes in all) with the challenges zs (wire).  ys_out receives nb wire
+// elements; fallback_out[i] != 0 marks the blobs this path does not cover (z on the domain, more than 2^VB_MAX_LOG elements): the
+// caller evaluates those one by one.  Slot 0's buffers and stream.
+int32_t vb_evaluate_run(kzg_ctx* ctx, const uint8_t* packed, size_t packed_len, const void* meta_host, size_t nb, const uint64_t* zs,
+                        uint64_t* ys_out, uint8_t* fallback_out) {
+    static_assert(sizeof(VbBlob) == 16, "VbBlob layout is part of the host interface (capi.hip)");
+    if (nb == 0) return KZG_OK;
+    PolySet& set = ctx->poly[0];
+    hipStream_t st = ctx->stream;
+    NttTables tb;
+    int32_t rc = ntt_get_tables(ctx, VB_MAX_LOG, false, &tb);
+    if (rc != KZG_OK) return rc;
+    const VbBlob* meta = static_cast<const VbBlob*>(meta_host);
+    uint32_t max_log = 0;
+    for (size_t i = 0; i < nb; ++i) if (meta[i].log_n <= (uint32_t)VB_MAX_LOG && meta[i].log_n > max_log) max_log = meta[i].log_n;
+    const uint32_t max_lf = std::min<uint32_t>(1u << max_log, (uint32_t)VB_THREADS);
+    const size_t lds = std::max<size_t>((size_t)NL * 2 * max_lf, (size_t)NL * VB_THREADS) * 4;
+    KZG_HIP_TRY(ctx, set.c.reserve(packed_len + 64));
+    KZG_HIP_TRY(ctx, set.a.reserve(nb * 32 * 2));                                      // zs | ys
+    KZG_HIP_TRY(ctx, set.b.reserve(nb * (sizeof(VbBlob) + sizeof(VbPrep))));
+    uint4* d_zs = set.a.as<uint4>();
+    uint4* d_ys = d_zs + 2 * nb;
+    VbBlob* d_meta = set.b.as<VbBlob>();
+    VbPrep* d_prep = reinterpret_cast<VbPrep*>(d_meta + nb);
+    static thread_local std::vector<VbPrep> prep_host;
+    KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vb_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NL * 2 * VB_THREADS * 4)));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zs, zs, nb * 32, hipMemcpyHostToDevice, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_meta, meta, nb * sizeof(VbBlob), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_vb_prep, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, d_zs, d_meta, (uint32_t)nb, d_prep);
+    if (packed_len) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.c.p, packed, packed_len, hipMemcpyHostToDevice, st));
+    KZG_HIP_TRY(ctx, hipMemsetAsync(d_ys, 0, nb * 32, st));
+    hipLaunchKernelGGL(k_vb_eval, dim3((unsigned)nb), dim3(VB_THREADS), lds, st, set.c.as<uint8_t>(), d_meta, d_prep, tb, d_ys);
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    prep_host.resize(nb);
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(ys_out, d_ys, nb * 32, hipMemcpyDeviceToHost, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(prep_host.data(), d_prep, nb * sizeof(VbPrep), hipMemcpyDeviceToHost, st));
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < nb; ++i) fallback_out[i] = prep_host[i].fallback ? 1 : 0;
+    return KZG_OK;
 }
 
 }  // namespace kzg

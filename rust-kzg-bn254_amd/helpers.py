@@ -231,7 +231,45 @@ def g2_mul_generator(scalar) -> np.ndarray:
 
 
 def compute_challenges_and_evaluate_polynomial(blobs, commitments, ctx=None):
-    """helpers.rs:613-665."""
+    """helpers.rs:613-665 in ONE call of the C-ABI (`kzg_compute_challenges_and_evaluate_polynomial`): the n transcripts are hashed
+    on a pool of host threads, the n barycentric evaluations are one batched GPU launch."""
+    if len(blobs) != len(commitments) and len(blobs) != 0:
+        raise GenericError("length's of the input are not the same or is empty")
+    n = len(blobs)
+    if n == 0:
+        return [], []
+    ctx = ctx or _lib.default_context()
+    ptrs, lens, _keep = _lib.blob_args(blobs)
+    cm = np.ascontiguousarray(np.stack([_lib.as_u64(c, 0).reshape(8) for c in commitments[:n]]))
+    zs = np.zeros((n, 4), dtype=np.uint64)
+    ys = np.zeros((n, 4), dtype=np.uint64)
+    rc = _lib.load().kzg_compute_challenges_and_evaluate_polynomial(ctx.handle, ptrs, lens, _lib.ptr(cm), n, _lib.ptr(zs), _lib.ptr(ys))
+    if rc == _lib.ERR_G1_NOT_ON_CURVE:
+        raise NotOnCurveError("G1 point not on curve")
+    ctx.check_device(rc)
+    if rc != _lib.OK:
+        raise GenericError(_lib.status_message(rc))
+    return list(zs), list(ys)
+
+
+def evaluate_blobs_in_evaluation_form_batch(blobs, zs, ctx=None):
+    """y_i = p_i(z_i) for n blobs in one batched GPU launch (`kzg_evaluate_blobs_in_evaluation_form_batch`; helpers.rs:475-535 each)."""
+    n = len(blobs)
+    if n == 0:
+        return []
+    ctx = ctx or _lib.default_context()
+    ptrs, lens, _keep = _lib.blob_args(blobs)
+    z = np.ascontiguousarray(np.stack([_lib.as_u64(v, 0).reshape(4) for v in zs[:n]]))
+    ys = np.zeros((n, 4), dtype=np.uint64)
+    rc = _lib.load().kzg_evaluate_blobs_in_evaluation_form_batch(ctx.handle, ptrs, lens, _lib.ptr(z), n, _lib.ptr(ys))
+    ctx.check_device(rc)
+    if rc != _lib.OK:
+        raise GenericError(_lib.status_message(rc))
+    return list(ys)
+
+
+def compute_challenges_and_evaluate_polynomial_py(blobs, commitments, ctx=None):
+    """The same, blob by blob through the single-blob entry points: kept as a cross-check of the batched call."""
     if len(blobs) != len(commitments) and len(blobs) != 0:
         raise GenericError("length's of the input are not the same or is empty")
     zs, ys = [], []

@@ -53,8 +53,30 @@ def verify_blob_kzg_proof(blob, commitment, proof, g2_tau=None, ctx=None) -> boo
     return verify_proof(commitment, proof, y, z, g2_tau)
 
 
+def _pack(items, cols):
+    n = len(items)
+    return np.ascontiguousarray(np.stack([_lib.as_u64(x, 0).reshape(cols) for x in items])) if n else np.zeros((0, cols), np.uint64)
+
+
 def compute_r_powers(commitments, zs, ys, proofs, blobs_as_field_elements_length) -> np.ndarray:
-    """batch.rs:76-168: r = H(domain || 0^8 || u64be(n) || n x u64be(len_i) || n x (C_i || z_i || y_i || proof_i))."""
+    """batch.rs:76-168 (`kzg_compute_r_powers`): r = H(domain || 0^8 || u64be(n) || n x u64be(len_i) || n x (C_i || z_i || y_i || proof_i)),
+    returns [r^0 .. r^(n-1)]."""
+    n = len(commitments)
+    if n == 0:
+        return np.zeros((0, 4), dtype=np.uint64)
+    if not (len(zs) >= n and len(ys) >= n and len(proofs) >= n and len(blobs_as_field_elements_length) >= n):
+        raise InvalidInputLength()
+    cm, pf, z_, y_ = _pack(commitments, 8), _pack(proofs[:n], 8), _pack(zs[:n], 4), _pack(ys[:n], 4)
+    lens = np.ascontiguousarray([int(v) for v in blobs_as_field_elements_length[:n]], dtype=np.uint64)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    rc = _lib.load().kzg_compute_r_powers(_lib.ptr(cm), _lib.ptr(z_), _lib.ptr(y_), _lib.ptr(pf), _lib.ptr(lens), n, _lib.ptr(out))
+    if rc != _lib.OK:
+        raise GenericError(_lib.status_message(rc))
+    return out
+
+
+def compute_r_powers_py(commitments, zs, ys, proofs, blobs_as_field_elements_length) -> np.ndarray:
+    """The same transcript assembled in Python (hashlib): an independent cross-check of the C path."""
     n = len(commitments)
     head = bytearray(40)
     head[0:24] = RANDOM_CHALLENGE_KZG_BATCH_DOMAIN
@@ -83,10 +105,7 @@ def verify_kzg_proof_batch(commitments, zs, ys, proofs, blobs_as_field_elements_
     n = len(commitments)
     r_powers = compute_r_powers(commitments, zs, ys, proofs, blobs_as_field_elements_length)
 
-    def pack(items, cols):
-        return np.ascontiguousarray(np.stack([_lib.as_u64(x, 0).reshape(cols) for x in items])) if n else np.zeros((0, cols), np.uint64)
-
-    cm, pf, z_, y_ = pack(commitments, 8), pack(proofs, 8), pack(zs, 4), pack(ys, 4)
+    cm, pf, z_, y_ = _pack(commitments, 8), _pack(proofs, 8), _pack(zs, 4), _pack(ys, 4)
     rp = np.ascontiguousarray(_lib.as_u64(r_powers, 4).reshape(-1, 4))
     tau = None if g2_tau is None else _lib.as_u64(g2_tau, 0).reshape(16)
     ok = _lib.i32(0)
@@ -99,7 +118,25 @@ def verify_kzg_proof_batch(commitments, zs, ys, proofs, blobs_as_field_elements_
 
 
 def verify_blob_kzg_proof_batch(blobs, commitments, proofs, g2_tau=None, ctx=None) -> bool:
-    """batch.rs:16-69."""
+    """batch.rs:16-69 as ONE call of the C-ABI (`kzg_verify_blob_kzg_proof_batch`): point validation, the n Fiat-Shamir challenges
+    (host thread pool), the n barycentric evaluations (one batched GPU launch), compute_r_powers, three batched GPU MSMs and the
+    host 2-pairing check."""
+    if not (len(commitments) == len(blobs) and len(proofs) == len(blobs)):
+        raise GenericError("length's of the input are not the same")
+    ctx = ctx or _lib.default_context()
+    n = len(blobs)
+    ptrs, lens, _keep = _lib.blob_args(blobs)
+    cm, pf = _pack(commitments, 8), _pack(proofs, 8)
+    tau = None if g2_tau is None else _lib.as_u64(g2_tau, 0).reshape(16)
+    ok = _lib.i32(0)
+    rc = _lib.load().kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs if n else None, lens if n else None, _lib.ptr(cm) if n else None,
+                                                     _lib.ptr(pf) if n else None, n, None if tau is None else _lib.ptr(tau), C.byref(ok))
+    _raise_for(rc, ctx)
+    return bool(ok.value)
+
+
+def verify_blob_kzg_proof_batch_py(blobs, commitments, proofs, g2_tau=None, ctx=None) -> bool:
+    """The same flow step by step through the separate entry points (cross-check of the one-call form)."""
     if not (len(commitments) == len(blobs) and len(proofs) == len(blobs)):
         raise GenericError("length's of the input are not the same")
     for c in commitments:

@@ -39,6 +39,21 @@ void hc_lazy(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
         fe_mul(r, t2, u); fe_to_wire(out, r);
     }
 }
+// The PAIRED routines the mixed addition runs on the GPU (fe_mul2 / fe_sqr2 / fe_mulsub, field29.h) against the one-product forms,
+// on raw SIGNED limb patterns (9 int32 each, no normalisation: the lazy operands of curve.h).  Returns 0 when all four pairs of
+// results are limb-for-limb equal.  The KZG_BOUND_CHECK asserts of both forms run on the way.
+int hc_paired_vs_single(const int32_t* a1, const int32_t* b1, const int32_t* a2, const int32_t* b2) {
+    Fq x1, y1, x2, y2;
+    for (int j = 0; j < NL; ++j) { x1.l[j] = a1[j]; y1.l[j] = b1[j]; x2.l[j] = a2[j]; y2.l[j] = b2[j]; }
+    Fq p1, p2, q1, q2, s1, s2, t1, t2;
+    fe_mul2(p1, x1, y1, p2, x2, y2);
+    fe_mul(q1, x1, y1); fe_mul(q2, x2, y2);
+    fe_sqr2(s1, x1, s2, y2);
+    fe_sqr(t1, x1); fe_sqr(t2, y2);
+    int bad = 0;
+    for (int j = 0; j < NL; ++j) bad |= (p1.l[j] != q1.l[j]) | (p2.l[j] != q2.l[j]) << 1 | (s1.l[j] != t1.l[j]) << 2 | (s2.l[j] != t2.l[j]) << 3;
+    return bad;
+}
 void hc_wire_to_canonical(int which, const uint32_t* a, uint32_t* out) {
     if (which == 0) fe_wire_to_canonical_words<FqParams>(out, a);
     else fe_wire_to_canonical_words<FrParams>(out, a);

@@ -231,3 +231,21 @@ def sha256(msg: bytes) -> bytes:
     buf = np.frombuffer(msg, dtype=np.uint8).copy() if msg else np.zeros(1, np.uint8)
     out = np.zeros(32, np.uint8)
     lib().orc_sha256(_b(buf), C.c_size_t(len(msg)), _b(out)); return out.tobytes()
+
+
+def compute_challenges_and_evaluate_polynomial(blobs, commitments):
+    """helpers.rs:613-662; `blobs` = list of padded blob bytes, commitments (n, 8)."""
+    n = len(blobs)
+    packed = np.frombuffer(b"".join(blobs) or b"\0", dtype=np.uint8).copy()
+    lens = np.array([len(b) for b in blobs], dtype=np.uint64)
+    cm = _u64(commitments, (-1, 8)); zs = np.zeros((n, 4), np.uint64); ys = np.zeros((n, 4), np.uint64)
+    rc = lib().orc_compute_challenges_and_evaluate_polynomial(_b(packed), _p(lens), _p(cm), C.c_size_t(n), _p(zs), _p(ys))
+    return rc, zs, ys
+
+
+def compute_r_powers(commitments, zs, ys, proofs, lens):
+    """verifier/src/batch.rs:76-168."""
+    cm = _u64(commitments, (-1, 8)); pf = _u64(proofs, (-1, 8)); z = _u64(zs, (-1, 4)); y = _u64(ys, (-1, 4))
+    n = len(cm); ln = np.array([int(v) for v in lens], dtype=np.uint64); out = np.zeros((n, 4), np.uint64)
+    lib().orc_compute_r_powers(_p(cm), _p(z), _p(y), _p(pf), _p(ln), C.c_size_t(n), _p(out))
+    return out

@@ -187,3 +187,23 @@ def test_affine_wire_to_device_format(hc, test_srs_points):
     zero = np.zeros(16, np.uint32); out[:] = 1
     hc.hc_affine_wire_to_device(zero.ctypes.data_as(u32p), out.ctypes.data_as(u32p))
     assert not out.any()
+
+
+def test_paired_multiplies_equal_the_single_forms_on_extreme_limbs(hc):
+    """k_msm_accumulate runs xyzz_madd on fe_mul2 / fe_sqr2; the host build now compiles the same paired form
+    (curve.h no longer gates it on the device pass: test_madd_chain_* above run it under KZG_BOUND_CHECK), and here the paired
+    routines are compared limb for limb with fe_mul / fe_sqr on the extreme SIGNED limb patterns the lazy formulas produce:
+    all limbs +-(2^29 - 1), alternating signs, a (-6m, 9m) style difference, zero, one hot limb."""
+    rnd = random.Random(29)
+    top = (1 << 29) - 1
+    hi = 1 << 22                                                  # top limb: keeps |value| < 2^254.1, i.e. |a * b| < 2^261 m
+    pats = [[top] * 8 + [hi], [-top] * 8 + [-hi], [top if j % 2 else -top for j in range(8)] + [hi], [0] * 9, [1] + [0] * 8, [0] * 8 + [-(1 << 21)],
+            [top] * 8 + [(1 << 22)], [-top] * 8 + [-(1 << 22)]]
+    pats += [[rnd.randrange(-top, top + 1) for _ in range(8)] + [rnd.randrange(-(1 << 22), 1 << 22)] for _ in range(200)]
+    arr = lambda v: (C.c_int32 * 9)(*v)                           # noqa: E731
+    hc.hc_paired_vs_single.restype = C.c_int
+    for i in range(len(pats)):
+        a1, b1 = pats[i], pats[(3 * i + 1) % len(pats)]
+        a2, b2 = pats[(5 * i + 2) % len(pats)], pats[(7 * i + 3) % len(pats)]
+        # value bound of a product: |a * b| < 2^261 m; top limbs within +-2^22 keep |value| < 2^(232+22) * 1.01
+        assert hc.hc_paired_vs_single(arr(a1), arr(b1), arr(a2), arr(b2)) == 0, i

@@ -159,3 +159,111 @@ def test_batch_4096_proofs_reuse(k, srs, g2_tau, gettysburg):
     assert k.verifier.verify_kzg_proof_batch(cs, zs, ys, ps, lens, g2_tau) is True
     ys[2077] = k.fr.fr_from_int(5)
     assert k.verifier.verify_kzg_proof_batch(cs, zs, ys, ps, lens, g2_tau) is False
+
+
+# ---------------------------------------------------------------------------------------------------------
+# verify_blob_kzg_proof_batch behind the C-ABI (BASELINE config 5 end to end)
+# ---------------------------------------------------------------------------------------------------------
+def _rand_blob(k, rng, n_raw):
+    return k.Blob.from_raw_data(rng.integers(32, 127, size=n_raw, dtype=np.uint8).tobytes())
+
+
+def test_batched_challenges_and_evaluations_match_oracle(k, srs):
+    """helpers.rs:613-662 in one call (`kzg_compute_challenges_and_evaluate_polynomial`: host thread pool for the n transcripts, one
+    batched GPU launch for the n barycentric evaluations) against the oracle's blob-by-blob restatement: every padded size 2^0 ..
+    2^12 (1, 2 and 4 denominators per lane; the 1-element domain), a ragged last chunk, non-canonical chunks (>= r: reduced by
+    to_fr_array), an all-zero blob, and a 2^13-element blob (beyond the batched kernel: single-polynomial path)."""
+    import oracle as orc
+    rng = np.random.default_rng(77)
+    blobs = [_rand_blob(k, rng, n_raw) for n_raw in (1, 31, 32, 62, 100, 300, 700, 1500, 3000, 7000, 15000, 31000, 50000, 63000, 126000, 127000)]
+    blobs.append(k.Blob.from_padded_unchecked(bytes(range(1, 46))))                      # 45 bytes: ragged second chunk
+    blobs.append(k.Blob.from_padded_unchecked(b"\xff" * 96 + bytes(32) + b"\x30" + b"\xee" * 31))   # chunks >= r
+    blobs.append(k.Blob.from_padded_unchecked(bytes(4096)))                              # zero polynomial
+    blobs.append(_rand_blob(k, rng, 200000))                                             # 8192 padded elements
+    sizes = sorted({len(b.to_polynomial_eval_form()) for b in blobs})
+    assert sizes[0] == 1 and 4096 in sizes and 8192 in sizes and 2048 in sizes
+    cms = [np.array(pyref.point_to_wire(pyref.ec_mul(1000 + i, (1, 2))), dtype=np.uint64) for i in range(len(blobs))]
+    cms[3] = np.zeros(8, dtype=np.uint64)                                                # identity commitment
+    zs, ys = k.helpers.compute_challenges_and_evaluate_polynomial(blobs, cms)
+    rc, zs_want, ys_want = orc.compute_challenges_and_evaluate_polynomial([b.data() for b in blobs], np.stack(cms))
+    assert rc == 0
+    assert np.array_equal(np.stack(zs), zs_want)
+    assert np.array_equal(np.stack(ys), ys_want)
+    # the single-blob entry points agree
+    zs2, ys2 = k.helpers.compute_challenges_and_evaluate_polynomial_py(blobs[:6], cms[:6])
+    assert np.array_equal(np.stack(zs2), zs_want[:6]) and np.array_equal(np.stack(ys2), ys_want[:6])
+    # errors (helpers.rs:413, :554-558)
+    off = np.array(pyref.point_to_wire((1, 3)), dtype=np.uint64)
+    with pytest.raises(k.errors.NotOnCurveError):
+        k.helpers.compute_challenges_and_evaluate_polynomial(blobs[:3], [cms[0], off, cms[2]])
+    with pytest.raises(k.errors.GenericError, match="Length of data after padding is 0"):
+        k.helpers.compute_challenges_and_evaluate_polynomial([blobs[0], k.Blob.from_padded_unchecked(b"")], cms[:2])
+    with pytest.raises(k.errors.GenericError, match="length's of the input are not the same or is empty"):
+        k.helpers.compute_challenges_and_evaluate_polynomial(blobs[:3], cms[:2])
+    assert k.helpers.compute_challenges_and_evaluate_polynomial([], []) == ([], [])
+
+
+def test_batched_evaluation_with_points_on_the_domain(k):
+    """`kzg_evaluate_blobs_in_evaluation_form_batch` with CALLER-given points: z on the domain (helpers.rs:497-504: the evaluation
+    itself is returned; the batched kernel flags 1 - z^n == 0 and the blob takes the single-polynomial path), z = 0, z = 1 on a
+    1-element domain, random z; all against the oracle."""
+    import oracle as orc
+    rng = np.random.default_rng(5)
+    rnd = random.Random(6)
+    blobs, zs = [], []
+    for n_raw in (20, 62, 500, 3000, 20000, 63000, 126000):
+        b = _rand_blob(k, rng, n_raw)
+        n = len(b.to_polynomial_eval_form())
+        log_n = n.bit_length() - 1
+        w = pyref.root_of_unity(log_n) if log_n else 1
+        for z in (pow(w, rnd.randrange(n), R_), pow(w, n - 1, R_), 1, 0, rnd.randrange(R_)):
+            blobs.append(b)
+            zs.append(k.fr.fr_from_int(z))
+    ys = k.helpers.evaluate_blobs_in_evaluation_form_batch(blobs, zs)
+    for b, z, y in zip(blobs, zs, ys):
+        ev = orc.to_fr_array(b.data())
+        n = len(b.to_polynomial_eval_form())
+        padded = np.zeros((n, 4), np.uint64); padded[:len(ev)] = ev
+        rc, want = orc.evaluate_polynomial_in_evaluation_form(padded, z)
+        assert rc == 0 and np.array_equal(y, want), (len(b), pyref.fr_from_mont(z))
+
+
+def test_verify_blob_kzg_proof_batch_4096_end_to_end(k, srs, g2_tau):
+    """verifier/tests/tests.rs:134-192 at BASELINE config 5's size through ONE C-ABI call (`kzg_verify_blob_kzg_proof_batch`):
+    4096 random blobs of 35 .. 50000 bytes with their GPU commitments and blob proofs verify; replacing the last blob, the last
+    commitment, the last proof, or all three makes the batch fail; a wrong trusted setup fails; the step-by-step form agrees."""
+    import oracle as orc
+    n = 4096
+    rng = np.random.default_rng(4096)
+    kz = k.KZG.new()
+    blobs, commitments, proofs = [], [], []
+    lens = rng.integers(35, 50000, size=n)
+    lens[:4] = (35, 49999, 31 * 1024, 31 * 1024 + 1)           # smallest / largest / exactly 1024 elements / one more
+    for n_raw in lens:
+        blob = _rand_blob(k, rng, int(n_raw))
+        kz.calculate_and_store_roots_of_unity(len(blob))
+        commitment, proof, _z, _y = kz.commit_and_prove_blob(blob, srs)
+        blobs.append(blob); commitments.append(commitment); proofs.append(proof)
+    assert k.verify_blob_kzg_proof_batch(blobs, commitments, proofs, g2_tau) is True
+    # the transcripts of the batch, against the oracle (first 64 blobs: the oracle evaluates with one inversion per element)
+    zs, ys = k.helpers.compute_challenges_and_evaluate_polynomial(blobs[:64], commitments[:64])
+    rc, zs_want, ys_want = orc.compute_challenges_and_evaluate_polynomial([b.data() for b in blobs[:64]], np.stack(commitments[:64]))
+    assert rc == 0 and np.array_equal(np.stack(zs), zs_want) and np.array_equal(np.stack(ys), ys_want)
+    lengths = [len(b.to_polynomial_eval_form()) for b in blobs[:64]]
+    assert np.array_equal(k.verifier.compute_r_powers(commitments[:64], zs, ys, proofs[:64], lengths),
+                          orc.compute_r_powers(np.stack(commitments[:64]), zs_want, ys_want, np.stack(proofs[:64]), lengths))
+    rand_pt = lambda s: np.array(pyref.point_to_wire(pyref.ec_mul(s, (1, 2))), dtype=np.uint64)   # noqa: E731
+    bad_blobs = blobs[:-1] + [k.Blob.from_raw_data(b"random")]
+    bad_commitments = commitments[:-1] + [rand_pt(123457)]
+    bad_proofs = proofs[:-1] + [rand_pt(7654321)]
+    assert k.verify_blob_kzg_proof_batch(bad_blobs, commitments, proofs, g2_tau) is False
+    assert k.verify_blob_kzg_proof_batch(blobs, bad_commitments, proofs, g2_tau) is False
+    assert k.verify_blob_kzg_proof_batch(blobs, commitments, bad_proofs, g2_tau) is False
+    assert k.verify_blob_kzg_proof_batch(bad_blobs, bad_commitments, bad_proofs, g2_tau) is False
+    assert k.verify_blob_kzg_proof_batch(blobs, commitments, proofs) is False                    # mainnet G2_TAU: another setup
+    assert k.verifier.verify_blob_kzg_proof_batch_py(blobs[:200], commitments[:200], proofs[:200], g2_tau) is True
+    assert k.verifier.verify_blob_kzg_proof_batch_py(blobs[:200], commitments[:199] + [rand_pt(5)], proofs[:200], g2_tau) is False
+    # a corrupted blob in the MIDDLE of the batch (one flipped byte)
+    data = bytearray(blobs[2000].data()); data[40] ^= 1
+    mid = blobs[:2000] + [k.Blob.from_padded_unchecked(bytes(data))] + blobs[2001:]
+    assert k.verify_blob_kzg_proof_batch(mid, commitments, proofs, g2_tau) is False

@@ -201,3 +201,30 @@ def test_g2_tau_matches_reference_g2_powers_fixture():
     got = tuple(kzg.fr.fq_to_int(lib_tau[4 * j:4 * j + 4]) for j in range(4))       # x.c0, x.c1, y.c0, y.c1
     assert got == (points[0][0][0], points[0][0][1], points[0][1][0], points[0][1][1])
     assert len(set(points)) == 28
+
+
+def test_compute_r_powers_c_abi_matches_oracle_and_hashlib():
+    """verifier/src/batch.rs:76-168 behind the C-ABI (`kzg_compute_r_powers`, host only) against the oracle's restatement and an
+    independent hashlib transcript: identity points, n = 1 .. 300 (the row serialisation runs on a thread pool)."""
+    import random
+    import oracle as orc
+    import rust_kzg_bn254_amd as k
+    from rust_kzg_bn254_amd import verifier
+    k.load()
+    rnd = random.Random(0xB47C)
+    base = [np.array(pyref.point_to_wire(pyref.ec_mul(rnd.randrange(1, pyref.R_), (1, 2))), dtype=np.uint64) for _ in range(12)]
+    base.append(np.zeros(8, np.uint64))                      # the identity serialises as 0x40 in the last byte
+    for n in (1, 2, 7, 300):
+        cm = [base[rnd.randrange(len(base))] for _ in range(n)]
+        pf = [base[rnd.randrange(len(base))] for _ in range(n)]
+        zs = pyref.frs_to_mont([rnd.randrange(pyref.R_) for _ in range(n)])
+        ys = pyref.frs_to_mont([rnd.choice([0, 1, pyref.R_ - 1, rnd.randrange(pyref.R_)]) for _ in range(n)])
+        lens = [1 << rnd.randrange(0, 12) for _ in range(n)]
+        got = verifier.compute_r_powers(cm, list(zs), list(ys), pf, lens)
+        assert np.array_equal(got, orc.compute_r_powers(np.stack(cm), zs, ys, np.stack(pf), lens)), n
+        assert np.array_equal(got, np.stack(verifier.compute_r_powers_py(cm, list(zs), list(ys), pf, lens))), n
+        assert pyref.fr_from_mont(got[0]) == 1
+        if n > 2:
+            r = pyref.fr_from_mont(got[1])
+            assert pyref.fr_from_mont(got[n - 1]) == pow(r, n - 1, pyref.R_)
+    assert len(verifier.compute_r_powers([], [], [], [], [])) == 0
