@@ -43,6 +43,7 @@ MAD_NS_PER_WAVE_INSTR_PER_SIMD = 2.0   # measured v_mad_u64_u32 issue rate on MI
 # (count, ns per wave-instruction per SIMD) -- mads, v_mul_lo_u32, 64-bit shifts, v_and, other 32-bit VALU, s_nop (asm barriers of the paired multiplies)
 VALU_MIX_PER_MIXED_ADD = ((1467, 2.13), (81, 2.03), (144 + 18, 1.85), (187, 1.24), (255, 1.24), (290, 0.42))
 N_SIMDS = 1024
+N_BUFFERS = 8                  # distinct resident scalar buffers the timed steps rotate through
 
 
 def pmc_traffic_bytes(log_n):
@@ -145,11 +146,23 @@ def main():
     # ---- inputs: this rank's shard of the SRS (resident) and of the scalars (resident) ---------------------------
     sh = ShardedMsm(ctx, n, rank, world, gather_device="cuda" if backend == "nccl" else None)
     srs = k.SRS.generate(tau, sh.len, ctx=ctx, first_power=sh.lo)
-    canon_a = blob_like_canonical(n, 0x4B5A472D424E3235 & 0x7FFFFFFF)   # Scalars-A, identical on every rank (seeded)
-    scalars = ints_to_wire(canon_a)
-    canon_b, scalars_b = uniform_scalars(n, (0x4B5A472D424E3235 & 0x7FFFFFFF) + 1)   # Scalars-B (seed + 1)
-    d_scalars = torch.from_numpy(scalars[sh.lo:sh.hi].view(np.int64)).cuda()
+    seed0 = 0x4B5A472D424E3235 & 0x7FFFFFFF
+    # Scalars-A, identical on every rank (seeded).  The timed steps ROTATE through N_BUFFERS distinct resident buffers (a commitment
+    # service sees fresh scalars; one 32 MiB buffer fed to every step could sit in the 256 MiB Infinity Cache): four independently
+    # drawn sets and the same four rotated by half their length (other data order, other addresses; 256 MiB in all at 2^20).
+    canon_sets, wire_sets = [], []
+    for j in range(N_BUFFERS // 2):
+        c = blob_like_canonical(n, seed0 if j == 0 else seed0 + 1 + j)
+        canon_sets.append(c); wire_sets.append(ints_to_wire(c))
+    for j in range(N_BUFFERS // 2):
+        sft = n // 2 + j
+        canon_sets.append(canon_sets[j][-sft:] + canon_sets[j][:-sft]); wire_sets.append(np.roll(wire_sets[j], sft, axis=0))
+    canon_a, scalars = canon_sets[0], wire_sets[0]
+    canon_b, scalars_b = uniform_scalars(n, seed0 + 1)                  # Scalars-B (seed + 1)
+    d_sets = [torch.from_numpy(np.ascontiguousarray(w[sh.lo:sh.hi]).view(np.int64)).cuda() for w in wire_sets]
+    d_scalars = d_sets[0]
     d_scalars_b = torch.from_numpy(scalars_b[sh.lo:sh.hi].view(np.int64)).cuda()
+    rot_ptrs = [d.data_ptr() for d in d_sets]
     torch.cuda.synchronize()
 
     def barrier():
@@ -165,21 +178,25 @@ def main():
 
     trace = os.environ.get("KZG_BENCH_TRACE") == "1"                    # per-step completion times on stderr (diagnostics)
 
-    def run_steps(count, ptr, depth):
+    def run_steps(count, ptr, depth, bucket=None, keep=None):
+        """`ptr`: one device pointer, or a list the steps cycle through.  keep: list receiving every step's result."""
         res = None
         t_prev = time.perf_counter()
         marks = []
-        for res in sh.commit_stream(srs, [ptr] * count, depth=depth):
+        ptrs = [ptr[i % len(ptr)] for i in range(count)] if isinstance(ptr, list) else [ptr] * count
+        for res in sh.commit_stream(srs, ptrs, depth=depth, bucket=bucket):
+            if keep is not None:
+                keep.append(res)
             if trace:
                 t = time.perf_counter(); marks.append((t - t_prev) * 1e3); t_prev = t
         if trace and rank == 0:
             print("steps(%d, depth %d) ms: %s" % (count, depth, " ".join("%.2f" % m for m in marks)), file=sys.stderr, flush=True)
         return res
 
-    def timed(count, ptr, depth):
+    def timed(count, ptr, depth, bucket=None, keep=None):
         barrier()
         t0 = time.perf_counter()
-        res = run_steps(count, ptr, depth)
+        res = run_steps(count, ptr, depth, bucket, keep)
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
@@ -197,9 +214,10 @@ def main():
     # The same step count on every rank (the exchange is a collective); none of this is timed, the W warm-up steps follow.
     barrier()
     spinup_steps = int(os.environ.get("KZG_BENCH_SPINUP_STEPS", str(min(48 * world, 384))))
-    run_steps(spinup_steps, d_scalars.data_ptr(), depth_used)
-    run_steps(args.warmup, d_scalars.data_ptr(), depth_used)            # the W untimed warm-up steps
-    elapsed, result = timed(args.steps, d_scalars.data_ptr(), depth_used)            # THE timed region: exactly --steps steps
+    run_steps(spinup_steps, rot_ptrs, depth_used)
+    run_steps(args.warmup, rot_ptrs, depth_used)                        # the W untimed warm-up steps
+    timed_results = []
+    elapsed, result = timed(args.steps, rot_ptrs, depth_used, keep=timed_results)    # THE timed region: exactly --steps steps, step k on buffer k mod N_BUFFERS
     if world > 1:
         # every rank must hold the same folded commitment
         chk = torch.from_numpy(result.view(np.int64).copy())
@@ -213,8 +231,8 @@ def main():
     side_steps = max(4, min(args.steps, 20))
     run_steps(2, d_scalars_b.data_ptr(), depth_used)
     elapsed_b, result_b = timed(side_steps, d_scalars_b.data_ptr(), depth_used)      # uniform scalars, same pipelining
-    run_steps(2, d_scalars.data_ptr(), 1)
-    elapsed_lat, result_lat = timed(side_steps, d_scalars.data_ptr(), 1)             # one commitment at a time: latency
+    run_steps(2, d_scalars.data_ptr(), 1, 1)
+    elapsed_lat, result_lat = timed(side_steps, d_scalars.data_ptr(), 1, 1)          # one commitment at a time, one exchange per step: latency
     # kernel durations: HIP events recorded by the library on its launch streams, one MSM at a time (no other MSM shares the GPU)
     lib.kzg_ctx_set_profiling(ctx.handle, 1)
     run_steps(side_steps, d_scalars.data_ptr(), 1)
@@ -235,9 +253,11 @@ def main():
     exit_code = 0
     if rank == 0:
         # parity at EVERY world size: the folded commitment against big-integer arithmetic on the inputs
-        want_a = expected_commitment(canon_a, tau)
+        wants = [expected_commitment(c, tau) for c in canon_sets]
+        want_a = wants[0]
         want_b = expected_commitment(canon_b, tau)
-        exact = bool(np.array_equal(result, want_a) and np.array_equal(result_lat, want_a) and np.array_equal(result_b, want_b))
+        exact = bool(np.array_equal(result_lat, want_a) and np.array_equal(result_b, want_b) and len(timed_results) == args.steps
+                     and all(np.array_equal(r, wants[i % N_BUFFERS]) for i, r in enumerate(timed_results)))
         if not exact:
             exit_code = 3
         ms_per_step = elapsed / args.steps * 1e3
@@ -265,14 +285,15 @@ def main():
             "dtype": "int32x9 (29-bit limbs, 64-bit accumulate)",
             "data": "synthetic: SRS P_i = tau^i G1 with known tau (generated on device); value: blob-like scalars < 2^248 (Scalars-A), "
                     "value_uniform: uniform scalars in [0, r) (Scalars-B, seed + 1); seeded",
-            "config": {"workload": "G1 MSM 2^%d scalars (KZG::commit_coeff_form), scalars resident in HBM" % LOG_N,
+            "config": {"workload": "G1 MSM 2^%d scalars (KZG::commit_coeff_form), scalars resident in HBM; step k commits buffer k mod %d "
+                                   "(%d distinct resident scalar sets, %d MiB)" % (LOG_N, N_BUFFERS, N_BUFFERS, N_BUFFERS * 32 * n >> 20),
                        "sharding": "by scalar index over %d GPU(s); all-gather of XYZZ partials + host fold" % world,
                        "pipeline_depth": depth_used,
                        "untimed_before_warmup": "set-up: %d steps (workspaces), the first device-wide synchronisation, %d steps (clock ramp); then the %d warm-up steps" % (depth_used, spinup_steps, args.warmup),
-                       "latency_ms_is": "one commitment at a time (depth 1), %d steps" % side_steps,
+                       "latency_ms_is": "one commitment at a time (depth 1, one exchange per step), %d steps" % side_steps,
                        "bit_exact_vs_oracle": exact,
-                       "bit_exact_check": "folded commitment == (sum_i c_i tau^i mod r) * G1 by big-integer arithmetic + one affine scalar "
-                                          "multiplication (tests/pyref.py), for value, value_uniform and latency_ms, on rank 0 at every world size"},
+                       "bit_exact_check": "EVERY timed step's folded commitment == (sum_i c_i tau^i mod r) * G1 of its buffer by big-integer arithmetic "
+                                          "+ one affine scalar multiplication (tests/pyref.py); likewise value_uniform and latency_ms; on rank 0 at every world size"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_msm_accumulate", "avg_launch_ms": acc_ms,
@@ -328,7 +349,7 @@ def main():
                 assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), None) == 0
             stream_host(2)
             t = time.perf_counter(); stream_host(8); cc_stream_ms = (time.perf_counter() - t) / 8 * 1e3
-            assert np.array_equal(o8, result), "streamed host-buffer commitment differs"
+            assert np.array_equal(o8, want_a), "streamed host-buffer commitment differs"
             # config 4 front end: blob bytes (host) -> Fr -> INTT -> MSM (kzg_commit_blob), 2^20 elements = 32 MiB of padded bytes
             blob_bytes = np.frombuffer(b"".join(b"\x00" + bytes(r) for r in np.random.default_rng(7).integers(32, 127, size=(n, 31), dtype=np.uint8)), dtype=np.uint8).copy()
             u8p = C.POINTER(C.c_uint8)
@@ -383,6 +404,33 @@ def main():
             o3 = np.zeros((3, 8), np.uint64); i3 = np.zeros(3, np.uint8)
             b3 = np.ascontiguousarray(np.concatenate([g1c, g1c, g1c])); s3 = np.ascontiguousarray(np.concatenate([fr_sel, fr_sel, fr_sel]))
             m3_ms = avg_ms(lambda: lib.kzg_msm_g1_batch(ctx.handle, _lib.ptr(b3), _lib.ptr(s3), nb, 3, _lib.ptr(o3), i3.ctypes.data_as(u8p)), reps=10)
+            # config 5 END TO END (verifier/src/batch.rs:16-69 in one C-ABI call): 4096 (blob, commitment, proof) rows -- 256 distinct
+            # random blobs of 35 .. 50000 raw bytes (verifier/tests/tests.rs:134-192) with their GPU commitments and blob proofs, each
+            # used 16 times -- through point validation, 4096 Fiat-Shamir transcripts (host thread pool), 4096 barycentric
+            # evaluations (one batched GPU launch), compute_r_powers, three batched GPU MSMs and the host pairing check
+            from rust_kzg_bn254_amd.helpers import pad_payload
+            rng5 = np.random.default_rng(5)
+            rows5 = []
+            for n_raw in rng5.integers(35, 50000, size=256):
+                data = pad_payload(rng5.integers(32, 127, size=int(n_raw), dtype=np.uint8).tobytes())
+                npad = 1
+                while npad < len(data) // 32:
+                    npad <<= 1
+                buf = np.frombuffer(data, dtype=np.uint8)
+                c5 = np.zeros(8, np.uint64); p5 = np.zeros(8, np.uint64); ci5 = C.c_uint8(0); pi5 = C.c_uint8(0)
+                assert lib.kzg_commit_and_prove_blob(ctx.handle, srs.handle, buf.ctypes.data_as(u8p), len(data), npad, _lib.ptr(c5), C.byref(ci5),
+                                                     _lib.ptr(p5), C.byref(pi5), None, None) == 0
+                rows5.append((data, c5, p5))
+            sel5 = [rows5[i % 256] for i in range(nb)]
+            ptrs5, lens5, _keep5 = _lib.blob_args([r[0] for r in sel5])
+            cm5 = np.ascontiguousarray(np.stack([r[1] for r in sel5])); pf5 = np.ascontiguousarray(np.stack([r[2] for r in sel5]))
+            ok5 = C.c_int32(0)
+            e2e_ms = avg_ms(lambda: lib.kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs5, lens5, _lib.ptr(cm5), _lib.ptr(pf5), nb, _lib.ptr(tau_g2),
+                                                                        C.byref(ok5)), reps=3, warm=1)
+            assert ok5.value == 1, "the 4096-row batch did not verify"
+            pf5[nb - 1] = pf5[0]
+            assert lib.kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs5, lens5, _lib.ptr(cm5), _lib.ptr(pf5), nb, _lib.ptr(tau_g2), C.byref(ok5)) == 0 and ok5.value == 0
+            e2e_bytes = sum(len(r[0]) for r in sel5)
             # measured copy ceiling of this box (device-to-device, 1 GiB): read + write bytes per second
             big = torch.empty(1 << 28, dtype=torch.int32, device="cuda"); big2 = torch.empty_like(big)
             copy_ms = avg_ms(lambda: big2.copy_(big), reps=10)
@@ -394,6 +442,8 @@ def main():
                 "compute_blob_proof_from_host_bytes_ms": bp_ms, "commit_and_prove_blob_from_host_bytes_ms": cp_ms,
                 "compute_challenge_host_sha256_ms": ch_ms,
                 "batch_verify_4096_core_ms": bv_ms, "batch_verify_4096_three_msms_ms": m3_ms,
+                "batch_verify_4096_end_to_end_ms": e2e_ms, "batch_verify_4096_end_to_end_blob_MiB": e2e_bytes / 2.0 ** 20,
+                "batch_verify_4096_end_to_end_host_threads": min(32, os.cpu_count() or 1),
                 "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,
                 "fr_ntt_algorithmic_GBps": 64.0 * n / (ntt_ms * 1e-3) / 1e9, "fr_ntt_frac_of_hbm_peak": 64.0 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -406,7 +456,7 @@ def main():
             t1 = time.perf_counter()
             want = orc.msm_pippenger(g1, scalars, threads=cores)
             cpu_s = time.perf_counter() - t1
-            if not np.array_equal(want, result):                   # second, independent check: the oracle's Pippenger
+            if not np.array_equal(want, want_a):                   # second, independent check: the oracle's Pippenger
                 out["config"]["bit_exact_vs_oracle"] = False
                 exit_code = 3
             out["cpu_baseline"] = {"value": n / cpu_s, "unit": "pairs/s", "cores": min(cores, 17), "kind": "port",
