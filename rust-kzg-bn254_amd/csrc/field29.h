@@ -21,6 +21,7 @@
 #pragma once
 #include <cstdint>
 #include "field_constants.h"
+#include "fe_asm.h"        // generated: the products below as single inline-asm statements (device pass)
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -160,6 +161,15 @@ template <class F>
 KZG_HD void fe_mul2(Fe<F>& r1, const Fe<F>& a1, const Fe<F>& b1, Fe<F>& r2, const Fe<F>& a2, const Fe<F>& b2) {
     KZG_CHECK_MUL(a1, b1, "fe_mul2");
     KZG_CHECK_MUL(a2, b2, "fe_mul2");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_FE_ASM)
+    {
+        int32_t q1[NL], q2[NL];
+        fe_mul2_asm<F>(q1, q2, a1.l, b1.l, a2.l, b2.l);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { r1.l[j] = q1[j]; r2.l[j] = q2[j]; }
+        return;
+    }
+#endif
     int64_t acc1 = 0, acc2 = 0;
     int32_t m1[NL], m2[NL], o1[NL], o2[NL];
     int32_t al1[NL], bl1[NL], al2[NL], bl2[NL];
@@ -199,6 +209,17 @@ template <class F>
 KZG_HD void fe_sqr2(Fe<F>& r1, const Fe<F>& a1, Fe<F>& r2, const Fe<F>& a2) {
     KZG_CHECK_MUL(a1, a1, "fe_sqr2");
     KZG_CHECK_MUL(a2, a2, "fe_sqr2");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_FE_ASM)
+    {
+        int32_t q1[NL], q2[NL], e1[NL], e2[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { e1[j] = a1.l[j] * 2; e2[j] = a2.l[j] * 2; }
+        fe_sqr2_asm<F>(q1, q2, a1.l, e1, a2.l, e2);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { r1.l[j] = q1[j]; r2.l[j] = q2[j]; }
+        return;
+    }
+#endif
     int64_t acc1 = 0, acc2 = 0;
     int32_t m1[NL], m2[NL], o1[NL], o2[NL];
     int32_t d1[NL], d2[NL], al1[NL], al2[NL];
@@ -260,6 +281,17 @@ KZG_HD void fe_mulsub(Fe<F>& r, const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, 
         long double m = fe_modulus_approx<F>();
         long double prod = fabsl(fe_approx(a)) * fabsl(fe_approx(b)) + fabsl(fe_approx(c)) * fabsl(fe_approx(d));
         if (prod >= ldexpl(1.0L, 261) * m) { fprintf(stderr, "KZG_BOUND_CHECK: fe_mulsub value bound violated\n"); abort(); }
+    }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_FE_ASM)
+    {
+        int32_t q[NL], nc[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) nc[j] = -c.l[j];
+        fe_mulsub_asm<F>(q, a.l, b.l, nc, d.l);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) r.l[j] = q[j];
+        return;
     }
 #endif
     int64_t acc = 0;

@@ -16,7 +16,7 @@
 // All kernels are integer/VALU bound (no MFMA: there is no dense contraction here).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "curve.h"
+#include "curve_pair.h"
 
 namespace kzg {
 
@@ -1027,6 +1027,159 @@ k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32
     } else {
         const int role = zeta_role(lane);
         if (role >= 0) xyzz_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + g, v);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 6c. the same two reduction levels on LANE PAIRS (curve_pair.h): one point per pair of lanes, 7 multiplications per lane and
+//     addition instead of 14; 64 values = one workgroup of two waves (32 pairs each).  Same inputs, same X1 / out_wire layout
+//     and the same group elements as 6b (-DKZG_NO_PAIR_REDUCE / KZG_PAIR_REDUCE=0: the one-lane kernels).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bucket_partial_half(HalfXyzz& v, const BucketSpan& s, uint32_t k, const int32_t* __restrict__ head, size_t head_stride,
+                                                    const int32_t* __restrict__ cont, size_t cont_stride, bool odd) {
+    if (k == 0) { half_load(v, head, head_stride, s.g, odd); return; }
+    const uint32_t first = s.t1 + 1;
+    const uint32_t t = !s.long_run ? s.t1 + k : (k == 1 ? first : (first / 64 + (k - 1)) * 64);
+    half_load(v, cont, cont_stride, t, odd);
+}
+// A heavy bucket (more than NP_SERIAL partials: skewed scalars, few distinct digits), summed by the 32 pairs of the wave: pair p
+// takes the partials p, p + 32, ..; then a 5-step tree; every lane returns the sum.  Out of line: rare, and its registers (a second
+// running sum) stay out of the kernel's budget.  ONE addition site for both phases.
+__device__ __noinline__ void bucket_sum_heavy_pairs(HalfXyzz& tot, uint32_t g, uint32_t t1, uint32_t np, uint32_t long_run, uint32_t lane,
+                                                    const int32_t* __restrict__ head, size_t head_stride, const int32_t* __restrict__ cont, size_t cont_stride) {
+    const uint32_t pair = lane >> 1;
+    const bool odd = (lane & 1u) != 0;
+    BucketSpan h;
+    h.g = g; h.t1 = t1; h.np = np; h.long_run = long_run != 0;
+    HalfXyzz part;
+    half_set_inf(part);
+    const uint32_t loads = (np + 31) / 32;
+#pragma unroll 1
+    for (uint32_t step = 0; step < loads + 5; ++step) {
+        HalfXyzz u;
+        bool on;
+        if (step < loads) {
+            const uint32_t k = pair + 32 * step;
+            on = k < np;
+            if (on) bucket_partial_half(u, h, k, head, head_stride, cont, cont_stride, odd);
+        } else {
+            const uint32_t d = 16u >> (step - loads);
+            half_shfl_down(u, part, (int)(2 * d));
+            on = pair < d;
+        }
+        if (on) {
+            HalfXyzz r;
+            pair_add(r, part, u, odd);
+            part = r;
+        }
+    }
+    half_shfl(tot, part, odd ? 1 : 0);                 // pair 0 holds the sum
+}
+// Sum of all partials of this PAIR's bucket (s is the same in both lanes of the pair).  Buckets with up to NP_SERIAL partials are
+// summed by their pair; heavier ones one after the other by the whole wave.  Every lane of the wave must call this.
+__device__ __forceinline__ void bucket_sum_pairs(HalfXyzz& acc, const BucketSpan& s, uint32_t lane, bool odd, const int32_t* __restrict__ head,
+                                                 size_t head_stride, const int32_t* __restrict__ cont, size_t cont_stride) {
+    half_set_inf(acc);
+    const bool heavy = s.np > NP_SERIAL;
+    if (!heavy) {
+#pragma unroll 1
+        for (uint32_t k = 0; k < s.np; ++k) {
+            HalfXyzz v, r;
+            bucket_partial_half(v, s, k, head, head_stride, cont, cont_stride, odd);
+            pair_add(r, acc, v, odd);
+            acc = r;
+        }
+    }
+    unsigned long long todo = __ballot(heavy && !odd);  // one bit per heavy pair (its even lane)
+    while (todo) {                                     // wave-uniform
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        HalfXyzz tot;
+        bucket_sum_heavy_pairs(tot, __shfl(s.g, src, 64), __shfl(s.t1, src, 64), __shfl(s.np, src, 64), (uint32_t)__shfl((int)s.long_run, src, 64), lane,
+                               head, head_stride, cont, cont_stride);
+        if ((int)(lane & ~1u) == src) acc = tot;
+    }
+}
+// Superset-sum transform over the 64 values of a two-wave group, value gp = 32 w + pair: afterwards gp = 0 holds the total and
+// gp = 2^k the sum over the values whose index has bit k set.  Steps 0..4 inside the wave, step 5 through LDS (wave 1 publishes,
+// wave 0 adds).  Called by every lane of both waves (one barrier inside).
+__device__ __forceinline__ void group_zeta64(HalfXyzz& v, uint32_t lane, uint32_t w, bool odd, int32_t* __restrict__ lds /* 2 NL x 64 words */) {
+    const uint32_t pair = lane >> 1;
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {                      // one addition site for the six steps
+        HalfXyzz u;
+        bool on;
+        if (k < 5) {
+            half_shfl_down(u, v, 2 << k);
+            on = ((pair >> k) & 1u) == 0;
+        } else {
+            if (w == 1) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) { lds[j * 64 + lane] = v.inf ? 0 : v.u.l[j]; lds[(NL + j) * 64 + lane] = v.inf ? 0 : v.v.l[j]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { u.u.l[j] = lds[j * 64 + lane]; u.v.l[j] = lds[(NL + j) * 64 + lane]; }
+            u.inf = fe_is_literal_zero(u.v);
+            on = w == 0;
+        }
+        if (on) {
+            HalfXyzz r;
+            pair_add(r, v, u, odd);
+            v = r;
+        }
+    }
+}
+#ifndef KZG_PAIR_WAVES
+#define KZG_PAIR_WAVES 3       // waves per SIMD of the pair kernels (3: <= 168 VGPRs, a wave fits beside two accumulate waves of the other MSM in flight)
+#endif
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
+k_msm_bucket_bits1p(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
+                    const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
+                    uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[2 * NL * 64];
+    const uint32_t g = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 32 + (lane >> 1);
+    const bool odd = (lane & 1u) != 0;
+    const uint32_t L = acc_seg_len(offs[B], nl);
+    const uint32_t bkt = g * 64 + gp;
+    BucketSpan s;
+    s.g = bkt; s.t1 = 0; s.np = 0; s.long_run = false;
+    if (bkt < B && L) s = bucket_span(offs, bkt, L);
+    HalfXyzz v;
+#ifdef KZG_PROBE_NOSUM          // diagnostic builds (tools/ab_reduce.sh): where does this kernel's time go
+    if (s.np) half_load(v, head, head_stride, s.g, odd); else half_set_inf(v);
+#else
+    bucket_sum_pairs(v, s, lane, odd, head, head_stride, cont, cont_stride);
+#endif
+#ifndef KZG_PROBE_NOZETA
+    group_zeta64(v, lane, w, odd, lds);
+#endif
+    const int role = zeta_role(gp);
+    if (role < 0) return;
+    if (G1 == 1) half_store_wire(out_wire, (size_t)role, v, odd);
+    else half_store(x1, x_stride, (size_t)role * G1 + g, v, odd);
+}
+// level 2: one two-wave group per job (the jobs of k_red_bits2)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
+k_red_bits2p(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[2 * NL * 64];
+    const uint32_t job = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 32 + (lane >> 1);
+    const bool odd = (lane & 1u) != 0;
+    const bool sum_job = job < 6u * G1p;
+    const uint32_t a = sum_job ? job / G1p : 6u;
+    const uint32_t g = sum_job ? job % G1p : job - 6u * G1p;
+    const uint32_t cnt = G1 - g * 64 < 64 ? G1 - g * 64 : 64;
+    HalfXyzz v;
+    if (gp < cnt) half_load(v, x1, x_stride, (size_t)a * G1 + (size_t)g * 64 + gp, odd);
+    else half_set_inf(v);
+    group_zeta64(v, lane, w, odd, lds);
+    if (sum_job) {
+        if (gp == 0) half_store_wire(out_wire, job, v, odd);
+    } else {
+        const int role = zeta_role(gp);
+        if (role >= 0) half_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + g, v, odd);
     }
 }
 
