@@ -115,6 +115,15 @@ KZG_HD void fe_mac(int64_t& acc, int32_t a, int32_t b) {
 template <class F>
 KZG_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
     KZG_CHECK_MUL(a, b, "fe_mul");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_FE_ASM)
+    {
+        int32_t q[NL];
+        fe_mul_asm<F>(q, a.l, b.l);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) r.l[j] = q[j];
+        return;
+    }
+#endif
     int64_t acc = 0;
     int32_t m[NL];
     int32_t out[NL];
@@ -337,6 +346,17 @@ KZG_HD void fe_mulsub(Fe<F>& r, const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, 
 template <class F>
 KZG_HD void fe_sqr(Fe<F>& r, const Fe<F>& a) {
     KZG_CHECK_MUL(a, a, "fe_sqr");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_FE_ASM)
+    {
+        int32_t q[NL], e[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) e[j] = a.l[j] * 2;
+        fe_sqr_asm<F>(q, a.l, e);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) r.l[j] = q[j];
+        return;
+    }
+#endif
     int64_t acc = 0;
     int32_t m[NL];
     int32_t out[NL];

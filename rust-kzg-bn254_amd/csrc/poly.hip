@@ -449,7 +449,7 @@ k_poly_roots(uint4* __restrict__ out, uint32_t n, NttTables tb) {
 // z on the domain (1 - z^n == 0; the early return of helpers.rs:497-504) and blobs beyond 2^VB_MAX_LOG elements are flagged and evaluated by
 // the single-polynomial path (proof_run) on the host's request.
 constexpr int VB_MAX_LOG = 12;
-constexpr int VB_THREADS = 1024;
+constexpr int VB_THREADS = 512;         // 8 waves: two per SIMD, 256 VGPRs each (the asm products keep inputs and outputs apart)
 struct VbBlob { uint64_t off; uint32_t len; uint32_t log_n; };          // byte offset (32-byte aligned, zero-filled to the next chunk), byte length, log2(padded elements)
 struct VbPrep { int32_t z[NL]; int32_t znm1[NL]; int32_t tinv[NL]; uint32_t fallback; };
 
@@ -498,7 +498,7 @@ __device__ __forceinline__ void vb_load_raw(Fr& x, const uint8_t* __restrict__ b
 }
 
 // lane t of a blob's workgroup: its M denominators, their product into the tree leaf (phase 1), and after the tree walk the M
-// barycentric terms (phase 2).  M = n / Lf in {1, 2, 4}: a template parameter so that d[] / pre[] stay in registers.
+// barycentric terms (phase 2).  M = n / Lf in {1, 2, 4, 8}: a template parameter so that d[] / pre[] stay in registers.
 template <int M>
 struct VbLane {
     Fr d[M], pre[M];
@@ -526,8 +526,9 @@ struct VbLane {
             fe_mul(term, x, w);                            // plain integer x internal form = plain residue f_j w^j
             fe_mul(term, term, inv);
             fe_add(sum, sum, term);
+            if (M > 4 && (k & 1) == 0) fe_norm(sum);       // at most four unnormalised 29-bit limbs fit an int32: keep the running sum normalised
         }
-        fe_norm(sum);                                      // <= 4 terms of (-m, 2m)
+        fe_norm(sum);                                      // <= 8 terms of (-m, 2m)
         fe_reduce(sum);
     }
 };
@@ -628,7 +629,8 @@ k_vb_eval(const uint8_t* __restrict__ bytes, const VbBlob* __restrict__ meta, co
     const uint32_t n = 1u << b.log_n;
     if (n <= (uint32_t)VB_THREADS) vb_eval_body<1>(tree, bytes, b, pr, tb, ys_wire);
     else if (n == 2u * VB_THREADS) vb_eval_body<2>(tree, bytes, b, pr, tb, ys_wire);
-    else vb_eval_body<4>(tree, bytes, b, pr, tb, ys_wire);
+    else if (n == 4u * VB_THREADS) vb_eval_body<4>(tree, bytes, b, pr, tb, ys_wire);
+    else vb_eval_body<8>(tree, bytes, b, pr, tb, ys_wire);
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------

@@ -165,6 +165,12 @@ namespace kzg {
                       [("r", "r1")], [("a", "a1"), ("b", "b1")],
                       lambda: [{"terms": mul_terms("a", "b"), "out": "r"}], 1)
     parts.append(t)
+    t, n5 = statement("fe_sqr_asm",
+                      "// d1 = 2 a1 limb by limb (the caller doubles)\ntemplate <class F>\n__device__ __forceinline__ void fe_sqr_asm(int32_t (&r1)[9], const int32_t (&a1)[9], const int32_t (&d1)[9])",
+                      [("r", "r1")], [("a", "a1"), ("b", "d1")],
+                      lambda: [{"terms": sqr_terms("b", "a"), "out": "r"}], 1)
+    parts.append(t)
+    parts.append("constexpr int FE_ASM_INSTRUCTIONS_SQR = %d;\n" % n5)
     parts.append("constexpr int FE_ASM_INSTRUCTIONS_MUL2 = %d, FE_ASM_INSTRUCTIONS_SQR2 = %d, FE_ASM_INSTRUCTIONS_MULSUB = %d, FE_ASM_INSTRUCTIONS_MUL = %d;\n" % (n1, n2, n3, n4))
     parts.append("}  // namespace kzg\n#endif\n")
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-kzg-bn254_amd", "csrc", "fe_asm.h")
