@@ -16,7 +16,7 @@
 //   * the scaling by n^-1 is folded into the scalars of the last stage (no chain of its own);
 //   * Jacobian -> affine by Montgomery's trick (one inversion per lane for 16 points) when there are many points.
 #include "engine.h"
-#include "curve.h"
+#include "curve_pair.h"
 
 #include <algorithm>
 #include <map>
@@ -294,6 +294,141 @@ k_g1fft_stage(int32_t* __restrict__ planes, uint32_t n, int log_n, int s, const 
     xyzz_store(planes, n, i1, r1);
 }
 
+// ---- the same two stage kernels on LANE PAIRS (curve_pair.h): one point per two lanes ----------------------------------------
+// A stage is one scalar multiplication deep: 127 doublings + 127 additions one after the other.  On a pair of lanes a doubling costs
+// 5 multiplications per lane instead of 9 and an addition 7 instead of 14, and the doubled number of waves fills the issue slots a
+// lone wave per SIMD leaves empty: 1.45 -> ~0.8 ms per stage.  Same group elements (the affine results are bit-identical).
+__device__ __forceinline__ void pair_dbl_any(HalfXyzz& r, const HalfXyzz& a, bool odd) {      // a may be the identity
+    if (__all(a.inf)) { r = a; return; }
+    HalfXyzz d;
+    pair_dbl(d, a, odd);
+    if (a.inf) r = a; else r = d;
+}
+// r = [k] p, k as its GLV halves (glv_decompose); every lane of a pair holds the same k
+__device__ __forceinline__ void pair_scalar_mul(HalfXyzz& r, const HalfXyzz& p, const uint32_t kk[8], bool odd) {
+    const uint32_t s1 = kk[3] >> 31, s2 = kk[7] >> 31;
+    Fq beta, kin, bx, y1, y2;
+    {
+        uint32_t bw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bw[j] = GLV_BETA[j];
+        fe_unpack(beta, bw);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) kin.l[j] = (int32_t)FqParams::K_PLAIN_IN[j];
+        fe_mul(beta, beta, kin);                                   // plain integer -> internal form
+    }
+    fe_mul(bx, p.u, beta);                                         // even lane: beta X
+    fe_cneg(y1, p.u, s1); fe_norm(y1);                             // odd lane: +-Y
+    fe_cneg(y2, p.u, s2); fe_norm(y2);
+    HalfXyzz P1 = p, P2 = p, S;
+    fe_select(P1.u, odd, y1, p.u);
+    fe_select(P2.u, odd, y2, bx);
+    pair_add(S, P1, P2, odd);
+    HalfXyzz acc;
+    half_set_inf(acc);
+#pragma unroll 1
+    for (int i = 126; i >= 0; --i) {
+        HalfXyzz t;
+        pair_dbl_any(t, acc, odd);
+        acc = t;
+        const uint32_t b1 = (kk[i >> 5] >> (i & 31)) & 1u, b2 = (kk[4 + (i >> 5)] >> (i & 31)) & 1u;
+        HalfXyzz op;
+        const bool both = b1 & b2;
+        fe_select(op.u, both, S.u, b1 ? P1.u : P2.u);
+        fe_select(op.v, both, S.v, p.v);
+        op.inf = p.inf || (both ? S.inf : !(b1 | b2));
+        pair_add(t, acc, op, odd);
+        acc = t;
+    }
+    r = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_g1fft_direct_pairs(const int32_t* __restrict__ x, int32_t* __restrict__ y, uint32_t n, int log_n, int K, int log_s,
+                     const uint4* __restrict__ scal, int last) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, pair = t >> 1;
+    const bool odd = (t & 1u) != 0;
+    const uint32_t R = 1u << K;
+    const uint32_t o = pair >> K, jp = pair & (R - 1);           // output element, term j'
+    const bool active = o < n;
+    HalfXyzz term;
+    half_set_inf(term);
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool plain = true;                                            // the term is the input itself (scalar 1)
+    if (active) {
+        const uint32_t nr = n >> K;
+        const uint32_t u = o & (nr - 1), j = o >> (log_n - K);
+        const uint32_t q = u & ((1u << log_s) - 1), p = u >> log_s;
+        const uint32_t e = (uint32_t)(((unsigned long long)p * jp << log_s) + (unsigned long long)nr * j * jp) & (n - 1);
+        half_load(term, x, n, (size_t)q + ((size_t)(R * p + jp) << log_s), odd);
+        if (!(e == 0 && !last)) {
+            const uint4 lo = scal[2 * (size_t)e], hi = scal[2 * (size_t)e + 1];
+            k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+            plain = false;
+        }
+    }
+    if (!__all(plain)) {                                          // wave-uniform: the multiplication runs for the whole wave or not at all
+        HalfXyzz m;
+        pair_scalar_mul(m, term, k, odd);
+        if (!plain) term = m;
+    }
+    // sum of the R terms of an output: R consecutive pairs (R <= 32: a wave holds whole outputs)
+#pragma unroll 1
+    for (int d = 1; d < (int)R; d <<= 1) {
+        HalfXyzz other;
+        half_shfl_down(other, term, 2 * d);
+        if (((lane >> 1) & (2 * d - 1)) == 0) {
+            HalfXyzz r;
+            pair_add(r, term, other, odd);
+            term = r;
+        }
+    }
+    if (active && jp == 0) half_store(y, n, o, term, odd);
+}
+
+__global__ void __launch_bounds__(256)
+k_g1fft_stage_pairs(int32_t* __restrict__ planes, uint32_t n, int log_n, int s, const uint4* __restrict__ scal, int last) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> 1;
+    const bool odd = (t & 1u) != 0;
+    const bool active = b < n / 2;                               // n / 2 >= 32 pairs here: whole waves are active or not, except the last one
+    const uint32_t half = 1u << (s - 1);
+    const uint32_t j = b & (half - 1);
+    const uint32_t i0 = active ? (((b >> (s - 1)) << s) | j) : 0, i1 = i0 + half;
+    HalfXyzz A, B, tB;
+    half_load(A, planes, n, i0, odd);
+    half_load(B, planes, n, i1, odd);
+    if (!active) { half_set_inf(A); half_set_inf(B); }
+    const uint32_t E = j << (log_n - s);
+    if (last) {                                                   // (A +- [w]B) / n = [1/n]A +- [w/n]B
+        const uint4 l0 = scal[0], h0 = scal[1];
+        const uint32_t k0[8] = {l0.x, l0.y, l0.z, l0.w, h0.x, h0.y, h0.z, h0.w};
+        HalfXyzz a2;
+        pair_scalar_mul(a2, A, k0, odd);
+        A = a2;
+    }
+    const bool plain = E == 0 && !last;
+    tB = B;
+    if (!__all(plain)) {
+        const uint4 lo = scal[2 * (size_t)E], hi = scal[2 * (size_t)E + 1];
+        const uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        HalfXyzz m;
+        pair_scalar_mul(m, B, k, odd);
+        if (!plain) tB = m;
+    }
+    HalfXyzz r0, r1, tn = tB;
+    {
+        Fq ny;
+        fe_neg(ny, tB.u); fe_norm(ny);
+        fe_select(tn.u, odd && !tB.inf, ny, tB.u);                // -[w]B: the odd lane's Y changes sign
+    }
+    pair_add(r0, A, tB, odd);
+    pair_add(r1, A, tn, odd);
+    if (active) {
+        half_store(planes, n, i0, r0, odd);
+        half_store(planes, n, i1, r1, odd);
+    }
+}
+
 // ---- XYZZ -> affine ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void affine_emit(uint4* __restrict__ out, size_t i, const Xyzz& r, const Fq& inv_zz_zzz /* 1 / (ZZ ZZZ) */, bool wire) {
     uint32_t o[16];
@@ -393,9 +528,31 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
     if (rc == KZG_OK) rc = get_scalars(ctx, log_n, true, &scal_n);
     if (rc != KZG_OK) return rc;
     const int32_t* result = bufA;
-    // small n: high-radix direct stages, at most 65536 lanes each (one wave per SIMD: the chains run at lone-wave latency)
+    // Stage plan.  A stage is one scalar multiplication deep whatever it computes, so the plan minimises (number of stages) x (time of a
+    // stage).  Measured stage times on MI355X (tools/time_g1ifft.py, round 3) while the stage fits ONE wave per SIMD (65536 lanes):
+    // 1.25 ms with one lane per point, 0.83 ms on lane pairs; beyond that a stage is throughput bound and scales with its lanes (a lone
+    // wave already issues most of what its SIMD can: two pair waves per SIMD took 1.44 ms).  Candidates:
+    //   direct stages of radix 2^K (one lane or pair per (output, term): n 2^K lanes or pairs), K <= 5
+    //   radix-2 butterflies (n / 2 lanes or pairs, work bound: one multiplication per two outputs)
+    static const int force_pairs = []() { const char* e = getenv("KZG_G1FFT_PAIRS"); return e ? atoi(e) : -1; }();   // 0 / 1: force one mode (A/B)
     int kmax = 0;
-    while (kmax < 5 && ((n << (kmax + 1)) <= 65536)) ++kmax;
+    bool pairs = false;
+    {
+        const double t_lane = 1.25, t_pair = 0.83, cap = 65536.0;
+        double best = 1e300;
+        for (int mode = 0; mode < 2; ++mode) {                        // 0: one lane per point, 1: lane pairs
+            if (force_pairs >= 0 && mode != (force_pairs ? 1 : 0)) continue;
+            const double t1 = mode ? t_pair : t_lane, width = mode ? 2.0 : 1.0;
+            for (int K = 2; K <= 5 && K <= std::max(log_n, 2); ++K) {  // direct stages
+                const double lanes = (double)n * (double)(1u << K) * width;
+                const double cost = (double)((log_n + K - 1) / K) * t1 * std::max(1.0, lanes / cap);
+                if (cost < best) { best = cost; kmax = K; pairs = mode != 0; }
+            }
+            const double lanes2 = (double)n / 2.0 * width;             // radix-2 butterflies (+ the scaling multiplication of the last stage)
+            const double cost2 = (double)(log_n + 1) * t1 * std::max(1.0, lanes2 / cap);
+            if (cost2 < best) { best = cost2; kmax = 0; pairs = mode != 0; }
+        }
+    }
     const char* env = getenv("KZG_G1FFT_RADIX_BITS");
     if (env) kmax = std::max(0, std::min(5, atoi(env)));
     if (log_n == 0) {
@@ -412,8 +569,12 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
             const int log_s = log_n - done;
             const bool last = i == stages - 1;
             const size_t lanes = n << K;
-            hipLaunchKernelGGL(k_g1fft_direct, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, src, dst, (uint32_t)n, log_n, K, log_s,
-                               last ? scal_n : scal, last ? 1 : 0);
+            if (pairs)
+                hipLaunchKernelGGL(k_g1fft_direct_pairs, dim3((unsigned)((2 * lanes + 255) / 256)), dim3(256), 0, st, src, dst, (uint32_t)n, log_n, K, log_s,
+                                   last ? scal_n : scal, last ? 1 : 0);
+            else
+                hipLaunchKernelGGL(k_g1fft_direct, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, src, dst, (uint32_t)n, log_n, K, log_s,
+                                   last ? scal_n : scal, last ? 1 : 0);
             std::swap(src, dst);
         }
         result = src;
@@ -421,8 +582,12 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
         hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, bufA, log_n);
         for (int s = 1; s <= log_n; ++s) {
             const bool last = s == log_n;
-            hipLaunchKernelGGL(k_g1fft_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, bufA, (uint32_t)n, log_n, s,
-                               last ? scal_n : scal, last ? 1 : 0);
+            if (pairs)
+                hipLaunchKernelGGL(k_g1fft_stage_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bufA, (uint32_t)n, log_n, s,
+                                   last ? scal_n : scal, last ? 1 : 0);
+            else
+                hipLaunchKernelGGL(k_g1fft_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, bufA, (uint32_t)n, log_n, s,
+                                   last ? scal_n : scal, last ? 1 : 0);
         }
     }
     const size_t lanes = std::max<size_t>(1, (n + AFF_PER - 1) / AFF_PER);

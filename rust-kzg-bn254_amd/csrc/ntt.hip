@@ -234,7 +234,11 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
                     lds[l * NTT_PL + e3] = c3.l[l];
                 }
             }
+#ifdef KZG_NTT_PROBE_NOBARRIER   // timing probe only (wrong results): what do the barriers of the first four radix-4 steps cost
+            if (log_h >= 6) __syncthreads();
+#else
             __syncthreads();
+#endif
         }
         if (log_h < (uint32_t)K) {
             const uint32_t h = 1u << log_h;
