@@ -105,6 +105,57 @@ def blob_like_scalars(n, seed):
     return ints_to_wire(blob_like_canonical(n, seed))
 
 
+def main_multi(args):
+    """`bench.py --multi --gpus N`: one process, N devices behind one kzg_multi handle (csrc/multi.hip): device g holds SRS powers and
+    scalars [g n / N, (g+1) n / N) resident, runs its own pipeline of partial MSMs on one host thread of the library, the host folds the
+    N partial sums of every step.  Same workload, same rotation of resident buffers and the same per-step check as the default mode."""
+    import rust_kzg_bn254_amd as k
+    from rust_kzg_bn254_amd.sharding import MultiKzg
+    n = 1 << LOG_N
+    tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % FR
+    have = torch.cuda.device_count()
+    ids = list(range(args.gpus)) if have >= args.gpus else [i % max(have, 1) for i in range(args.gpus)]   # fewer devices than asked: several contexts per GPU (rehearsal)
+    mk = MultiKzg(ids)
+    mk.srs_generate(tau, n)
+    seed0 = 0x4B5A472D424E3235 & 0x7FFFFFFF
+    canon_sets = [blob_like_canonical(n, seed0 if j == 0 else seed0 + 1 + j) for j in range(N_BUFFERS // 2)]
+    canon_sets += [c[-(n // 2 + j):] + c[:-(n // 2 + j)] for j, c in enumerate(canon_sets[:N_BUFFERS // 2])]
+    for j, c in enumerate(canon_sets):
+        mk.scalars_upload(j, ints_to_wire(c))
+    rot = lambda count, start=0: [(start + i) % N_BUFFERS for i in range(count)]           # noqa: E731
+    mk.commit_resident_stream(rot(4))                                                        # workspaces
+    mk.commit_resident_stream(rot(min(48 * args.gpus, 384)))                                 # clock ramp (as the default mode)
+    mk.commit_resident_stream(rot(args.warmup))
+    for d in set(ids):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    res = mk.commit_resident_stream(rot(args.steps))
+    for d in set(ids):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    wants = [expected_commitment(c, tau) for c in canon_sets]
+    exact = bool(all(np.array_equal(res[i], wants[i % N_BUFFERS]) for i in range(args.steps)))
+    out = {
+        "metric": "G1-MSM (scalar,point) pairs/s = 2^%d x KZG coeff-form commitments/s, 2^%d-point SRS" % (LOG_N, LOG_N),
+        "value": n * args.steps / elapsed, "unit": "pairs/s", "commitments_per_s": args.steps / elapsed,
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32x9 (29-bit limbs, 64-bit accumulate)",
+        "data": "synthetic: SRS P_i = tau^i G1 with known tau (generated on the devices); blob-like scalars < 2^248 (Scalars-A); seeded",
+        "config": {"workload": "G1 MSM 2^%d scalars (KZG::commit_coeff_form), scalars resident in HBM; step k commits buffer k mod %d" % (LOG_N, N_BUFFERS),
+                   "sharding": "--multi: ONE process, %d device(s) %s behind one kzg_multi handle (one host thread and one software pipeline per "
+                               "device, no collective; host fold of the partial sums)" % (args.gpus, ids),
+                   "bit_exact_vs_oracle": exact,
+                   "bit_exact_check": "every timed step's commitment == (sum_i c_i tau^i mod r) * G1 of its buffer (big integers + tests/pyref.py)"},
+        "roofline": {"bound": "hbm", "achieved": BYTES_PER_PAIR * n * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * args.gpus, "unit": "GB/s",
+                     "frac": BYTES_PER_PAIR * n * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * args.gpus), "traffic": None,
+                     "kernel": "whole step (the per-kernel figures are in the default mode's line)"},
+    }
+    print(json.dumps(out), flush=True)
+    mk.close()
+    if not exact:
+        raise SystemExit("bench.py --multi: a commitment differs from the expected point")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,7 +163,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (profiling runs)")
+    ap.add_argument("--multi", action="store_true", help="ONE process driving --gpus devices through kzg_multi_* (no torch.distributed, no "
+                    "collective): the other partitioning of SURVEY.md 8e; the driver's contract (one rank per GPU over RCCL) is the default mode")
     args = ap.parse_args()
+    if args.multi:
+        return main_multi(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

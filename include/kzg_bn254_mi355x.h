@@ -228,6 +228,14 @@ int32_t kzg_multi_commit_coeff_form(kzg_multi* m, const uint64_t* coeffs_mont, s
 int32_t kzg_multi_commit_eval_form(kzg_multi* m, const uint64_t* evals_mont, size_t n, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
 int32_t kzg_multi_compute_proof(kzg_multi* m, const uint64_t* evals_mont, size_t n, size_t n_roots, const uint64_t z_mont[4],
                                 uint64_t out_xy_mont[8], uint8_t* out_is_infinity, uint64_t* out_y_mont);
+/* Resident inputs and streams (a commitment service; what `bench.py --multi` times): kzg_multi_scalars_upload keeps the slice
+ * [g N / G, (g+1) N / G) of polynomial `buffer_id` (0 .. 15, n coefficients) in the HBM of device g; kzg_multi_commit_resident_stream
+ * commits `count` of the uploaded polynomials (buffer_ids[k]) -- every device runs its own software pipeline over the stream (two
+ * or three MSMs in flight, the asynchronous slots of kzg_msm_g1_srs_device_begin), the count x G partial sums are folded on the
+ * host -- and writes count affine points. */
+int32_t kzg_multi_scalars_upload(kzg_multi* m, int32_t buffer_id, const uint64_t* coeffs_mont, size_t n);
+int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids, size_t count, uint64_t* out_xy_mont,
+                                         uint8_t* out_is_infinity);
 
 /* helpers::compute_challenge (primitives/src/helpers.rs:411-472): the Fiat-Shamir evaluation point of a blob,
  *   z = SHA-256( "EIGENDA_FSBLOBVERIFY_V1_" || u64be(n) || n x 32 B evaluations (big-endian, canonical) || commitment ) mod r,

@@ -93,6 +93,8 @@ PROTOTYPES = {
     "kzg_multi_commit_coeff_form": (i32, [vp, u64p, sz, u64p, u8p]),
     "kzg_multi_commit_eval_form": (i32, [vp, u64p, sz, u64p, u8p]),
     "kzg_multi_compute_proof": (i32, [vp, u64p, sz, sz, u64p, u64p, u8p, u64p]),
+    "kzg_multi_scalars_upload": (i32, [vp, i32, u64p, sz]),
+    "kzg_multi_commit_resident_stream": (i32, [vp, C.POINTER(i32), sz, u64p, u8p]),
     "kzg_compute_challenge": (i32, [u8p, sz, u64p, u64p]),
     "kzg_compute_blob_proof": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, u8p, u64p, u64p]),
     "kzg_commit_and_prove_blob": (i32, [vp, vp, u8p, sz, sz, u64p, u8p, u64p, u8p, u64p, u64p]),

@@ -9,12 +9,36 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
 #include <new>
 #include <thread>
 #include <vector>
 
 namespace kzg {
+
+// roctx ranges through dlopen (engine.h)
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        const char* e = getenv("KZG_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+const RoctxApi& roctx_api() { static const RoctxApi api; return api; }
+}  // namespace
+void roctx_push(const char* name) { const RoctxApi& a = roctx_api(); if (a.push) (void)a.push(name); }
+void roctx_pop() { const RoctxApi& a = roctx_api(); if (a.pop) (void)a.pop(); }
 
 int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where) {
     if (ctx) {
@@ -1003,6 +1027,8 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
             ctx->vb_pinned_bytes = cap;
         }
         uint8_t* stage = static_cast<uint8_t*>(ctx->vb_pinned);
+        RoctxPhases phases;
+        phases.begin("kzg:batch_verify:transcripts+pack (host threads)");
         parallel_for(g1 - g0, [&](size_t k) {
             const size_t i = g0 + k;
             if (status[i] != KZG_OK) return;
@@ -1027,6 +1053,7 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
             challenge_finish(sh, c, zs + 4 * i);
         });
         for (size_t i = g0; i < g1; ++i) if (status[i] != KZG_OK) return status[i];      // the first failing blob, in order
+        phases.begin("kzg:batch_verify:evaluations (GPU)");
         int32_t rc = vb_evaluate_run(ctx, stage, bytes, meta.data() + g0, g1 - g0, zs + 4 * g0, ys + 4 * g0, fallback.data() + g0);
         if (rc != KZG_OK) return rc;
         g0 = g1;
@@ -1116,8 +1143,10 @@ int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blob
         int32_t rc = challenges_and_evaluations(ctx, blobs, blob_lens, commitments_xy_mont, n, true, zs.data(), ys.data());   // batch.rs:43-44
         if (rc != KZG_OK) return rc;
         for (size_t i = 0; i < n; ++i) lens_elems[i] = (uint64_t)blob_padded_len(blob_lens[i]);                              // batch.rs:48-54
+        RoctxRange range_rp("kzg:batch_verify:r_powers (host)");
         r_powers_host(commitments_xy_mont, zs.data(), ys.data(), proofs_xy_mont, lens_elems.data(), n, rp.data());           // batch.rs:222
     }
+    RoctxRange range_core("kzg:batch_verify:lincombs (GPU) + pairing (host)");
     return verify_batch_core(ctx, commitments_xy_mont, zs.data(), ys.data(), proofs_xy_mont, rp.data(), n, g2_tau_mont, out_ok);   // batch.rs:62-68
 }
 

@@ -174,6 +174,28 @@ int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);
 
 }  // namespace kzg
 
+// ---- roctx phase ranges (tracing) ------------------------------------------------------------------------
+// KZG_ROCTX=1 makes the library mark its host-side phases (enqueue of the sort / accumulate / reduction kernels of an MSM, the host
+// epilogue, NTT, proof pipeline, the stages of batch verification) with roctx ranges, visible in `rocprofv3 --marker-trace`.  The
+// marker library (librocprofiler-sdk-roctx.so, else libroctx64.so) is loaded with dlopen on first use: no link-time dependency,
+// no cost when the variable is unset.
+namespace kzg {
+void roctx_push(const char* name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+struct RoctxPhases {             // consecutive phases of one function; whatever is open closes on every return path
+    bool open = false;
+    void begin(const char* name) { end(); roctx_push(name); open = true; }
+    void end() { if (open) { roctx_pop(); open = false; } }
+    ~RoctxPhases() { end(); }
+};
+}  // namespace kzg
+
 #define KZG_HIP_TRY(ctx, expr)                                                     \
     do {                                                                           \
         hipError_t _e = (expr);                                                    \

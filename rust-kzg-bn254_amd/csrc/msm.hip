@@ -228,6 +228,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     };
 
     KZG_MARK(0);
+    RoctxPhases phases;
+    phases.begin("kzg:msm:sort");
     const uint32_t n_total = p.n * batch;
     const uint32_t gn = (n_total + 255) / 256;
     const size_t lds_bytes = (size_t)p.B * 4;
@@ -285,10 +287,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_MARK(3);
     }
     KZG_MARK(4);
+    phases.begin("kzg:msm:accumulate");
     // (64- and 128-thread workgroups measured the same as 256)
     hipLaunchKernelGGL(k_msm_accumulate, dim3(p.nl / 256), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.G,
                        ws.head.as<int32_t>(), (size_t)p.G, ws.cont.as<int32_t>(), (size_t)p.nl, p.idx_log, p.stride_adj);
     KZG_MARK(5);
+    phases.begin("kzg:msm:bucket reduction");
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
         // the two reduction levels: on lane pairs (curve_pair.h; one 128-thread group per 64 values) unless KZG_PAIR_REDUCE=0
@@ -328,6 +332,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         n_out = n_windows;
     }
     KZG_MARK(7);
+    phases.end();
     KZG_HIP_TRY(ctx, hipGetLastError());
     // this launch owns [out_off, out_off + out_cap) of the pinned result buffer (one MSM_PART_OUT window per part of a multi-part MSM)
     if (n_out > out_cap || out_off + n_out > MSM_MAX_OUT) {
@@ -353,7 +358,11 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     const uint32_t n_out = pend.n_out, batch = pend.batch;
     const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
     (void)st;
-    KZG_HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+    {
+        RoctxRange range_wait("kzg:msm:wait");
+        KZG_HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
+    }
+    RoctxRange range_epi("kzg:msm:host epilogue");
     if (ctx->profiling && ws.ev_ready && pend.profiled) {
         for (int i = 0; i < 7; ++i) {
             float ms = 0;

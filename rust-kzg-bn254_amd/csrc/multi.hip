@@ -12,12 +12,16 @@
 #include <thread>
 #include <vector>
 
+constexpr int KZG_MULTI_BUFFERS = 16;    // resident scalar buffers per handle (kzg_multi_scalars_upload)
 struct kzg_multi {
     std::vector<kzg_ctx*> ctx;
     std::vector<kzg_srs*> shard;
     std::vector<size_t> lo;          // first SRS power of shard g; lo[G] = N
     size_t n_total = 0;
     std::mutex mu;
+    // resident scalars: buffer b of device g holds the coefficients [lo[g], min(lo[g+1], n_b)) of polynomial b
+    std::vector<std::vector<void*>> dbuf;         // [g][b]
+    size_t buf_n[KZG_MULTI_BUFFERS] = {};
 };
 
 namespace {
@@ -43,6 +47,13 @@ void set_bounds(kzg_multi* m, size_t n) {
 void drop_shards(kzg_multi* m) {
     for (auto& s : m->shard) { if (s) kzg_srs_free(s); s = nullptr; }
 }
+void drop_buffers(kzg_multi* m) {
+    for (size_t g = 0; g < m->dbuf.size(); ++g) {
+        (void)hipSetDevice(m->ctx[g]->device);
+        for (auto& p : m->dbuf[g]) { if (p) (void)hipFree(p); p = nullptr; }
+    }
+    for (auto& n : m->buf_n) n = 0;
+}
 
 }  // namespace
 
@@ -60,12 +71,14 @@ int32_t kzg_multi_create(const int32_t* device_ids, int32_t n_devices, kzg_multi
         m->ctx.push_back(c);
     }
     m->shard.assign((size_t)n_devices, nullptr);
+    m->dbuf.assign((size_t)n_devices, std::vector<void*>(KZG_MULTI_BUFFERS, nullptr));
     *out = m;
     return KZG_OK;
 }
 
 void kzg_multi_destroy(kzg_multi* m) {
     if (!m) return;
+    drop_buffers(m);
     drop_shards(m);
     for (auto* c : m->ctx) kzg_ctx_destroy(c);
     delete m;
@@ -145,6 +158,63 @@ int32_t kzg_multi_compute_proof(kzg_multi* m, const uint64_t* evals_mont, size_t
     if (rc != KZG_OK) return rc;
     if (out_y_mont) memcpy(out_y_mont, ys.data(), 32);
     return fold(parts, G, out_xy_mont, out_is_infinity);
+}
+
+// ---- resident scalars and streams of commitments (what bench.py --multi times: inputs in HBM, several MSMs in flight per device) ----
+int32_t kzg_multi_scalars_upload(kzg_multi* m, int32_t buffer_id, const uint64_t* coeffs_mont, size_t n) {
+    if (!m || buffer_id < 0 || buffer_id >= KZG_MULTI_BUFFERS || (n && !coeffs_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (n > m->n_total) return KZG_ERR_POLY_LENGTH;
+    int32_t rc = for_each_device(m, [&](size_t g) -> int32_t {
+        kzg_ctx* c = m->ctx[g];
+        KZG_HIP_TRY(c, hipSetDevice(c->device));
+        void*& p = m->dbuf[g][(size_t)buffer_id];
+        if (p) { (void)hipFree(p); p = nullptr; }
+        const size_t lo = m->lo[g], hi = std::min(m->lo[g + 1], n);
+        if (lo >= hi) return KZG_OK;
+        KZG_HIP_TRY(c, hipMalloc(&p, (hi - lo) * 32));
+        KZG_HIP_TRY(c, hipMemcpy(p, coeffs_mont + 4 * lo, (hi - lo) * 32, hipMemcpyHostToDevice));
+        return KZG_OK;
+    });
+    if (rc == KZG_OK) m->buf_n[buffer_id] = n;
+    return rc;
+}
+
+int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids, size_t count, uint64_t* out_xy_mont, uint8_t* out_is_infinity) {
+    if (!m || (count && (!buffer_ids || !out_xy_mont))) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (size_t k = 0; k < count; ++k)
+        if (buffer_ids[k] < 0 || buffer_ids[k] >= KZG_MULTI_BUFFERS || m->buf_n[buffer_ids[k]] == 0) return KZG_ERR_INVALID_ARG;
+    const size_t G = m->ctx.size();
+    std::vector<uint64_t> parts(16 * G * count, 0);                                   // [k][g]
+    int32_t rc = for_each_device(m, [&](size_t g) -> int32_t {
+        // this device's software pipeline: MSM k + depth - 1 is enqueued before MSM k is waited for (engine.h slots)
+        const size_t shard_len = m->lo[g + 1] - m->lo[g];
+        const int depth = shard_len >= ((size_t)1 << 20) ? 2 : 3;
+        std::vector<size_t> inflight;                                                 // step indices, oldest first
+        auto retire = [&]() -> int32_t {
+            const size_t k = inflight.front();
+            inflight.erase(inflight.begin());
+            return kzg_msm_g1_srs_end(m->ctx[g], (int32_t)(k % (size_t)depth), nullptr, nullptr, parts.data() + 16 * (k * G + g));
+        };
+        int32_t r = KZG_OK;
+        for (size_t k = 0; k < count && r == KZG_OK; ++k) {
+            const size_t n = m->buf_n[buffer_ids[k]], lo = m->lo[g], hi = std::min(m->lo[g + 1], n);
+            if (lo >= hi) continue;                                                   // identity partial (zeros)
+            if (inflight.size() == (size_t)depth) r = retire();
+            if (r != KZG_OK) break;
+            r = kzg_msm_g1_srs_device_begin(m->ctx[g], m->shard[g], 0, m->dbuf[g][(size_t)buffer_ids[k]], hi - lo, (int32_t)(k % (size_t)depth));
+            if (r == KZG_OK) inflight.push_back(k);
+        }
+        while (!inflight.empty()) { const int32_t r2 = retire(); if (r == KZG_OK) r = r2; }   // drain whatever is in flight, also after an error
+        return r;
+    });
+    if (rc != KZG_OK) return rc;
+    for (size_t k = 0; k < count; ++k) {
+        rc = kzg_g1_fold_partials(parts.data() + 16 * k * G, G, out_xy_mont + 8 * k, out_is_infinity ? out_is_infinity + k : nullptr);
+        if (rc != KZG_OK) return rc;
+    }
+    return KZG_OK;
 }
 
 }  // extern "C"

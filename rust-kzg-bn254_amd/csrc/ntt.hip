@@ -391,6 +391,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
     if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
     if (n == 1) return KZG_OK;
+    RoctxRange range(inverse ? "kzg:fr_intt" : "kzg:fr_ntt");
     int log_n = 0;
     while (((size_t)1 << log_n) < n) ++log_n;
     NttTables tb;

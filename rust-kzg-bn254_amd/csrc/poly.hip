@@ -748,6 +748,7 @@ const uint64_t* h_on_domain_constants() {
 // stream has been synchronised); the quotient's coefficients are left in ps_set.c.
 static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWorkspace* nttws, const uint64_t* evals, size_t n,
                              const uint64_t z[4], bool want_proof) {
+    RoctxRange range(want_proof ? "kzg:proof:inverses + y + quotient + intt" : "kzg:evaluate:inverses + y");
     int log_n = ilog2_exact(n);
     NttTables tb;
     int32_t rc = ntt_get_tables(ctx, log_n, false, &tb);

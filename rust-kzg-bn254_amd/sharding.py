@@ -430,6 +430,19 @@ class MultiKzg:
                                                         _lib.ptr(out), C.byref(inf), _lib.ptr(y)))
         return out, y
 
+    def scalars_upload(self, buffer_id: int, coeffs):
+        """Keep polynomial `buffer_id` (0 .. 15) resident: device g stores its slice of the coefficients."""
+        c = _lib.as_u64(coeffs, 4).reshape(-1, 4)
+        self._check(_lib.load().kzg_multi_scalars_upload(self.handle, buffer_id, _lib.ptr(c), len(c)))
+
+    def commit_resident_stream(self, buffer_ids):
+        """Commitments of the uploaded polynomials buffer_ids[k], every device pipelining its own MSMs: (count, 8) affine points."""
+        ids = (C.c_int32 * max(1, len(buffer_ids)))(*buffer_ids)
+        out = np.zeros((len(buffer_ids), 8), dtype=np.uint64)
+        inf = np.zeros(max(1, len(buffer_ids)), dtype=np.uint8)
+        self._check(_lib.load().kzg_multi_commit_resident_stream(self.handle, ids, len(buffer_ids), _lib.ptr(out), inf.ctypes.data_as(_lib.u8p)))
+        return out
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.load().kzg_multi_destroy(self.handle)

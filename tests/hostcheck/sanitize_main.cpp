@@ -1,0 +1,122 @@
+// tests/hostcheck/sanitize_main.cpp — TEST-ONLY driver for an AddressSanitizer + UndefinedBehaviorSanitizer build (g++, CPU) of
+//   * the product's device math headers in their host form (field29.h / curve.h through hostcheck.cpp, with KZG_BOUND_CHECK):
+//     signed-limb arithmetic must never overflow an int32 / int64 (UB) on the lazy-reduction paths the kernels run,
+//   * the product's host code that needs no GPU: host_sha256.h (both the portable and, when the CPU has it, the SHA-NI path),
+//     host_curve.h's fold of partial sums,
+//   * the oracle (plain C, linked in): Pippenger with threads, NTT, g1_ifft, decompression, transcripts.
+// The reference's CI runs its suite on two targets (.github/workflows/rust.yml:35-49); this is this repo's counterpart for memory
+// and UB errors.  Built and run by tests/test_sanitizers_host.py; prints "sanitize ok" at the end.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hostcheck.cpp"          // hc_* entry points over field29.h / curve.h
+#include "host_sha256.h"
+#include "host_curve.h"
+
+extern "C" {
+void orc_init(void);
+void orc_g1_scalar_mul(uint64_t out[8], const uint64_t p[8], const uint64_t k_mont[4]);
+void orc_constants(int which, uint64_t m[4], uint64_t* inv, uint64_t one[4], uint64_t r2[4]);
+int orc_msm_pippenger(const uint64_t* bases, const uint64_t* scalars, size_t n, uint64_t out[8], int threads);
+int orc_msm_naive(const uint64_t* bases, const uint64_t* scalars, size_t n, uint64_t out[8]);
+int orc_fr_ntt(uint64_t* a, size_t n, int inverse);
+int orc_fr_ntt_mt(uint64_t* a, size_t n, int inverse, int threads);
+int orc_g1_ifft(const uint64_t* points, size_t n, uint64_t* out);
+int orc_compute_challenge(const uint8_t* blob, size_t blob_len, const uint64_t commitment_xy[8], uint64_t z_out[4]);
+int orc_compute_r_powers(const uint64_t* c, const uint64_t* zs, const uint64_t* ys, const uint64_t* p, const uint64_t* lens, size_t n, uint64_t* out);
+int orc_compute_challenges_and_evaluate_polynomial(const uint8_t* blobs, const uint64_t* lens, const uint64_t* commitments_xy, size_t n, uint64_t* zs, uint64_t* ys);
+void orc_sha256(const uint8_t* msg, size_t len, uint8_t out[32]);
+void orc_f_mul(int which, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]);
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ULL;
+static uint64_t rnd() { rng_state ^= rng_state << 7; rng_state ^= rng_state >> 9; return rng_state * 0x2545F4914F6CDD1DULL; }
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "sanitize_main: check failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+int main() {
+    orc_init();
+    // generator (1, 2) in wire form = (R mod p, 2R mod p): build from the oracle's field multiply of the Montgomery one
+    const uint64_t one_plain[4] = {1, 0, 0, 0}, two_plain[4] = {2, 0, 0, 0};
+    uint64_t FQ_M[4], FQ_ONE_M[4], FQ_R2[4], fq_inv;
+    orc_constants(0, FQ_M, &fq_inv, FQ_ONE_M, FQ_R2);           // modulus, -p^-1 mod 2^64, R mod p, R^2 mod p
+    uint64_t g[8];
+    orc_f_mul(0, g, one_plain, FQ_R2);
+    orc_f_mul(0, g + 4, two_plain, FQ_R2);
+    const size_t n = 96;
+    std::vector<uint64_t> pts(8 * n), sc(4 * n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t k[4] = {rnd(), rnd(), rnd(), rnd() >> 3};
+        orc_g1_scalar_mul(pts.data() + 8 * i, g, k);
+        for (int j = 0; j < 4; ++j) sc[4 * i + j] = rnd();
+        sc[4 * i + 3] >>= 4;                                   // < 2^252 < r: canonical Montgomery residues
+    }
+    // 1. device math headers (host form, bound checks on): a chain of mixed additions with signs, doublings, a running sum
+    {
+        std::vector<uint32_t> w(16 * n);
+        memcpy(w.data(), pts.data(), 64 * n);
+        std::vector<uint8_t> sign(n);
+        for (size_t i = 0; i < n; ++i) sign[i] = (uint8_t)(rnd() & 1);
+        memcpy(w.data() + 16 * 5, w.data() + 16 * 4, 64);      // P + P (doubling path)
+        sign[5] = sign[4];
+        uint32_t out[32], out2[32];
+        hc_madd_chain(w.data(), sign.data(), n, out);
+        hc_add_halves(w.data(), sign.data(), n, 3, out2);
+        hc_running_sum(w.data(), 24, out2);
+        uint32_t a32[8], b32[8], r32[8];
+        memcpy(a32, sc.data(), 32); memcpy(b32, sc.data() + 4, 32);
+        for (int which = 0; which < 2; ++which) { hc_mul(which, a32, b32, r32, 0); hc_mul(which, a32, a32, r32, 1); hc_lazy(which, a32, b32, r32); }
+    }
+    // 2. host SHA-256 against the oracle's
+    for (size_t len : {(size_t)0, (size_t)1, (size_t)55, (size_t)56, (size_t)64, (size_t)1000, (size_t)100000}) {
+        std::vector<uint8_t> msg(len + 1);
+        for (size_t i = 0; i < len; ++i) msg[i] = (uint8_t)rnd();
+        uint8_t d1[32], d2[32];
+        kzg_host::Sha256 sh;
+        kzg_host::sha256_init(sh);
+        kzg_host::sha256_update(sh, msg.data(), len / 3);
+        kzg_host::sha256_update(sh, msg.data() + len / 3, len - len / 3);
+        kzg_host::sha256_final(sh, d1);
+        orc_sha256(msg.data(), len, d2);
+        CHECK(memcmp(d1, d2, 32) == 0);
+    }
+    // 3. oracle: Pippenger (threads) == naive; NTT round trip; g1_ifft; transcripts
+    uint64_t a[8], b[8];
+    CHECK(orc_msm_pippenger(pts.data(), sc.data(), n, a, 4) == 0);
+    CHECK(orc_msm_naive(pts.data(), sc.data(), n, b) == 0);
+    CHECK(memcmp(a, b, 64) == 0);
+    std::vector<uint64_t> v(sc.begin(), sc.begin() + 4 * 64), v0 = v;
+    CHECK(orc_fr_ntt(v.data(), 64, 0) == 0 && orc_fr_ntt_mt(v.data(), 64, 1, 3) == 0 && v == v0);
+    std::vector<uint64_t> lag(8 * 8);
+    CHECK(orc_g1_ifft(pts.data(), 8, lag.data()) == 0);
+    {
+        std::vector<uint8_t> blobs;
+        const uint64_t lens[3] = {32, 96, 45};
+        for (uint64_t l : lens) for (uint64_t i = 0; i < l; ++i) blobs.push_back((uint8_t)(i % 32 == 0 ? 0 : rnd()));
+        uint64_t zs[12], ys[12], rp[12];
+        CHECK(orc_compute_challenges_and_evaluate_polynomial(blobs.data(), lens, pts.data(), 3, zs, ys) == 0);
+        const uint64_t elems[3] = {1, 4, 2};
+        CHECK(orc_compute_r_powers(pts.data(), zs, ys, pts.data() + 24, elems, 3, rp) == 0);
+    }
+    // 4. host fold of partial sums (host_curve.h): affine points as XYZZ partials with ZZ = ZZZ = 1
+    {
+        uint64_t one_m[4];
+        orc_f_mul(0, one_m, one_plain, FQ_R2);
+        kzg_host::Xyzz acc = kzg_host::xyzz_inf();
+        for (size_t i = 0; i < 8; ++i) {
+            kzg_host::Xyzz p;
+            memcpy(&p, pts.data() + 8 * i, 64);
+            memcpy(reinterpret_cast<uint64_t*>(&p) + 8, one_m, 32);
+            memcpy(reinterpret_cast<uint64_t*>(&p) + 12, one_m, 32);
+            acc = kzg_host::xyzz_add(acc, p);
+            acc = kzg_host::xyzz_dbl(acc);
+        }
+        uint64_t xy[8]; uint8_t inf = 0;
+        kzg_host::xyzz_to_affine(acc, xy, &inf);
+        CHECK(inf == 0);
+    }
+    printf("sanitize ok\n");
+    return 0;
+}

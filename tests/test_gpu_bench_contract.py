@@ -63,3 +63,17 @@ def test_bench_two_ranks_gloo_is_bit_exact():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bit_exact_vs_oracle"] is True
     assert d["value"] > 0 and d["value_uniform"] > 0 and d["latency_ms"] > 0
+
+
+def test_bench_multi_mode_two_contexts_on_one_gpu_is_bit_exact():
+    """`bench.py --multi --gpus 2` (one process, two kzg_multi contexts -- on this one-GPU box both on device 0): the line is well
+    formed and every timed step's commitment matched its expected point (non-zero exit otherwise)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KZG_BENCH_LOG_N="17")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--multi", "--gpus", "2", "--steps", "9", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-800:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 9 and line["config"]["bit_exact_vs_oracle"] is True
+    assert "roofline" in line and line["value"] > 0
