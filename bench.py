@@ -37,11 +37,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured cop
 BYTES_PER_PAIR = 96            # 64 B packed affine point + 32 B scalar, each read once
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 MADS_PER_MIXED_ADD = 1467      # v_mad_i64_i32 per xyzz_madd (8 x 162 + 2 x 126 - 81 for the fused Y3)
-MAD_NS_PER_WAVE_INSTR_PER_SIMD = 2.0   # measured v_mad_u64_u32 issue rate on MI355X (profiles/r01_valu_rates_mi355x.txt)
-# The whole instruction stream of one mixed addition in the accumulate loop (ISA of the loop body, tools/ubench/acc_variants.hip V4 built
-# with the out-of-line slow path: 2 564 instructions) priced at the issue rates measured with FOUR waves per SIMD (the kernel runs three):
-# (count, ns per wave-instruction per SIMD) -- mads, v_mul_lo_u32, 64-bit shifts, v_and, other 32-bit VALU, s_nop (asm barriers of the paired multiplies)
-VALU_MIX_PER_MIXED_ADD = ((1467, 2.13), (81, 2.03), (144 + 18, 1.85), (187, 1.24), (255, 1.24), (290, 0.42))
+# The whole instruction stream of one mixed addition in the accumulate loop, by class, from the ISA of the round-3 kernel (the Montgomery
+# products are single asm statements: generated csrc/fe_asm.h; loop body of k_msm_accumulate, `hipcc -S`: 2 088 instructions + ~70 of
+# loop control, index / address arithmetic and the prefetch in the blocks around it): v_mad_i64_i32, v_mul_lo_u32, v_ashrrev_i64,
+# v_and_b32, other 32-bit VALU / SALU, s_nop.  Priced with the issue rates of THIS box, measured in set-up at the kernel's occupancy
+# (kzg_ctx_measure_valu_rates, three waves per SIMD); the constants below are only the fallback for world > 1.
+VALU_MIX_COUNTS = (1467, 81, 153, 179, 273, 5)
+VALU_RATES_FALLBACK_NS = (2.13, 2.03, 1.85, 1.24, 1.24, 0.42)     # profiles/r01_valu_rates_mi355x.txt, four waves per SIMD
 N_SIMDS = 1024
 N_BUFFERS = 8                  # distinct resident scalar buffers the timed steps rotate through
 
@@ -360,18 +362,25 @@ def main():
             "phases_ms_per_launch_pipelined": dict(zip(phase_names, phase_piped)),
         }
         if plan and acc_ms > 0:
-            # VALU roofline of the same kernel: multiply-adds it must issue / the measured v_mad_i64_i32 issue rate of the chip
+            # VALU roofline of the same kernel: multiply-adds it must issue / the v_mad_i64_i32 issue rate of THIS chip, measured in this run
+            rates = (C.c_double * 6)()
+            measured = world == 1 and lib.kzg_ctx_measure_valu_rates(ctx.handle, 3, rates) == 0
+            rates = tuple(rates[i] for i in range(6)) if measured else VALU_RATES_FALLBACK_NS
             entries = plan["windows"] * units_per_launch
-            floor_ms = entries / 64.0 * MADS_PER_MIXED_ADD * MAD_NS_PER_WAVE_INSTR_PER_SIMD / N_SIMDS * 1e-6
-            mix_ns = sum(c * r for c, r in VALU_MIX_PER_MIXED_ADD)
+            floor_ms = entries / 64.0 * MADS_PER_MIXED_ADD * rates[0] / N_SIMDS * 1e-6
+            mix_ns = sum(c * r for c, r in zip(VALU_MIX_COUNTS, rates))
             mix_floor_ms = entries / 64.0 * mix_ns / N_SIMDS * 1e-6
             out["roofline"]["valu"] = {"mixed_adds_per_launch": entries, "mads_per_mixed_add": MADS_PER_MIXED_ADD,
                                        "mad_issue_floor_ms": floor_ms, "frac_of_mad_issue_floor": floor_ms / acc_ms,
                                        "instruction_issue_floor_ms": mix_floor_ms, "frac_of_instruction_issue_floor": mix_floor_ms / acc_ms,
-                                       "instruction_issue_floor_is": "all %d instructions of one mixed addition at their measured issue rates (4 waves per SIMD): "
-                                                                     "what this instruction stream costs on a saturated SIMD; only removing instructions goes below it"
-                                                                     % sum(c for c, _ in VALU_MIX_PER_MIXED_ADD),
-                                       "peak": "v_mad_i64_i32: %.1f ns per wave-instruction per SIMD, %d SIMDs (measured)" % (MAD_NS_PER_WAVE_INSTR_PER_SIMD, N_SIMDS)}
+                                       "instructions_per_mixed_add": sum(VALU_MIX_COUNTS),
+                                       "instruction_issue_floor_is": "all %d instructions of one mixed addition (v_mad_i64_i32, v_mul_lo_u32, v_ashrrev_i64, v_and_b32, "
+                                                                     "other, s_nop: %s) at the issue rates below: what this instruction stream costs on a saturated SIMD"
+                                                                     % (sum(VALU_MIX_COUNTS), "/".join(str(c) for c in VALU_MIX_COUNTS)),
+                                       "rates_ns_per_wave_instruction_per_simd": list(rates),
+                                       "rates_source": "measured in this run on this device, 3 waves per SIMD (kzg_ctx_measure_valu_rates)" if measured
+                                                       else "profiles/r01_valu_rates_mi355x.txt (another box; world > 1)",
+                                       "peak": "v_mad_i64_i32: %.2f ns per wave-instruction per SIMD, %d SIMDs" % (rates[0], N_SIMDS)}
         if world == 1 and not args.no_secondary:
             # secondary figures of the same run (outside the timed region; BASELINE configs 3 and 4 on one GPU)
             def avg_ms(fn, reps=10, warm=2):

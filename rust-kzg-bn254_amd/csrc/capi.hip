@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,8 +58,10 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
 int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot);
 int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
-int32_t vb_evaluate_run(kzg_ctx* ctx, const uint8_t* packed, size_t packed_len, const void* meta_host, size_t nb, const uint64_t* zs,
-                        uint64_t* ys_out, uint8_t* fallback_out);
+int32_t vb_evaluate_setup(kzg_ctx* ctx, size_t packed_len, size_t nb);
+int32_t vb_evaluate_enqueue(kzg_ctx* ctx, const uint8_t* packed, const void* meta_host, size_t nb, size_t b0, size_t b1, const uint64_t* zs,
+                            uint8_t* small_pinned);
+int32_t vb_evaluate_finish(kzg_ctx* ctx, size_t nb, uint64_t* ys_out, uint8_t* fallback_out);
 int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_padded, void** d_out,
                        hipStream_t st = nullptr, DeviceBuffer* d_bytes = nullptr, DeviceBuffer* d_elems = nullptr);
 
@@ -972,17 +976,66 @@ unsigned host_threads(size_t jobs) {
     return t ? t : 1;
 }
 // run job(i) for i in [0, n) on a pool of host threads (the calling thread included)
-void parallel_for(size_t n, const std::function<void(size_t)>& job) {
-    const unsigned T = host_threads(n);
-    if (T <= 1) { for (size_t i = 0; i < n; ++i) job(i); return; }
-    std::atomic<size_t> next{0};
-    auto body = [&] { for (;;) { const size_t i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) return; job(i); } };
-    std::vector<std::thread> pool;
-    pool.reserve(T - 1);
-    for (unsigned t = 1; t < T; ++t) pool.emplace_back(body);
-    body();
-    for (auto& th : pool) th.join();
-}
+// A persistent pool of host threads (created on first use, parked on a condition variable between calls): spawning 31 threads
+// per call cost 0.3-1 ms, three times per batch verification.  run(n, job) executes job(i) for i in [0, n) on the pool AND the
+// calling thread; one run at a time.
+class HostPool {
+public:
+    static HostPool& get() { static HostPool pool; return pool; }
+    void run(size_t n, const std::function<void(size_t)>& job) {
+        if (n == 0) return;
+        const unsigned T = host_threads(n);
+        if (T <= 1) { for (size_t i = 0; i < n; ++i) job(i); return; }
+        std::lock_guard<std::mutex> one(run_mu_);
+        ensure(T - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &job; n_ = n; next_.store(0, std::memory_order_relaxed);
+            wanted_ = T - 1; joined_ = 0; running_ = 0;
+            ++generation_;
+        }
+        cv_work_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        wanted_ = 0;                                               // late wakers of this generation find nothing to join
+        cv_done_.wait(lk, [&] { return running_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    HostPool() = default;
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_work_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    void ensure(unsigned count) { while (threads_.size() < count) threads_.emplace_back([this] { loop(); }); }
+    void work() { for (;;) { const size_t i = next_.fetch_add(1, std::memory_order_relaxed); if (i >= n_) return; (*job_)(i); } }
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            if (joined_ >= wanted_) continue;                      // this run wants fewer threads than the pool has
+            ++joined_; ++running_;
+            lk.unlock();
+            work();
+            lk.lock();
+            if (--running_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(size_t)>* job_ = nullptr;
+    size_t n_ = 0;
+    std::atomic<size_t> next_{0};
+    unsigned wanted_ = 0, joined_ = 0, running_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+void parallel_for(size_t n, const std::function<void(size_t)>& job) { HostPool::get().run(n, job); }
 
 // The data-parallel front end of verify_blob_kzg_proof_batch: z_i = compute_challenge(blob_i, C_i), y_i = p_i(z_i) for all n blobs.
 // Transcripts: n independent SHA-256 streams on a pool of host threads (each also packs its blob into the pinned staging buffer);
@@ -1020,24 +1073,63 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
     for (size_t g1 : group_end) {
         size_t bytes = 0;
         for (size_t i = g0; i < g1; ++i) if (meta[i].log_n != 99u) bytes = std::max(bytes, (size_t)meta[i].off + ((size_t)meta[i].len + 31) / 32 * 32);
-        if (bytes > ctx->vb_pinned_bytes) {
+        const size_t bytes_al = (bytes + 4095) / 4096 * 4096, small_bytes = (g1 - g0) * 48 + 4096;   // packed blobs | challenges + descriptors
+        if (bytes_al + small_bytes > ctx->vb_pinned_bytes) {
             if (ctx->vb_pinned) { (void)hipHostFree(ctx->vb_pinned); ctx->vb_pinned = nullptr; ctx->vb_pinned_bytes = 0; }
-            const size_t cap = bytes + bytes / 4 + 4096;
+            const size_t cap = bytes_al + bytes_al / 4 + 2 * small_bytes;
             KZG_HIP_TRY(ctx, hipHostMalloc(&ctx->vb_pinned, cap, hipHostMallocDefault));
             ctx->vb_pinned_bytes = cap;
         }
         uint8_t* stage = static_cast<uint8_t*>(ctx->vb_pinned);
         RoctxPhases phases;
-        phases.begin("kzg:batch_verify:transcripts+pack (host threads)");
-        parallel_for(g1 - g0, [&](size_t k) {
+        phases.begin("kzg:batch_verify:transcripts + pack (host threads) | uploads + evaluation kernels (GPU)");
+        const auto t_hash0 = std::chrono::steady_clock::now();
+        const size_t nb = g1 - g0;
+        int32_t rc = vb_evaluate_setup(ctx, bytes, nb);
+        if (rc != KZG_OK) return rc;
+        // Chunks of ~16 MiB of packed bytes: the thread that finishes the LAST blob of a chunk enqueues the chunk's upload and its two
+        // kernels, so the PCIe transfer and the evaluations run beside the hashing of the later blobs (3 ms of host work and 3 ms of
+        // upload + kernels one after the other before).  The pool hands blobs out in index order, so chunks complete roughly in order.
+        std::vector<size_t> chunk_of(nb), chunk_lo, chunk_hi;
+        {
+            size_t acc_bytes = 0;
+            for (size_t k = 0; k < nb; ++k) {
+                if (chunk_lo.empty() || acc_bytes >= ((size_t)16 << 20)) { chunk_lo.push_back(k); chunk_hi.push_back(k); acc_bytes = 0; }
+                chunk_of[k] = chunk_lo.size() - 1;
+                chunk_hi.back() = k + 1;
+                if (meta[g0 + k].log_n != 99u) acc_bytes += ((size_t)meta[g0 + k].len + 31) / 32 * 32;
+            }
+        }
+        std::vector<std::atomic<uint32_t>> left(chunk_lo.size());
+        for (size_t c = 0; c < chunk_lo.size(); ++c) left[c].store((uint32_t)(chunk_hi[c] - chunk_lo[c]));
+        std::atomic<int32_t> enqueue_rc{KZG_OK};
+        static const bool trace_chunks = []() { const char* e = getenv("KZG_VB_TRACE"); return e && atoi(e) >= 2; }();
+        std::vector<double> enq_at(chunk_lo.size(), 0.0), enq_took(chunk_lo.size(), 0.0);
+        std::vector<hipEvent_t> chunk_ev(trace_chunks ? chunk_lo.size() : 0);
+        hipEvent_t ev0 = nullptr;
+        if (trace_chunks) { for (auto& e : chunk_ev) (void)hipEventCreate(&e); (void)hipEventCreate(&ev0); (void)hipEventRecord(ev0, ctx->stream); }
+        parallel_for(nb, [&](size_t k) {
             const size_t i = g0 + k;
-            if (status[i] != KZG_OK) return;
+            auto done = [&] {
+                const size_t c = chunk_of[k];
+                if (left[c].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                    const auto e0 = std::chrono::steady_clock::now();
+                    const int32_t r = vb_evaluate_enqueue(ctx, stage, meta.data() + g0, nb, chunk_lo[c], chunk_hi[c], zs + 4 * g0, stage + bytes_al);
+                    if (r != KZG_OK) enqueue_rc.store(r);
+                    if (trace_chunks) {
+                        (void)hipEventRecord(chunk_ev[c], ctx->stream);
+                        enq_at[c] = std::chrono::duration<double, std::milli>(e0 - t_hash0).count();
+                        enq_took[c] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e0).count();
+                    }
+                }
+            };
+            if (status[i] != KZG_OK) { done(); return; }
             G1 c;
             if (commitments) {
                 c = g1_from_wire(commitments + 8 * i);
-                if (!validated && !g1_on_curve(c)) { status[i] = KZG_ERR_G1_NOT_ON_CURVE; return; }
+                if (!validated && !g1_on_curve(c)) { status[i] = KZG_ERR_G1_NOT_ON_CURVE; done(); return; }
             }
-            if (lens[i] == 0) { status[i] = KZG_ERR_ZERO_LENGTH; return; }
+            if (lens[i] == 0) { status[i] = KZG_ERR_ZERO_LENGTH; done(); return; }
             const uint8_t* src = blobs[i];
             if (meta[i].log_n != 99u) {                       // pack (zero-filled to the 32-byte chunk) and hash the packed copy
                 uint8_t* dst = stage + meta[i].off;
@@ -1046,16 +1138,37 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
                 if (span > lens[i]) memset(dst + lens[i], 0, span - lens[i]);
                 src = dst;
             }
-            if (!commitments) return;
-            Sha256 sh;
-            sha256_init(sh);
-            challenge_absorb_prefix(sh, src, lens[i], blob_padded_len(lens[i]));
-            challenge_finish(sh, c, zs + 4 * i);
+            if (commitments) {
+                Sha256 sh;
+                sha256_init(sh);
+                challenge_absorb_prefix(sh, src, lens[i], blob_padded_len(lens[i]));
+                challenge_finish(sh, c, zs + 4 * i);
+            }
+            done();
         });
-        for (size_t i = g0; i < g1; ++i) if (status[i] != KZG_OK) return status[i];      // the first failing blob, in order
-        phases.begin("kzg:batch_verify:evaluations (GPU)");
-        int32_t rc = vb_evaluate_run(ctx, stage, bytes, meta.data() + g0, g1 - g0, zs + 4 * g0, ys + 4 * g0, fallback.data() + g0);
+        const auto t_hash_done = std::chrono::steady_clock::now();
+        rc = vb_evaluate_finish(ctx, nb, ys + 4 * g0, fallback.data() + g0);         // (also drains the stream before any early return below)
+        if (trace_chunks) {
+            for (size_t c = 0; c < chunk_lo.size(); ++c) {
+                float gpu_ms = 0;
+                (void)hipEventElapsedTime(&gpu_ms, ev0, chunk_ev[c]);
+                fprintf(stderr, "    chunk %zu blobs [%zu, %zu): enqueued at %.3f ms (call took %.3f ms), done on the GPU %.3f ms after the first enqueue point\n", c, chunk_lo[c],
+                        chunk_hi[c], enq_at[c], enq_took[c], gpu_ms);
+                (void)hipEventDestroy(chunk_ev[c]);
+            }
+            (void)hipEventDestroy(ev0);
+        }
+        if (enqueue_rc.load() != KZG_OK) return enqueue_rc.load();
         if (rc != KZG_OK) return rc;
+        for (size_t i = g0; i < g1; ++i) if (status[i] != KZG_OK) return status[i];      // the first failing blob, in order
+        {
+            static const bool trace = []() { const char* e = getenv("KZG_VB_TRACE"); return e && atoi(e) != 0; }();
+            if (trace)
+                fprintf(stderr, "  blobs [%zu, %zu): %zu packed bytes in %zu chunks; transcripts + pack %.3f ms (%u host threads, uploads and kernels beside them), "
+                        "the rest of the GPU work + D2H %.3f ms\n", g0, g1, bytes, chunk_lo.size(),
+                        std::chrono::duration<double, std::milli>(t_hash_done - t_hash0).count(), host_threads(nb),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_hash_done).count());
+        }
         g0 = g1;
     }
     for (size_t i = 0; i < n; ++i) {                          // z on the domain, or more than 4096 elements: one polynomial at a time
@@ -1129,6 +1242,10 @@ int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blob
     if (!ctx || !out_ok) return KZG_ERR_INVALID_ARG;
     if (n && (!blobs || !blob_lens || !commitments_xy_mont || !proofs_xy_mont)) return KZG_ERR_INVALID_ARG;
     using namespace kzg_host;
+    static const bool trace = []() { const char* e = getenv("KZG_VB_TRACE"); return e && atoi(e) != 0; }();   // phase times on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_start = now();
     // batch.rs:29-37: every commitment, then every proof, on the curve (cofactor 1: no subgroup check to make) -- before anything else
     {
         std::atomic<int> bad{0};
@@ -1138,16 +1255,24 @@ int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blob
         });
         if (bad.load()) return KZG_ERR_G1_NOT_ON_CURVE;
     }
+    const auto t_valid = now();
     std::vector<uint64_t> zs(4 * n), ys(4 * n), rp(4 * n), lens_elems(n);
+    auto t_eval = t_valid, t_rp = t_valid;
     if (n) {
         int32_t rc = challenges_and_evaluations(ctx, blobs, blob_lens, commitments_xy_mont, n, true, zs.data(), ys.data());   // batch.rs:43-44
         if (rc != KZG_OK) return rc;
+        t_eval = now();
         for (size_t i = 0; i < n; ++i) lens_elems[i] = (uint64_t)blob_padded_len(blob_lens[i]);                              // batch.rs:48-54
         RoctxRange range_rp("kzg:batch_verify:r_powers (host)");
         r_powers_host(commitments_xy_mont, zs.data(), ys.data(), proofs_xy_mont, lens_elems.data(), n, rp.data());           // batch.rs:222
+        t_rp = now();
     }
     RoctxRange range_core("kzg:batch_verify:lincombs (GPU) + pairing (host)");
-    return verify_batch_core(ctx, commitments_xy_mont, zs.data(), ys.data(), proofs_xy_mont, rp.data(), n, g2_tau_mont, out_ok);   // batch.rs:62-68
+    const int32_t rc = verify_batch_core(ctx, commitments_xy_mont, zs.data(), ys.data(), proofs_xy_mont, rp.data(), n, g2_tau_mont, out_ok);   // batch.rs:62-68
+    if (trace)
+        fprintf(stderr, "kzg_verify_blob_kzg_proof_batch n=%zu: point validation %.3f ms, challenges + evaluations %.3f ms, r_powers %.3f ms, lincombs + pairing %.3f ms\n",
+                n, ms(t_start, t_valid), ms(t_valid, t_eval), ms(t_eval, t_rp), ms(t_rp, now()));
+    return rc;
 }
 
 }  // extern "C"

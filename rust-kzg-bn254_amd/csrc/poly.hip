@@ -895,40 +895,86 @@ int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, 
     return rc;
 }
 
-// Batched y_i = p_i(z_i) for `nb` blobs whose bytes sit packed in host memory `packed` (blob i at meta[i].off, 32-byte aligned,
-// zero-filled up to the next 32-byte chunk; `packed_len` bytes in all) with the challenges zs (wire).  ys_out receives nb wire
-// elements; fallback_out[i] != 0 marks the blobs this path does not cover (z on the domain, more than 2^VB_MAX_LOG elements): the
-// caller evaluates those one by one.  Slot 0's buffers and stream.
-int32_t vb_evaluate_run(kzg_ctx* ctx, const uint8_t* packed, size_t packed_len, const void* meta_host, size_t nb, const uint64_t* zs,
-                        uint64_t* ys_out, uint8_t* fallback_out) {
+// Batched y_i = p_i(z_i) for `nb` blobs whose bytes sit packed in PINNED host memory `packed` (blob i at meta[i].off, 32-byte aligned,
+// zero-filled up to the next 32-byte chunk) with the challenges zs (wire).  Three steps so that the caller can overlap the uploads with
+// the hashing of later blobs:
+//   vb_evaluate_setup(ctx, packed_len, nb)                     buffers, the 4096-point domain table, kernel attribute
+//   vb_evaluate_enqueue(ctx, packed, meta, b0, b1, zs)         blobs [b0, b1): their bytes, challenges and descriptors go up and the two
+//                                                              kernels are enqueued on the context's stream; returns at once; may be called
+//                                                              from any host thread, chunks in any order (they touch disjoint ranges)
+//   vb_evaluate_finish(ctx, nb, ys_out, fallback_out)          waits; ys_out = nb wire elements; fallback_out[i] != 0 marks the blobs this
+//                                                              path does not cover (z on the domain, more than 2^VB_MAX_LOG elements)
+// Slot 0's buffers and stream.
+int32_t vb_evaluate_setup(kzg_ctx* ctx, size_t packed_len, size_t nb) {
     static_assert(sizeof(VbBlob) == 16, "VbBlob layout is part of the host interface (capi.hip)");
-    if (nb == 0) return KZG_OK;
     PolySet& set = ctx->poly[0];
-    hipStream_t st = ctx->stream;
     NttTables tb;
     int32_t rc = ntt_get_tables(ctx, VB_MAX_LOG, false, &tb);
     if (rc != KZG_OK) return rc;
-    const VbBlob* meta = static_cast<const VbBlob*>(meta_host);
-    uint32_t max_log = 0;
-    for (size_t i = 0; i < nb; ++i) if (meta[i].log_n <= (uint32_t)VB_MAX_LOG && meta[i].log_n > max_log) max_log = meta[i].log_n;
-    const uint32_t max_lf = std::min<uint32_t>(1u << max_log, (uint32_t)VB_THREADS);
-    const size_t lds = std::max<size_t>((size_t)NL * 2 * max_lf, (size_t)NL * VB_THREADS) * 4;
     KZG_HIP_TRY(ctx, set.c.reserve(packed_len + 64));
-    KZG_HIP_TRY(ctx, set.a.reserve(nb * 32 * 2));                                      // zs | ys
-    KZG_HIP_TRY(ctx, set.b.reserve(nb * (sizeof(VbBlob) + sizeof(VbPrep))));
+    KZG_HIP_TRY(ctx, set.a.reserve(nb * 32 * 2 + 64));                                 // zs | ys
+    KZG_HIP_TRY(ctx, set.b.reserve(nb * (sizeof(VbBlob) + sizeof(VbPrep)) + 64));
+    KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vb_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NL * 2 * VB_THREADS * 4)));
+    KZG_HIP_TRY(ctx, hipMemsetAsync(set.a.as<uint4>() + 2 * nb, 0, nb * 32, ctx->stream));
+    return KZG_OK;
+}
+// `small_pinned`: pinned staging of at least nb x 48 bytes for the chunk's challenges and descriptors (a copy from pageable memory would
+// make this call wait for everything queued on the stream before it)
+int32_t vb_evaluate_enqueue(kzg_ctx* ctx, const uint8_t* packed, const void* meta_host, size_t nb, size_t b0, size_t b1, const uint64_t* zs,
+                            uint8_t* small_pinned) {
+    if (b1 <= b0) return KZG_OK;
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));                                       // (worker threads of the caller's pool)
+    PolySet& set = ctx->poly[0];
+    hipStream_t st = ctx->stream, st_copy = nullptr;
+    // the blob bytes go up on a second stream (slot 1's): k_vb_prep is one inversion deep (~0.2 ms on a few lone waves, whatever the
+    // chunk size) and needs the challenges only, so it runs while the chunk's bytes are still on the bus; k_vb_eval waits for them
+    int32_t rc = msm_slot_stream(ctx, 1, &st_copy);
+    if (rc != KZG_OK) return rc;
+    NttTables tb;
+    rc = ntt_get_tables(ctx, VB_MAX_LOG, false, &tb);
+    if (rc != KZG_OK) return rc;
+    const VbBlob* meta = static_cast<const VbBlob*>(meta_host);
     uint4* d_zs = set.a.as<uint4>();
     uint4* d_ys = d_zs + 2 * nb;
     VbBlob* d_meta = set.b.as<VbBlob>();
     VbPrep* d_prep = reinterpret_cast<VbPrep*>(d_meta + nb);
-    static thread_local std::vector<VbPrep> prep_host;
-    KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vb_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NL * 2 * VB_THREADS * 4)));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zs, zs, nb * 32, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_meta, meta, nb * sizeof(VbBlob), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_vb_prep, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, d_zs, d_meta, (uint32_t)nb, d_prep);
-    if (packed_len) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.c.p, packed, packed_len, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemsetAsync(d_ys, 0, nb * 32, st));
-    hipLaunchKernelGGL(k_vb_eval, dim3((unsigned)nb), dim3(VB_THREADS), lds, st, set.c.as<uint8_t>(), d_meta, d_prep, tb, d_ys);
+    uint32_t max_log = 0;
+    size_t lo = SIZE_MAX, hi = 0;
+    for (size_t i = b0; i < b1; ++i) {
+        if (meta[i].log_n > (uint32_t)VB_MAX_LOG) continue;
+        max_log = std::max(max_log, meta[i].log_n);
+        lo = std::min<size_t>(lo, meta[i].off);
+        hi = std::max<size_t>(hi, meta[i].off + ((size_t)meta[i].len + 31) / 32 * 32);
+    }
+    const uint32_t max_lf = std::min<uint32_t>(1u << max_log, (uint32_t)VB_THREADS);
+    const size_t lds = std::max<size_t>((size_t)NL * 2 * max_lf, (size_t)NL * VB_THREADS) * 4;
+    hipEvent_t up = nullptr;
+    if (hi > lo) {
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(set.c.as<uint8_t>() + lo, packed + lo, hi - lo, hipMemcpyHostToDevice, st_copy));
+        KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&up, hipEventDisableTiming));
+        KZG_HIP_TRY(ctx, hipEventRecord(up, st_copy));
+    }
+    uint8_t* pz = small_pinned + b0 * 32;
+    uint8_t* pm = small_pinned + nb * 32 + b0 * sizeof(VbBlob);
+    memcpy(pz, zs + 4 * b0, (b1 - b0) * 32);
+    memcpy(pm, meta + b0, (b1 - b0) * sizeof(VbBlob));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zs + 2 * b0, pz, (b1 - b0) * 32, hipMemcpyHostToDevice, st));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_meta + b0, pm, (b1 - b0) * sizeof(VbBlob), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_vb_prep, dim3((unsigned)((b1 - b0 + 63) / 64)), dim3(64), 0, st, d_zs + 2 * b0, d_meta + b0, (uint32_t)(b1 - b0), d_prep + b0);
+    if (up) {
+        KZG_HIP_TRY(ctx, hipStreamWaitEvent(st, up, 0));
+        (void)hipEventDestroy(up);                                                     // released by the runtime once the wait has been satisfied
+    }
+    hipLaunchKernelGGL(k_vb_eval, dim3((unsigned)(b1 - b0)), dim3(VB_THREADS), lds, st, set.c.as<uint8_t>(), d_meta + b0, d_prep + b0, tb, d_ys + 2 * b0);
     KZG_HIP_TRY(ctx, hipGetLastError());
+    return KZG_OK;
+}
+int32_t vb_evaluate_finish(kzg_ctx* ctx, size_t nb, uint64_t* ys_out, uint8_t* fallback_out) {
+    PolySet& set = ctx->poly[0];
+    hipStream_t st = ctx->stream;
+    uint4* d_ys = set.a.as<uint4>() + 2 * nb;
+    VbPrep* d_prep = reinterpret_cast<VbPrep*>(set.b.as<VbBlob>() + nb);
+    static thread_local std::vector<VbPrep> prep_host;
     prep_host.resize(nb);
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ys_out, d_ys, nb * 32, hipMemcpyDeviceToHost, st));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(prep_host.data(), d_prep, nb * sizeof(VbPrep), hipMemcpyDeviceToHost, st));
