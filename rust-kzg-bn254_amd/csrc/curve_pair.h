@@ -169,6 +169,17 @@ __device__ __forceinline__ void half_shfl_down(HalfXyzz& r, const HalfXyzz& h, i
     for (int j = 0; j < NL; ++j) { r.u.l[j] = __shfl_down(h.u.l[j], d, 64); r.v.l[j] = __shfl_down(h.v.l[j], d, 64); }
     r.inf = __shfl_down((int)h.inf, d, 64) != 0;
 }
+// the half of lane ^ d (d even: the same role)
+__device__ __forceinline__ void half_shfl_xor(HalfXyzz& r, const HalfXyzz& h, int d) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { r.u.l[j] = __shfl_xor(h.u.l[j], d, 64); r.v.l[j] = __shfl_xor(h.v.l[j], d, 64); }
+    r.inf = __shfl_xor((int)h.inf, d, 64) != 0;
+}
+__device__ __forceinline__ void half_select(HalfXyzz& r, bool c, const HalfXyzz& a, const HalfXyzz& b) {   // r = c ? a : b
+    fe_select(r.u, c, a.u, b.u);
+    fe_select(r.v, c, a.v, b.v);
+    r.inf = c ? a.inf : b.inf;
+}
 // the half held by lane `src` (same parity as the caller)
 __device__ __forceinline__ void half_shfl(HalfXyzz& r, const HalfXyzz& h, int src) {
 #pragma unroll

@@ -295,7 +295,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     phases.begin("kzg:msm:bucket reduction");
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
-        // the two reduction levels: on lane pairs (curve_pair.h; one 128-thread group per 64 values) unless KZG_PAIR_REDUCE=0
+        // the two reduction levels: on lane pairs (curve_pair.h; one 128-thread workgroup per 64 buckets, then per two groups of 64 sums) unless KZG_PAIR_REDUCE=0
         static const bool pair_reduce = []() { const char* e = getenv("KZG_PAIR_REDUCE"); return !(e && atoi(e) == 0); }();
         if (pair_reduce)
             hipLaunchKernelGGL(k_msm_bucket_bits1p, dim3(G1), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
@@ -309,7 +309,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         } else {
             const uint32_t waves2 = 7 * G1p;
             if (pair_reduce)
-                hipLaunchKernelGGL(k_red_bits2p, dim3(waves2), dim3(128), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, ws.out_wire.as<uint32_t>());
+                hipLaunchKernelGGL(k_red_bits2p, dim3((waves2 + 1) / 2), dim3(128), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, ws.out_wire.as<uint32_t>());
             else
                 hipLaunchKernelGGL(k_red_bits2, dim3((waves2 * 64 + 255) / 256), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p,
                                    ws.out_wire.as<uint32_t>());

@@ -1160,26 +1160,76 @@ k_msm_bucket_bits1p(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, 
     if (G1 == 1) half_store_wire(out_wire, (size_t)role, v, odd);
     else half_store(x1, x_stride, (size_t)role * G1 + g, v, odd);
 }
-// level 2: one two-wave group per job (the jobs of k_red_bits2)
+// Superset-sum transforms of TWO groups of 64 values at once on a two-wave workgroup, pair gp = 32 w + (lane >> 1).
+// (Used by the second level only.  On the first level it HALVES the waves of a kernel that runs two waves per SIMD at 2^16 buckets and
+// doubles the serial bucket sums of each: k_msm_bucket_bits1p went 0.123 -> 0.207 ms at 2^20 pairs, 77 -> 131 us at 2^11 (same box).)
+// A zeta step k adds, for the pairs whose index has bit k CLEAR, the value of the pair 2^k further up -- the other half of the pairs
+// would idle while the wave pays the issue slots.  So the workgroup carries a second group B in complemented order (pair gp holds
+// B's value 63 - gp): B's step k is due exactly on the pairs whose bit k is SET, and its partner is the same pair gp ^ 2^k.  Every
+// pair does one addition per step (for A or for B), six steps transform both groups: half the issue slots per group.
+//   afterwards  A: gp = 0 holds the total, gp = 2^k the sum over the values whose index has bit k set;
+//               B: gp = 63 the total,     gp = 63 - 2^k that sum.
+// Steps 0..4 exchange inside the wave (ds_bpermute, xor partner), step 5 through LDS (wave 0 needs wave 1's A values, wave 1 needs
+// wave 0's B values).  Called by every lane of both waves (one barrier inside).
+__device__ __forceinline__ void group_zeta64_dual(HalfXyzz& vA, HalfXyzz& vB, uint32_t lane, uint32_t w, bool odd, int32_t* __restrict__ lds /* 2 x 2 NL x 64 words */) {
+    const uint32_t gp = w * 32 + (lane >> 1);
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {
+        const bool bit = ((gp >> k) & 1u) != 0;
+        HalfXyzz mine, pub, u, r;
+        half_select(mine, bit, vB, vA);
+        half_select(pub, bit, vA, vB);                 // what the partner pair (opposite bit k) adds
+        if (k < 5) {
+            half_shfl_xor(u, pub, 2 << k);
+        } else {
+            int32_t* mine_slot = lds + w * (2 * NL * 64);
+            const int32_t* other_slot = lds + (1 - w) * (2 * NL * 64);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { mine_slot[j * 64 + lane] = pub.inf ? 0 : pub.u.l[j]; mine_slot[(NL + j) * 64 + lane] = pub.inf ? 0 : pub.v.l[j]; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { u.u.l[j] = other_slot[j * 64 + lane]; u.v.l[j] = other_slot[(NL + j) * 64 + lane]; }
+            u.inf = fe_is_literal_zero(u.v);
+        }
+        pair_add(r, mine, u, odd);
+        half_select(vA, bit, vA, r);
+        half_select(vB, bit, r, vB);
+    }
+}
+// level 2: one two-wave workgroup per TWO jobs of k_red_bits2 (jobs 2 blk and 2 blk + 1)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
 k_red_bits2p(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
     latency_bound_kernel();
-    __shared__ int32_t lds[2 * NL * 64];
-    const uint32_t job = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 32 + (lane >> 1);
+    __shared__ int32_t lds[2 * 2 * NL * 64];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 32 + (lane >> 1);
     const bool odd = (lane & 1u) != 0;
-    const bool sum_job = job < 6u * G1p;
-    const uint32_t a = sum_job ? job / G1p : 6u;
-    const uint32_t g = sum_job ? job % G1p : job - 6u * G1p;
-    const uint32_t cnt = G1 - g * 64 < 64 ? G1 - g * 64 : 64;
-    HalfXyzz v;
-    if (gp < cnt) half_load(v, x1, x_stride, (size_t)a * G1 + (size_t)g * 64 + gp, odd);
-    else half_set_inf(v);
-    group_zeta64(v, lane, w, odd, lds);
-    if (sum_job) {
-        if (gp == 0) half_store_wire(out_wire, job, v, odd);
-    } else {
-        const int role = zeta_role(gp);
-        if (role >= 0) half_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + g, v, odd);
+    const uint32_t n_jobs = 7u * G1p;
+    HalfXyzz v[2];
+    bool sum_job[2];
+    uint32_t job[2], grp[2];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        job[which] = 2 * blockIdx.x + which;
+        const bool valid = job[which] < n_jobs;
+        sum_job[which] = job[which] < 6u * G1p;
+        const uint32_t a = sum_job[which] ? job[which] / G1p : 6u;
+        grp[which] = sum_job[which] ? job[which] % G1p : job[which] - 6u * G1p;
+        const uint32_t cnt = valid ? (G1 - grp[which] * 64 < 64 ? G1 - grp[which] * 64 : 64) : 0;
+        const uint32_t idx = which ? 63 - gp : gp;
+        if (idx < cnt) half_load(v[which], x1, x_stride, (size_t)a * G1 + (size_t)grp[which] * 64 + idx, odd);
+        else half_set_inf(v[which]);
+    }
+    group_zeta64_dual(v[0], v[1], lane, w, odd, lds);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (job[which] >= n_jobs) continue;
+        const uint32_t idx = which ? 63 - gp : gp;
+        if (sum_job[which]) {
+            if (idx == 0) half_store_wire(out_wire, job[which], v[which], odd);
+        } else {
+            const int role = zeta_role(idx);
+            if (role >= 0) half_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + grp[which], v[which], odd);
+        }
     }
 }
 

@@ -8,52 +8,35 @@ namespace kzg {
 
 constexpr int UB_ITERS = 16384;      // ~2 ms per kernel: long enough for the clock to settle
 
-#define KZG_UB_KERNEL64(NAME, ASM, ...)                                                                    \
+// the eight chains are ONE asm statement: hipcc pads every asm statement with an s_nop, which would otherwise be measured along
+#define KZG_UB_ASM8(I)                                                                                         \
+    I("%0") "\n\t" I("%1") "\n\t" I("%2") "\n\t" I("%3") "\n\t" I("%4") "\n\t" I("%5") "\n\t" I("%6") "\n\t" I("%7")
+#define KZG_UB_KERNEL(NAME, T, I, ...)                                                                         \
     __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t seed) {                                \
-        long long a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;                  \
-        long long a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;                     \
+        T a0 = (T)(seed + threadIdx.x), a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;                     \
+        T a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;                              \
         int b = (int)(seed * 2654435761u + threadIdx.x), c = (int)(seed ^ 0x9e3779b9u);                       \
         for (int i = 0; i < UB_ITERS; ++i) {                                                                   \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                    \
-                asm volatile(ASM : "+v"(a0) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a1) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a2) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a3) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a4) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a5) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a6) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a7) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-            }                                                                                                  \
+            asm volatile(KZG_UB_ASM8(I) "\n\t" KZG_UB_ASM8(I)                                                  \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)      \
+                         : "v"(b), "v"(c) : __VA_ARGS__);                                                      \
         }                                                                                                      \
-        long long x = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                                   \
+        const long long x = (long long)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);                                \
         out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)x ^ (uint32_t)(x >> 32);                        \
     }
-#define KZG_UB_KERNEL32(NAME, ASM, ...)                                                                    \
-    __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t seed) {                                \
-        int a0 = (int)(seed + threadIdx.x), a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;                 \
-        int a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;                            \
-        int b = (int)(seed * 2654435761u + threadIdx.x), c = (int)(seed ^ 0x9e3779b9u);                       \
-        for (int i = 0; i < UB_ITERS; ++i) {                                                                   \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                    \
-                asm volatile(ASM : "+v"(a0) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a1) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a2) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a3) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a4) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a5) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a6) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-                asm volatile(ASM : "+v"(a7) : "v"(b), "v"(c) : __VA_ARGS__);                                   \
-            }                                                                                                  \
-        }                                                                                                      \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);        \
-    }
+#define KZG_UB_I_MAD(R) "v_mad_i64_i32 " R ", vcc, %8, %9, " R
+#define KZG_UB_I_MULLO(R) "v_mul_lo_u32 " R ", %8, " R
+#define KZG_UB_I_ASHR(R) "v_ashrrev_i64 " R ", 29, " R
+#define KZG_UB_I_AND(R) "v_and_b32 " R ", %8, " R
+#define KZG_UB_I_SUB(R) "v_sub_u32 " R ", %8, " R
+#define KZG_UB_I_NOP(R) "s_nop 0"
 
-KZG_UB_KERNEL64(k_ub_mad_i64_i32, "v_mad_i64_i32 %0, vcc, %1, %2, %0", "vcc")
-KZG_UB_KERNEL32(k_ub_mul_lo_u32, "v_mul_lo_u32 %0, %1, %0", "memory")
-KZG_UB_KERNEL64(k_ub_ashr_i64, "v_ashrrev_i64 %0, 29, %0", "memory")
-KZG_UB_KERNEL32(k_ub_and_b32, "v_and_b32 %0, %1, %0", "memory")
-KZG_UB_KERNEL32(k_ub_sub_u32, "v_sub_u32 %0, %1, %0", "memory")
-KZG_UB_KERNEL32(k_ub_nop, "s_nop 0", "memory")
+KZG_UB_KERNEL(k_ub_mad_i64_i32, long long, KZG_UB_I_MAD, "vcc")
+KZG_UB_KERNEL(k_ub_mul_lo_u32, int, KZG_UB_I_MULLO, "memory")
+KZG_UB_KERNEL(k_ub_ashr_i64, long long, KZG_UB_I_ASHR, "memory")
+KZG_UB_KERNEL(k_ub_and_b32, int, KZG_UB_I_AND, "memory")
+KZG_UB_KERNEL(k_ub_sub_u32, int, KZG_UB_I_SUB, "memory")
+KZG_UB_KERNEL(k_ub_nop, int, KZG_UB_I_NOP, "memory")
 
 }  // namespace kzg
 
