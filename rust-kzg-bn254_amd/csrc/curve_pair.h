@@ -128,6 +128,65 @@ __device__ __forceinline__ void pair_add(HalfXyzz& r, const HalfXyzz& a, const H
     if (any_inf) r = keep;
 }
 
+// acc += (neg ? -p : p) for an AFFINE point p that is not the identity: the even lane passes c = x, the odd lane c = y (canonical, as
+// unpacked from the device affine format).  madd-2008-s split like pair_add: five multiplications per lane instead of ten.
+//     even lane                              odd lane
+//     U2 = x2 ZZ1,  P = U2 - X1,  PP = P^2       S2 = y2 ZZZ1,  R = S2 - Y1,  RR = R^2
+//            -- exchange (P, PP) <-> (R, RR) --
+//     Q = X1 PP,    ZZ3 = ZZ1 PP                 PPP = P PP,    ZZZ3 = ZZZ1 PPP
+//            -- PPP -> even --
+//     X3 = RR - PPP - 2Q,  W1 = R (Q - X3)       W2 = Y1 PPP
+//            -- W1 -> odd --                     Y3 = W1 - W2
+__device__ __forceinline__ void pair_madd(HalfXyzz& r, const HalfXyzz& acc, const Fq& c, uint32_t neg, bool odd) {
+    HalfXyzz from;                             // the point itself as XYZZ (ZZ = ZZZ = 1)
+    {
+        Fq cs;
+        fe_cneg(cs, c, odd ? neg : 0u);
+        fe_norm(cs);
+        from.u = cs;
+        fe_set_one(from.v);
+        from.inf = false;
+    }
+    if (__all(acc.inf)) { r = from; return; }
+    Fq m, df, sq, odf, osq;
+    fe_mul(m, from.u, acc.v);                  // U2 | S2
+    fe_sub(df, m, acc.u);                      // P in (-6m, 9m) | R in (-4m, 5m): limbs within +-2^29
+    fe_sqr(sq, df);                            // PP | RR (81 m^2)
+    const int zero_here = (!acc.inf && fe_is_zero_mod(sq)) ? 1 : 0;
+    const int zero_there = pair_swap(zero_here);
+    const bool exc = odd ? zero_there != 0 : zero_here != 0;
+    const bool same = exc && (odd ? zero_here != 0 : zero_there != 0);
+    fe_pair_swap(odf, df);
+    fe_pair_swap(osq, sq);
+    Fq e1, e2, ta, f, tb, ota;
+    fe_select(e1, odd, odf, acc.u);
+    fe_select(e2, odd, osq, sq);
+    fe_mul(ta, e1, e2);                        // Q = X1 PP (7m * 2m) | PPP = P PP (9m * 2m)
+    fe_select(f, odd, ta, sq);
+    fe_mul(tb, acc.v, f);                      // ZZ3 | ZZZ3
+    fe_pair_swap(ota, ta);                     // even: PPP
+    Fq x3, t, g1, g2, w, ow, y3;
+    fe_sub(x3, osq, ota); fe_sub(x3, x3, ta); fe_sub(x3, x3, ta); fe_norm(x3);      // even: X3 in (-7m, 5m)
+    fe_sub(t, ta, x3);                         // even: Q - X3 in (-6m, 9m)
+    fe_select(g1, odd, acc.u, odf);            // R | Y1
+    fe_select(g2, odd, ta, t);                 // Q - X3 | PPP
+    fe_mul(w, g1, g2);                         // W1 = R (Q - X3) (5m * 9m) | W2 = Y1 PPP (3m * 2m)
+    fe_pair_swap(ow, w);
+    fe_sub(y3, ow, w); fe_norm(y3);            // odd: Y3 in (-3m, 3m)
+    fe_select(r.u, odd, y3, x3);
+    r.v = tb;
+    r.inf = false;
+    if (__builtin_expect(__any(exc), 0)) {     // the bucket already holds +-p
+        HalfXyzz d;
+        pair_dbl(d, from, odd);
+        if (exc) {
+            if (same) r = d;
+            else half_set_inf(r);
+        }
+    }
+    if (acc.inf) r = from;
+}
+
 // ---- memory: the struct-of-arrays XYZZ layout of curve.h (36 limb planes), each lane touching its half ----------------------
 __device__ __forceinline__ void half_load(HalfXyzz& h, const int32_t* __restrict__ base, size_t stride, size_t i, bool odd) {
     const int q = odd ? 1 : 0;

@@ -288,16 +288,26 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     }
     KZG_MARK(4);
     phases.begin("kzg:msm:accumulate");
+    // the two reduction levels: on lane pairs (curve_pair.h; one 128-thread workgroup per 64 buckets, then per two groups of 64 sums) unless KZG_PAIR_REDUCE=0
+    static const bool pair_reduce = []() { const char* e = getenv("KZG_PAIR_REDUCE"); return !(e && atoi(e) == 0); }();
+    // sparse table-mode MSMs (at most KZG_FUSED_PER_BUCKET = 2.5 entries per bucket on average: commitments of <= 2^11 coefficients on
+    // the c = 15 tables): the first reduction level adds the entries itself (k_msm_bucket_bits1p_fused), there is no accumulate kernel and
+    // there are no partial sums.  Measured (tools/phases_small.py, same box, device time of one commitment): 2^8 170 -> 125 us, 2^9 163 -> 128,
+    // 2^10 165 -> 152, 2^11 199 -> 195; at 2^12 (4.25 per bucket) 206 -> 261: a wave waits for its fullest bucket, the equal split does not.
+    static const double fused_per_bucket = []() { const char* e = getenv("KZG_FUSED_PER_BUCKET"); return e ? atof(e) : 2.5; }();
+    const bool fused = p.tables && pair_reduce && (double)entries <= fused_per_bucket * (double)p.B;
     // (64- and 128-thread workgroups measured the same as 256)
-    hipLaunchKernelGGL(k_msm_accumulate, dim3(p.nl / 256), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.G,
-                       ws.head.as<int32_t>(), (size_t)p.G, ws.cont.as<int32_t>(), (size_t)p.nl, p.idx_log, p.stride_adj);
+    if (!fused)
+        hipLaunchKernelGGL(k_msm_accumulate, dim3(p.nl / 256), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.G,
+                           ws.head.as<int32_t>(), (size_t)p.G, ws.cont.as<int32_t>(), (size_t)p.nl, p.idx_log, p.stride_adj);
     KZG_MARK(5);
     phases.begin("kzg:msm:bucket reduction");
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
-        // the two reduction levels: on lane pairs (curve_pair.h; one 128-thread workgroup per 64 buckets, then per two groups of 64 sums) unless KZG_PAIR_REDUCE=0
-        static const bool pair_reduce = []() { const char* e = getenv("KZG_PAIR_REDUCE"); return !(e && atoi(e) == 0); }();
-        if (pair_reduce)
+        if (fused)
+            hipLaunchKernelGGL(k_msm_bucket_bits1p_fused, dim3(G1), dim3(128), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.B, p.idx_log,
+                               p.stride_adj, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, ws.out_wire.as<uint32_t>());
+        else if (pair_reduce)
             hipLaunchKernelGGL(k_msm_bucket_bits1p, dim3(G1), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, ws.out_wire.as<uint32_t>());
         else

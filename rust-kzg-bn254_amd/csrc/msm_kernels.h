@@ -1160,6 +1160,56 @@ k_msm_bucket_bits1p(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, 
     if (G1 == 1) half_store_wire(out_wire, (size_t)role, v, odd);
     else half_store(x1, x_stride, (size_t)role * G1 + g, v, odd);
 }
+// level 1 FUSED with the accumulation, for sparse MSMs (a few entries per bucket: commitments of <= 2^12 coefficients on the c = 15
+// tables): pair = bucket, it adds its own sorted entries with pair_madd (5 multiplications per lane and entry) -- no k_msm_accumulate,
+// no head / continuation partials to gather and sum -- then the zeta transform as above.  With ~2 entries per bucket the equal-split
+// accumulate kernel spent a binary search and 4 dependent one-lane mixed additions (57 us) to leave ~2 partials per bucket, which the
+// first level then added again (another ~30 us).
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
+k_msm_bucket_bits1p_fused(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs, uint32_t B,
+                          uint32_t idx_log, uint32_t stride_adj, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
+                          uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[2 * NL * 64];
+    const uint32_t g = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 32 + (lane >> 1);
+    const bool odd = (lane & 1u) != 0;
+    const uint32_t bkt = g * 64 + gp;
+    uint32_t e = 0, end = 0;
+    if (bkt < B) { e = offs[bkt]; end = offs[bkt + 1]; }
+    HalfXyzz v;
+    half_set_inf(v);
+    // two-deep software pipeline as in k_msm_accumulate: entry e + 2 and the point of entry e + 1 are in flight while entry e is added
+    // (clamped, unconditional prefetches: the dependent index -> point gather would otherwise be exposed in every iteration)
+    const uint32_t last = end ? end - 1 : 0;
+    uint32_t ent = e < end ? sorted[e] : 0u;
+    uint32_t ent1 = e < end ? sorted[e + 1 < end ? e + 1 : last] : 0u;
+    const uint4* src = points + 4 * acc_point_index(ent & 0x7FFFFFFFu, idx_log, stride_adj) + (odd ? 2 : 0);
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    if (e < end) { q0 = src[0]; q1 = src[1]; }          // even lane: x, odd lane: y
+#pragma unroll 1
+    for (; e < end; ++e) {                              // pair-uniform trip count
+        const uint32_t cur = ent;
+        const uint32_t w32[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        int any = (q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w) != 0 ? 1 : 0;
+        ent = ent1;
+        src = points + 4 * acc_point_index(ent & 0x7FFFFFFFu, idx_log, stride_adj) + (odd ? 2 : 0);
+        q0 = src[0]; q1 = src[1];
+        ent1 = sorted[e + 2 < end ? e + 2 : last];
+        any |= pair_swap(any);
+        if (!any) continue;                             // identity base (pair-uniform)
+        Fq c;
+        fe_unpack(c, w32);
+        HalfXyzz r;
+        pair_madd(r, v, c, cur >> 31, odd);
+        v = r;
+    }
+    group_zeta64(v, lane, w, odd, lds);
+    const int role = zeta_role(gp);
+    if (role < 0) return;
+    if (G1 == 1) half_store_wire(out_wire, (size_t)role, v, odd);
+    else half_store(x1, x_stride, (size_t)role * G1 + g, v, odd);
+}
+
 // Superset-sum transforms of TWO groups of 64 values at once on a two-wave workgroup, pair gp = 32 w + (lane >> 1).
 // (Used by the second level only.  On the first level it HALVES the waves of a kernel that runs two waves per SIMD at 2^16 buckets and
 // doubles the serial bucket sums of each: k_msm_bucket_bits1p went 0.123 -> 0.207 ms at 2^20 pairs, 77 -> 131 us at 2^11 (same box).)
