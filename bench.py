@@ -495,6 +495,16 @@ def main():
             pf5[nb - 1] = pf5[0]
             assert lib.kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs5, lens5, _lib.ptr(cm5), _lib.ptr(pf5), nb, _lib.ptr(tau_g2), C.byref(ok5)) == 0 and ok5.value == 0
             e2e_bytes = sum(len(r[0]) for r in sel5)
+            # the reference's own commit / proof bench shapes (prover/benches/bench_kzg_commit.rs:17-42, bench_kzg_proof.rs:17-58: 10 000 .. 50 000
+            # byte blobs = 512 .. 2 048 coefficients) from host buffers against the loaded SRS, one call at a time, and g1_ifft(2048)
+            small = {}
+            for nn in (512, 1024, 2048):
+                sc_s = np.ascontiguousarray(scalars[:nn]); zq_s = np.ascontiguousarray(scalars_b[77])
+                small["commit_coeff_%d_ms" % nn] = avg_ms(lambda: lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(sc_s), nn, _lib.ptr(o8), C.byref(oi)), reps=30, warm=5)
+                small["compute_proof_%d_ms" % nn] = avg_ms(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(sc_s), nn, None, nn, _lib.ptr(zq_s), _lib.ptr(o8),
+                                                                                           C.byref(oi), _lib.ptr(o4)), reps=30, warm=5)
+            lag = np.zeros((2048, 8), np.uint64)
+            small["g1_ifft_2048_ms"] = avg_ms(lambda: lib.kzg_g1_ifft(ctx.handle, srs.handle, 2048, _lib.ptr(lag)), reps=5, warm=1) if n >= 2048 else None
             # measured copy ceiling of this box (device-to-device, 1 GiB): read + write bytes per second
             big = torch.empty(1 << 28, dtype=torch.int32, device="cuda"); big2 = torch.empty_like(big)
             copy_ms = avg_ms(lambda: big2.copy_(big), reps=10)
@@ -508,6 +518,7 @@ def main():
                 "batch_verify_4096_core_ms": bv_ms, "batch_verify_4096_three_msms_ms": m3_ms,
                 "batch_verify_4096_end_to_end_ms": e2e_ms, "batch_verify_4096_end_to_end_blob_MiB": e2e_bytes / 2.0 ** 20,
                 "batch_verify_4096_end_to_end_host_threads": min(32, os.cpu_count() or 1),
+                "reference_bench_shapes": small,
                 "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,
                 "fr_ntt_algorithmic_GBps": 64.0 * n / (ntt_ms * 1e-3) / 1e9, "fr_ntt_frac_of_hbm_peak": 64.0 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

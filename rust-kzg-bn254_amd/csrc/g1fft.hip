@@ -17,6 +17,7 @@
 //   * Jacobian -> affine by Montgomery's trick (one inversion per lane for 16 points) when there are many points.
 #include "engine.h"
 #include "curve_pair.h"
+#include "host_curve.h"
 
 #include <algorithm>
 #include <map>
@@ -178,8 +179,9 @@ __device__ __forceinline__ void tw_load(Fr& w, const NttTables& tb, uint32_t E) 
 }
 
 // scal[e] = the GLV halves (glv_decompose) of the canonical integer of w^-e, or of w^-e / n (scaled != 0), e < n: the scalars of every stage
+// (canon != 0: the canonical 256-bit integer itself, for the window-table stage)
 __global__ void __launch_bounds__(256)
-k_g1fft_scalars(uint4* __restrict__ scal, uint32_t n, int log_n, NttTables tb_inv, int scaled) {
+k_g1fft_scalars(uint4* __restrict__ scal, uint32_t n, int log_n, NttTables tb_inv, int scaled, int canon) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     Fr w;
@@ -197,7 +199,12 @@ k_g1fft_scalars(uint4* __restrict__ scal, uint32_t n, int log_n, NttTables tb_in
     fe_canon(c);
     uint32_t kc[8], k[8];
     fe_pack(kc, c);
-    glv_decompose(k, kc);
+    if (canon) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = kc[j];
+    } else {
+        glv_decompose(k, kc);
+    }
     scal[2 * (size_t)e] = make_uint4(k[0], k[1], k[2], k[3]);
     scal[2 * (size_t)e + 1] = make_uint4(k[4], k[5], k[6], k[7]);
 }
@@ -429,6 +436,100 @@ k_g1fft_stage_pairs(int32_t* __restrict__ planes, uint32_t n, int log_n, int s, 
     }
 }
 
+// ---- the FIRST stage through the SRS window tables --------------------------------------------------------------------------------
+// The inputs of the first stage are SRS points, and the SRS carries window tables T_w[i] = 2^(c w) P_i for its MSMs.  So a term
+// [k] P_i = sum_w d_w(k) T_w[i] with the signed c-bit digits of k: W small multiplications of c double-and-add steps (the addend is an
+// AFFINE table point: pair_madd) instead of one 127-step GLV chain -- c x (5 + 5) multiplications deep instead of 127 x (5 + 7) -- and
+// a tree over the R W terms of an output.  One PAIR of lanes per (output, term, window); a wave holds 32 (term, window) slots of one
+// output and leaves their sum; k_g1fft_sum_partials adds the waves of an output.  Same group elements.
+__global__ void __launch_bounds__(256)
+k_g1fft_first_tables(const uint4* __restrict__ tables, uint32_t table_stride, int c, int W, uint32_t n, int log_n, int K,
+                     const uint4* __restrict__ scal_canon, uint32_t waves_per_out, int32_t* __restrict__ partial) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, pair = lane >> 1;
+    const bool odd = (t & 1u) != 0;
+    const uint32_t gw = t >> 6;
+    const uint32_t o = gw / waves_per_out, wv = gw - o * waves_per_out;
+    if (o >= n) return;                                           // wave-uniform
+    const uint32_t R = 1u << K, nr = n >> K;
+    const uint32_t tt = wv * 32 + pair;
+    const bool valid = tt < R * (uint32_t)W;
+    const uint32_t jp = valid ? tt / (uint32_t)W : 0, w = valid ? tt - jp * (uint32_t)W : 0;
+    const uint32_t u = o & (nr - 1), j = o >> (log_n - K);
+    const uint32_t e = (uint32_t)((unsigned long long)nr * j * jp) & (n - 1);
+    const uint32_t i = u + nr * jp;                               // first stage: stride s = N / R, p = 0
+    // signed c-bit digit number w of the canonical scalar (the MSM's digit rule: k_msm_digits)
+    uint32_t mag = 0, neg = 0;
+    {
+        const uint4 lo = scal_canon[2 * (size_t)e], hi = scal_canon[2 * (size_t)e + 1];
+        uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+        uint32_t carry = 0;
+        for (uint32_t ww = 0; ww <= w; ++ww) {
+            const uint32_t raw = (k[0] & mask) + carry;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) k[q] = (k[q] >> c) | (k[q + 1] << (32 - c));
+            k[7] >>= c;
+            neg = raw > half;
+            mag = neg ? (1u << c) - raw : raw;
+            carry = neg;
+        }
+        if (!valid) mag = 0;
+    }
+    const uint4* src = tables + 4 * ((size_t)w * table_stride + i) + (odd ? 2 : 0);
+    const uint4 q0 = src[0], q1 = src[1];                         // even lane: x, odd lane: y
+    const uint32_t w32[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    int any = (q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w) != 0 ? 1 : 0;
+    any |= pair_swap(any);
+    if (!any) mag = 0;                                            // identity table point
+    Fq cpt;
+    fe_unpack(cpt, w32);
+    HalfXyzz acc;
+    half_set_inf(acc);
+#pragma unroll 1
+    for (int b = c - 1; b >= 0; --b) {
+        HalfXyzz r;
+        pair_dbl_any(r, acc, odd);
+        acc = r;
+        if ((mag >> b) & 1u) {                                    // pair-uniform
+            pair_madd(r, acc, cpt, neg, odd);
+            acc = r;
+        }
+    }
+#pragma unroll 1
+    for (int d = 1; d < 32; d <<= 1) {                            // sum of the wave's 32 slots
+        HalfXyzz other;
+        half_shfl_down(other, acc, 2 * d);
+        if ((pair & (2 * d - 1)) == 0) {
+            HalfXyzz r;
+            pair_add(r, acc, other, odd);
+            acc = r;
+        }
+    }
+    if (pair == 0) half_store(partial, (size_t)n * waves_per_out, (size_t)o * waves_per_out + wv, acc, odd);
+}
+// y[o] = sum of the waves_per_out (<= 32) partial sums of output o: one wave per output
+__global__ void __launch_bounds__(256)
+k_g1fft_sum_partials(const int32_t* __restrict__ partial, uint32_t waves_per_out, uint32_t n, int32_t* __restrict__ y) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, pair = lane >> 1;
+    const bool odd = (t & 1u) != 0;
+    const uint32_t o = t >> 6;
+    if (o >= n) return;
+    HalfXyzz acc;
+    if (pair < waves_per_out) half_load(acc, partial, (size_t)n * waves_per_out, (size_t)o * waves_per_out + pair, odd);
+    else half_set_inf(acc);
+#pragma unroll 1
+    for (int d = 1; d < 32; d <<= 1) {
+        HalfXyzz other;
+        half_shfl_down(other, acc, 2 * d);
+        if ((pair & (2 * d - 1)) == 0) {
+            HalfXyzz r;
+            pair_add(r, acc, other, odd);
+            acc = r;
+        }
+    }
+    if (pair == 0) half_store(y, n, o, acc, odd);
+}
+
 // ---- XYZZ -> affine ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void affine_emit(uint4* __restrict__ out, size_t i, const Xyzz& r, const Fq& inv_zz_zzz /* 1 / (ZZ ZZZ) */, bool wire) {
     uint32_t o[16];
@@ -492,12 +593,12 @@ k_g1fft_to_affine(const int32_t* __restrict__ planes, uint32_t n, uint4* __restr
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------
-struct ScalKey { int dev, log_n, scaled; bool operator<(const ScalKey& o) const { return dev != o.dev ? dev < o.dev : (log_n != o.log_n ? log_n < o.log_n : scaled < o.scaled); } };
+struct ScalKey { int dev, log_n, scaled; bool operator<(const ScalKey& o) const { return dev != o.dev ? dev < o.dev : (log_n != o.log_n ? log_n < o.log_n : scaled < o.scaled); } };   // scaled: bit 0 = times 1/n, bit 1 = canonical (not GLV-split)
 static std::map<ScalKey, uint4*> g_scal;
 static std::mutex g_scal_mu;
-static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** out) {
+static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** out, bool canon = false) {
     std::lock_guard<std::mutex> lk(g_scal_mu);
-    ScalKey key{ctx->device, log_n, scaled ? 1 : 0};
+    ScalKey key{ctx->device, log_n, (scaled ? 1 : 0) | (canon ? 2 : 0)};
     auto it = g_scal.find(key);
     if (it != g_scal.end()) { *out = it->second; return KZG_OK; }
     NttTables tb{};
@@ -505,7 +606,7 @@ static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** o
     const size_t n = (size_t)1 << log_n;
     uint4* p = nullptr;
     KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&p), n * 32));
-    hipLaunchKernelGGL(k_g1fft_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, (uint32_t)n, log_n, tb, scaled ? 1 : 0);
+    hipLaunchKernelGGL(k_g1fft_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, (uint32_t)n, log_n, tb, scaled ? 1 : 0, canon ? 1 : 0);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     g_scal[key] = p;
@@ -513,8 +614,21 @@ static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** o
     return KZG_OK;
 }
 
-// Lagrange basis of the first n SRS points -> d_out (n affine points: wire format, or the device format of curve.h)
-int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out, bool wire) {
+// XYZZ planes -> wire XYZZ words (32 u32 per point) for the host-side affine conversion of small transforms
+__global__ void __launch_bounds__(256)
+k_g1fft_planes_to_wire(const int32_t* __restrict__ planes, uint32_t n, uint32_t* __restrict__ out_wire) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xyzz v;
+    xyzz_load(v, planes, n, i);
+    uint32_t w[32];
+    xyzz_to_wire(w, v);
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) *reinterpret_cast<uint4*>(out_wire + (size_t)i * 32 + j) = make_uint4(w[j], w[j + 1], w[j + 2], w[j + 3]);
+}
+
+// The stages of the transform: *result_out = XYZZ planes (stride n) of the Lagrange basis of the first n SRS points, natural order
+static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const int32_t** result_out) {
     int log_n = 0;
     while (((size_t)1 << log_n) < n) ++log_n;
     hipStream_t st = ctx->stream;
@@ -558,8 +672,19 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
     if (log_n == 0) {
         hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, bufA, 0);
     } else if (kmax >= 2) {
-        hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, bufA, 0);
         const int stages = (log_n + kmax - 1) / kmax;
+        // the first stage through the SRS window tables when the SRS has them and the stage fits four waves per SIMD
+        // (KZG_G1FFT_TABLES=0: off).  Prefers the narrow (c = 15) set: fewer double-and-add steps per digit.
+        static const bool use_tables = []() { const char* e = getenv("KZG_G1FFT_TABLES"); return !(e && atoi(e) == 0); }();
+        const uint4* tab = nullptr; int tab_c = 0, tab_W = 0;
+        if (use_tables && srs->lagrange_of == 0) {
+            if (srs->d_small) { tab = srs->d_small; tab_c = srs->small_c; tab_W = srs->small_W; }
+            else if (srs->pre_W > 0) { tab = srs->d_points; tab_c = srs->pre_c; tab_W = srs->pre_W; }
+        }
+        const int K0 = (log_n + stages - 1) / stages;                       // radix bits of the first stage (balanced split)
+        const uint32_t wpo = tab ? (uint32_t)((((size_t)1 << K0) * tab_W + 31) / 32) : 0;
+        const bool first_tables = tab && wpo <= 32 && n * (size_t)wpo <= 4096;
+        if (!first_tables) hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, bufA, 0);
         int done = 0;
         int32_t* src = bufA;
         int32_t* dst = bufB;
@@ -569,7 +694,16 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
             const int log_s = log_n - done;
             const bool last = i == stages - 1;
             const size_t lanes = n << K;
-            if (pairs)
+            if (i == 0 && first_tables) {
+                const uint4* sc = nullptr;
+                rc = get_scalars(ctx, log_n, last, &sc, true);                // canonical scalars (scaled by 1/n when this is also the last stage)
+                if (rc != KZG_OK) return rc;
+                KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)n * wpo * 36 * 4));
+                int32_t* partial = ctx->poly[0].c.as<int32_t>();
+                hipLaunchKernelGGL(k_g1fft_first_tables, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, tab, (uint32_t)srs->n, tab_c, tab_W,
+                                   (uint32_t)n, log_n, K, sc, wpo, partial);
+                hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, wpo, (uint32_t)n, dst);
+            } else if (pairs)
                 hipLaunchKernelGGL(k_g1fft_direct_pairs, dim3((unsigned)((2 * lanes + 255) / 256)), dim3(256), 0, st, src, dst, (uint32_t)n, log_n, K, log_s,
                                    last ? scal_n : scal, last ? 1 : 0);
             else
@@ -590,14 +724,42 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
                                    last ? scal_n : scal, last ? 1 : 0);
         }
     }
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    *result_out = result;
+    return KZG_OK;
+}
+
+// Lagrange basis of the first n SRS points -> d_out (n affine points: wire format, or the device format of curve.h)
+int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out, bool wire) {
+    const int32_t* result = nullptr;
+    int32_t rc = g1_ifft_stages(ctx, srs, n, &result);
+    if (rc != KZG_OK) return rc;
     const size_t lanes = std::max<size_t>(1, (n + AFF_PER - 1) / AFF_PER);
     const unsigned blocks = (unsigned)std::min<size_t>((lanes + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_g1fft_to_affine, dim3(blocks), dim3(256), 0, st, result, (uint32_t)n, d_out, wire ? 1 : 0, ctx->poly[0].a.as<int32_t>());
+    hipLaunchKernelGGL(k_g1fft_to_affine, dim3(blocks), dim3(256), 0, ctx->stream, result, (uint32_t)n, d_out, wire ? 1 : 0, ctx->poly[0].a.as<int32_t>());
     KZG_HIP_TRY(ctx, hipGetLastError());
     return KZG_OK;
 }
 
+// Up to this many points the one inversion of the affine conversion runs on the HOST (Montgomery's trick over the n points, ~20 us):
+// on the device it is a 380-multiplication chain on lone lanes, 0.2 ms whatever n -- two thirds of a g1_ifft of 2..32 points.
+constexpr size_t G1FFT_HOST_AFFINE_MAX = 256;
+
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy) {
+    if (n <= G1FFT_HOST_AFFINE_MAX) {
+        const int32_t* result = nullptr;
+        int32_t rc = g1_ifft_stages(ctx, srs, n, &result);
+        if (rc != KZG_OK) return rc;
+        KZG_HIP_TRY(ctx, ctx->msm.bases_wire.reserve(n * 128));
+        hipLaunchKernelGGL(k_g1fft_planes_to_wire, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, result, (uint32_t)n, ctx->msm.bases_wire.as<uint32_t>());
+        KZG_HIP_TRY(ctx, hipGetLastError());
+        static thread_local std::vector<kzg_host::Xyzz> host_pts;
+        host_pts.resize(n);
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(host_pts.data(), ctx->msm.bases_wire.p, n * 128, hipMemcpyDeviceToHost, ctx->stream));
+        KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        kzg_host::xyzz_batch_to_affine(host_pts.data(), n, out_xy);
+        return KZG_OK;
+    }
     KZG_HIP_TRY(ctx, ctx->msm.bases_wire.reserve(n * 64));
     int32_t rc = g1_ifft_device(ctx, srs, n, ctx->msm.bases_wire.as<uint4>(), true);
     if (rc != KZG_OK) return rc;

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 namespace kzg_host {
 
@@ -107,6 +108,24 @@ inline void xyzz_to_affine(const Xyzz& p, uint64_t out_xy[8], uint8_t* is_infini
     Fq x = mul(p.x, mul(i, p.zzz)), y = mul(p.y, mul(i, p.zz));
     memcpy(out_xy, x.l, 32); memcpy(out_xy + 4, y.l, 32);
     if (is_infinity) *is_infinity = 0;
+}
+// n points at once with ONE field inversion (Montgomery's trick): out_xy = n x (x || y) wire words, identity -> zeros
+inline void xyzz_batch_to_affine(const Xyzz* p, size_t n, uint64_t* out_xy) {
+    std::vector<Fq> pre(n);
+    Fq run = FQ_ONE;
+    for (size_t i = 0; i < n; ++i) {                     // prefix products of the denominators ZZ ZZZ (identity points contribute 1)
+        pre[i] = run;
+        if (!is_inf(p[i])) run = mul(run, mul(p[i].zz, p[i].zzz));
+    }
+    Fq rinv = inv(run);
+    for (size_t i = n; i-- > 0;) {
+        if (is_inf(p[i])) { memset(out_xy + 8 * i, 0, 64); continue; }
+        const Fq d = mul(p[i].zz, p[i].zzz);
+        const Fq iv = mul(rinv, pre[i]);                 // 1 / (ZZ ZZZ)
+        rinv = mul(rinv, d);
+        const Fq x = mul(p[i].x, mul(iv, p[i].zzz)), y = mul(p[i].y, mul(iv, p[i].zz));
+        memcpy(out_xy + 8 * i, x.l, 32); memcpy(out_xy + 8 * i + 4, y.l, 32);
+    }
 }
 // sum_w 2^(c w) * S_w, windows given low to high
 inline Xyzz horner_windows(const Xyzz* sums, int W, int c) {
