@@ -70,6 +70,27 @@ int main(void) {
     }
     CHECK(kzg_msm_g1_srs_end(ctx, prev, got, &inf, NULL)); matches += memcmp(got, want, 64) == 0;
     printf("streamed commitments equal the synchronous one: %d / 4\n", matches);
+
+    /* 5. verify_blob_kzg_proof_batch (verifier/src/batch.rs:16-69) in ONE call: 16 blobs of different lengths with their commitments
+     *    and blob proofs (kzg_commit_and_prove_blob), then one corrupted blob */
+    enum { NB = 16 };
+    uint8_t* blobs[NB]; size_t lens[NB];
+    uint64_t cs[NB * 8], ps[NB * 8];
+    for (int b = 0; b < NB; ++b) {
+        lens[b] = 32 * (size_t)(1 + 61 * b);                                 /* 1 .. 916 field elements */
+        blobs[b] = (uint8_t*)calloc(lens[b], 1);
+        for (size_t i = 0; i < lens[b]; ++i) blobs[b][i] = (i % 32 == 0) ? 0 : (uint8_t)(32 + ((i + 977 * (size_t)b) * 2654435761u >> 9) % 95);
+        size_t np = 1; while (np < lens[b] / 32) np <<= 1;                   /* KZG::expanded_roots_of_unity.len() of this blob */
+        uint8_t ci = 0, pi = 0;
+        CHECK(kzg_commit_and_prove_blob(ctx, srs, blobs[b], lens[b], np, cs + 8 * b, &ci, ps + 8 * b, &pi, NULL, NULL));
+    }
+    CHECK(kzg_verify_blob_kzg_proof_batch(ctx, (const uint8_t* const*)blobs, lens, cs, ps, NB, g2_tau, &ok));
+    printf("verify_blob_kzg_proof_batch of %d blobs: %s\n", NB, ok ? "batch verifies" : "BATCH REJECTED");
+    if (!ok) return 6;
+    blobs[7][33] ^= 1;
+    CHECK(kzg_verify_blob_kzg_proof_batch(ctx, (const uint8_t* const*)blobs, lens, cs, ps, NB, g2_tau, &ok));
+    if (ok) { fprintf(stderr, "a corrupted blob verified\n"); return 7; }
+    for (int b = 0; b < NB; ++b) free(blobs[b]);
     free(evals); free(blob);
     kzg_srs_free(srs);
     kzg_ctx_destroy(ctx);

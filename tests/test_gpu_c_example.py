@@ -1,5 +1,6 @@
 """-m gpu: the C-ABI used from plain C (examples/commit_and_verify.c), built with gcc against the in-tree library and run
-as its own process: commit_blob, compute_proof, verify_proof against [tau]G2, and the two-slot stream — no Python, no torch
+as its own process: commit_blob, compute_proof, verify_proof against [tau]G2, the two-slot stream and the one-call batch verification
+of 16 blobs — no Python, no torch
 on the product side."""
 import os
 import subprocess
@@ -17,7 +18,7 @@ def test_c_example_builds_and_runs(tmp_path):
                            "-L" + libdir, "-lkzg_bn254_mi355x", "-Wl,-rpath," + libdir, "-o", exe])
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
-    assert "proof verifies" in res.stdout and "4 / 4" in res.stdout
+    assert "proof verifies" in res.stdout and "4 / 4" in res.stdout and "batch verifies" in res.stdout
 
 
 def test_multi_device_c_example(tmp_path):
