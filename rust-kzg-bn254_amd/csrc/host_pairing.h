@@ -715,9 +715,13 @@ inline void ate_dbl_step(G2Jac& T, const G1& P, AteLine& l) {
     l.c = sub(mul(E, T.X), dbl2(B));
     T.X = X3; T.Y = Y3; T.Z = Z3;
 }
-inline void ate_add_step(G2Jac& T, const G2& Q, const G1& P, AteLine& l) {
+// Returns false in the degenerate case H == 0 (T == +-Q): it cannot happen for Q in the order-r subgroup of the twist (the loop scalar
+// 6x + 2 and the Frobenius steps never bring a multiple of Q back onto +-Q), only for a caller-supplied point outside it -- which is
+// merely checked to be on the curve, as in the reference.  The chord formula has no meaning there; the caller answers "not equal".
+inline bool ate_add_step(G2Jac& T, const G2& Q, const G1& P, AteLine& l) {
     const Fq2 Z2 = sqr(T.Z);
     const Fq2 H = sub(mul(Q.x, Z2), T.X);
+    if (is_zero(H)) return false;
     const Fq2 r = sub(mul(Q.y, mul(Z2, T.Z)), T.Y);
     const Fq2 Z3 = mul(T.Z, H);
     l.a = mul_fq(Z3, P.y);
@@ -727,6 +731,7 @@ inline void ate_add_step(G2Jac& T, const G2& Q, const G1& P, AteLine& l) {
     const Fq2 X3 = sub(sub(sqr(r), HHH), dbl2(V));
     T.Y = sub(mul(r, sub(V, X3)), mul(T.Y, HHH));
     T.X = X3; T.Z = Z3;
+    return true;
 }
 // f * (a + b w + c w^3): f is read as six Fq2 coefficients g_i of w^i (g_i = (c_i + 9 c_{i+6}) + c_{i+6} u), w^6 = xi = 9 + u
 inline Fq12 mul_by_line(const Fq12& f, const AteLine& l) {
@@ -779,7 +784,10 @@ struct AteNaf {
 };
 inline const AteNaf& ate_naf() { static const AteNaf n; return n; }
 // product over the pairs of the optimal-ate Miller functions (pairs with an identity point contribute 1)
-inline Fq12 miller_ate_product(const G1* ps, const G2* qs, int count) {
+// *degenerate (optional) is set when an addition step met T == +-Q (see ate_add_step): the value returned is then meaningless
+inline Fq12 miller_ate_product(const G1* ps, const G2* qs, int count, bool* degenerate = nullptr) {
+    if (degenerate) *degenerate = false;
+    bool bad = false;
     struct Pt { G2Jac T; G2 q, nq; G1 p; } pts[4];
     int m = 0;
     for (int k = 0; k < count && m < 4; ++k) {
@@ -795,12 +803,13 @@ inline Fq12 miller_ate_product(const G1* ps, const G2* qs, int count) {
     for (int i = naf.len - 2; i >= 0; --i) {
         f = sqr(f);
         for (int k = 0; k < m; ++k) { ate_dbl_step(pts[k].T, pts[k].p, l); f = mul_by_line(f, l); }
-        if (naf.d[i]) for (int k = 0; k < m; ++k) { ate_add_step(pts[k].T, naf.d[i] > 0 ? pts[k].q : pts[k].nq, pts[k].p, l); f = mul_by_line(f, l); }
+        if (naf.d[i]) for (int k = 0; k < m; ++k) { bad |= !ate_add_step(pts[k].T, naf.d[i] > 0 ? pts[k].q : pts[k].nq, pts[k].p, l); f = mul_by_line(f, l); }
     }
     for (int k = 0; k < m; ++k) {
-        ate_add_step(pts[k].T, g2_frobenius(pts[k].q), pts[k].p, l); f = mul_by_line(f, l);
-        ate_add_step(pts[k].T, g2_frobenius2_neg(pts[k].q), pts[k].p, l); f = mul_by_line(f, l);
+        bad |= !ate_add_step(pts[k].T, g2_frobenius(pts[k].q), pts[k].p, l); f = mul_by_line(f, l);
+        bad |= !ate_add_step(pts[k].T, g2_frobenius2_neg(pts[k].q), pts[k].p, l); f = mul_by_line(f, l);
     }
+    if (degenerate) *degenerate = bad;
     return f;
 }
 inline Fq12 pairing_ate(const G1& p, const G2& q) { return final_exponentiation_x(miller_ate_product(&p, &q, 1)); }
@@ -809,7 +818,10 @@ inline Fq12 pairing_ate(const G1& p, const G2& q) { return final_exponentiation_
 inline bool pairings_verify(const G1& a1, const G2& a2, const G1& b1, const G2& b2) {
     G1 ps[2] = {a1, g1_neg(b1)};
     G2 qs[2] = {a2, b2};
-    return fq12_is_one(final_exponentiation_x(miller_ate_product(ps, qs, 2)));
+    bool degenerate = false;
+    const Fq12 f = miller_ate_product(ps, qs, 2, &degenerate);
+    if (degenerate) return false;                      // a G2 input outside the order-r subgroup: no pairing value to compare (header: kzg_verify_proof)
+    return fq12_is_one(final_exponentiation_x(f));
 }
 // the same predicate through the Tate construction (self-check builds compare the two)
 inline bool pairings_verify_tate(const G1& a1, const G2& a2, const G1& b1, const G2& b2) {

@@ -305,13 +305,14 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
         uint4* table = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&table), bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); return KZG_OK; }      // not enough memory: stay without
-        KZG_HIP_TRY(ctx, hipMemcpyAsync(table, srs->d_points, n * 64, hipMemcpyDeviceToDevice, ctx->stream));
-        for (int w = 1; w < W; ++w) {
+        e = hipMemcpyAsync(table, srs->d_points, n * 64, hipMemcpyDeviceToDevice, ctx->stream);
+        for (int w = 1; w < W && e == hipSuccess; ++w) {
             hipLaunchKernelGGL(k_srs_window_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                                table + 4 * (size_t)(w - 1) * n, table + 4 * (size_t)w * n, n, cw);
         }
-        KZG_HIP_TRY(ctx, hipGetLastError());
-        KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(table); return set_error(ctx, e, "building the SRS window tables"); }   // (the table leaked on these paths)
         *out = table; *out_W = W;
         return KZG_OK;
     };
