@@ -1051,6 +1051,9 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
     std::vector<int32_t> status(n, KZG_OK);
     std::vector<VbMeta> meta(n);
     std::vector<size_t> group_end;                            // blob index where each GPU round ends
+    // (KZG_VB_GROUP_BYTES / KZG_VB_CHUNK_BYTES: test hooks that make small batches take the multi-round / multi-chunk paths)
+    static const size_t group_bytes = []() { const char* e = getenv("KZG_VB_GROUP_BYTES"); return e && atol(e) > 0 ? (size_t)atol(e) : VB_GROUP_BYTES; }();
+    static const size_t chunk_bytes = []() { const char* e = getenv("KZG_VB_CHUNK_BYTES"); return e && atol(e) > 0 ? (size_t)atol(e) : ((size_t)16 << 20); }();
     size_t off = 0;
     for (size_t i = 0; i < n; ++i) {
         const size_t elems = (lens[i] + 31) / 32;
@@ -1060,7 +1063,7 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
         while (np < elems) { np <<= 1; ++lg; }
         const bool batched = lens[i] != 0 && lg <= VB_BATCH_MAX_LOG;
         const size_t span = batched ? elems * 32 : 0;
-        if (off && off + span > VB_GROUP_BYTES) { group_end.push_back(i); off = 0; }
+        if (off && off + span > group_bytes) { group_end.push_back(i); off = 0; }
         meta[i] = VbMeta{(uint64_t)off, (uint32_t)(batched ? lens[i] : 0), batched ? lg : 99u};
         off += span;
     }
@@ -1094,7 +1097,7 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
         {
             size_t acc_bytes = 0;
             for (size_t k = 0; k < nb; ++k) {
-                if (chunk_lo.empty() || acc_bytes >= ((size_t)16 << 20)) { chunk_lo.push_back(k); chunk_hi.push_back(k); acc_bytes = 0; }
+                if (chunk_lo.empty() || acc_bytes >= chunk_bytes) { chunk_lo.push_back(k); chunk_hi.push_back(k); acc_bytes = 0; }
                 chunk_of[k] = chunk_lo.size() - 1;
                 chunk_hi.back() = k + 1;
                 if (meta[g0 + k].log_n != 99u) acc_bytes += ((size_t)meta[g0 + k].len + 31) / 32 * 32;

@@ -267,3 +267,39 @@ def test_verify_blob_kzg_proof_batch_4096_end_to_end(k, srs, g2_tau):
     data = bytearray(blobs[2000].data()); data[40] ^= 1
     mid = blobs[:2000] + [k.Blob.from_padded_unchecked(bytes(data))] + blobs[2001:]
     assert k.verify_blob_kzg_proof_batch(mid, commitments, proofs, g2_tau) is False
+
+
+def test_batch_front_end_multi_round_and_multi_chunk_paths(k, srs, g2_tau):
+    """A batch larger than one GPU round (256 MiB of packed blobs) is processed in rounds, a round in chunks of 16 MiB whose uploads
+    run beside the hashing: with the test hooks KZG_VB_GROUP_BYTES / KZG_VB_CHUNK_BYTES a 60-blob batch takes both paths (several rounds,
+    several chunks per round, a 2^13-element blob in the middle of a round) in a fresh process; results must equal the one-round run."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, hashlib
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np, torch
+        import rust_kzg_bn254_amd as k, pyref
+        k.load(); k.default_context()
+        TAU = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") %% pyref.R_
+        srs = k.SRS.generate(TAU, 4096)
+        g2 = k.helpers.g2_mul_generator(k.fr.fr_from_int(TAU))
+        rng = np.random.default_rng(99)
+        kz = k.KZG.new(); blobs = []; cs = []; ps = []
+        for i in range(60):
+            n_raw = int(rng.integers(35, 60000))
+            b = k.Blob.from_raw_data(rng.integers(32, 127, size=n_raw, dtype=np.uint8).tobytes())
+            kz.calculate_and_store_roots_of_unity(len(b))
+            c, p, _, _ = kz.commit_and_prove_blob(b, srs)
+            blobs.append(b); cs.append(c); ps.append(p)
+        big = k.Blob.from_raw_data(rng.integers(32, 127, size=200000, dtype=np.uint8).tobytes())     # 8192 elements: single-polynomial path
+        zs, ys = k.helpers.compute_challenges_and_evaluate_polynomial(blobs[:30] + [big] + blobs[30:], cs[:30] + [cs[0]] + cs[30:])
+        print("ZY", hashlib.sha256(np.stack(zs).tobytes() + np.stack(ys).tobytes()).hexdigest())
+        print("OK", k.verify_blob_kzg_proof_batch(blobs, cs, ps, g2), k.verify_blob_kzg_proof_batch(blobs, cs[1:] + cs[:1], ps, g2))
+    ''') % (root, os.path.join(root, "tests"))
+    outs = []
+    for env_extra in ({}, {"KZG_VB_GROUP_BYTES": str(300000), "KZG_VB_CHUNK_BYTES": str(70000)}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("ZY", "OK"))])
+    assert outs[0] == outs[1] and outs[0][1] == "OK True False", outs
