@@ -118,7 +118,7 @@ int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out) {
             ctx->acc_wave_slots = (uint32_t)cus * 4u * 3u;                // k_msm_accumulate: 3 waves per SIMD (KZG_ACC_WAVES)
         else (void)hipGetLastError();
         const char* env = getenv("KZG_ACC_SLOTS");
-        if (env && atoi(env) > 0) ctx->acc_wave_slots = (uint32_t)atoi(env);
+        if (env && atoi(env) > 0) { ctx->acc_wave_slots = (uint32_t)atoi(env); ctx->acc_slots_forced = true; }
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete ctx; return KZG_ERR_DEVICE; }
     *out = ctx;

@@ -75,6 +75,7 @@ struct kzg_ctx {
     bool lds_attr_set = false;
     bool poly_lds_attr_set = false;
     uint32_t acc_wave_slots = 3 * 1024;   // resident waves of the accumulate kernel on this device: 3 per SIMD x 4 SIMDs x CUs (set at kzg_ctx_create)
+    bool acc_slots_forced = false;         // KZG_ACC_SLOTS given: use exactly that many (else make_plan takes 2 of the 3 per SIMD where that pays)
     kzg::MsmWorkspace msm;
     kzg::MsmWorkspace msm_x[KZG_NUM_SLOTS - 1];   // workspaces of slots 1.. of the asynchronous calls
     hipStream_t stream_x[KZG_NUM_SLOTS - 1] = {}; // one stream per slot (slot 0: `stream`), created on first use

@@ -93,7 +93,19 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
             lanes = (entries + (size_t)L - 1) / (size_t)L;                 // forced trip count (tests, sweeps): no cap
         } else {
             const size_t lmin = entries >= ((size_t)1 << 21) ? 24 : 4;
-            lanes = std::min<size_t>((size_t)ctx->acc_wave_slots * 64, (entries + lmin - 1) / lmin);
+            // Round 3: TWO waves per SIMD (of the three the 168-VGPR kernel could hold) unless this is a large MSM running alone.
+            // A grid that fills all three slots leaves no registers for any other kernel on the chip, so the sort and the reductions
+            // of the other MSM in flight only ran in the tail of this kernel; with a third of the slots free they run beside it:
+            // pipelined step 1.183-1.192 -> 1.160-1.166 ms (same box, KZG_ACC_SLOTS=3072 / 2048; 2560 = 2.5 waves per SIMD: 1.17-1.18),
+            // and below 2^19 pairs fewer lanes also mean fewer partial sums for the first reduction level (2^16: 0.464 -> 0.403 ms,
+            // 2^17: 0.534 -> 0.486).  Alone, a 2^19 / 2^20-pair MSM is 2-3 % faster on three (0.929 / 1.474 against 0.961 / 1.496 ms).
+            size_t slots = ctx->acc_wave_slots;
+            if (!ctx->acc_slots_forced) {
+                bool other_in_flight = false;
+                for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) other_in_flight |= ctx->slot_pending[sl] != nullptr;
+                if (other_in_flight || entries < ((size_t)1 << 23)) slots = slots / 3 * 2;
+            }
+            lanes = std::min<size_t>(slots * 64, (entries + lmin - 1) / lmin);
         }
         lanes = std::max<size_t>(256, (lanes + 255) / 256 * 256);
         p.nl = (uint32_t)std::min<size_t>(lanes, (size_t)1 << 24);
