@@ -119,7 +119,11 @@ __device__ __forceinline__ size_t ntt_in_index(const NttPassArgs& a, uint32_t ti
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, NttPassArgs a,
            const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
-           const uint4* __restrict__ next_tw /* or nullptr: w_N^(E(idx)) of the next pass for every output index, canonical words of the internal form */) {
+           const uint4* __restrict__ next_tw /* or nullptr: w_N^(E(idx)) of the next pass for every output index, canonical words of the internal form */
+#ifdef KZG_NTT_STAMPS
+           , unsigned long long* __restrict__ stamps /* diagnostic build (tools/ntt_stamps.py): 8 phase sums per workgroup, 100 MHz ticks */
+#endif
+           ) {
     __shared__ int32_t lds[NL * NTT_PL];
     __shared__ int32_t twl[NL * NTT_TW];
     const int K = a.K, log_n = a.log_n;
@@ -155,8 +159,15 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
             else { pre[k][0] = make_uint4(0, 0, 0, 0); pre[k][1] = make_uint4(0, 0, 0, 0); }
         }
     }
+#ifdef KZG_NTT_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
+#define KZG_NTT_STAMP(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); ph[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define KZG_NTT_STAMP(i) do { } while (0)
+#endif
     for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const uint32_t tile_u0 = tile << log_c;
+        KZG_NTT_STAMP(0);                                  // (set-up, or the previous tile's trailing barrier)
         // ---- registers -> LDS (bit-reversed rows) ----------------------------------------------
 #pragma unroll
         for (int k = 0; k < NTT_EPT; ++k) {
@@ -171,6 +182,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
             for (int l = 0; l < NL; ++l) lds[l * NTT_PL + e] = v.l[l];
         }
         __syncthreads();
+        KZG_NTT_STAMP(1);                                  // wait for the tile's words + unpack + LDS fill
         // ---- prefetch the next tile's words: in flight during the butterfly stages ---------------
         {
             const uint32_t nt = tile + gridDim.x;
@@ -188,6 +200,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
         // Radix-4 step over half-sizes h and 2h on rows i0, i0+h, i0+2h, i0+3h (same butterflies and twiddles as two radix-2
         // stages, so the results are identical): one LDS round trip, one barrier and four limb normalisations per four elements.
         uint32_t log_h = 0;
+        KZG_NTT_STAMP(2);                                  // issue of the prefetch
         for (; log_h + 1 < (uint32_t)K; log_h += 2) {
             const uint32_t h = 1u << log_h;
             for (uint32_t gt = tid; gt < (uint32_t)(NTT_TILE / 4); gt += NTT_THREADS) {
@@ -239,6 +252,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
 #else
             __syncthreads();
 #endif
+            KZG_NTT_STAMP(3);                              // the radix-4 steps
         }
         if (log_h < (uint32_t)K) {
             const uint32_t h = 1u << log_h;
@@ -268,6 +282,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
             }
             __syncthreads();
         }
+        KZG_NTT_STAMP(4);                                  // the odd radix-2 stage
         // ---- LDS -> global: rows j, C consecutive units each -------------------------------------------------
 #pragma unroll
         for (int k = 0; k < NTT_EPT; ++k) {
@@ -313,8 +328,13 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
             out_words[2 * idx] = make_uint4(w32[0], w32[1], w32[2], w32[3]);
             out_words[2 * idx + 1] = make_uint4(w32[4], w32[5], w32[6], w32[7]);
         }
+        KZG_NTT_STAMP(5);                                  // LDS read + the store-side multiply + pack + global stores (issue)
         __syncthreads();                   // the tile's rows are read before the next tile overwrites them
     }
+#ifdef KZG_NTT_STAMPS
+    KZG_NTT_STAMP(6);
+    if (tid == 0 && stamps) for (int i = 0; i < 8; ++i) stamps[(size_t)blockIdx.x * 8 + i] = ph[i];
+#endif
 }
 
 __global__ void __launch_bounds__(256)
@@ -385,6 +405,15 @@ static int32_t ntt_get_pass_twiddles(kzg_ctx* ctx, int log_n, bool inverse, int 
     return KZG_OK;
 }
 
+#ifdef KZG_NTT_STAMPS
+static unsigned long long* g_ntt_stamps = nullptr;
+}  // namespace kzg
+extern "C" int32_t kzg_debug_ntt_stamps(unsigned long long* out /* 4 x 1024 x 8 */) {
+    if (!kzg::g_ntt_stamps) return -1;
+    return hipMemcpy(out, kzg::g_ntt_stamps, 4 * 1024 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+namespace kzg {
+#endif
 int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t st, NttWorkspace* ws) {
     if (!st) st = ctx->stream;
     if (!ws) ws = &ctx->ntt;
@@ -431,7 +460,14 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
             rc = ntt_get_pass_twiddles(ctx, log_n, inverse, a.next_K, a.next_log_s, tb, lo_bits, &next_tw);
             if (rc != KZG_OK) return rc;
         }
+#ifdef KZG_NTT_STAMPS
+        static unsigned long long* d_stamps = nullptr;     // [pass][workgroup][8]; read back by kzg_debug_ntt_stamps
+        if (!d_stamps) KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_stamps), 4 * 1024 * 8 * 8));
+        g_ntt_stamps = d_stamps;
+        hipLaunchKernelGGL(k_ntt_pass, dim3(grid), dim3(NTT_THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw, d_stamps + (size_t)pi * 1024 * 8);
+#else
         hipLaunchKernelGGL(k_ntt_pass, dim3(grid), dim3(NTT_THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
+#endif
     }
     KZG_HIP_TRY(ctx, hipGetLastError());
     return KZG_OK;
