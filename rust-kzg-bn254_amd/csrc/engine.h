@@ -30,7 +30,7 @@ struct MsmWorkspace {
     DeviceBuffer blob;         // staging for blob bytes (asynchronous commit_blob)
     DeviceBuffer bases;        // staging for ad-hoc bases (n x 64 B, device format)
     DeviceBuffer bases_wire;   // staging for ad-hoc bases in wire format
-    DeviceBuffer digits, sorted, count, blockbase, sort_tmp, sort_small, offs, block_sums, bucket, chunkS, chunkTmp, chunkA, out_wire;
+    DeviceBuffer digits, sorted, count, blockbase, sort_tmp, sort_key, sort_small, offs, block_sums, bucket, chunkS, chunkTmp, chunkA, out_wire;
     DeviceBuffer head, cont;   // accumulate partials: head[g] per bucket, cont[t] per lane (36 limb planes each; msm_kernels.h section 4)
     void* pinned_out = nullptr;   // pinned host buffer for window sums
     // optional per-phase timing with HIP events on the launch stream (kzg_ctx_set_profiling)
@@ -101,6 +101,8 @@ struct kzg_srs {
     uint4* d_small = nullptr;
     int small_c = 0;
     int small_W = 0;
+    // per-bit tables Bit_j[i] = 2^j P_i, j < 255, n points apart (srs.hip srs_build_bit_tables): the NAF mode of MSMs of >= SRS_NAF_MIN pairs; may be absent
+    uint4* d_bits = nullptr;
     // Lagrange-basis copies of the first m points (KZG::g1_ifft(m), kzg.rs:263-285), built by kzg_srs_cache_lagrange and used by
     // the eval-form commitments of exactly m evaluations instead of IFFT + MSM over the monomial basis; owned by this SRS
     std::map<size_t, kzg_srs*> lagrange;
@@ -116,9 +118,17 @@ struct MsmBases {
     uint32_t table_stride = 0;
     int c = 0;
     int W = 0;
+    bool naf = false;     // `points` = the per-bit tables (Bit_j[i] = 2^j P_i, j < 255, table_stride points apart): width-(c + 1) NAF digits
 };
 constexpr int SRS_SMALL_C = 15;                       // window bits of the second table set
 constexpr size_t SRS_SMALL_MAX = (size_t)1 << 13;     // MSMs of up to this many pairs use it
+constexpr size_t SRS_NAF_MIN = (size_t)1 << 15;       // MSMs of at least this many pairs use the per-bit tables (width-w NAF digits)
+// bucket bits (c: 2^(c-1) buckets, NAF width c + 1) of an MSM of n pairs over the per-bit tables: the window policy of srs_precompute, by MSM length
+inline int srs_naf_c(size_t n) {
+    static const int forced = []() { const char* e = getenv("KZG_NAF_C"); return e ? atoi(e) : 0; }();
+    if (forced >= 15 && forced <= 17) return forced;          // (NAF_DIGITS = 16 words per scalar: width >= 16)
+    return n >= ((size_t)1 << 18) ? 17 : 15;
+}
 // bases of an MSM of n pairs over srs[offset .. offset + n)
 inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, size_t n, bool allow_tables) {
     MsmBases b;
@@ -126,6 +136,10 @@ inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, size_t n, bool allo
     if (allow_tables && srs->pre_W > 0) {
         b.table_stride = (uint32_t)srs->n; b.c = srs->pre_c; b.W = srs->pre_W;
         if (srs->d_small && n <= SRS_SMALL_MAX) { b.points = srs->d_small + 4 * offset; b.c = srs->small_c; b.W = srs->small_W; }
+        static const bool naf_off = []() { const char* e = getenv("KZG_NAF_OFF"); return e && atoi(e) != 0; }();   // A/B: tables built, not used
+        if (srs->d_bits && n >= SRS_NAF_MIN && !naf_off) {
+            b.points = srs->d_bits + 4 * offset; b.c = srs_naf_c(n); b.W = 255; b.naf = true;
+        }
     }
     return b;
 }
@@ -144,6 +158,7 @@ int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars
 
 // Precompute the window tables of an SRS in place (reallocates srs->d_points); no-op for small / huge SRS.
 int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs);
+int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs);
 
 // wire affine points (device memory) -> device affine format (curve.h), asynchronous on ctx->stream
 // d_off_curve_flag != nullptr: also check y^2 == x^3 + 3 of every non-identity point, *flag |= 1 on a violation (device word, zeroed by the caller)

@@ -12,9 +12,11 @@
 #include <new>
 #include "msm_kernels.h"
 #include "host_curve.h"
+#include "host_pairing.h"      // fr_wire_to_canonical (KZG_DEBUG_SORT)
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -24,7 +26,7 @@ constexpr uint32_t MSM_MAX_OUT = 4096;         // XYZZ values one launch may han
 constexpr size_t SORT1_MAX_LDS = 131072;       // single-pass sort: one LDS counter per bucket (<= 2^15 buckets)
 
 void MsmWorkspace::release() {
-    DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &blockbase, &sort_tmp, &sort_small, &offs, &block_sums,
+    DeviceBuffer* all[] = {&scalars, &bases, &bases_wire, &digits, &sorted, &count, &blockbase, &sort_tmp, &sort_key, &sort_small, &offs, &block_sums,
                            &head, &cont, &blob, &bucket, &chunkS, &chunkTmp, &chunkA, &out_wire};
     for (auto* b : all) b->release();
     if (pinned_out) { (void)hipHostFree(pinned_out); pinned_out = nullptr; }
@@ -38,6 +40,7 @@ struct Plan {
     uint32_t n;          // pairs per MSM in this launch
     uint32_t batch;      // independent MSMs of n pairs each (generic mode only; 1 otherwise)
     bool tables;         // table mode
+    bool naf;            // table mode over the per-bit tables: width-(c + 1) NAF digits (msm_kernels.h), W = most entries per scalar
     int c, W;
     uint32_t B;          // buckets per set
     uint32_t sets;       // bucket sets (1 in table mode, W otherwise)
@@ -66,6 +69,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     p.n = (uint32_t)n;
     p.batch = batch;
     p.tables = bases.table_stride != 0;
+    p.naf = p.tables && bases.naf;
     int c;
     if (p.tables) {
         c = bases.c;
@@ -76,11 +80,13 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         c = std::min(16, std::max(2, c));
     }
     p.c = c;
-    p.W = (255 + c - 1) / c;
+    p.W = p.naf ? naf_max_digits(c + 1) : (255 + c - 1) / c;
     p.B = 1u << (c - 1);
     p.sets = p.tables ? 1u : (uint32_t)p.W * batch;
     p.G = p.sets * p.B;
-    const size_t entries = (size_t)p.W * n * batch;
+    const size_t entries_cap = (size_t)p.W * n * batch;                  // buffer sizes
+    // NAF: the entry count is only known on the device (offs[G]); 254 / (w + 1) per scalar on average sizes the accumulate grid
+    const size_t entries = p.naf ? std::max<size_t>(1, (size_t)((double)n * 254.0 / (double)(c + 2))) : entries_cap;
     {
         // Lanes of the accumulate kernel.  Large MSMs: one full round of resident waves (ctx->acc_wave_slots = 3 per SIMD), every
         // lane with the same trip count.  Small MSMs: at least Lmin entries per lane -- short trips keep them from serialising
@@ -110,9 +116,9 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         lanes = std::max<size_t>(256, (lanes + 255) / 256 * 256);
         p.nl = (uint32_t)std::min<size_t>(lanes, (size_t)1 << 24);
     }
-    p.set_len = (uint32_t)(p.tables ? entries : n);
+    p.set_len = (uint32_t)(p.tables ? entries_cap : n);
     p.idx_stride = bases.table_stride; p.idx_log = 31; p.stride_adj = 0;
-    if (p.tables && (size_t)p.W * bases.table_stride > ((size_t)1 << SORT2_IDX_BITS)) {
+    if (p.tables && !p.naf && (size_t)p.W * bases.table_stride > ((size_t)1 << SORT2_IDX_BITS)) {
         int lg = ilog2_floor(n);
         if (((size_t)1 << lg) < n) ++lg;
         if (((size_t)p.W << lg) <= ((size_t)1 << SORT2_IDX_BITS) && ((size_t)1 << lg) <= bases.table_stride) {
@@ -131,17 +137,22 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         const char* env = getenv("KZG_SORT2");
         const bool want = !(env && atoi(env) == 0);
         const bool lds_fits = (size_t)p.B * 4 <= SORT1_MAX_LDS;            // single-pass sort: one LDS counter per bucket
-        p.sort_small = entries < ((size_t)1 << 18);
+        p.sort_small = !p.naf && entries < ((size_t)1 << 18);
         const bool can2 = p.tables && p.c - 1 > SORT2_LO_BITS && (p.B >> SORT2_LO_BITS) <= SORT2_MAX_BINS &&
-                          (size_t)p.W * p.idx_stride <= ((size_t)1 << SORT2_IDX_BITS);
+                          (p.naf ? (size_t)NAF_POSITIONS * p.idx_stride < ((size_t)1 << 31)
+                                 : (size_t)p.W * p.idx_stride <= ((size_t)1 << SORT2_IDX_BITS));
         int min_log = 18;                                                  // (was 2^23: the scalar-tile pass 1 and the per-bin pass 2 win from the first size the single-pass sort is not "small" for)
         { const char* e2 = getenv("KZG_SORT2_MIN_LOG"); if (e2 && atoi(e2) >= 18 && atoi(e2) <= 30) min_log = atoi(e2); }
-        p.sort2 = !p.sort_small && can2 && ((want && entries >= ((size_t)1 << min_log)) || !lds_fits);
+        p.sort2 = !p.sort_small && can2 && ((want && entries >= ((size_t)1 << min_log)) || !lds_fits || p.naf);
         if (!p.sort2 && !lds_fits) p.sort_small = true;                    // (slow but correct: a forced odd configuration)
         p.Hb = p.sort2 ? (p.B >> SORT2_LO_BITS) : 0;
         p.tile1 = n >= ((size_t)1 << 19) ? 2048 : 1024;                    // SCALARS per pass-1 tile (W entries each)
+        if (p.naf) {                                                       // the recoding is a long dependent chain per scalar: more, smaller tiles
+            static const int naf_tile = []() { const char* e = getenv("KZG_NAF_TILE"); return e ? atoi(e) : 0; }();
+            p.tile1 = naf_tile >= 256 && naf_tile <= 4096 ? (uint32_t)naf_tile : 512;
+        }
         p.tiles1 = (uint32_t)((n + p.tile1 - 1) / p.tile1);
-        p.tiles2cap = (uint32_t)(entries / SORT2_CHUNK + p.Hb + 1);
+        p.tiles2cap = (uint32_t)(entries_cap / SORT2_CHUNK + p.Hb + 1);
     }
     p.T = std::min<uint32_t>(p.B, RED_T);
     p.m = p.B / p.T;
@@ -169,6 +180,61 @@ struct MsmPending {
     uint32_t n_parts = 0;
 };
 
+// KZG_DEBUG_SORT=1 (diagnostic): after the sort of a table-mode MSM, recompute every scalar's digits on the host and compare the
+// device's sorted entries with them bucket by bucket (as multisets).  Slow; reports the first differences on stderr.
+static int32_t debug_check_sort(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const Plan& p, const uint4* d_scalars) {
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::vector<uint64_t> sc((size_t)p.n * 4);
+    std::vector<uint32_t> offs((size_t)p.G + 1);
+    KZG_HIP_TRY(ctx, hipMemcpy(sc.data(), d_scalars, sc.size() * 8, hipMemcpyDeviceToHost));
+    KZG_HIP_TRY(ctx, hipMemcpy(offs.data(), ws.offs.p, offs.size() * 4, hipMemcpyDeviceToHost));
+    const uint32_t E = offs[p.G];
+    std::vector<uint32_t> sorted(E ? E : 1);
+    if (E) KZG_HIP_TRY(ctx, hipMemcpy(sorted.data(), ws.sorted.p, (size_t)E * 4, hipMemcpyDeviceToHost));
+    std::vector<std::vector<uint32_t>> want(p.G);
+    for (uint32_t i = 0; i < p.n; ++i) {
+        uint64_t k64[4];
+        kzg_host::fr_wire_to_canonical(&sc[(size_t)i * 4], k64);
+        uint32_t k[8];
+        memcpy(k, k64, 32);
+        if (p.naf) {
+            naf_for_digits(k, p.c + 1, [&](uint32_t pos, uint32_t key, uint32_t neg) { want[naf_bucket(key, p.c - 1)].push_back((neg << 31) | (pos * p.idx_stride + i)); });
+        } else {
+            const uint32_t mask = (1u << p.c) - 1u, half = 1u << (p.c - 1);
+            uint32_t carry = 0;
+            for (int w = 0; w < p.W; ++w) {
+                const uint32_t raw = (k[0] & mask) + carry;
+                for (int j = 0; j < 7; ++j) k[j] = (k[j] >> p.c) | (k[j + 1] << (32 - p.c));
+                k[7] >>= p.c;
+                const uint32_t neg = raw > half, mag = neg ? (1u << p.c) - raw : raw;
+                carry = neg;
+                if (mag) want[mag - 1].push_back((neg << 31) | ((uint32_t)w * p.idx_stride + i));
+            }
+        }
+    }
+    size_t total = 0, bad = 0;
+    for (uint32_t g = 0; g < p.G; ++g) {
+        total += want[g].size();
+        const uint32_t lo = offs[g], hi = offs[g + 1];
+        bool ok = hi >= lo && hi - lo == want[g].size() && hi <= E;
+        if (ok) {
+            std::vector<uint32_t> got(sorted.begin() + lo, sorted.begin() + hi);
+            std::sort(got.begin(), got.end());
+            std::sort(want[g].begin(), want[g].end());
+            ok = got == want[g];
+            if (!ok && bad < 8)
+                for (size_t q = 0; q < got.size(); ++q)
+                    if (got[q] != want[g][q]) { fprintf(stderr, "KZG_DEBUG_SORT: bucket %u entry %zu: device %08x host %08x\n", g, q, got[q], want[g][q]); break; }
+        } else if (bad < 8) {
+            fprintf(stderr, "KZG_DEBUG_SORT: bucket %u: device range [%u, %u) host count %zu (E = %u)\n", g, lo, hi, want[g].size(), E);
+        }
+        if (!ok) ++bad;
+    }
+    fprintf(stderr, "KZG_DEBUG_SORT: n = %u c = %d naf = %d: E device %u host %zu, %zu of %u buckets differ\n", p.n, p.c, (int)p.naf, E, total, bad, p.G);
+    if (bad || total != E) { ctx->last_error = "KZG_DEBUG_SORT: the sorted entries differ from the host's digits"; return KZG_ERR_DEVICE; }
+    return KZG_OK;
+}
+
 // Enqueue every kernel of one MSM (or batch) plus the D2H copy of its O(100) result points on `st`, using `ws`.
 static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
                            uint32_t batch, Pending* pend, uint32_t out_off = 0, uint32_t out_cap = MSM_MAX_OUT) {
@@ -188,6 +254,10 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     KZG_HIP_TRY(ctx, ws.count.reserve((size_t)p.G * 4 + 16));
     if (p.sort2) {
         KZG_HIP_TRY(ctx, ws.sort_tmp.reserve(entries * 4));
+        if (p.naf) {
+            KZG_HIP_TRY(ctx, ws.sort_key.reserve(entries + 16));
+            KZG_HIP_TRY(ctx, ws.digits.reserve((size_t)n * NAF_DIGITS * 4));
+        }
         KZG_HIP_TRY(ctx, ws.sort_small.reserve(((size_t)3 * (p.Hb + 1) + p.tiles2cap) * 4 + 64));
         KZG_HIP_TRY(ctx, ws.blockbase.reserve(std::max((size_t)p.tiles1 * p.Hb, (size_t)p.tiles2cap * SORT2_LO) * 4));
     } else if (p.sort_small) {
@@ -216,8 +286,10 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     if (!ctx->lds_attr_set) {
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
-        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort2_scatter1_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort2_scatter1_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)((3 * SORT2_MAX_BINS + SORT2_P1_THREADS * 31) * 4)));
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort2_scatter1_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)((3 * SORT2_MAX_BINS + SORT2_P1_THREADS * 31) * 4 + SORT2_P1_THREADS * 31 * 2)));
         ctx->lds_attr_set = true;
     }
 
@@ -252,27 +324,46 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         uint32_t* cstart = small + (p.Hb + 1);          // Hb + 1
         uint32_t* tstart = small + 2 * (p.Hb + 1);      // Hb + 1
         uint32_t* tile_bin = small + 3 * (p.Hb + 1);    // tiles2cap
+        uint32_t* bin_cap = tile_bin + p.tiles2cap;     // 1: the LARGE-bin threshold of this launch (k_sort2_scan)
         KZG_HIP_TRY(ctx, hipMemsetAsync(ccount, 0, (size_t)p.Hb * 4, st));
+        uint8_t* tmpk = p.naf ? ws.sort_key.as<uint8_t>() : nullptr;
+        if (p.naf)
+            hipLaunchKernelGGL(k_naf_digits, dim3(p.tiles1), dim3(256), ((size_t)p.Hb + (11 + NAF_DIGITS) * 256) * 4, st, d_scalars, p.n, p.c, p.tile1, p.Hb, ccount,
+                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>());
+        else
         hipLaunchKernelGGL(k_sort2_scalars<false>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
                            ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, p.idx_stride, (uint32_t*)nullptr);
         KZG_MARK(1);
-        hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart, tile_bin, ws.count.as<uint32_t>());
+        hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart, tile_bin, ws.count.as<uint32_t>(), bin_cap);
         static const bool direct_scatter = []() { const char* e = getenv("KZG_SORT2_DIRECT"); return e && atoi(e) != 0; }();   // A/B: pass 1 without the LDS staging
-        if (direct_scatter || p.W > 31) {
+        if (p.naf) {
+            const size_t lds1 = ((size_t)3 * p.Hb + (size_t)SORT2_P1_THREADS * p.W) * 4 + (size_t)SORT2_P1_THREADS * p.W * 2;
+            hipLaunchKernelGGL(k_sort2_scatter1_lds<true>, dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, ws.digits.as<uint4>(), p.n, p.c, p.W, p.tile1, p.Hb,
+                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), tmpk);
+        } else if (direct_scatter || p.W > 31) {
             hipLaunchKernelGGL(k_sort2_scalars<true>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
                                ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>());
         } else {
             const size_t lds1 = ((size_t)3 * p.Hb + (size_t)SORT2_P1_THREADS * p.W) * 4;
-            hipLaunchKernelGGL(k_sort2_scatter1_lds, dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb,
-                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>());
+            hipLaunchKernelGGL(k_sort2_scatter1_lds<false>, dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb,
+                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), (uint8_t*)nullptr);
         }
         KZG_MARK(2);
-        hipLaunchKernelGGL(k_sort2_hist2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
-                           ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>());
-        hipLaunchKernelGGL(k_sort2_bin, dim3(p.Hb), dim3(SORT2_BIN_THREADS), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, p.Hb, ws.count.as<uint32_t>(),
-                           d_offs, ws.sorted.as<uint32_t>());
-        hipLaunchKernelGGL(k_sort2_scatter2, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
-                           d_offs, ws.blockbase.as<uint32_t>(), ws.sorted.as<uint32_t>());
+        if (p.naf) {
+            hipLaunchKernelGGL(k_sort2_hist2<true>, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
+                               ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>(), (const uint8_t*)tmpk);
+            hipLaunchKernelGGL(k_sort2_bin<true>, dim3(p.Hb), dim3(SORT2_BIN_THREADS), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, p.Hb, ws.count.as<uint32_t>(),
+                               d_offs, ws.sorted.as<uint32_t>(), (const uint32_t*)bin_cap, (const uint8_t*)tmpk);
+            hipLaunchKernelGGL(k_sort2_scatter2<true>, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
+                               d_offs, ws.blockbase.as<uint32_t>(), ws.sorted.as<uint32_t>(), (const uint8_t*)tmpk);
+        } else {
+        hipLaunchKernelGGL(k_sort2_hist2<false>, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
+                           ws.count.as<uint32_t>(), ws.blockbase.as<uint32_t>(), (const uint8_t*)nullptr);
+        hipLaunchKernelGGL(k_sort2_bin<false>, dim3(p.Hb), dim3(SORT2_BIN_THREADS), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, p.Hb, ws.count.as<uint32_t>(),
+                           d_offs, ws.sorted.as<uint32_t>(), (const uint32_t*)bin_cap, (const uint8_t*)nullptr);
+        hipLaunchKernelGGL(k_sort2_scatter2<false>, dim3(p.tiles2cap), dim3(256), 0, st, ws.sort_tmp.as<uint32_t>(), cstart, tstart, tile_bin, p.Hb,
+                           d_offs, ws.blockbase.as<uint32_t>(), ws.sorted.as<uint32_t>(), (const uint8_t*)nullptr);
+        }
         KZG_MARK(3);
     } else {
         KZG_HIP_TRY(ctx, hipMemsetAsync(ws.count.p, 0, (size_t)p.G * 4, st));
@@ -299,6 +390,11 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_MARK(3);
     }
     KZG_MARK(4);
+    static const bool debug_sort = []() { const char* e = getenv("KZG_DEBUG_SORT"); return e && atoi(e) != 0; }();
+    if (debug_sort && p.tables && batch == 1) {
+        int32_t rc = debug_check_sort(ctx, ws, st, p, d_scalars);
+        if (rc != KZG_OK) return rc;
+    }
     phases.begin("kzg:msm:accumulate");
     // the two reduction levels: on lane pairs (curve_pair.h; one 128-thread workgroup per 64 buckets, then per two groups of 64 sums) unless KZG_PAIR_REDUCE=0
     static const bool pair_reduce = []() { const char* e = getenv("KZG_PAIR_REDUCE"); return !(e && atoi(e) == 0); }();
@@ -307,7 +403,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     // there are no partial sums.  Measured (tools/phases_small.py, same box, device time of one commitment): 2^8 170 -> 125 us, 2^9 163 -> 128,
     // 2^10 165 -> 152, 2^11 199 -> 195; at 2^12 (4.25 per bucket) 206 -> 261: a wave waits for its fullest bucket, the equal split does not.
     static const double fused_per_bucket = []() { const char* e = getenv("KZG_FUSED_PER_BUCKET"); return e ? atof(e) : 2.5; }();
-    const bool fused = p.tables && pair_reduce && (double)entries <= fused_per_bucket * (double)p.B;
+    const bool fused = p.tables && !p.naf && pair_reduce && (double)entries <= fused_per_bucket * (double)p.B;
     // (64- and 128-thread workgroups measured the same as 256)
     if (!fused)
         hipLaunchKernelGGL(k_msm_accumulate, dim3(p.nl / 256), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.G,
@@ -436,8 +532,14 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
             S[nbits++] = a;
         }
     }
+    if (p.naf) {                                          // the bucket index is the key rotated by six bits (naf.h naf_bucket)
+        Xyzz Sk[32];
+        for (int t = 0; t < nbits; ++t) Sk[naf_key_bit_of_bucket_bit(t, nbits)] = S[t];
+        for (int j = 0; j < nbits; ++j) S[j] = Sk[j];
+    }
     Xyzz acc = kzg_host::xyzz_inf();
     for (int j = nbits - 1; j >= 0; --j) { acc = kzg_host::xyzz_dbl(acc); acc = kzg_host::xyzz_add(acc, S[j]); }
+    if (p.naf) acc = kzg_host::xyzz_dbl(acc);             // bucket b holds the odd digit 2 b + 1: sum_b (2 b + 1) V_b = 2 sum_b b V_b + T
     *result = kzg_host::xyzz_add(acc, total);
     return KZG_OK;
 }
@@ -446,6 +548,7 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
 // Pairs per launch of an MSM over `bases`.  Tables more than 2^24 / W points apart (an SRS beyond 2^20 points at c = 17) are walked
 // in power-of-two chunks whose COMPACT indices fit the two-level sort (make_plan): a 2^22-point commitment is four 2^20 launches.
 static size_t msm_launch_len(const MsmBases& bases) {
+    if (bases.naf) return MSM_MAX_LAUNCH;
     if (bases.table_stride != 0 && (size_t)bases.W * bases.table_stride > ((size_t)1 << SORT2_IDX_BITS)) {
         size_t cpow = 1;
         while (((size_t)bases.W * cpow * 2) <= ((size_t)1 << SORT2_IDX_BITS)) cpow *= 2;

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve_pair.h"
+#include "naf.h"
 
 namespace kzg {
 
@@ -288,6 +289,13 @@ constexpr uint32_t SORT2_MAX_BINS = 512;
 // 2^20 commitment; these two move 127 MB and drop one launch).
 //   SCATTER = false : coarse histogram of the tile -> ccount (global) and the tile's base inside every bin (blockbase1)
 //   SCATTER = true  : entries -> tmp1, grouped by coarse bin
+// NAF mode (round 3, second half): the SRS carries one table per BIT position (srs.hip: Bit_j[i] = 2^j P_i, 255 x 64 B per point: HBM
+// capacity spent to remove additions), so a scalar is recoded in width-w non-adjacent form, w = c + 1: odd digits |d| < 2^(w-1) at
+// arbitrary bit positions, at least w positions apart -> 254 / (w + 1) entries per scalar on average instead of 255 / c (13.4 instead
+// of 15 at 2^16 buckets) into the SAME number of buckets (key = (|d| - 1) / 2 < 2^(c-1)); the point of an entry is Bit_pos[i].  An
+// index pos * stride + i needs 28 bits at 2^20 points, so between the passes the low 7 key bits travel in a byte array of their own
+// (tmpk) beside the u32 entries sign << 31 | index.  The consuming recoder: skip the zeros of k + carry (trailing ones of k when a
+// negative digit left a carry), take w bits, shift.
 template <bool SCATTER>
 __global__ void __launch_bounds__(256)
 k_sort2_scalars(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32_t tile_s, uint32_t Hb, uint32_t* __restrict__ ccount,
@@ -330,6 +338,60 @@ k_sort2_scalars(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uin
         blockbase1[(size_t)blockIdx.x * Hb + b] = h ? atomicAdd(&ccount[b], h) : 0u;
     }
 }
+// NAF mode, pass 0: scalars -> digit array (NAF_DIGITS words per scalar: sign << 31 | position << 16 | bucket, NAF_NO_DIGIT in the
+// unused slots) + the coarse histogram per tile, as k_sort2_scalars<false> leaves it.  The recoding runs ONCE, here (in the ISA the
+// register recoder is 100 instructions per digit, the LDS-window one 45: recoding in all three passes, as the fixed windows do
+// with their 12-instruction digits, cost more than the additions the NAF saves).  The digits of 256 scalars are staged in LDS and
+// leave as 16-byte stores of consecutive lanes: one store per digit and lane (64 lines per wave instruction) bound the kernel at
+// 82 us per 2^20 scalars whatever the recoder.
+__global__ void __launch_bounds__(256)
+k_naf_digits(const uint4* __restrict__ scalars, uint32_t n, int c, uint32_t tile_s, uint32_t Hb, uint32_t* __restrict__ ccount,
+             uint32_t* __restrict__ blockbase1, uint4* __restrict__ digs) {
+    latency_bound_kernel();
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* hist = lds_u32;                             // Hb
+    uint32_t* col = hist + Hb + threadIdx.x;              // 11 x 256: this thread's scalar words (naf_for_digits_lds), words 8..10 zero
+    uint32_t* stage = hist + Hb + 11 * 256;               // NAF_DIGITS x 256: digit m of thread t at [m * 256 + t]
+    const uint32_t t = threadIdx.x;
+    const uint32_t lo = blockIdx.x * tile_s;
+    const uint32_t hi = (n - lo < tile_s) ? n : lo + tile_s;
+    for (uint32_t b = t; b < Hb; b += 256) hist[b] = 0u;
+    col[8 * 256] = 0; col[9 * 256] = 0; col[10 * 256] = 0;
+    for (uint32_t base = lo; base < hi; base += 256) {
+        __syncthreads();                                  // histogram zeroed / the stage of the previous round written out
+#pragma unroll
+        for (int m = 0; m < NAF_DIGITS; ++m) stage[m * 256 + t] = NAF_NO_DIGIT;
+        const uint32_t i = base + t;
+        if (i < hi) {
+            const uint4 s_lo = scalars[2 * (size_t)i], s_hi = scalars[2 * (size_t)i + 1];
+            uint32_t w32[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
+            uint32_t k[8];
+            fe_wire_to_canonical_words<FrParams>(k, w32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) col[j * 256] = k[j];
+            uint32_t m = 0;
+            naf_for_digits_lds(col, 256, c + 1, [&](uint32_t pos, uint32_t key, uint32_t neg) {
+                const uint32_t g = naf_bucket(key, c - 1);
+                atomicAdd(&hist[g >> SORT2_LO_BITS], 1u);
+                stage[m * 256 + t] = (neg << 31) | (pos << 16) | g;
+                ++m;
+            });
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NAF_DIGITS / 4; ++r) {
+            const uint32_t idx = t + 256 * r, sc = idx >> 2, q = idx & 3u;
+            if (base + sc < hi)
+                digs[(size_t)(base + sc) * (NAF_DIGITS / 4) + q] = make_uint4(stage[(4 * q) * 256 + sc], stage[(4 * q + 1) * 256 + sc],
+                                                                            stage[(4 * q + 2) * 256 + sc], stage[(4 * q + 3) * 256 + sc]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = t; b < Hb; b += 256) {
+        const uint32_t h = hist[b];
+        blockbase1[(size_t)blockIdx.x * Hb + b] = h ? atomicAdd(&ccount[b], h) : 0u;
+    }
+}
 // Pass-1 scatter through LDS: the tile is walked in chunks of SORT2_P1_THREADS scalars (one per thread); a chunk's entries are
 // counted per bin, placed bin by bin in an LDS buffer and written out from there, so that the lanes of a wave store runs of
 // consecutive words (~15 entries per bin and chunk) instead of 64 single words to 64 different lines.  The digits are computed
@@ -352,15 +414,19 @@ __device__ __forceinline__ void sort2_for_digits(uint32_t k[8], int c, int W, F&
         if (mag != 0) f((uint32_t)w, mag - 1, neg);
     }
 }
+// NAF = true: W = most entries per scalar; LDS entry = sign << 31 | position << 9 | scalar index inside the chunk, the 16-bit key in a
+// second LDS array behind it; tmp1 gets sign << 31 | position * table_stride + i, tmpk the low 7 key bits.
+template <bool NAF = false>
 __global__ void __launch_bounds__(SORT2_P1_THREADS)
 k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32_t tile_s, uint32_t Hb, const uint32_t* __restrict__ blockbase1,
-                     const uint32_t* __restrict__ cstart, uint32_t table_stride, uint32_t* __restrict__ tmp1) {
+                     const uint32_t* __restrict__ cstart, uint32_t table_stride, uint32_t* __restrict__ tmp1, uint8_t* __restrict__ tmpk = nullptr) {
     latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
     uint32_t* gpos = lds_u32;                 // Hb: next global position of the tile in every bin
     uint32_t* hist = gpos + Hb;               // Hb: entries of the chunk per bin, then the placement cursor
     uint32_t* lstart = hist + Hb;             // Hb: first buffer slot of every bin
     uint32_t* buf = lstart + Hb;              // SORT2_P1_THREADS * W
+    uint16_t* bufk = reinterpret_cast<uint16_t*>(buf + (size_t)SORT2_P1_THREADS * W);   // NAF: SORT2_P1_THREADS * W keys
     const uint32_t t = threadIdx.x, lane = t & 63;
     const uint32_t lo = blockIdx.x * tile_s;
     const uint32_t hi = (n - lo < tile_s) ? n : lo + tile_s;
@@ -373,6 +439,26 @@ k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W
         const uint32_t i = base + t;
         const bool have = i < hi;
         uint32_t kk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t dg[NAF ? NAF_DIGITS : 1];                 // NAF: the scalar's digits as k_sort2_scalars<false, true> left them
+        if (NAF) {
+#pragma unroll
+            for (int m = 0; m < (NAF ? NAF_DIGITS : 1); ++m) dg[m] = NAF_NO_DIGIT;
+            if (have) {
+                const uint4* src = reinterpret_cast<const uint4*>(scalars) + (size_t)i * (NAF_DIGITS / 4);
+#pragma unroll
+                for (int q = 0; q < (NAF ? NAF_DIGITS / 4 : 0); ++q) {
+                    const uint4 v = src[q];
+                    dg[4 * q] = v.x; dg[4 * q + 1] = v.y; dg[4 * q + 2] = v.z; dg[4 * q + 3] = v.w;
+                }
+                bool live = true;                           // words behind the first NAF_NO_DIGIT are stale
+#pragma unroll
+                for (int m = 0; m < (NAF ? NAF_DIGITS : 0); ++m) {
+                    live = live && dg[m] != NAF_NO_DIGIT;
+                    if (!live) dg[m] = NAF_NO_DIGIT;
+                    else atomicAdd(&hist[(dg[m] & 0xFFFFu) >> SORT2_LO_BITS], 1u);
+                }
+            }
+        } else
         if (have) {
             const uint4 s_lo = scalars[2 * (size_t)i], s_hi = scalars[2 * (size_t)i + 1];
             const uint32_t w32[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
@@ -400,13 +486,34 @@ k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W
         for (uint32_t b = t; b < Hb; b += SORT2_P1_THREADS) hist[b] = 0;
         __syncthreads();
         if (have) {
-            sort2_for_digits(kk, c, W, [&](uint32_t w, uint32_t key, uint32_t neg) {
-                const uint32_t bin = key >> SORT2_LO_BITS;
-                const uint32_t slot = lstart[bin] + atomicAdd(&hist[bin], 1u);
-                buf[slot] = (bin << 22) | ((key & (SORT2_LO - 1)) << 15) | (neg << 14) | (w << 9) | t;
-            });
+            if (NAF) {
+#pragma unroll
+                for (int m = 0; m < (NAF ? NAF_DIGITS : 0); ++m) {
+                    if (dg[m] == NAF_NO_DIGIT) continue;
+                    const uint32_t key = dg[m] & 0xFFFFu;
+                    const uint32_t bin = key >> SORT2_LO_BITS;
+                    const uint32_t slot = lstart[bin] + atomicAdd(&hist[bin], 1u);
+                    buf[slot] = (dg[m] & 0x80000000u) | (((dg[m] >> 16) & 255u) << 9) | t;
+                    bufk[slot] = (uint16_t)key;
+                }
+            } else {
+                sort2_for_digits(kk, c, W, [&](uint32_t w, uint32_t key, uint32_t neg) {
+                    const uint32_t bin = key >> SORT2_LO_BITS;
+                    const uint32_t slot = lstart[bin] + atomicAdd(&hist[bin], 1u);
+                    buf[slot] = (bin << 22) | ((key & (SORT2_LO - 1)) << 15) | (neg << 14) | (w << 9) | t;
+                });
+            }
         }
         __syncthreads();
+        if (NAF) {
+            for (uint32_t q = t; q < cn; q += SORT2_P1_THREADS) {
+                const uint32_t x = buf[q], key = bufk[q], bin = key >> SORT2_LO_BITS;
+                const uint32_t idx = ((x >> 9) & 255u) * table_stride + base + (x & 511u);
+                const uint32_t dst = gpos[bin] + (q - lstart[bin]);
+                tmp1[dst] = (x & 0x80000000u) | idx;
+                tmpk[dst] = (uint8_t)(key & (SORT2_LO - 1));
+            }
+        } else
         for (uint32_t q = t; q < cn; q += SORT2_P1_THREADS) {
             const uint32_t x = buf[q], bin = x >> 22;
             const uint32_t idx = ((x >> 9) & 31u) * table_stride + base + (x & 511u);
@@ -420,15 +527,26 @@ k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W
 // short top window) are LARGE: they are cut into tiles of SORT2_CHUNK entries for the tiled pass-2 kernels (tstart = exclusive
 // scan of their tile counts, tile_bin = tile -> bin), and their fine counters are zeroed here; all other bins are sorted by one
 // workgroup each in k_sort2_bin.
+// The cap follows the load: a bin is LARGE above 5/4 of the average bin + 2 048 entries (at most SORT2_BIN_CAP): k_sort2_bin gives
+// every other bin to ONE workgroup, so a bin of twice the average is a tail of twice the kernel's time (NAF mode: the bins that hold
+// a heavy small-key bucket).  *cap_out tells k_sort2_bin.
 constexpr uint32_t SORT2_BIN_CAP = 65536;
 __global__ void __launch_bounds__(512)
 k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restrict__ cstart, uint32_t* __restrict__ tstart,
-             uint32_t* __restrict__ tile_bin, uint32_t* __restrict__ count) {
+             uint32_t* __restrict__ tile_bin, uint32_t* __restrict__ count, uint32_t* __restrict__ cap_out) {
     latency_bound_kernel();
     __shared__ uint32_t a[512], b[512];
+    __shared__ uint32_t total;
     const uint32_t t = threadIdx.x;
     uint32_t c = t < Hb ? ccount[t] : 0u;
-    uint32_t k = c > SORT2_BIN_CAP ? (c + SORT2_CHUNK - 1) / SORT2_CHUNK : 0u;
+    if (t == 0) total = 0;
+    __syncthreads();
+    if (c) atomicAdd(&total, c);
+    __syncthreads();
+    const uint32_t cap_dyn = total / Hb + total / Hb / 4 + 2048u;
+    const uint32_t cap = cap_dyn < SORT2_BIN_CAP ? cap_dyn : SORT2_BIN_CAP;
+    if (t == 0) *cap_out = cap;
+    uint32_t k = c > cap ? (c + SORT2_CHUNK - 1) / SORT2_CHUNK : 0u;
     a[t] = c; b[t] = k;
     __syncthreads();
     for (uint32_t d = 1; d < 512; d <<= 1) {
@@ -444,9 +562,16 @@ k_sort2_scan(const uint32_t* __restrict__ ccount, uint32_t Hb, uint32_t* __restr
     }
     if (t == Hb - 1) { cstart[Hb] = a[t]; tstart[Hb] = b[t]; }
 }
+// low key bits of the entry at position e between the passes (NAF: a byte array of its own)
+template <bool NAF>
+__device__ __forceinline__ uint32_t sort2_low_key(const uint32_t* __restrict__ tmp1, const uint8_t* __restrict__ tmpk, uint32_t e) {
+    return NAF ? (uint32_t)tmpk[e] : (tmp1[e] >> SORT2_IDX_BITS) & (SORT2_LO - 1);
+}
+template <bool NAF = false>
 __global__ void __launch_bounds__(256)
 k_sort2_hist2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
-              const uint32_t* __restrict__ tile_bin, uint32_t Hb, uint32_t* __restrict__ count, uint32_t* __restrict__ blockbase2) {
+              const uint32_t* __restrict__ tile_bin, uint32_t Hb, uint32_t* __restrict__ count, uint32_t* __restrict__ blockbase2,
+              const uint8_t* __restrict__ tmpk = nullptr) {
     latency_bound_kernel();
     __shared__ uint32_t hist[SORT2_LO];
     const uint32_t tile = blockIdx.x;
@@ -456,17 +581,18 @@ k_sort2_hist2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cs
     const uint32_t hi = (cstart[h + 1] - lo < SORT2_CHUNK) ? cstart[h + 1] : lo + SORT2_CHUNK;
     if (threadIdx.x < SORT2_LO) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&hist[(tmp1[e] >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+    for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&hist[sort2_low_key<NAF>(tmp1, tmpk, e)], 1u);
     __syncthreads();
     if (threadIdx.x < SORT2_LO) {
         uint32_t c = hist[threadIdx.x];
         blockbase2[(size_t)tile * SORT2_LO + threadIdx.x] = c ? atomicAdd(&count[(size_t)h * SORT2_LO + threadIdx.x], c) : 0u;
     }
 }
+template <bool NAF = false>
 __global__ void __launch_bounds__(256)
 k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ tstart,
                  const uint32_t* __restrict__ tile_bin, uint32_t Hb, const uint32_t* __restrict__ offs,
-                 const uint32_t* __restrict__ blockbase2, uint32_t* __restrict__ sorted) {
+                 const uint32_t* __restrict__ blockbase2, uint32_t* __restrict__ sorted, const uint8_t* __restrict__ tmpk = nullptr) {
     latency_bound_kernel();
     __shared__ uint32_t cur[SORT2_LO];
     const uint32_t tile = blockIdx.x;
@@ -479,8 +605,8 @@ k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__
     __syncthreads();
     for (uint32_t e = lo + threadIdx.x; e < hi; e += blockDim.x) {
         uint32_t v = tmp1[e];
-        uint32_t pos = atomicAdd(&cur[(v >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
-        sorted[pos] = v & (0x80000000u | SORT2_IDX_MASK);
+        uint32_t pos = atomicAdd(&cur[sort2_low_key<NAF>(tmp1, tmpk, e)], 1u);
+        sorted[pos] = NAF ? v : v & (0x80000000u | SORT2_IDX_MASK);
     }
 }
 
@@ -493,26 +619,29 @@ k_sort2_scatter2(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__
 constexpr int SORT2_BIN_THREADS = 1024;
 constexpr int SORT2_BIN_PER = 8;                                        // entries per thread and chunk
 constexpr uint32_t SORT2_BIN_CHUNK = SORT2_BIN_THREADS * SORT2_BIN_PER;
+template <bool NAF = false>
 __global__ void __launch_bounds__(SORT2_BIN_THREADS)
 k_sort2_bin(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ cstart, uint32_t Hb, const uint32_t* __restrict__ count,
-            uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+            uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted, const uint32_t* __restrict__ cap_ptr, const uint8_t* __restrict__ tmpk = nullptr) {
     latency_bound_kernel();
     __shared__ uint32_t hist[SORT2_LO], gpos[SORT2_LO], lstart[SORT2_LO], buf[SORT2_BIN_CHUNK];
+    __shared__ uint8_t bufk[NAF ? SORT2_BIN_CHUNK : 4];
     const uint32_t h = blockIdx.x, t = threadIdx.x;
     const uint32_t lo = cstart[h], hi = cstart[h + 1];
-    const bool large = hi - lo > SORT2_BIN_CAP;
+    const bool large = hi - lo > *cap_ptr;
     if (t < SORT2_LO) hist[t] = large ? count[(size_t)h * SORT2_LO + t] : 0u;
     __syncthreads();
     if (!large) {
         uint32_t e = lo + t;
         for (; e + 3 * SORT2_BIN_THREADS < hi; e += 4 * SORT2_BIN_THREADS) {
-            const uint32_t v0 = tmp1[e], v1 = tmp1[e + SORT2_BIN_THREADS], v2 = tmp1[e + 2 * SORT2_BIN_THREADS], v3 = tmp1[e + 3 * SORT2_BIN_THREADS];
-            atomicAdd(&hist[(v0 >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
-            atomicAdd(&hist[(v1 >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
-            atomicAdd(&hist[(v2 >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
-            atomicAdd(&hist[(v3 >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+            const uint32_t k0 = sort2_low_key<NAF>(tmp1, tmpk, e), k1 = sort2_low_key<NAF>(tmp1, tmpk, e + SORT2_BIN_THREADS),
+                           k2 = sort2_low_key<NAF>(tmp1, tmpk, e + 2 * SORT2_BIN_THREADS), k3 = sort2_low_key<NAF>(tmp1, tmpk, e + 3 * SORT2_BIN_THREADS);
+            atomicAdd(&hist[k0], 1u);
+            atomicAdd(&hist[k1], 1u);
+            atomicAdd(&hist[k2], 1u);
+            atomicAdd(&hist[k3], 1u);
         }
-        for (; e < hi; e += SORT2_BIN_THREADS) atomicAdd(&hist[(tmp1[e] >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+        for (; e < hi; e += SORT2_BIN_THREADS) atomicAdd(&hist[sort2_low_key<NAF>(tmp1, tmpk, e)], 1u);
         __syncthreads();
     }
     // exclusive scan of the SORT2_LO fine counts by wave 0 (two counters per lane)
@@ -533,12 +662,16 @@ k_sort2_bin(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ csta
         __syncthreads();                                           // (gpos of the previous chunk updated, buf free)
         if (t < SORT2_LO) hist[t] = 0;
         __syncthreads();
-        uint32_t v[SORT2_BIN_PER], r[SORT2_BIN_PER];
+        uint32_t v[SORT2_BIN_PER], r[SORT2_BIN_PER], kq[SORT2_BIN_PER];
 #pragma unroll
-        for (int j = 0; j < SORT2_BIN_PER; ++j) { const uint32_t i = j * SORT2_BIN_THREADS + t; v[j] = i < cn ? tmp1[base + i] : 0u; }
+        for (int j = 0; j < SORT2_BIN_PER; ++j) {
+            const uint32_t i = j * SORT2_BIN_THREADS + t;
+            v[j] = i < cn ? tmp1[base + i] : 0u;
+            kq[j] = NAF ? (i < cn ? (uint32_t)tmpk[base + i] : 0u) : (v[j] >> SORT2_IDX_BITS) & (SORT2_LO - 1);
+        }
 #pragma unroll
         for (int j = 0; j < SORT2_BIN_PER; ++j)
-            if (j * SORT2_BIN_THREADS + t < cn) r[j] = atomicAdd(&hist[(v[j] >> SORT2_IDX_BITS) & (SORT2_LO - 1)], 1u);
+            if (j * SORT2_BIN_THREADS + t < cn) r[j] = atomicAdd(&hist[kq[j]], 1u);
         __syncthreads();
         if (t < 64) {
             const uint32_t c0 = hist[2 * t], c1 = hist[2 * t + 1];
@@ -549,11 +682,15 @@ k_sort2_bin(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ csta
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SORT2_BIN_PER; ++j)
-            if (j * SORT2_BIN_THREADS + t < cn) buf[lstart[(v[j] >> SORT2_IDX_BITS) & (SORT2_LO - 1)] + r[j]] = v[j];
+            if (j * SORT2_BIN_THREADS + t < cn) {
+                const uint32_t slot = lstart[kq[j]] + r[j];
+                buf[slot] = v[j];
+                if (NAF) bufk[slot] = (uint8_t)kq[j];
+            }
         __syncthreads();
         for (uint32_t i = t; i < cn; i += SORT2_BIN_THREADS) {
-            const uint32_t x = buf[i], k = (x >> SORT2_IDX_BITS) & (SORT2_LO - 1);
-            sorted[gpos[k] + (i - lstart[k])] = x & (0x80000000u | SORT2_IDX_MASK);
+            const uint32_t x = buf[i], k = NAF ? (uint32_t)bufk[i] : (x >> SORT2_IDX_BITS) & (SORT2_LO - 1);
+            sorted[gpos[k] + (i - lstart[k])] = NAF ? x : x & (0x80000000u | SORT2_IDX_MASK);
         }
         __syncthreads();
         if (t < SORT2_LO) gpos[t] += hist[t];

@@ -144,6 +144,71 @@ k_srs_window_step(const uint4* __restrict__ prev, uint4* __restrict__ next, size
     next[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
 }
 
+// One level of the per-bit tables: next[i] = 2 * prev[i], affine in, affine out (y^2 = x^3 + 3: lambda = 3 x^2 / (2 y),
+// x3 = lambda^2 - 2 x, y3 = lambda (x - x3) - y; no point of BN254 G1 has y = 0, the group order is odd).  The inversions are
+// batched: a lane owns BITS_K points (a grid stride apart, so the loads of a wave stay contiguous), keeps the running products
+// of their denominators in LDS, inverts the last one (Fermat, 381 products) and walks back: 7 products per point + 381 / BITS_K
+// instead of the 400 of k_srs_window_step's one-inversion-per-point form.  255 levels of a 2^20-point SRS: ~0.1 s, once.
+constexpr int BITS_K = 7;                               // 7 x 9 limbs x 256 lanes x 4 B = 63 KiB of LDS
+__global__ void __launch_bounds__(256)
+k_srs_double_batch(const uint4* __restrict__ prev, uint4* __restrict__ next, size_t n) {
+    __shared__ int32_t pre[BITS_K * NL * 256];
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tl = threadIdx.x;
+    Fq run;
+    fe_set_one(run);
+    for (int q = 0; q < BITS_K; ++q) {
+        const size_t i = i0 + (size_t)q * lanes;
+        Affine p;
+        Fq den;
+        fe_set_one(den);
+        if (i < n && affine_load(p, prev + 4 * i)) { fe_dbl(den, p.y); fe_norm(den); }     // 2 y in [0, 2m)
+        fe_mul(run, run, den);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) pre[(q * NL + j) * 256 + tl] = run.l[j];
+    }
+    Fq inv;
+    fe_inverse(inv, run);                               // 1 / (product of the lane's denominators)
+    for (int q = BITS_K - 1; q >= 0; --q) {
+        const size_t i = i0 + (size_t)q * lanes;
+        if (i >= n) continue;                           // (its denominator was 1)
+        Affine p;
+        uint32_t o[16];
+        if (!affine_load(p, prev + 4 * i)) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = 0;
+        } else {
+            Fq before, den, iq, xx, m3, lam, x3, y3, t;
+            if (q == 0) fe_set_one(before);
+            else {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) before.l[j] = pre[((q - 1) * NL + j) * 256 + tl];
+            }
+            fe_mul(iq, inv, before);                    // 1 / (2 y)
+            fe_dbl(den, p.y); fe_norm(den);
+            fe_mul(inv, inv, den);
+            fe_sqr(xx, p.x);
+            fe_add(m3, xx, xx); fe_add(m3, m3, xx); fe_norm(m3);          // 3 x^2 in (-3m, 6m)
+            fe_mul(lam, m3, iq);
+            fe_sqr(x3, lam);
+            fe_canon(x3);
+            fe_sub(x3, x3, p.x); fe_norm(x3); fe_canon(x3);               // (-m, m) -> [0, m)
+            fe_sub(x3, x3, p.x); fe_norm(x3); fe_canon(x3);
+            fe_sub(t, p.x, x3); fe_norm(t);                               // (-m, m)
+            fe_mul(y3, lam, t);
+            fe_canon(y3);
+            fe_sub(y3, y3, p.y); fe_norm(y3); fe_canon(y3);
+            fe_pack(o, x3);
+            fe_pack(o + 8, y3);
+        }
+        next[4 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+        next[4 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+        next[4 * i + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+        next[4 * i + 3] = make_uint4(o[12], o[13], o[14], o[15]);
+    }
+}
+
 // Batch decompression of gnark-format compressed G1 points (prover/src/srs.rs:51-68 -> primitives/src/helpers.rs:175-226):
 // 32 big-endian bytes per point, top two bits of byte 0: 01 = infinity (rest must be zero), 10 = smaller y, 11 = larger y;
 // x = remaining 254 bits mod p; y = sqrt(x^3 + 3) = (x^3 + 3)^((p+1)/4) (p = 3 mod 4), sign chosen by
@@ -335,6 +400,33 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
     srs->d_points = table;
     srs->pre_c = c;
     srs->pre_W = W;
+    return srs_build_bit_tables(ctx, srs);
+}
+
+// Per-bit tables Bit_j[i] = 2^j P_i, j < 255 (msm_kernels.h "NAF mode"): 255 x 64 B per point -- 15.9 GiB for a 2^20-point SRS, of
+// the 288 GB this GPU has -- so that MSMs of >= SRS_NAF_MIN pairs recode their scalars in width-w NAF: 254 / (w + 1) mixed additions
+// per scalar instead of 255 / c into the same 2^(c-1) buckets (13.4 instead of 15 at 2^16 buckets; measured in DESIGN.md section 4c).
+// Built for SRS of 2^15 .. 2^22 points when they fit beside a quarter of the free memory; KZG_NO_NAF=1: never.
+int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs) {
+    const char* env = getenv("KZG_NO_NAF");
+    if (env && atoi(env) != 0) return KZG_OK;
+    const size_t n = srs->n;
+    if (n < SRS_NAF_MIN || n > ((size_t)1 << 22) || srs->d_bits) return KZG_OK;
+    const size_t bytes = (size_t)255 * n * 64;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return KZG_OK; }
+    if (bytes + (bytes >> 2) + ((size_t)8 << 30) > free_b) return KZG_OK;               // keep room for workspaces and other SRS
+    uint4* bits = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&bits), bytes) != hipSuccess) { (void)hipGetLastError(); return KZG_OK; }
+    hipError_t e = hipMemcpyAsync(bits, srs->d_points, n * 64, hipMemcpyDeviceToDevice, ctx->stream);
+    const size_t lanes = (n + BITS_K - 1) / BITS_K;
+    const unsigned blocks = (unsigned)((lanes + 255) / 256);
+    for (int j = 1; j < 255 && e == hipSuccess; ++j)
+        hipLaunchKernelGGL(k_srs_double_batch, dim3(blocks), dim3(256), 0, ctx->stream, bits + 4 * (size_t)(j - 1) * n, bits + 4 * (size_t)j * n, n);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(bits); return set_error(ctx, e, "building the per-bit SRS tables"); }
+    srs->d_bits = bits;
     return KZG_OK;
 }
 

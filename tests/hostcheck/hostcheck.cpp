@@ -6,6 +6,7 @@
 #include <cstring>
 #include "field29.h"
 #include "curve.h"
+#include "naf.h"
 
 using namespace kzg;
 
@@ -102,4 +103,13 @@ void hc_running_sum(const uint32_t* pts_wire, size_t n, uint32_t* out) {
     }
     xyzz_to_wire(out, acc);
 }
+// width-w NAF digits of the canonical integer k (8 u32 words): pos / key = (|d| - 1) / 2 / sign of every digit; returns the count
+int hc_naf(const uint32_t* k_words, int w, uint32_t* pos, uint32_t* key, uint32_t* neg, int cap) {
+    uint32_t k[8];
+    memcpy(k, k_words, 32);
+    int n = 0;
+    naf_for_digits(k, w, [&](uint32_t p, uint32_t kk, uint32_t s) { if (n < cap) { pos[n] = p; key[n] = kk; neg[n] = s; } ++n; });
+    return n;
+}
+int hc_naf_max_digits(int w) { return naf_max_digits(w); }
 }

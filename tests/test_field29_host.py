@@ -29,7 +29,7 @@ u8p = C.POINTER(C.c_uint8)
 
 @pytest.fixture(scope="module")
 def hc():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("field29.h", "curve.h", "field_constants.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("field29.h", "curve.h", "field_constants.h", "naf.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-DKZG_BOUND_CHECK", "-Wno-unknown-pragmas", "-fPIC",
                                "-shared", "-I" + CSRC, "-o", SO, SRC])
@@ -207,3 +207,31 @@ def test_paired_multiplies_equal_the_single_forms_on_extreme_limbs(hc):
         a2, b2 = pats[(5 * i + 2) % len(pats)], pats[(7 * i + 3) % len(pats)]
         # value bound of a product: |a * b| < 2^261 m; top limbs within +-2^22 keep |value| < 2^(232+22) * 1.01
         assert hc.hc_paired_vs_single(arr(a1), arr(b1), arr(a2), arr(b2)) == 0, i
+
+
+def test_naf_recoding(hc):
+    """naf.h: the digits of the MSM's NAF mode reproduce the scalar, are odd, at least w positions apart, below position 255."""
+    rng = random.Random(2024)
+    cap = 300
+    pos = np.zeros(cap, np.uint32); key = np.zeros(cap, np.uint32); neg = np.zeros(cap, np.uint32)
+    special = [0, 1, 2, 3, R_ - 1, R_ - 2, (1 << 253), (1 << 254) - 1, (1 << 254) - (1 << 200), 0xFFFFFFFF, (1 << 32), (1 << 64) - 1,
+               int("01" * 127, 2), int("10" * 127, 2), int("0111" * 63, 2), (1 << 253) + (1 << 17) - 1, (1 << 248) - 1]
+    for w in (10, 14, 16, 17, 18):
+        assert hc.hc_naf_max_digits(w) == 254 // w + 1
+        total = 0
+        cases = special + [rng.randrange(R_) for _ in range(300)] + [rng.randrange(1 << rng.randrange(1, 254)) for _ in range(100)]
+        for k in cases:
+            words = np.array([(k >> (32 * j)) & 0xFFFFFFFF for j in range(8)], np.uint32)
+            n = hc.hc_naf(words.ctypes.data_as(u32p), w, pos.ctypes.data_as(u32p), key.ctypes.data_as(u32p), neg.ctypes.data_as(u32p), cap)
+            assert 0 <= n <= 254 // w + 1
+            val, last = 0, None
+            for t in range(n):
+                p_, mag = int(pos[t]), 2 * int(key[t]) + 1
+                assert mag < (1 << (w - 1)) and int(key[t]) < (1 << (w - 2)) and p_ <= 254
+                assert last is None or p_ >= last + w
+                last = p_
+                val += (-mag if neg[t] else mag) << p_
+            assert val == k, (w, hex(k))
+            total += n
+        if w == 18:
+            assert total / len(cases) < 14.2          # ~254 / 19 on the random part
