@@ -297,9 +297,12 @@ def main():
     phase = (C.c_double * 8)()
     launches, pairs = C.c_uint64(0), C.c_uint64(0)
     lib.kzg_ctx_get_msm_profile(ctx.handle, phase, C.byref(launches), C.byref(pairs))
+    prof_entries = C.c_uint64(0)
+    lib.kzg_ctx_get_msm_profile_entries(ctx.handle, C.byref(prof_entries))
     lib.kzg_ctx_set_profiling(ctx.handle, 0)
     phase_alone = [phase[i] / max(1, launches.value) for i in range(8)]
     units_per_launch = pairs.value / max(1, launches.value)
+    entries_per_launch = prof_entries.value / max(1, launches.value)      # sorted entries = mixed additions (NAF mode: data dependent)
     lib.kzg_ctx_set_profiling(ctx.handle, 1)
     run_steps(side_steps, d_scalars.data_ptr(), depth_used)
     barrier()
@@ -322,7 +325,7 @@ def main():
         acc_ms = phase_alone[4]                                   # k_msm_accumulate, average launch duration, running alone
         achieved = BYTES_PER_PAIR * units_per_launch / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic_bytes(LOG_N) if world == 1 else (None, "PMC passes are single-GPU")
-        plan = {"window_bits": 17, "windows": 15} if sh.len == (1 << 20) else None
+        plan = {"entries": entries_per_launch} if entries_per_launch > 0 else None
         # table mode (two-level sort from the scalars): coarse histogram | scan + pass 1 | pass 2; other modes: digits | histogram + scan | scatter
         phase_names = ["digits_or_coarse_hist", "sort_pass1", "sort_pass2", "unused", "accumulate", "bucket_sums_reduce1", "reduce2", "device_total"]
         out = {
@@ -357,7 +360,7 @@ def main():
                          "avg_launch_ms_pipelined": phase_piped[4],
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIR * units_per_launch,
                          "note": "the binding resource is integer-VALU issue (254-bit modular multiply), see `valu`; traffic (PMC) exceeds the "
-                                 "algorithmic bytes by design: one 64-byte precomputed-table point is gathered per (scalar, window)"},
+                                 "algorithmic bytes by design: one 64-byte precomputed-table point is gathered per (scalar, digit)"},
             "phases_ms_per_launch": dict(zip(phase_names, phase_alone)),
             "phases_ms_per_launch_pipelined": dict(zip(phase_names, phase_piped)),
         }
@@ -366,11 +369,14 @@ def main():
             rates = (C.c_double * 6)()
             measured = world == 1 and lib.kzg_ctx_measure_valu_rates(ctx.handle, 3, rates) == 0
             rates = tuple(rates[i] for i in range(6)) if measured else VALU_RATES_FALLBACK_NS
-            entries = plan["windows"] * units_per_launch
+            entries = plan["entries"]
             floor_ms = entries / 64.0 * MADS_PER_MIXED_ADD * rates[0] / N_SIMDS * 1e-6
             mix_ns = sum(c * r for c, r in zip(VALU_MIX_COUNTS, rates))
             mix_floor_ms = entries / 64.0 * mix_ns / N_SIMDS * 1e-6
-            out["roofline"]["valu"] = {"mixed_adds_per_launch": entries, "mads_per_mixed_add": MADS_PER_MIXED_ADD,
+            out["roofline"]["valu"] = {"mixed_adds_per_launch": entries, "mixed_adds_per_pair": entries / max(1.0, units_per_launch),
+                                       "mixed_adds_source": "sorted entries of the profiled launches, counted on the device (per-bit SRS tables, width-18 NAF digits: "
+                                                            "~13.8 per scalar; 15 with the fixed 17-bit windows, KZG_NAF_OFF=1)",
+                                       "mads_per_mixed_add": MADS_PER_MIXED_ADD,
                                        "mad_issue_floor_ms": floor_ms, "frac_of_mad_issue_floor": floor_ms / acc_ms,
                                        "instruction_issue_floor_ms": mix_floor_ms, "frac_of_instruction_issue_floor": mix_floor_ms / acc_ms,
                                        "instructions_per_mixed_add": sum(VALU_MIX_COUNTS),

@@ -72,6 +72,9 @@ int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len
  * *launches / *pairs = launches and (scalar, point) pairs covered.  Enabling resets the counters. */
 int32_t kzg_ctx_set_profiling(kzg_ctx* ctx, int32_t enable);
 int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* launches, uint64_t* pairs);
+/* *entries = sorted entries (= mixed additions of the accumulate kernel) of the launches profiled since kzg_ctx_set_profiling(ctx, 1):
+ * windows x pairs with the fixed-window tables, data dependent (~254 / (w + 1) + 1/2 per scalar) in the NAF mode of the per-bit tables. */
+int32_t kzg_ctx_get_msm_profile_entries(kzg_ctx* ctx, uint64_t* entries);
 /* Measurement aid: issue rate of the instruction classes the MSM accumulate kernel consists of, on this device, with
  * `waves_per_simd` waves per SIMD (the kernel runs 3): out_ns[0..5] = nanoseconds per wave-instruction per SIMD of
  * v_mad_i64_i32, v_mul_lo_u32, v_ashrrev_i64, v_and_b32, v_sub_u32 (the plain 32-bit class), s_nop.  ~60 ms of GPU time. */

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "kzg_srs_generate": (i32, [vp, u64p, C.c_uint64, sz, C.POINTER(vp)]),
     "kzg_ctx_set_profiling": (i32, [vp, i32]),
     "kzg_ctx_get_msm_profile": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "kzg_ctx_get_msm_profile_entries": (i32, [vp, C.POINTER(C.c_uint64)]),
     "kzg_ctx_measure_valu_rates": (i32, [vp, i32, C.POINTER(C.c_double)]),
     "kzg_srs_download": (i32, [vp, vp, sz, sz, u64p]),
     "kzg_srs_free": (None, [vp]),

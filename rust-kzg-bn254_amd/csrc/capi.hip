@@ -161,6 +161,7 @@ int32_t kzg_ctx_set_profiling(kzg_ctx* ctx, int32_t enable) {
         for (auto& v : w.phase_ms) v = 0;
         w.profiled_launches = 0;
         w.profiled_pairs = 0;
+        w.profiled_entries = 0;
     }
     return KZG_OK;
 }
@@ -178,6 +179,14 @@ int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* 
     }
     if (launches) *launches = nl;
     if (pairs) *pairs = np;
+    return KZG_OK;
+}
+int32_t kzg_ctx_get_msm_profile_entries(kzg_ctx* ctx, uint64_t* entries) {
+    if (!ctx || !entries) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    uint64_t ne = 0;
+    for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) ne += ctx->slot_msm(sl).profiled_entries;
+    *entries = ne;
     return KZG_OK;
 }
 

@@ -41,6 +41,7 @@ struct MsmWorkspace {
     double phase_ms[N_PHASES] = {};
     uint64_t profiled_launches = 0;
     uint64_t profiled_pairs = 0;
+    uint64_t profiled_entries = 0;   // sorted entries (= mixed additions) of the profiled launches
     void release();
 };
 
@@ -127,7 +128,9 @@ constexpr size_t SRS_NAF_MIN = (size_t)1 << 15;       // MSMs of at least this m
 inline int srs_naf_c(size_t n) {
     static const int forced = []() { const char* e = getenv("KZG_NAF_C"); return e ? atoi(e) : 0; }();
     if (forced >= 15 && forced <= 17) return forced;          // (NAF_DIGITS = 16 words per scalar: width >= 16)
-    return n >= ((size_t)1 << 18) ? 17 : 15;
+    // measured (tools/time_shard_inflight.py, KZG_NAF_C = 15 / 16 / 17, two or three MSMs in flight, ms per MSM): 2^17 0.257 / 0.264 / 0.284,
+    // 2^18 0.362 / 0.355 / 0.404, 2^19 0.678 / 0.631 / 0.629, 2^20 1.307 / 1.227 / 1.188 (profiles/r03_naf.md)
+    return n >= ((size_t)1 << 20) ? 17 : n >= ((size_t)1 << 18) ? 16 : 15;
 }
 // bases of an MSM of n pairs over srs[offset .. offset + n)
 inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, size_t n, bool allow_tables) {

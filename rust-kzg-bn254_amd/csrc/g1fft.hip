@@ -17,6 +17,7 @@
 //   * Jacobian -> affine by Montgomery's trick (one inversion per lane for 16 points) when there are many points.
 #include "engine.h"
 #include "curve_pair.h"
+#include "naf.h"
 #include "host_curve.h"
 
 #include <algorithm>
@@ -507,6 +508,75 @@ k_g1fft_first_tables(const uint4* __restrict__ tables, uint32_t table_stride, in
     }
     if (pair == 0) half_store(partial, (size_t)n * waves_per_out, (size_t)o * waves_per_out + wv, acc, odd);
 }
+// ---- the WHOLE transform of 64 .. 256 points through the per-bit SRS tables ----------------------------------------------------------
+// An SRS of >= 2^15 points carries Bit_p[j] = 2^p P_j for every bit position p (srs.hip srs_build_bit_tables, the NAF mode of its
+// MSMs).  With the scalars in plain non-adjacent form (digits +-1, ~85 per scalar) a term [k] P_j is a SUM OF TABLE POINTS,
+// sum_t +-Bit_(p_t)[j], and an output L_o = sum_j [w^(-o j) / n] P_j is n x 85 signed table points: no doubling, no scalar
+// multiplication, no stages -- mixed additions at the chip's throughput (n^2 x 85: 5.6 M for n = 256) and one tree.  The n distinct
+// scalars are recoded once per size (k_g1fft_naf2); one PAIR of lanes per (output, term, slice of the digit list) adds its digits
+// (pair_madd, 5 multiplications per lane); a wave holds 32 slots of one output and leaves their sum; k_g1fft_sum_partials adds the
+// <= 32 waves of an output.  Same group elements as the staged transform.
+constexpr uint32_t NAF2_MAX = 128;                       // digits of a scalar < 2^254 in width-2 NAF: at most 254 / 2 + 1
+__global__ void __launch_bounds__(64)
+k_g1fft_naf2(const uint4* __restrict__ scal_canon, uint32_t n, uint16_t* __restrict__ list, uint32_t* __restrict__ cnt) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const uint4 lo = scal_canon[2 * (size_t)e], hi = scal_canon[2 * (size_t)e + 1];
+    uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t m = 0;
+    naf_for_digits(k, 2, [&](uint32_t pos, uint32_t, uint32_t neg) { if (m < NAF2_MAX) list[(size_t)e * NAF2_MAX + m] = (uint16_t)(pos | (neg << 15)); ++m; });
+    cnt[e] = m < NAF2_MAX ? m : NAF2_MAX;
+}
+__global__ void __launch_bounds__(256)
+k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, uint32_t n, const uint16_t* __restrict__ list, const uint32_t* __restrict__ cnt,
+             uint32_t Q, uint32_t waves_per_out, int32_t* __restrict__ partial) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, pair = lane >> 1;
+    const bool odd = (t & 1u) != 0;
+    const uint32_t gw = t >> 6;
+    const uint32_t o = gw / waves_per_out, wv = gw - o * waves_per_out;
+    if (o >= n) return;                                           // wave-uniform
+    const uint32_t slot = wv * 32 + pair;                         // < n Q (the host makes n Q a multiple of 32)
+    const uint32_t j = slot / Q, q = slot - j * Q;
+    const uint32_t e = (uint32_t)((unsigned long long)o * j) & (n - 1);
+    const uint16_t* L = list + (size_t)e * NAF2_MAX;
+    const uint32_t c = cnt[e];
+    HalfXyzz acc;
+    half_set_inf(acc);
+    // digit m of the list: the table point Bit_pos[j], even lane x, odd lane y; one point in flight ahead of the addition
+    auto fetch = [&](uint32_t m, uint4& a, uint4& b, uint32_t& neg) {
+        const uint32_t d = L[m < c ? m : (c ? c - 1 : 0)];
+        neg = d >> 15;
+        const uint4* src = bits + 4 * ((size_t)(d & 0x7FFFu) * stride + j) + (odd ? 2 : 0);
+        a = src[0]; b = src[1];
+    };
+    uint4 a0, b0; uint32_t neg0 = 0;
+    if (c) fetch(q, a0, b0, neg0);
+#pragma unroll 1
+    for (uint32_t m = q; m < c; m += Q) {                         // pair-uniform trip count
+        const uint32_t w32[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
+        const uint32_t neg = neg0;
+        int any = (a0.x | a0.y | a0.z | a0.w | b0.x | b0.y | b0.z | b0.w) != 0 ? 1 : 0;
+        any |= pair_swap(any);
+        fetch(m + Q, a0, b0, neg0);
+        if (!any) continue;                                       // identity SRS point
+        Fq cpt;
+        fe_unpack(cpt, w32);
+        HalfXyzz r;
+        pair_madd(r, acc, cpt, neg, odd);
+        acc = r;
+    }
+#pragma unroll 1
+    for (int d = 1; d < 32; d <<= 1) {                            // sum of the wave's 32 slots
+        HalfXyzz other;
+        half_shfl_down(other, acc, 2 * d);
+        if ((pair & (2 * d - 1)) == 0) {
+            HalfXyzz r;
+            pair_add(r, acc, other, odd);
+            acc = r;
+        }
+    }
+    if (pair == 0) half_store(partial, (size_t)n * waves_per_out, (size_t)o * waves_per_out + wv, acc, odd);
+}
 // y[o] = sum of the waves_per_out (<= 32) partial sums of output o: one wave per output
 __global__ void __launch_bounds__(256)
 k_g1fft_sum_partials(const int32_t* __restrict__ partial, uint32_t waves_per_out, uint32_t n, int32_t* __restrict__ y) {
@@ -614,6 +684,29 @@ static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** o
     return KZG_OK;
 }
 
+// width-2 NAF digit lists of the n scalars w^-e / n (k_g1fft_naf2), cached per (device, log n)
+struct Naf2Lists { uint16_t* list = nullptr; uint32_t* cnt = nullptr; };
+static std::map<std::pair<int, int>, Naf2Lists> g_naf2;
+static int32_t get_naf2(kzg_ctx* ctx, int log_n, Naf2Lists* out) {
+    const uint4* sc = nullptr;
+    int32_t rc = get_scalars(ctx, log_n, true, &sc, true);              // canonical integers of w^-e / n
+    if (rc != KZG_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_scal_mu);
+    auto key = std::make_pair(ctx->device, log_n);
+    auto it = g_naf2.find(key);
+    if (it != g_naf2.end()) { *out = it->second; return KZG_OK; }
+    const size_t n = (size_t)1 << log_n;
+    Naf2Lists l;
+    KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&l.list), n * NAF2_MAX * 2));
+    KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&l.cnt), n * 4));
+    hipLaunchKernelGGL(k_g1fft_naf2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, sc, (uint32_t)n, l.list, l.cnt);
+    KZG_HIP_TRY(ctx, hipGetLastError());
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    g_naf2[key] = l;
+    *out = l;
+    return KZG_OK;
+}
+
 // XYZZ planes -> wire XYZZ words (32 u32 per point) for the host-side affine conversion of small transforms
 __global__ void __launch_bounds__(256)
 k_g1fft_planes_to_wire(const int32_t* __restrict__ planes, uint32_t n, uint32_t* __restrict__ out_wire) {
@@ -642,6 +735,26 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
     if (rc == KZG_OK) rc = get_scalars(ctx, log_n, true, &scal_n);
     if (rc != KZG_OK) return rc;
     const int32_t* result = bufA;
+    // 64 .. 256 points of an SRS with per-bit tables: the whole transform as sums of table points (k_g1fft_bits; KZG_G1FFT_BITS=0: off)
+    static const bool use_bits = []() { const char* e = getenv("KZG_G1FFT_BITS"); return !(e && atoi(e) == 0); }();
+    if (use_bits && srs->d_bits && srs->lagrange_of == 0 && n >= 64 && n <= 256) {     // (512 points: 2.1 ms here, 1.85 ms staged)
+        Naf2Lists nl;
+        rc = get_naf2(ctx, log_n, &nl);
+        if (rc != KZG_OK) return rc;
+        // slices per term: two waves per SIMD in all (n^2 Q / 32 = 2048 waves) -- more waves only add tree additions (every wave ends in a
+        // 5-level tree: a third of the work at 21 digits per pair), fewer leave lone waves at half the issue rate.  Measured: 256 points
+        // 0.71 ms with Q = 4, 0.66 with Q = 1; 128 points 0.28 -> 0.26 (tools/time_g1ifft.py).  The floor is the additions themselves:
+        // n^2 x 85 (5.6 M at 256 points = 0.36 ms of the chip).
+        const uint32_t Q = (uint32_t)std::max<size_t>(1, 65536 / (n * n)), wpo = (uint32_t)(n * Q / 32);
+        KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)n * wpo * 36 * 4));
+        int32_t* partial = ctx->poly[0].c.as<int32_t>();
+        hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, srs->d_bits, (uint32_t)srs->n, (uint32_t)n,
+                           nl.list, nl.cnt, Q, wpo, partial);
+        hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, wpo, (uint32_t)n, bufA);
+        KZG_HIP_TRY(ctx, hipGetLastError());
+        *result_out = bufA;
+        return KZG_OK;
+    }
     // Stage plan.  A stage is one scalar multiplication deep whatever it computes, so the plan minimises (number of stages) x (time of a
     // stage).  Measured stage times on MI355X (tools/time_g1ifft.py, round 3) while the stage fits ONE wave per SIMD (65536 lanes):
     // 1.25 ms with one lane per point, 0.83 ms on lane pairs; beyond that a stage is throughput bound and scales with its lanes (a lone

@@ -282,7 +282,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_HIP_TRY(ctx, ws.chunkA.reserve((size_t)n_chunks * 36 * 4));
     }
     KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)MSM_MAX_OUT * 32 * 4));
-    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, (size_t)MSM_MAX_OUT * 32 * 4, hipHostMallocDefault));
+    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, (size_t)MSM_MAX_OUT * 32 * 4 + MSM_MAX_PARTS * 4, hipHostMallocDefault));   // + entry counts of profiled launches
     if (!ctx->lds_attr_set) {
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
@@ -459,6 +459,9 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         return KZG_ERR_INVALID_ARG;
     }
     KZG_HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ws.pinned_out) + (size_t)out_off * 128, ws.out_wire.p, (size_t)n_out * 128, hipMemcpyDeviceToHost, st));
+    if (prof)                                             // sorted entries = mixed additions of this launch (NAF mode: data dependent)
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ws.pinned_out) + (size_t)MSM_MAX_OUT * 128 + (out_off / MSM_PART_OUT) * 4, d_offs + p.G, 4,
+                                        hipMemcpyDeviceToHost, st));
     if (!ws.ev_done) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
     KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_done, st));        // msm_finish waits for THIS launch, not for the stream: a later MSM may already be queued behind it
 #undef KZG_MARK
@@ -492,6 +495,7 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
         ws.phase_ms[7] += ms;
         ws.profiled_launches += 1;
         ws.profiled_pairs += pend.n * batch;
+        ws.profiled_entries += reinterpret_cast<const uint32_t*>(static_cast<const char*>(ws.pinned_out) + (size_t)MSM_MAX_OUT * 128)[pend.out_off / MSM_PART_OUT];
     }
 
     // host epilogue on O(100) points

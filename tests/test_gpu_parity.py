@@ -1029,6 +1029,29 @@ def test_g1_ifft_paths_and_lagrange_cache(k, tau_srs, ref_srs, test_srs_wire):
         ref_srs.cache_lagrange(48)
 
 
+@pytest.mark.parametrize("log_n", [6, 7, 8, 9])
+def test_g1_ifft_through_the_per_bit_tables(k, tau_srs, log_n):
+    """g1_ifft of 64 .. 512 points of an SRS that carries per-bit tables (>= 2^15 points): the whole transform as sums of table points
+    (k_g1fft_bits: plain-NAF digit lists of the n scalars w^-e / n).  EVERY output against the known-tau value L_i = l_i(tau) G by
+    big-integer arithmetic, and the same transform through the staged kernels (a copy of the first n points as an SRS of its own,
+    which is too small for per-bit tables)."""
+    kzg = k.KZG.new()
+    n = 1 << log_n
+    L = kzg.g1_ifft(n, tau_srs)
+    w = pyref.root_of_unity(log_n)
+    zn = (pow(TAU, n, R_) - 1) * pow(n, -1, R_) % R_
+    step = 1 if n <= 128 else 7
+    for i in list(range(0, n, step)) + [n - 1]:
+        wi = pow(w, i, R_)
+        li = zn * wi % R_ * pow(TAU - wi, -1, R_) % R_
+        assert pyref.point_from_wire(L[i]) == pyref.ec_mul(li, (1, 2)), i
+    small = k.SRS(np.ascontiguousarray(tau_srs.g1[:n]), order=n)
+    try:
+        assert np.array_equal(kzg.g1_ifft(n, small), L)
+    finally:
+        small.close()
+
+
 def test_multi_device_handle_three_contexts_on_one_gpu(k, test_srs_wire, tau_srs):
     """kzg_multi_*: the multi-GPU split behind the C-ABI (one context + one host thread per entry), here three contexts on GPU 0:
     uploaded SRS (3000 reference points, uneven shards) against the oracle, generated known-tau SRS against big-integer values."""
