@@ -162,6 +162,21 @@ int32_t kzg_fr_ntt_device(kzg_ctx* ctx, void* d_data_mont, size_t n, int32_t inv
 /* KZG::commit_coeff_form (kzg.rs:107-125): n > srs len -> KZG_ERR_POLY_LENGTH. */
 int32_t kzg_commit_coeff_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* coeffs_mont, size_t n,
                               uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+/* Batched forms (no counterpart in the reference, which commits one polynomial per call): `count` polynomials of n coefficients
+ * (evaluations) each, one after the other in memory, against the first n points of ONE SRS -> count commitments, out_xy_mont = count x 8
+ * words, out_is_infinity = count bytes (may be NULL).  Same values and errors as count calls of kzg_commit_coeff_form /
+ * kzg_commit_eval_form; ONE kernel sequence per 1 024 polynomials (width-8 NAF digits over the SRS's per-bit tables, 64 buckets per
+ * polynomial): a few microseconds per commitment of 512..2048 coefficients instead of 0.14-0.2 ms.  The SRS handle is not const:
+ * an SRS of fewer than 2^15 points gets its per-bit tables (16 KiB per point) on the first batched call, and the eval form keeps
+ * the Lagrange basis of n points with the SRS (kzg_srs_cache_lagrange).  _device: the scalars are already in device memory. */
+int32_t kzg_commit_coeff_form_batch(kzg_ctx* ctx, kzg_srs* srs, const uint64_t* coeffs_mont, size_t n, size_t count,
+                                    uint64_t* out_xy_mont, uint8_t* out_is_infinity);
+int32_t kzg_commit_coeff_form_batch_device(kzg_ctx* ctx, kzg_srs* srs, const void* d_coeffs_mont, size_t n, size_t count,
+                                           uint64_t* out_xy_mont, uint8_t* out_is_infinity);
+int32_t kzg_commit_eval_form_batch(kzg_ctx* ctx, kzg_srs* srs, const uint64_t* evals_mont, size_t n, size_t count,
+                                   uint64_t* out_xy_mont, uint8_t* out_is_infinity);
+int32_t kzg_commit_eval_form_batch_device(kzg_ctx* ctx, kzg_srs* srs, const void* d_evals_mont, size_t n, size_t count,
+                                          uint64_t* out_xy_mont, uint8_t* out_is_infinity);
 /* KZG::commit_eval_form (kzg.rs:84-104): n > srs len -> KZG_ERR_SRS_CAPACITY_EXCEEDED; n not a power of
  * two -> KZG_ERR_NOT_POWER_OF_TWO.  Computed as MSM(srs, IFFT(evals)), identical to the reference's
  * MSM(g1_ifft(srs), evals) (prover/src/lib.rs:43-47; prover/tests/kzg_test.rs:57-89). */

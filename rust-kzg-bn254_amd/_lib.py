@@ -75,6 +75,10 @@ PROTOTYPES = {
     "kzg_fr_ntt_device": (i32, [vp, vp, sz, i32]),
     "kzg_commit_coeff_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
     "kzg_commit_eval_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
+    "kzg_commit_coeff_form_batch": (i32, [vp, vp, u64p, sz, sz, u64p, u8p]),
+    "kzg_commit_coeff_form_batch_device": (i32, [vp, vp, vp, sz, sz, u64p, u8p]),
+    "kzg_commit_eval_form_batch": (i32, [vp, vp, u64p, sz, sz, u64p, u8p]),
+    "kzg_commit_eval_form_batch_device": (i32, [vp, vp, vp, sz, sz, u64p, u8p]),
     "kzg_commit_eval_form_begin": (i32, [vp, vp, u64p, sz, i32]),
     "kzg_commit_blob_begin": (i32, [vp, vp, u8p, sz, i32]),
     "kzg_g1_ifft": (i32, [vp, vp, sz, u64p]),

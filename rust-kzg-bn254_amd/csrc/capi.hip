@@ -634,6 +634,69 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     return msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
 }
 
+// ---- batched commitments: `count` polynomials of n coefficients / evaluations over one SRS in ONE kernel sequence -------------------
+// The reference commits one blob per call (kzg.rs:84-125); a service that commits many small blobs pays the fixed depth of an MSM
+// (~0.14-0.2 ms at 512..2048 coefficients: sort, ~13 dependent point additions, host epilogue) per blob.  Here the polynomials share the
+// bases, so they are one MSM problem: width-8 NAF digits over the SRS's per-bit tables, 64 buckets per polynomial in one bucket
+// array (msm.hip msm_run_batch_tables).  An SRS without per-bit tables (fewer than 2^15 points) gets them on the first batched call.
+static int32_t commit_batch_device(kzg_ctx* ctx, kzg_srs* basis, const void* d_scalars, size_t n, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!basis->d_bits) {
+        int32_t rc = srs_build_bit_tables(ctx, basis, true);
+        if (rc != KZG_OK) return rc;
+    }
+    if (!basis->d_bits) {                                  // no room for tables (or KZG_NO_NAF): one commitment after the other
+        for (size_t k = 0; k < count; ++k) {
+            int32_t rc = msm_run(ctx, srs_bases(basis, 0, n, ctx->msm_c_override == 0), static_cast<const char*>(d_scalars) + k * n * 32, n,
+                                 out_xy + 8 * k, out_inf ? out_inf + k : nullptr, nullptr);
+            if (rc != KZG_OK) return rc;
+        }
+        return KZG_OK;
+    }
+    MsmBases b;
+    b.points = basis->d_bits; b.table_stride = (uint32_t)basis->n; b.c = 7; b.W = 255; b.naf = true;
+    return msm_run_batch_tables(ctx, b, d_scalars, n, count, out_xy, out_inf);
+}
+static int32_t commit_batch_common(kzg_ctx* ctx, kzg_srs* srs, const void* scalars, bool on_device, bool eval_form, size_t n, size_t count,
+                                   uint64_t* out_xy, uint8_t* out_inf) {
+    if (!ctx || !srs || srs->ctx != ctx || !out_xy || (n && count && !scalars)) return KZG_ERR_INVALID_ARG;
+    if (n > srs->n) return eval_form ? KZG_ERR_SRS_CAPACITY_EXCEEDED : KZG_ERR_POLY_LENGTH;          // kzg.rs:89-94, :112-116
+    if (eval_form && (n == 0 || (n & (n - 1)) != 0)) return KZG_ERR_NOT_POWER_OF_TWO;                // kzg.rs:265-269
+    if (count == 0) return KZG_OK;
+    if (n == 0) { memset(out_xy, 0, count * 64); if (out_inf) memset(out_inf, 1, count); return KZG_OK; }
+    if (count > ((size_t)1 << 40) / n) return KZG_ERR_TOO_LARGE;
+    kzg_srs* basis = srs;
+    if (eval_form) {                                       // the reference's literal form: MSM over the Lagrange basis of n points, kept with the SRS
+        int32_t rc = kzg_srs_cache_lagrange(ctx, srs, n);
+        if (rc != KZG_OK) return rc;
+        basis = srs->lagrange[n];
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const void* d = scalars;
+    if (!on_device) {
+        KZG_HIP_TRY(ctx, ctx->msm.scalars.reserve(count * n * 32 + 32));
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm.scalars.p, scalars, count * n * 32, hipMemcpyHostToDevice, ctx->stream));
+        d = ctx->msm.scalars.p;
+    }
+    return commit_batch_device(ctx, basis, d, n, count, out_xy, out_inf);
+}
+int32_t kzg_commit_coeff_form_batch(kzg_ctx* ctx, kzg_srs* srs, const uint64_t* coeffs_mont, size_t n, size_t count,
+                                    uint64_t* out_xy_mont, uint8_t* out_is_infinity) {
+    return commit_batch_common(ctx, srs, coeffs_mont, false, false, n, count, out_xy_mont, out_is_infinity);
+}
+int32_t kzg_commit_coeff_form_batch_device(kzg_ctx* ctx, kzg_srs* srs, const void* d_coeffs_mont, size_t n, size_t count,
+                                           uint64_t* out_xy_mont, uint8_t* out_is_infinity) {
+    return commit_batch_common(ctx, srs, d_coeffs_mont, true, false, n, count, out_xy_mont, out_is_infinity);
+}
+int32_t kzg_commit_eval_form_batch(kzg_ctx* ctx, kzg_srs* srs, const uint64_t* evals_mont, size_t n, size_t count,
+                                   uint64_t* out_xy_mont, uint8_t* out_is_infinity) {
+    return commit_batch_common(ctx, srs, evals_mont, false, true, n, count, out_xy_mont, out_is_infinity);
+}
+int32_t kzg_commit_eval_form_batch_device(kzg_ctx* ctx, kzg_srs* srs, const void* d_evals_mont, size_t n, size_t count,
+                                          uint64_t* out_xy_mont, uint8_t* out_is_infinity) {
+    return commit_batch_common(ctx, srs, d_evals_mont, true, true, n, count, out_xy_mont, out_is_infinity);
+}
+
 // ---- multi-GPU forms: this rank's SRS shard holds the powers [shard_lo, shard_lo + len(srs_shard)) -----------------------
 int32_t kzg_commit_eval_form_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo, const uint64_t* evals_mont, size_t n,
                                      uint64_t out_xyzz_mont[16]) {

@@ -161,7 +161,9 @@ int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars
 
 // Precompute the window tables of an SRS in place (reallocates srs->d_points); no-op for small / huge SRS.
 int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs);
-int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs);
+int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs, bool force);
+// `polys` commitments over the first n points of one SRS in one kernel sequence (bases: the SRS's per-bit tables; msm.hip)
+int32_t msm_run_batch_tables(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n, size_t polys, uint64_t* out_xy, uint8_t* out_inf);
 
 // wire affine points (device memory) -> device affine format (curve.h), asynchronous on ctx->stream
 // d_off_curve_flag != nullptr: also check y^2 == x^3 + 3 of every non-identity point, *flag |= 1 on a violation (device word, zeroed by the caller)

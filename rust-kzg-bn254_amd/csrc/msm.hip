@@ -22,6 +22,7 @@
 
 namespace kzg {
 
+constexpr uint32_t MSM_BATCH_POLYS_MAX = 1024;  // polynomials of one batched table-mode launch (64 buckets each: 2^16 buckets)
 constexpr uint32_t MSM_MAX_OUT = 4096;         // XYZZ values one launch may hand to the host epilogue (generic mode: W * batch window sums)
 constexpr size_t SORT1_MAX_LDS = 131072;       // single-pass sort: one LDS counter per bucket (<= 2^15 buckets)
 
@@ -41,6 +42,8 @@ struct Plan {
     uint32_t batch;      // independent MSMs of n pairs each (generic mode only; 1 otherwise)
     bool tables;         // table mode
     bool naf;            // table mode over the per-bit tables: width-(c + 1) NAF digits (msm_kernels.h), W = most entries per scalar
+    uint32_t polys;      // BATCHED table mode (NAF, c = 7): the n scalars are `polys` polynomials of n / polys coefficients over the same bases,
+                         // 64 buckets each: B = 64 polys buckets, one group of the first reduction level per polynomial (0: one MSM)
     int c, W;
     uint32_t B;          // buckets per set
     uint32_t sets;       // bucket sets (1 in table mode, W otherwise)
@@ -64,14 +67,17 @@ static int generic_window(size_t n, uint32_t batch) {
     return c;
 }
 
-static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint32_t batch) {
+static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint32_t batch, uint32_t polys = 0) {
     Plan p;
     p.n = (uint32_t)n;
     p.batch = batch;
     p.tables = bases.table_stride != 0;
     p.naf = p.tables && bases.naf;
+    p.polys = p.naf ? polys : 0;
     int c;
-    if (p.tables) {
+    if (p.polys) {
+        c = 7;                                             // width-8 digits: keys < 64
+    } else if (p.tables) {
         c = bases.c;
     } else {
         c = ctx->msm_c_override;
@@ -81,7 +87,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     }
     p.c = c;
     p.W = p.naf ? naf_max_digits(c + 1) : (255 + c - 1) / c;
-    p.B = 1u << (c - 1);
+    p.B = p.polys ? 64u * ((p.polys + 1u) & ~1u) : 1u << (c - 1);      // (a multiple of 128: whole coarse bins)
     p.sets = p.tables ? 1u : (uint32_t)p.W * batch;
     p.G = p.sets * p.B;
     const size_t entries_cap = (size_t)p.W * n * batch;                  // buffer sizes
@@ -138,7 +144,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         const bool want = !(env && atoi(env) == 0);
         const bool lds_fits = (size_t)p.B * 4 <= SORT1_MAX_LDS;            // single-pass sort: one LDS counter per bucket
         p.sort_small = !p.naf && entries < ((size_t)1 << 18);
-        const bool can2 = p.tables && p.c - 1 > SORT2_LO_BITS && (p.B >> SORT2_LO_BITS) <= SORT2_MAX_BINS &&
+        const bool can2 = p.tables && (p.c - 1 > SORT2_LO_BITS || p.polys) && (p.B >> SORT2_LO_BITS) <= SORT2_MAX_BINS &&
                           (p.naf ? (size_t)NAF_POSITIONS * p.idx_stride < ((size_t)1 << 31)
                                  : (size_t)p.W * p.idx_stride <= ((size_t)1 << SORT2_IDX_BITS));
         int min_log = 18;                                                  // (was 2^23: the scalar-tile pass 1 and the per-bin pass 2 win from the first size the single-pass sort is not "small" for)
@@ -150,6 +156,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         if (p.naf) {                                                       // the recoding is a long dependent chain per scalar: more, smaller tiles
             static const int naf_tile = []() { const char* e = getenv("KZG_NAF_TILE"); return e ? atoi(e) : 0; }();
             p.tile1 = naf_tile >= 256 && naf_tile <= 4096 ? (uint32_t)naf_tile : 512;
+            if (p.polys) p.tile1 = 2048;                                    // (twice the entries per scalar: fewer, larger tiles)
         }
         p.tiles1 = (uint32_t)((n + p.tile1 - 1) / p.tile1);
         p.tiles2cap = (uint32_t)(entries_cap / SORT2_CHUNK + p.Hb + 1);
@@ -237,9 +244,11 @@ static int32_t debug_check_sort(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, 
 
 // Enqueue every kernel of one MSM (or batch) plus the D2H copy of its O(100) result points on `st`, using `ws`.
 static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
-                           uint32_t batch, Pending* pend, uint32_t out_off = 0, uint32_t out_cap = MSM_MAX_OUT) {
+                           uint32_t batch, Pending* pend, uint32_t out_off = 0, uint32_t out_cap = MSM_MAX_OUT, uint32_t polys = 0) {
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
-    const Plan p = make_plan(ctx, n, bases, batch);
+    if (polys && (!bases.naf || n % polys != 0 || polys > MSM_BATCH_POLYS_MAX)) return KZG_ERR_INVALID_ARG;
+    const Plan p = make_plan(ctx, n, bases, batch, polys);
+    const int ND = p.polys ? 32 : NAF_DIGITS;              // digit words per scalar
     const size_t entries = (size_t)p.W * n * batch;
     const uint32_t n_windows = (uint32_t)p.W * batch;          // window sums produced in generic mode
     if (!p.tables && n_windows > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
@@ -256,7 +265,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_HIP_TRY(ctx, ws.sort_tmp.reserve(entries * 4));
         if (p.naf) {
             KZG_HIP_TRY(ctx, ws.sort_key.reserve(entries + 16));
-            KZG_HIP_TRY(ctx, ws.digits.reserve((size_t)n * NAF_DIGITS * 4));
+            KZG_HIP_TRY(ctx, ws.digits.reserve((size_t)n * ND * 4));
         }
         KZG_HIP_TRY(ctx, ws.sort_small.reserve(((size_t)3 * (p.Hb + 1) + p.tiles2cap) * 4 + 64));
         KZG_HIP_TRY(ctx, ws.blockbase.reserve(std::max((size_t)p.tiles1 * p.Hb, (size_t)p.tiles2cap * SORT2_LO) * 4));
@@ -290,6 +299,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
                                              (int)((3 * SORT2_MAX_BINS + SORT2_P1_THREADS * 31) * 4)));
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort2_scatter1_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)((3 * SORT2_MAX_BINS + SORT2_P1_THREADS * 31) * 4 + SORT2_P1_THREADS * 31 * 2)));
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort2_scatter1_lds<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)((3 * SORT2_MAX_BINS + SORT2_P1_THREADS * 32) * 4 + SORT2_P1_THREADS * 32 * 2)));
         ctx->lds_attr_set = true;
     }
 
@@ -327,9 +338,13 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         uint32_t* bin_cap = tile_bin + p.tiles2cap;     // 1: the LARGE-bin threshold of this launch (k_sort2_scan)
         KZG_HIP_TRY(ctx, hipMemsetAsync(ccount, 0, (size_t)p.Hb * 4, st));
         uint8_t* tmpk = p.naf ? ws.sort_key.as<uint8_t>() : nullptr;
-        if (p.naf)
-            hipLaunchKernelGGL(k_naf_digits, dim3(p.tiles1), dim3(256), ((size_t)p.Hb + (11 + NAF_DIGITS) * 256) * 4, st, d_scalars, p.n, p.c, p.tile1, p.Hb, ccount,
-                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>());
+        const uint32_t poly_len = p.polys ? p.n / p.polys : 0u;
+        if (p.naf && p.polys)
+            hipLaunchKernelGGL(k_naf_digits<32>, dim3(p.tiles1), dim3(256), ((size_t)p.Hb + (11 + 32) * 256) * 4, st, d_scalars, p.n, p.c, p.tile1, p.Hb, ccount,
+                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), poly_len);
+        else if (p.naf)
+            hipLaunchKernelGGL(k_naf_digits<NAF_DIGITS>, dim3(p.tiles1), dim3(256), ((size_t)p.Hb + (11 + NAF_DIGITS) * 256) * 4, st, d_scalars, p.n, p.c, p.tile1, p.Hb, ccount,
+                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), 0u);
         else
         hipLaunchKernelGGL(k_sort2_scalars<false>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
                            ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, p.idx_stride, (uint32_t*)nullptr);
@@ -338,8 +353,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         static const bool direct_scatter = []() { const char* e = getenv("KZG_SORT2_DIRECT"); return e && atoi(e) != 0; }();   // A/B: pass 1 without the LDS staging
         if (p.naf) {
             const size_t lds1 = ((size_t)3 * p.Hb + (size_t)SORT2_P1_THREADS * p.W) * 4 + (size_t)SORT2_P1_THREADS * p.W * 2;
+            if (p.polys)
+                hipLaunchKernelGGL((k_sort2_scatter1_lds<true, 32>), dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, ws.digits.as<uint4>(), p.n, p.c, p.W, p.tile1, p.Hb,
+                                   ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), tmpk, poly_len);
+            else
             hipLaunchKernelGGL(k_sort2_scatter1_lds<true>, dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, ws.digits.as<uint4>(), p.n, p.c, p.W, p.tile1, p.Hb,
-                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), tmpk);
+                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), tmpk, 0u);
         } else if (direct_scatter || p.W > 31) {
             hipLaunchKernelGGL(k_sort2_scalars<true>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
                                ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>());
@@ -391,7 +410,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     }
     KZG_MARK(4);
     static const bool debug_sort = []() { const char* e = getenv("KZG_DEBUG_SORT"); return e && atoi(e) != 0; }();
-    if (debug_sort && p.tables && batch == 1) {
+    if (debug_sort && p.tables && batch == 1 && !p.polys) {
         int32_t rc = debug_check_sort(ctx, ws, st, p, d_scalars);
         if (rc != KZG_OK) return rc;
     }
@@ -422,7 +441,10 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
             hipLaunchKernelGGL(k_msm_bucket_bits1, dim3((G1 * 64 + 255) / 256), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, ws.out_wire.as<uint32_t>());
         KZG_MARK(6);
-        if (G1 == 1) {
+        if (p.polys) {
+            hipLaunchKernelGGL(k_batch_finish, dim3((p.polys + 63) / 64), dim3(64), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, ws.out_wire.as<uint32_t>());
+            n_out = p.polys;
+        } else if (G1 == 1) {
             n_out = 7;
         } else {
             const uint32_t waves2 = 7 * G1p;
@@ -508,6 +530,10 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     if (!p.tables) {
         for (uint32_t b = 0; b < batch; ++b)
             result[b] = kzg_host::horner_windows(vals + (size_t)b * p.W, p.W, p.c);   // sum_w 2^(c w) S_w: <= 255 doublings
+        return KZG_OK;
+    }
+    if (p.polys) {                                         // batched table mode: k_batch_finish left one commitment per polynomial
+        for (uint32_t b = 0; b < p.polys; ++b) result[b] = vals[b];
         return KZG_OK;
     }
     // sum_b (b+1) V_b = T + sum_j 2^j S_j over the bits j of the 0-based bucket index
@@ -697,6 +723,36 @@ int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars
     if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, res);
     if (rc != KZG_OK) return rc;
     for (uint32_t i = 0; i < batch; ++i) kzg_host::xyzz_to_affine(res[i], out_xy + 8 * i, out_inf ? out_inf + i : nullptr);
+    return KZG_OK;
+}
+
+// `polys` MSMs of n pairs each over the SAME bases (the first n points of an SRS with per-bit tables): the commitments of `polys`
+// polynomials in one kernel sequence per MSM_BATCH_POLYS_MAX polynomials.  d_scalars: polys x n wire scalars, polynomial after polynomial.
+int32_t msm_run_batch_tables(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n, size_t polys, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!bases.naf || n == 0) return KZG_ERR_INVALID_ARG;
+    if (ctx->slot_pending[0]) {
+        ctx->last_error = "a kzg_*_begin on slot 0 is still in flight: call kzg_msm_g1_srs_end(ctx, 0, ..) first";
+        return KZG_ERR_INVALID_ARG;
+    }
+    // polynomials per launch: 64 buckets each in one 2^16-bucket array, 2^24 pairs at most
+    size_t per = std::min<size_t>(MSM_BATCH_POLYS_MAX, MSM_MAX_LAUNCH / n);
+    if (per == 0) return KZG_ERR_TOO_LARGE;
+    static thread_local std::vector<kzg_host::Xyzz> res;
+    res.resize(std::min(per, polys));
+    const uint4* sc = reinterpret_cast<const uint4*>(d_scalars);
+    for (size_t done = 0; done < polys; done += per) {
+        const size_t k = std::min(per, polys - done);
+        Pending pend;
+        int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, bases, sc + 2 * done * n, n * k, 1, &pend, 0, MSM_MAX_OUT, (uint32_t)k);
+        if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, res.data());
+        if (rc != KZG_OK) return rc;
+        kzg_host::xyzz_batch_to_affine(res.data(), k, out_xy + 8 * done);
+        if (out_inf)
+            for (size_t i = 0; i < k; ++i) {
+                const uint64_t* q = out_xy + 8 * (done + i);
+                out_inf[done + i] = (q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | q[6] | q[7]) == 0 ? 1 : 0;
+            }
+    }
     return KZG_OK;
 }
 

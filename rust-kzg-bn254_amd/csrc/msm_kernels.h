@@ -344,14 +344,19 @@ k_sort2_scalars(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uin
 // with their 12-instruction digits, cost more than the additions the NAF saves).  The digits of 256 scalars are staged in LDS and
 // leave as 16-byte stores of consecutive lanes: one store per digit and lane (64 lines per wave instruction) bound the kernel at
 // 82 us per 2^20 scalars whatever the recoder.
+// ND = words per scalar (16: widths >= 16; 32: the width-8 digits of the batched mode).  poly_len != 0: BATCHED table mode -- the
+// scalars are `n / poly_len` polynomials of poly_len coefficients over the same bases and scalar s belongs to polynomial s / poly_len,
+// whose 64 buckets (width-8 NAF: keys < 64) are the group s / poly_len of the bucket array: one group of the first reduction level per
+// polynomial, whose seven sums k_batch_finish turns into the polynomial's commitment.
+template <int ND>
 __global__ void __launch_bounds__(256)
 k_naf_digits(const uint4* __restrict__ scalars, uint32_t n, int c, uint32_t tile_s, uint32_t Hb, uint32_t* __restrict__ ccount,
-             uint32_t* __restrict__ blockbase1, uint4* __restrict__ digs) {
+             uint32_t* __restrict__ blockbase1, uint4* __restrict__ digs, uint32_t poly_len) {
     latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
     uint32_t* hist = lds_u32;                             // Hb
     uint32_t* col = hist + Hb + threadIdx.x;              // 11 x 256: this thread's scalar words (naf_for_digits_lds), words 8..10 zero
-    uint32_t* stage = hist + Hb + 11 * 256;               // NAF_DIGITS x 256: digit m of thread t at [m * 256 + t]
+    uint32_t* stage = hist + Hb + 11 * 256;               // ND x 256: digit m of thread t at [m * 256 + t]
     const uint32_t t = threadIdx.x;
     const uint32_t lo = blockIdx.x * tile_s;
     const uint32_t hi = (n - lo < tile_s) ? n : lo + tile_s;
@@ -360,7 +365,7 @@ k_naf_digits(const uint4* __restrict__ scalars, uint32_t n, int c, uint32_t tile
     for (uint32_t base = lo; base < hi; base += 256) {
         __syncthreads();                                  // histogram zeroed / the stage of the previous round written out
 #pragma unroll
-        for (int m = 0; m < NAF_DIGITS; ++m) stage[m * 256 + t] = NAF_NO_DIGIT;
+        for (int m = 0; m < ND; ++m) stage[m * 256 + t] = NAF_NO_DIGIT;
         const uint32_t i = base + t;
         if (i < hi) {
             const uint4 s_lo = scalars[2 * (size_t)i], s_hi = scalars[2 * (size_t)i + 1];
@@ -370,20 +375,21 @@ k_naf_digits(const uint4* __restrict__ scalars, uint32_t n, int c, uint32_t tile
 #pragma unroll
             for (int j = 0; j < 8; ++j) col[j * 256] = k[j];
             uint32_t m = 0;
+            const uint32_t group = poly_len ? (i / poly_len) << 6 : 0u;
             naf_for_digits_lds(col, 256, c + 1, [&](uint32_t pos, uint32_t key, uint32_t neg) {
-                const uint32_t g = naf_bucket(key, c - 1);
+                const uint32_t g = poly_len ? group | key : naf_bucket(key, c - 1);
                 atomicAdd(&hist[g >> SORT2_LO_BITS], 1u);
-                stage[m * 256 + t] = (neg << 31) | (pos << 16) | g;
+                if (m < (uint32_t)ND) stage[m * 256 + t] = (neg << 31) | (pos << 16) | g;
                 ++m;
             });
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NAF_DIGITS / 4; ++r) {
-            const uint32_t idx = t + 256 * r, sc = idx >> 2, q = idx & 3u;
+        for (int r = 0; r < ND / 4; ++r) {
+            const uint32_t idx = t + 256 * r, sc = idx / (ND / 4), q = idx % (ND / 4);
             if (base + sc < hi)
-                digs[(size_t)(base + sc) * (NAF_DIGITS / 4) + q] = make_uint4(stage[(4 * q) * 256 + sc], stage[(4 * q + 1) * 256 + sc],
-                                                                            stage[(4 * q + 2) * 256 + sc], stage[(4 * q + 3) * 256 + sc]);
+                digs[(size_t)(base + sc) * (ND / 4) + q] = make_uint4(stage[(4 * q) * 256 + sc], stage[(4 * q + 1) * 256 + sc],
+                                                                    stage[(4 * q + 2) * 256 + sc], stage[(4 * q + 3) * 256 + sc]);
         }
     }
     __syncthreads();
@@ -416,10 +422,11 @@ __device__ __forceinline__ void sort2_for_digits(uint32_t k[8], int c, int W, F&
 }
 // NAF = true: W = most entries per scalar; LDS entry = sign << 31 | position << 9 | scalar index inside the chunk, the 16-bit key in a
 // second LDS array behind it; tmp1 gets sign << 31 | position * table_stride + i, tmpk the low 7 key bits.
-template <bool NAF = false>
+template <bool NAF = false, int ND = NAF_DIGITS>
 __global__ void __launch_bounds__(SORT2_P1_THREADS)
 k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uint32_t tile_s, uint32_t Hb, const uint32_t* __restrict__ blockbase1,
-                     const uint32_t* __restrict__ cstart, uint32_t table_stride, uint32_t* __restrict__ tmp1, uint8_t* __restrict__ tmpk = nullptr) {
+                     const uint32_t* __restrict__ cstart, uint32_t table_stride, uint32_t* __restrict__ tmp1, uint8_t* __restrict__ tmpk = nullptr,
+                     uint32_t poly_len = 0) {
     latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
     uint32_t* gpos = lds_u32;                 // Hb: next global position of the tile in every bin
@@ -439,20 +446,20 @@ k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W
         const uint32_t i = base + t;
         const bool have = i < hi;
         uint32_t kk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t dg[NAF ? NAF_DIGITS : 1];                 // NAF: the scalar's digits as k_sort2_scalars<false, true> left them
+        uint32_t dg[NAF ? ND : 1];                         // NAF: the scalar's digits as k_naf_digits left them
         if (NAF) {
 #pragma unroll
-            for (int m = 0; m < (NAF ? NAF_DIGITS : 1); ++m) dg[m] = NAF_NO_DIGIT;
+            for (int m = 0; m < (NAF ? ND : 1); ++m) dg[m] = NAF_NO_DIGIT;
             if (have) {
-                const uint4* src = reinterpret_cast<const uint4*>(scalars) + (size_t)i * (NAF_DIGITS / 4);
+                const uint4* src = reinterpret_cast<const uint4*>(scalars) + (size_t)i * (ND / 4);
 #pragma unroll
-                for (int q = 0; q < (NAF ? NAF_DIGITS / 4 : 0); ++q) {
+                for (int q = 0; q < (NAF ? ND / 4 : 0); ++q) {
                     const uint4 v = src[q];
                     dg[4 * q] = v.x; dg[4 * q + 1] = v.y; dg[4 * q + 2] = v.z; dg[4 * q + 3] = v.w;
                 }
                 bool live = true;                           // words behind the first NAF_NO_DIGIT are stale
 #pragma unroll
-                for (int m = 0; m < (NAF ? NAF_DIGITS : 0); ++m) {
+                for (int m = 0; m < (NAF ? ND : 0); ++m) {
                     live = live && dg[m] != NAF_NO_DIGIT;
                     if (!live) dg[m] = NAF_NO_DIGIT;
                     else atomicAdd(&hist[(dg[m] & 0xFFFFu) >> SORT2_LO_BITS], 1u);
@@ -488,7 +495,7 @@ k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W
         if (have) {
             if (NAF) {
 #pragma unroll
-                for (int m = 0; m < (NAF ? NAF_DIGITS : 0); ++m) {
+                for (int m = 0; m < (NAF ? ND : 0); ++m) {
                     if (dg[m] == NAF_NO_DIGIT) continue;
                     const uint32_t key = dg[m] & 0xFFFFu;
                     const uint32_t bin = key >> SORT2_LO_BITS;
@@ -508,7 +515,8 @@ k_sort2_scatter1_lds(const uint4* __restrict__ scalars, uint32_t n, int c, int W
         if (NAF) {
             for (uint32_t q = t; q < cn; q += SORT2_P1_THREADS) {
                 const uint32_t x = buf[q], key = bufk[q], bin = key >> SORT2_LO_BITS;
-                const uint32_t idx = ((x >> 9) & 255u) * table_stride + base + (x & 511u);
+                const uint32_t sidx = base + (x & 511u);                                // scalar index; batched mode: base point = index inside its polynomial
+                const uint32_t idx = ((x >> 9) & 255u) * table_stride + (poly_len ? sidx % poly_len : sidx);
                 const uint32_t dst = gpos[bin] + (q - lstart[bin]);
                 tmp1[dst] = (x & 0x80000000u) | idx;
                 tmpk[dst] = (uint8_t)(key & (SORT2_LO - 1));
@@ -1418,6 +1426,25 @@ k_red_bits2p(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint3
             if (role >= 0) half_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + grp[which], v[which], odd);
         }
     }
+}
+
+// Batched table mode (k_naf_digits with poly_len != 0): group g of the first reduction level IS polynomial g.  Its seven sums
+// (x1[role * G1 + g]: S_0 .. S_5 over the key bits, T the total) give the commitment sum_key (2 key + 1) V_key = 2 sum_j 2^j S_j + T:
+// six doublings and six additions on one lane per polynomial, XYZZ wire words out.
+__global__ void __launch_bounds__(64)
+k_batch_finish(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t* __restrict__ out_wire) {
+    latency_bound_kernel();
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G1) return;
+    Xyzz acc, s, t;
+    xyzz_load(acc, x1, x_stride, (size_t)5 * G1 + g);
+#pragma unroll 1
+    for (int j = 4; j >= -1; --j) {
+        xyzz_dbl_impl(t, acc);
+        xyzz_load(s, x1, x_stride, (size_t)(j >= 0 ? j : 6) * G1 + g);      // j = -1: the total
+        xyzz_add<true>(acc, t, s);
+    }
+    xyzz_store_wire(out_wire, g, acc);
 }
 
 // -------------------------------------------------------------------------------------------------

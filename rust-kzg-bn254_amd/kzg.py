@@ -76,6 +76,52 @@ class KZG:
             raise GenericError(_lib.status_message(rc))
         return out
 
+    # ---- batched commitments: many polynomials of one length against one SRS in one kernel sequence (no counterpart in the
+    # reference, which commits one polynomial per call; same values as that many calls) -----------------------------------------
+    def _commit_batch(self, rows, srs, eval_form):
+        ctx = self._ctx()
+        rows = [_lib.as_u64(r, 4).reshape(-1, 4) for r in rows]
+        if not rows:
+            return np.zeros((0, 8), dtype=np.uint64)
+        n = len(rows[0])
+        if any(len(r) != n for r in rows):
+            raise GenericError("batched commitments need polynomials of one length")
+        if n > len(srs):
+            if eval_form:
+                raise SrsCapacityExceeded(n, len(srs))
+            raise SerializationError("polynomial length is not correct")
+        data = np.ascontiguousarray(np.concatenate(rows, axis=0)) if n else np.zeros((0, 4), dtype=np.uint64)
+        out = np.zeros((len(rows), 8), dtype=np.uint64)
+        fn = _lib.load().kzg_commit_eval_form_batch if eval_form else _lib.load().kzg_commit_coeff_form_batch
+        rc = fn(ctx.handle, srs.handle, _lib.ptr(data) if n else None, n, len(rows), _lib.ptr(out), None)
+        ctx.check_device(rc)
+        if rc == _lib.ERR_NOT_POWER_OF_TWO:
+            raise FFTError("length provided is not a power of 2")
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
+        return out
+
+    def commit_coeff_form_batch(self, polynomials, srs):
+        """commit_coeff_form of every polynomial (all of one length) in ONE call: (count, 8) wire points."""
+        return self._commit_batch([p.coeffs() for p in polynomials], srs, False)
+
+    def commit_eval_form_batch(self, polynomials, srs):
+        """commit_eval_form of every polynomial (all of one padded length) in ONE call; the Lagrange basis of that length stays cached with the SRS."""
+        return self._commit_batch([p.evaluations() for p in polynomials], srs, True)
+
+    def commit_blob_batch(self, blobs, srs):
+        """commit_blob (kzg.rs:182-185) of every blob; blobs whose polynomials differ in length are grouped by length."""
+        polys = [b.to_polynomial_eval_form() for b in blobs]
+        out = np.zeros((len(polys), 8), dtype=np.uint64)
+        by_len = {}
+        for i, p in enumerate(polys):
+            by_len.setdefault(len(p), []).append(i)
+        for _, idx in sorted(by_len.items()):
+            res = self.commit_eval_form_batch([polys[i] for i in idx], srs)
+            for i, r in zip(idx, res):
+                out[i] = r
+        return out
+
     # ---- streams of commitments, two in flight (kzg_*_begin(slot) / kzg_msm_g1_srs_end(slot)) --------------------------
     def _pipelined(self, items, begin):
         """begin(item, slot) -> status, or None when the item needs no device work (yields the identity)."""

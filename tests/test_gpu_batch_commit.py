@@ -1,0 +1,124 @@
+"""-m gpu: batched commitments (kzg_commit_*_form_batch: many polynomials of one length against one SRS in ONE kernel sequence --
+width-8 NAF digits over the SRS's per-bit tables, 64 buckets per polynomial).  No counterpart in the reference, which commits one
+polynomial per call (prover/src/kzg.rs:84-125): the batch must equal that many single commitments, the oracle and known-tau values."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import pyref
+from pyref import R_
+
+pytestmark = pytest.mark.gpu
+
+TAU = int.from_bytes(__import__("hashlib").sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % R_
+
+
+@pytest.fixture(scope="module")
+def k():
+    import rust_kzg_bn254_amd as k
+    k.load()
+    k.default_context()
+    return k
+
+
+@pytest.fixture(scope="module")
+def tau_srs(k):
+    s = k.SRS.generate(TAU, 1 << 15)
+    yield s
+    s.close()
+
+
+def rand_poly(k, n, seed, mod=R_):
+    rnd = random.Random(seed)
+    return k.PolynomialCoeffForm(pyref.frs_to_mont([rnd.randrange(mod) for _ in range(n)]))
+
+
+def test_batch_equals_singles_and_oracle_on_the_reference_srs(k, test_srs_wire):
+    """3000 reference points (no per-bit tables until the first batched call builds them): 5 polynomials of 512 coefficients."""
+    srs = k.SRS(test_srs_wire, order=3000)
+    kzg = k.KZG.new()
+    polys = [rand_poly(k, 512, 100 + i) for i in range(5)]
+    got = kzg.commit_coeff_form_batch(polys, srs)
+    assert got.shape == (5, 8)
+    for p, g in zip(polys, got):
+        assert np.array_equal(g, kzg.commit_coeff_form(p, srs))
+        assert np.array_equal(g, orc.msm_pippenger(test_srs_wire[:512], p.coeffs()))
+    # a second call (tables already there), another length, a single polynomial
+    one = kzg.commit_coeff_form_batch([rand_poly(k, 1000, 7)], srs)
+    assert np.array_equal(one[0], kzg.commit_coeff_form(rand_poly(k, 1000, 7), srs))
+    assert kzg.commit_coeff_form_batch([], srs).shape == (0, 8)
+    with pytest.raises(k.errors.SerializationError):
+        kzg.commit_coeff_form_batch([rand_poly(k, 4096, 1)], srs)
+    with pytest.raises(k.errors.GenericError):
+        kzg.commit_coeff_form_batch([rand_poly(k, 512, 1), rand_poly(k, 256, 2)], srs)
+    srs.close()
+
+
+def test_batch_of_special_polynomials_known_tau(k, tau_srs):
+    """1 030 polynomials of 512 coefficients (two launches: 1 024 + 6) on a known-tau SRS: random ones, the zero polynomial, one-hot,
+    all r - 1, all 1, 2^253 - 1 beside 2^36 - 1 (the digit patterns that exposed the recoder's miscompiled branch): every commitment
+    against (sum_i c_i tau^i) G by big-integer arithmetic."""
+    kzg = k.KZG.new()
+    n, count = 512, 1030
+    rnd = random.Random(9)
+    tp = [pow(TAU, i, R_) for i in range(n)]
+    rows = []
+    for j in range(count):
+        kind = j % 8
+        if kind == 0:
+            v = [0] * n
+        elif kind == 1:
+            v = [0] * n; v[(j * 37) % n] = rnd.randrange(R_)
+        elif kind == 2:
+            v = [R_ - 1] * n
+        elif kind == 3:
+            v = [1] * n
+        elif kind == 4:
+            v = [(1 << 253) - 1 if i % 2 == 0 else (1 << 36) - 1 for i in range(n)]
+        else:
+            v = [rnd.randrange(R_) for _ in range(n)]
+        rows.append(v)
+    polys = [k.PolynomialCoeffForm(pyref.frs_to_mont(v)) for v in rows]
+    got = kzg.commit_coeff_form_batch(polys, tau_srs)
+    for j in list(range(0, 40)) + list(range(1000, count)):
+        s = sum(c * t for c, t in zip(rows[j], tp)) % R_
+        want = pyref.ec_mul(s, (1, 2)) if s else None
+        assert pyref.point_from_wire(got[j]) == want, j
+    # and all of them against single commitments at a stride
+    for j in range(0, count, 97):
+        assert np.array_equal(got[j], kzg.commit_coeff_form(polys[j], tau_srs)), j
+
+
+def test_batch_2048_coefficients_equals_singles(k, tau_srs):
+    kzg = k.KZG.new()
+    polys = [rand_poly(k, 2048, 500 + i, mod=1 << 248) for i in range(64)]
+    got = kzg.commit_coeff_form_batch(polys, tau_srs)
+    for p, g in zip(polys, got):
+        assert np.array_equal(g, kzg.commit_coeff_form(p, tau_srs))
+
+
+def test_eval_form_and_blob_batches(k, tau_srs):
+    """commit_eval_form_batch == commit_eval_form per polynomial (the batch goes through the cached Lagrange basis: the reference's
+    literal form, kzg.rs:98-100); blobs of several lengths; error cases of the single call."""
+    kzg = k.KZG.new()
+    rnd = random.Random(3)
+    polys = [k.PolynomialEvalForm(pyref.frs_to_mont([rnd.randrange(R_) for _ in range(1024)])) for _ in range(8)]
+    got = kzg.commit_eval_form_batch(polys, tau_srs)
+    for p, g in zip(polys, got):
+        assert np.array_equal(g, kzg.commit_eval_form(p, tau_srs))
+    blobs = [k.Blob.from_raw_data(bytes(rnd.randrange(32, 127) for _ in range(ln))) for ln in (1000, 31 * 64, 5000, 31 * 64 - 3, 20000, 999)]
+    gotb = kzg.commit_blob_batch(blobs, tau_srs)
+    for b, g in zip(blobs, gotb):
+        assert np.array_equal(g, kzg.commit_blob(b, tau_srs))
+    lib = k._lib.load()
+    ctx = tau_srs.ctx
+    out = np.zeros((2, 8), np.uint64)
+    data = np.zeros((2 * 48, 4), np.uint64)
+    assert lib.kzg_commit_eval_form_batch(ctx.handle, tau_srs.handle, k._lib.ptr(data), 48, 2, k._lib.ptr(out), None) == k._lib.ERR_NOT_POWER_OF_TWO
+    assert lib.kzg_commit_eval_form_batch(ctx.handle, tau_srs.handle, k._lib.ptr(data), 1 << 16, 2, k._lib.ptr(out), None) == k._lib.ERR_SRS_CAPACITY_EXCEEDED
+    assert lib.kzg_commit_coeff_form_batch(ctx.handle, tau_srs.handle, k._lib.ptr(data), 1 << 16, 2, k._lib.ptr(out), None) == k._lib.ERR_POLY_LENGTH
+    tau_srs.drop_lagrange()
