@@ -21,6 +21,8 @@
 #include "host_curve.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -200,7 +202,9 @@ k_g1fft_scalars(uint4* __restrict__ scal, uint32_t n, int log_n, NttTables tb_in
     fe_canon(c);
     uint32_t kc[8], k[8];
     fe_pack(kc, c);
-    if (canon) {
+    if (canon == 2) {                                // wire words (arkworks Montgomery form): the scalars of an MSM
+        fe_to_wire(k, w);
+    } else if (canon) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) k[j] = kc[j];
     } else {
@@ -577,6 +581,16 @@ k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, uint32_t n, const 
     }
     if (pair == 0) half_store(partial, (size_t)n * waves_per_out, (size_t)o * waves_per_out + wv, acc, odd);
 }
+// scalars of the transform as n MSMs of n pairs (the batched table mode of msm.hip): out[o n + j] = w^(-o j) / n, wire words
+__global__ void __launch_bounds__(256)
+k_g1fft_expand_scalars(const uint4* __restrict__ tab_wire, uint32_t n, uint4* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * n) return;
+    const uint32_t o = (uint32_t)(t / n), j = (uint32_t)(t - (size_t)o * n);
+    const uint32_t e = (uint32_t)((unsigned long long)o * j) & (n - 1);
+    out[2 * t] = tab_wire[2 * (size_t)e];
+    out[2 * t + 1] = tab_wire[2 * (size_t)e + 1];
+}
 // y[o] = sum of the waves_per_out (<= 32) partial sums of output o: one wave per output
 __global__ void __launch_bounds__(256)
 k_g1fft_sum_partials(const int32_t* __restrict__ partial, uint32_t waves_per_out, uint32_t n, int32_t* __restrict__ y) {
@@ -666,9 +680,9 @@ k_g1fft_to_affine(const int32_t* __restrict__ planes, uint32_t n, uint4* __restr
 struct ScalKey { int dev, log_n, scaled; bool operator<(const ScalKey& o) const { return dev != o.dev ? dev < o.dev : (log_n != o.log_n ? log_n < o.log_n : scaled < o.scaled); } };   // scaled: bit 0 = times 1/n, bit 1 = canonical (not GLV-split)
 static std::map<ScalKey, uint4*> g_scal;
 static std::mutex g_scal_mu;
-static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** out, bool canon = false) {
+static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** out, int canon = 0) {     // canon: 0 GLV halves, 1 canonical integers, 2 wire words
     std::lock_guard<std::mutex> lk(g_scal_mu);
-    ScalKey key{ctx->device, log_n, (scaled ? 1 : 0) | (canon ? 2 : 0)};
+    ScalKey key{ctx->device, log_n, (scaled ? 1 : 0) | (canon << 1)};
     auto it = g_scal.find(key);
     if (it != g_scal.end()) { *out = it->second; return KZG_OK; }
     NttTables tb{};
@@ -676,7 +690,7 @@ static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** o
     const size_t n = (size_t)1 << log_n;
     uint4* p = nullptr;
     KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&p), n * 32));
-    hipLaunchKernelGGL(k_g1fft_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, (uint32_t)n, log_n, tb, scaled ? 1 : 0, canon ? 1 : 0);
+    hipLaunchKernelGGL(k_g1fft_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, (uint32_t)n, log_n, tb, scaled ? 1 : 0, canon);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     g_scal[key] = p;
@@ -689,7 +703,7 @@ struct Naf2Lists { uint16_t* list = nullptr; uint32_t* cnt = nullptr; };
 static std::map<std::pair<int, int>, Naf2Lists> g_naf2;
 static int32_t get_naf2(kzg_ctx* ctx, int log_n, Naf2Lists* out) {
     const uint4* sc = nullptr;
-    int32_t rc = get_scalars(ctx, log_n, true, &sc, true);              // canonical integers of w^-e / n
+    int32_t rc = get_scalars(ctx, log_n, true, &sc, 1);              // canonical integers of w^-e / n
     if (rc != KZG_OK) return rc;
     std::lock_guard<std::mutex> lk(g_scal_mu);
     auto key = std::make_pair(ctx->device, log_n);
@@ -809,7 +823,7 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
             const size_t lanes = n << K;
             if (i == 0 && first_tables) {
                 const uint4* sc = nullptr;
-                rc = get_scalars(ctx, log_n, last, &sc, true);                // canonical scalars (scaled by 1/n when this is also the last stage)
+                rc = get_scalars(ctx, log_n, last, &sc, 1);                // canonical scalars (scaled by 1/n when this is also the last stage)
                 if (rc != KZG_OK) return rc;
                 KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)n * wpo * 36 * 4));
                 int32_t* partial = ctx->poly[0].c.as<int32_t>();
@@ -858,7 +872,44 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
 // on the device it is a 380-multiplication chain on lone lanes, 0.2 ms whatever n -- two thirds of a g1_ifft of 2..32 points.
 constexpr size_t G1FFT_HOST_AFFINE_MAX = 256;
 
+// The transform as n MSMs of n pairs over the per-bit tables: L_o = sum_j [w^(-o j) / n] P_j is the "commitment" of the scalar row o,
+// so the batched table mode of the MSM engine (msm.hip msm_run_batch_tables: width-8 NAF digits, 64 buckets per output, one sort, the
+// accumulate kernel, one reduction group per output) computes all n outputs in one kernel sequence: n^2 x 28.7 mixed additions instead
+// of the n^2 x 85 of k_g1fft_bits.  The n^2 scalars are expanded once per size (32 n^2 bytes: 8 MiB at 512 points) and kept.
+static std::map<std::pair<int, int>, uint4*> g_expanded;
+static int32_t g1_ifft_as_batched_msm(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy) {
+    int log_n = 0;
+    while (((size_t)1 << log_n) < n) ++log_n;
+    const uint4* tabw = nullptr;
+    int32_t rc = get_scalars(ctx, log_n, true, &tabw, 2);
+    if (rc != KZG_OK) return rc;
+    uint4* exp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_scal_mu);
+        auto key = std::make_pair(ctx->device, log_n);
+        auto it = g_expanded.find(key);
+        if (it != g_expanded.end()) exp = it->second;
+        else {
+            KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&exp), n * n * 32));
+            hipLaunchKernelGGL(k_g1fft_expand_scalars, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, tabw, (uint32_t)n, exp);
+            KZG_HIP_TRY(ctx, hipGetLastError());
+            g_expanded[key] = exp;
+        }
+    }
+    MsmBases b;
+    b.points = srs->d_bits; b.table_stride = (uint32_t)srs->n; b.c = 7; b.W = 255; b.naf = true;
+    return msm_run_batch_tables(ctx, b, exp, n, n, out_xy, nullptr);
+}
+
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy) {
+    // sizes the batched MSM wins at (measured, tools/time_g1ifft.py): KZG_G1FFT_BATCH="lo,hi" overrides, "0" switches it off
+    static const std::pair<size_t, size_t> batch_range = []() {
+        size_t lo = 512, hi = 512;     // 64 / 128 / 256 / 512 / 1024 points: 0.49 / 0.55 / 0.70 / 1.15 / 3.0 ms this way, 0.19 / 0.26 / 0.68 / 1.84 / 1.96 ms otherwise
+        if (const char* e = getenv("KZG_G1FFT_BATCH")) { unsigned long a = 0, b2 = 0; int k = sscanf(e, "%lu,%lu", &a, &b2); lo = a; hi = k == 2 ? b2 : a; if (a == 0) { lo = 1; hi = 0; } }
+        return std::make_pair(lo, hi);
+    }();
+    if (srs->d_bits && srs->lagrange_of == 0 && n >= batch_range.first && n <= batch_range.second && n <= 1024 && !ctx->slot_pending[0])
+        return g1_ifft_as_batched_msm(ctx, srs, n, out_xy);
     if (n <= G1FFT_HOST_AFFINE_MAX) {
         const int32_t* result = nullptr;
         int32_t rc = g1_ifft_stages(ctx, srs, n, &result);
