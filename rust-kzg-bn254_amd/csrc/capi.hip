@@ -676,6 +676,7 @@ static int32_t commit_batch_common(kzg_ctx* ctx, kzg_srs* srs, const void* scala
     if (!on_device) {
         KZG_HIP_TRY(ctx, ctx->msm.scalars.reserve(count * n * 32 + 32));
         KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm.scalars.p, scalars, count * n * 32, hipMemcpyHostToDevice, ctx->stream));
+        KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the launches run on the slots' streams
         d = ctx->msm.scalars.p;
     }
     return commit_batch_device(ctx, basis, d, n, count, out_xy, out_inf);

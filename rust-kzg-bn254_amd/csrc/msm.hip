@@ -67,6 +67,16 @@ static int generic_window(size_t n, uint32_t batch) {
     return c;
 }
 
+// Batched table mode: bucket bits per polynomial by its length (width c + 1 digits over the per-bit tables).  Short polynomials: 64
+// buckets, one group of the first reduction level each; from 2^13 coefficients whole units of 4 096 buckets, reduced like a single MSM.
+static int batch_bucket_bits(size_t poly_len) {
+    static const int forced = []() { const char* e = getenv("KZG_BATCH_C"); return e ? atoi(e) : 0; }();
+    if (forced == 7 || forced == 13 || forced == 15 || forced == 16) return forced;
+    if (poly_len < ((size_t)1 << 13)) return 7;
+    if (poly_len < ((size_t)1 << 15)) return 13;
+    if (poly_len < ((size_t)1 << 18)) return 15;
+    return 16;
+}
 static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint32_t batch, uint32_t polys = 0) {
     Plan p;
     p.n = (uint32_t)n;
@@ -76,7 +86,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     p.polys = p.naf ? polys : 0;
     int c;
     if (p.polys) {
-        c = 7;                                             // width-8 digits: keys < 64
+        c = batch_bucket_bits(n / p.polys);                // 7: 64 buckets per polynomial (k_batch_finish); 13 / 15 / 16: whole units of 4 096 buckets (second level + host epilogue per polynomial)
     } else if (p.tables) {
         c = bases.c;
     } else {
@@ -87,7 +97,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     }
     p.c = c;
     p.W = p.naf ? naf_max_digits(c + 1) : (255 + c - 1) / c;
-    p.B = p.polys ? 64u * ((p.polys + 1u) & ~1u) : 1u << (c - 1);      // (a multiple of 128: whole coarse bins)
+    p.B = p.polys ? (c == 7 ? 64u * ((p.polys + 1u) & ~1u) : p.polys << (c - 1)) : 1u << (c - 1);      // (a multiple of 128: whole coarse bins)
     p.sets = p.tables ? 1u : (uint32_t)p.W * batch;
     p.G = p.sets * p.B;
     const size_t entries_cap = (size_t)p.W * n * batch;                  // buffer sizes
@@ -248,7 +258,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
     if (polys && (!bases.naf || n % polys != 0 || polys > MSM_BATCH_POLYS_MAX)) return KZG_ERR_INVALID_ARG;
     const Plan p = make_plan(ctx, n, bases, batch, polys);
-    const int ND = p.polys ? 32 : NAF_DIGITS;              // digit words per scalar
+    if (p.polys && p.B > 65536) return KZG_ERR_INVALID_ARG;
+    const int ND = p.c + 1 >= 16 ? NAF_DIGITS : 32;        // digit words per scalar (width >= 16: at most 16 digits)
     const size_t entries = (size_t)p.W * n * batch;
     const uint32_t n_windows = (uint32_t)p.W * batch;          // window sums produced in generic mode
     if (!p.tables && n_windows > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
@@ -339,12 +350,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_HIP_TRY(ctx, hipMemsetAsync(ccount, 0, (size_t)p.Hb * 4, st));
         uint8_t* tmpk = p.naf ? ws.sort_key.as<uint8_t>() : nullptr;
         const uint32_t poly_len = p.polys ? p.n / p.polys : 0u;
-        if (p.naf && p.polys)
+        if (p.naf && ND == 32)
             hipLaunchKernelGGL(k_naf_digits<32>, dim3(p.tiles1), dim3(256), ((size_t)p.Hb + (11 + 32) * 256) * 4, st, d_scalars, p.n, p.c, p.tile1, p.Hb, ccount,
                                ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), poly_len);
         else if (p.naf)
             hipLaunchKernelGGL(k_naf_digits<NAF_DIGITS>, dim3(p.tiles1), dim3(256), ((size_t)p.Hb + (11 + NAF_DIGITS) * 256) * 4, st, d_scalars, p.n, p.c, p.tile1, p.Hb, ccount,
-                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), 0u);
+                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), poly_len);
         else
         hipLaunchKernelGGL(k_sort2_scalars<false>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
                            ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, p.idx_stride, (uint32_t*)nullptr);
@@ -353,12 +364,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         static const bool direct_scatter = []() { const char* e = getenv("KZG_SORT2_DIRECT"); return e && atoi(e) != 0; }();   // A/B: pass 1 without the LDS staging
         if (p.naf) {
             const size_t lds1 = ((size_t)3 * p.Hb + (size_t)SORT2_P1_THREADS * p.W) * 4 + (size_t)SORT2_P1_THREADS * p.W * 2;
-            if (p.polys)
+            if (ND == 32)
                 hipLaunchKernelGGL((k_sort2_scatter1_lds<true, 32>), dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, ws.digits.as<uint4>(), p.n, p.c, p.W, p.tile1, p.Hb,
                                    ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), tmpk, poly_len);
             else
             hipLaunchKernelGGL(k_sort2_scatter1_lds<true>, dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, ws.digits.as<uint4>(), p.n, p.c, p.W, p.tile1, p.Hb,
-                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), tmpk, 0u);
+                               ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), tmpk, poly_len);
         } else if (direct_scatter || p.W > 31) {
             hipLaunchKernelGGL(k_sort2_scalars<true>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
                                ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>());
@@ -441,7 +452,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
             hipLaunchKernelGGL(k_msm_bucket_bits1, dim3((G1 * 64 + 255) / 256), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, ws.out_wire.as<uint32_t>());
         KZG_MARK(6);
-        if (p.polys) {
+        if (p.polys && p.c == 7) {
             hipLaunchKernelGGL(k_batch_finish, dim3((p.polys + 63) / 64), dim3(64), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, ws.out_wire.as<uint32_t>());
             n_out = p.polys;
         } else if (G1 == 1) {
@@ -532,48 +543,56 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
             result[b] = kzg_host::horner_windows(vals + (size_t)b * p.W, p.W, p.c);   // sum_w 2^(c w) S_w: <= 255 doublings
         return KZG_OK;
     }
-    if (p.polys) {                                         // batched table mode: k_batch_finish left one commitment per polynomial
+    if (p.polys && p.c == 7) {                             // batched table mode, 64 buckets per polynomial: k_batch_finish left one commitment each
         for (uint32_t b = 0; b < p.polys; ++b) result[b] = vals[b];
         return KZG_OK;
     }
-    // sum_b (b+1) V_b = T + sum_j 2^j S_j over the bits j of the 0-based bucket index
-    Xyzz S[32];
-    int nbits = 0;
-    Xyzz total;
-    if (G1 == 1) {
-        for (int j = 0; j < 6; ++j) S[j] = vals[j];
-        nbits = 6;
-        total = vals[6];
-    } else {
-        const Xyzz* Y = vals;
-        const Xyzz* X2 = vals + 6 * G1p;
-        for (int j = 0; j < 6; ++j) {
-            Xyzz a = kzg_host::xyzz_inf(), b = kzg_host::xyzz_inf();
-            for (uint32_t g = 0; g < G1p; ++g) { a = kzg_host::xyzz_add(a, Y[j * G1p + g]); b = kzg_host::xyzz_add(b, X2[j * G1p + g]); }
-            S[j] = a;
-            S[6 + j] = b;
+    // sum_b (b+1) V_b = T + sum_j 2^j S_j over the bits j of the 0-based bucket index, for the units [unit_lo, unit_lo + units) of 4 096
+    // buckets each (one MSM: all of them; batched table mode: the units of one polynomial)
+    auto epilogue = [&](uint32_t unit_lo, uint32_t units) -> Xyzz {
+        Xyzz S[32];
+        int nbits = 0;
+        Xyzz total;
+        if (G1 == 1) {
+            for (int j = 0; j < 6; ++j) S[j] = vals[j];
+            nbits = 6;
+            total = vals[6];
+        } else {
+            const Xyzz* Y = vals;
+            const Xyzz* X2 = vals + 6 * G1p;
+            for (int j = 0; j < 6; ++j) {
+                Xyzz a = kzg_host::xyzz_inf(), b = kzg_host::xyzz_inf();
+                for (uint32_t g = unit_lo; g < unit_lo + units; ++g) { a = kzg_host::xyzz_add(a, Y[j * G1p + g]); b = kzg_host::xyzz_add(b, X2[j * G1p + g]); }
+                S[j] = a;
+                S[6 + j] = b;
+            }
+            nbits = 12;
+            total = kzg_host::xyzz_inf();
+            for (uint32_t g = unit_lo; g < unit_lo + units; ++g) total = kzg_host::xyzz_add(total, X2[6 * G1p + g]);
+            for (int i = 0; (1u << i) < units; ++i) {
+                Xyzz a = kzg_host::xyzz_inf();
+                for (uint32_t g = 0; g < units; ++g) if ((g >> i) & 1u) a = kzg_host::xyzz_add(a, X2[6 * G1p + unit_lo + g]);
+                S[nbits++] = a;
+            }
         }
-        nbits = 12;
-        total = kzg_host::xyzz_inf();
-        for (uint32_t g = 0; g < G1p; ++g) total = kzg_host::xyzz_add(total, X2[6 * G1p + g]);
-        for (int i = 0; (1u << i) < G1p; ++i) {
-            Xyzz a = kzg_host::xyzz_inf();
-            for (uint32_t g = 0; g < G1p; ++g) if ((g >> i) & 1u) a = kzg_host::xyzz_add(a, X2[6 * G1p + g]);
-            S[nbits++] = a;
+        if (p.naf) {                                      // the bucket index is the key rotated by six bits (naf.h naf_bucket)
+            Xyzz Sk[32];
+            for (int t = 0; t < nbits; ++t) Sk[naf_key_bit_of_bucket_bit(t, nbits)] = S[t];
+            for (int j = 0; j < nbits; ++j) S[j] = Sk[j];
         }
+        Xyzz acc = kzg_host::xyzz_inf();
+        for (int j = nbits - 1; j >= 0; --j) { acc = kzg_host::xyzz_dbl(acc); acc = kzg_host::xyzz_add(acc, S[j]); }
+        if (p.naf) acc = kzg_host::xyzz_dbl(acc);         // bucket b holds the odd digit 2 b + 1: sum_b (2 b + 1) V_b = 2 sum_b b V_b + T
+        return kzg_host::xyzz_add(acc, total);
+    };
+    if (p.polys) {                                         // batched table mode with whole units per polynomial
+        const uint32_t units = (1u << (p.c - 1)) / 4096u;
+        for (uint32_t b = 0; b < p.polys; ++b) result[b] = epilogue(b * units, units);
+        return KZG_OK;
     }
-    if (p.naf) {                                          // the bucket index is the key rotated by six bits (naf.h naf_bucket)
-        Xyzz Sk[32];
-        for (int t = 0; t < nbits; ++t) Sk[naf_key_bit_of_bucket_bit(t, nbits)] = S[t];
-        for (int j = 0; j < nbits; ++j) S[j] = Sk[j];
-    }
-    Xyzz acc = kzg_host::xyzz_inf();
-    for (int j = nbits - 1; j >= 0; --j) { acc = kzg_host::xyzz_dbl(acc); acc = kzg_host::xyzz_add(acc, S[j]); }
-    if (p.naf) acc = kzg_host::xyzz_dbl(acc);             // bucket b holds the odd digit 2 b + 1: sum_b (2 b + 1) V_b = 2 sum_b b V_b + T
-    *result = kzg_host::xyzz_add(acc, total);
+    *result = epilogue(0, G1p);
     return KZG_OK;
 }
-
 // ---- two-slot asynchronous form: begin enqueues, end waits and runs the host epilogue ---------------------------------
 // Pairs per launch of an MSM over `bases`.  Tables more than 2^24 / W points apart (an SRS beyond 2^20 points at c = 17) are walked
 // in power-of-two chunks whose COMPACT indices fit the two-level sort (make_plan): a 2^22-point commitment is four 2^20 launches.
@@ -730,30 +749,61 @@ int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars
 // polynomials in one kernel sequence per MSM_BATCH_POLYS_MAX polynomials.  d_scalars: polys x n wire scalars, polynomial after polynomial.
 int32_t msm_run_batch_tables(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n, size_t polys, uint64_t* out_xy, uint8_t* out_inf) {
     if (!bases.naf || n == 0) return KZG_ERR_INVALID_ARG;
-    if (ctx->slot_pending[0]) {
-        ctx->last_error = "a kzg_*_begin on slot 0 is still in flight: call kzg_msm_g1_srs_end(ctx, 0, ..) first";
-        return KZG_ERR_INVALID_ARG;
-    }
-    // polynomials per launch: 64 buckets each in one 2^16-bucket array, 2^24 pairs at most
-    size_t per = std::min<size_t>(MSM_BATCH_POLYS_MAX, MSM_MAX_LAUNCH / n);
+    for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl)
+        if (ctx->slot_pending[sl]) {
+            ctx->last_error = "a kzg_*_begin is still in flight: the batched commitments use the slots' streams and workspaces themselves";
+            return KZG_ERR_INVALID_ARG;
+        }
+    // polynomials per launch: 2^(c-1) buckets each in one 2^16-bucket array, 2^24 pairs at most
+    const int cb = batch_bucket_bits(n);
+    const size_t per = std::min<size_t>(std::min<size_t>(MSM_BATCH_POLYS_MAX, (size_t)65536 >> (cb - 1)), MSM_MAX_LAUNCH / n);
     if (per == 0) return KZG_ERR_TOO_LARGE;
+    // The launches run as a software pipeline over the slots (their own streams and workspaces): launch k + 1 .. k + 2 are enqueued
+    // before launch k is collected, so the latency-bound kernels of one overlap the accumulate kernel of another -- a launch of 2^17
+    // scalars takes 0.42 ms alone and 0.22 ms with three in flight (section 6b of DESIGN.md).
+    constexpr int DEPTH = 3;
+    static_assert(DEPTH <= KZG_NUM_SLOTS, "one slot per launch in flight");
+    Pending pend[DEPTH];
+    size_t first[DEPTH] = {}, cnt[DEPTH] = {};
+    bool busy[DEPTH] = {};
     static thread_local std::vector<kzg_host::Xyzz> res;
     res.resize(std::min(per, polys));
     const uint4* sc = reinterpret_cast<const uint4*>(d_scalars);
-    for (size_t done = 0; done < polys; done += per) {
-        const size_t k = std::min(per, polys - done);
-        Pending pend;
-        int32_t rc = msm_enqueue(ctx, ctx->msm, ctx->stream, bases, sc + 2 * done * n, n * k, 1, &pend, 0, MSM_MAX_OUT, (uint32_t)k);
-        if (rc == KZG_OK) rc = msm_finish(ctx, ctx->msm, ctx->stream, pend, res.data());
+    auto collect = [&](int s) -> int32_t {
+        hipStream_t st = nullptr;
+        (void)msm_slot_stream(ctx, s, &st);
+        int32_t rc = msm_finish(ctx, ctx->slot_msm(s), st, pend[s], res.data());
+        busy[s] = false;
         if (rc != KZG_OK) return rc;
-        kzg_host::xyzz_batch_to_affine(res.data(), k, out_xy + 8 * done);
+        kzg_host::xyzz_batch_to_affine(res.data(), cnt[s], out_xy + 8 * first[s]);
         if (out_inf)
-            for (size_t i = 0; i < k; ++i) {
-                const uint64_t* q = out_xy + 8 * (done + i);
-                out_inf[done + i] = (q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | q[6] | q[7]) == 0 ? 1 : 0;
+            for (size_t i = 0; i < cnt[s]; ++i) {
+                const uint64_t* q = out_xy + 8 * (first[s] + i);
+                out_inf[first[s] + i] = (q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | q[6] | q[7]) == 0 ? 1 : 0;
             }
+        return KZG_OK;
+    };
+    int32_t rc = KZG_OK;
+    size_t launch = 0;
+    for (size_t done = 0; done < polys && rc == KZG_OK; done += per, ++launch) {
+        const int s = (int)(launch % DEPTH);
+        if (busy[s]) rc = collect(s);
+        if (rc != KZG_OK) break;
+        const size_t k = std::min(per, polys - done);
+        hipStream_t st = nullptr;
+        rc = msm_slot_stream(ctx, s, &st);
+        if (rc != KZG_OK) break;
+        rc = msm_enqueue(ctx, ctx->slot_msm(s), st, bases, sc + 2 * done * n, n * k, 1, &pend[s], 0, MSM_MAX_OUT, (uint32_t)k);
+        if (rc != KZG_OK) break;
+        first[s] = done; cnt[s] = k; busy[s] = true;
     }
-    return KZG_OK;
+    for (size_t q = 0; q < DEPTH; ++q) {                   // drain in launch order (also after an error: nothing stays in flight)
+        const int s = (int)((launch + q) % DEPTH);
+        if (!busy[s]) continue;
+        const int32_t r2 = collect(s);
+        if (rc == KZG_OK) rc = r2;
+    }
+    return rc;
 }
 
 }  // namespace kzg

@@ -375,9 +375,9 @@ k_naf_digits(const uint4* __restrict__ scalars, uint32_t n, int c, uint32_t tile
 #pragma unroll
             for (int j = 0; j < 8; ++j) col[j * 256] = k[j];
             uint32_t m = 0;
-            const uint32_t group = poly_len ? (i / poly_len) << 6 : 0u;
+            const uint32_t group = poly_len ? (i / poly_len) << (c - 1) : 0u;        // batched mode: the polynomial's 2^(c-1) buckets
             naf_for_digits_lds(col, 256, c + 1, [&](uint32_t pos, uint32_t key, uint32_t neg) {
-                const uint32_t g = poly_len ? group | key : naf_bucket(key, c - 1);
+                const uint32_t g = group | (c - 1 > 6 ? naf_bucket(key, c - 1) : key);
                 atomicAdd(&hist[g >> SORT2_LO_BITS], 1u);
                 if (m < (uint32_t)ND) stage[m * 256 + t] = (neg << 31) | (pos << 16) | g;
                 ++m;

@@ -101,6 +101,21 @@ def test_batch_2048_coefficients_equals_singles(k, tau_srs):
         assert np.array_equal(g, kzg.commit_coeff_form(p, tau_srs))
 
 
+@pytest.mark.parametrize("log_n,count", [(13, 19), (14, 5), (15, 6)])
+def test_batch_of_long_polynomials_equals_singles(k, tau_srs, log_n, count):
+    """From 2^13 coefficients a polynomial gets whole units of 4 096 buckets (13 bucket bits: 16 polynomials per launch; 15: four) and the
+    second reduction level + host epilogue of a single MSM, per polynomial: batch == single calls, incl. a zero polynomial and r - 1."""
+    kzg = k.KZG.new()
+    n = 1 << log_n
+    polys = [rand_poly(k, n, 900 + 31 * log_n + i, mod=(1 << 248) if i % 2 else R_) for i in range(count - 2)]
+    polys.append(k.PolynomialCoeffForm(pyref.frs_to_mont([0] * n)))
+    polys.append(k.PolynomialCoeffForm(pyref.frs_to_mont([R_ - 1] * n)))
+    got = kzg.commit_coeff_form_batch(polys, tau_srs)
+    for j, (p, g) in enumerate(zip(polys, got)):
+        assert np.array_equal(g, kzg.commit_coeff_form(p, tau_srs)), (log_n, j)
+    assert not got[count - 2].any()
+
+
 def test_eval_form_and_blob_batches(k, tau_srs):
     """commit_eval_form_batch == commit_eval_form per polynomial (the batch goes through the cached Lagrange basis: the reference's
     literal form, kzg.rs:98-100); blobs of several lengths; error cases of the single call."""

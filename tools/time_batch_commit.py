@@ -10,7 +10,7 @@ lib = _lib.load()
 ctx = k.Context(0)
 tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % bench.FR
 srs = k.SRS.generate(tau, 1 << 16, ctx=ctx)
-for n, count in ((512, 1024), (1024, 1024), (2048, 1024), (4096, 1024), (2048, 64), (2048, 4096), (16384, 256)):
+for n, count in ((512, 1024), (1024, 1024), (2048, 1024), (4096, 1024), (2048, 64), (2048, 4096), (8192, 256), (16384, 256), (32768, 64), (65536, 32)):
     sc = bench.blob_like_scalars(n * count, 77)
     d = torch.from_numpy(sc.view(np.int64)).cuda(); torch.cuda.synchronize()
     out = np.zeros((count, 8), np.uint64)

@@ -71,7 +71,9 @@ template <class K> int run(const char* name, K kern, int blocks, uint32_t* d_out
 int main(int argc, char** argv) {
     const int max_log = argc > 1 ? atoi(argv[1]) : 28;            // points of 64 B: 2^28 = 16 GiB
     const size_t pts = (size_t)1 << max_log;
-    uint4* d_pts; CHECK(hipMalloc(&d_pts, pts * 64));
+    uint4* d_pts;
+    if (getenv("GATHER_CONTIGUOUS")) { CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&d_pts), pts * 64, hipDeviceMallocContiguous)); printf("hipDeviceMallocContiguous\n"); }
+    else CHECK(hipMalloc(&d_pts, pts * 64));
     std::vector<uint32_t> h(1 << 22);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)(i * 2654435761u + 12345u) & 0x0FFFFFFFu;
     CHECK(hipMemcpy(d_pts, h.data(), h.size() * 4, hipMemcpyHostToDevice));
