@@ -233,6 +233,10 @@ def main():
     pipelined = os.environ.get("KZG_BENCH_PIPELINE", "1") != "0"
     depth_used = (DEPTH or (2 if sh.len >= (1 << 20) else 3)) if pipelined else 1
 
+    # shard-sized steps (N > 1: 2^20 / N pairs per rank) CAN share launches: `GROUP` consecutive steps as ONE batched launch of the MSM engine
+    # (KZG_SHARD_GROUP_AUTO=1: 4 below 2^18 pairs per rank, 2 below 2^19; 0.164 against 0.22-0.24 ms per step in steady state at 2^17).  Off by
+    # default: the first grouped launch on an idle GPU stalls 6-7 ms (ShardedMsm.group_depth), which a 20-step run cannot amortise
+    GROUP = sh.auto_group() if pipelined else 1
     trace = os.environ.get("KZG_BENCH_TRACE") == "1"                    # per-step completion times on stderr (diagnostics)
 
     def run_steps(count, ptr, depth, bucket=None, keep=None):
@@ -241,7 +245,7 @@ def main():
         t_prev = time.perf_counter()
         marks = []
         ptrs = [ptr[i % len(ptr)] for i in range(count)] if isinstance(ptr, list) else [ptr] * count
-        for res in sh.commit_stream(srs, ptrs, depth=depth, bucket=bucket):
+        for res in sh.commit_stream(srs, ptrs, depth=depth, bucket=bucket, group=(GROUP if depth > 1 else 1)):
             if keep is not None:
                 keep.append(res)
             if trace:
@@ -348,7 +352,7 @@ def main():
             "config": {"workload": "G1 MSM 2^%d scalars (KZG::commit_coeff_form), scalars resident in HBM; step k commits buffer k mod %d "
                                    "(%d distinct resident scalar sets, %d MiB)" % (LOG_N, N_BUFFERS, N_BUFFERS, N_BUFFERS * 32 * n >> 20),
                        "sharding": "by scalar index over %d GPU(s); all-gather of XYZZ partials + host fold" % world,
-                       "pipeline_depth": depth_used,
+                       "pipeline_depth": sh.group_depth(depth_used, GROUP), "steps_per_launch": GROUP,
                        "untimed_before_warmup": "set-up: %d steps (workspaces), the first device-wide synchronisation, %d steps (clock ramp); then the %d warm-up steps" % (depth_used, spinup_steps, args.warmup),
                        "latency_ms_is": "one commitment at a time (depth 1, one exchange per step), %d steps" % side_steps,
                        "bit_exact_vs_oracle": exact,

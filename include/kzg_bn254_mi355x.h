@@ -177,6 +177,13 @@ int32_t kzg_commit_eval_form_batch(kzg_ctx* ctx, kzg_srs* srs, const uint64_t* e
                                    uint64_t* out_xy_mont, uint8_t* out_is_infinity);
 int32_t kzg_commit_eval_form_batch_device(kzg_ctx* ctx, kzg_srs* srs, const void* d_evals_mont, size_t n, size_t count,
                                           uint64_t* out_xy_mont, uint8_t* out_is_infinity);
+/* ONE batched launch, asynchronous (the building block of the calls above, for streams of resident scalar sets -- e.g. the ranks of a
+ * sharded commitment, which group several steps into one launch): `count` scalar sets of n scalars each, in SEPARATE device buffers,
+ * against srs[offset .. offset + n) on `slot`; count <= min(16, kzg_msm_batch_capacity(n)).  _end_batch waits and returns count affine
+ * points (count x 8 words) and / or count XYZZ partials (count x 16 words), in order. */
+size_t kzg_msm_batch_capacity(size_t n);
+int32_t kzg_msm_g1_srs_device_begin_batch(kzg_ctx* ctx, kzg_srs* srs, size_t offset, const void* const* d_scalars_mont, size_t n, size_t count, int32_t slot);
+int32_t kzg_msm_g1_srs_end_batch(kzg_ctx* ctx, int32_t slot, size_t count, uint64_t* out_xy_mont, uint8_t* out_is_infinity, uint64_t* out_xyzz_mont);
 /* KZG::commit_eval_form (kzg.rs:84-104): n > srs len -> KZG_ERR_SRS_CAPACITY_EXCEEDED; n not a power of
  * two -> KZG_ERR_NOT_POWER_OF_TWO.  Computed as MSM(srs, IFFT(evals)), identical to the reference's
  * MSM(g1_ifft(srs), evals) (prover/src/lib.rs:43-47; prover/tests/kzg_test.rs:57-89). */

@@ -75,6 +75,9 @@ PROTOTYPES = {
     "kzg_fr_ntt_device": (i32, [vp, vp, sz, i32]),
     "kzg_commit_coeff_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
     "kzg_commit_eval_form": (i32, [vp, vp, u64p, sz, u64p, u8p]),
+    "kzg_msm_batch_capacity": (sz, [sz]),
+    "kzg_msm_g1_srs_device_begin_batch": (i32, [vp, vp, sz, C.POINTER(C.c_void_p), sz, sz, i32]),
+    "kzg_msm_g1_srs_end_batch": (i32, [vp, i32, sz, u64p, u8p, u64p]),
     "kzg_commit_coeff_form_batch": (i32, [vp, vp, u64p, sz, sz, u64p, u8p]),
     "kzg_commit_coeff_form_batch_device": (i32, [vp, vp, vp, sz, sz, u64p, u8p]),
     "kzg_commit_eval_form_batch": (i32, [vp, vp, u64p, sz, sz, u64p, u8p]),

@@ -467,6 +467,29 @@ int32_t kzg_msm_g1_srs_end(kzg_ctx* ctx, int32_t slot, uint64_t* out_xy_mont, ui
     return msm_end(ctx, slot, out_xy_mont, out_is_infinity, out_xyzz_mont);
 }
 
+// ---- one batched launch, asynchronous: `count` scalar sets (separate device buffers, n scalars each) against srs[offset .. offset + n)
+size_t kzg_msm_batch_capacity(size_t n) { return kzg::msm_batch_capacity(n); }
+int32_t kzg_msm_g1_srs_device_begin_batch(kzg_ctx* ctx, kzg_srs* srs, size_t offset, const void* const* d_scalars_mont, size_t n, size_t count, int32_t slot) {
+    if (!ctx || !srs || srs->ctx->device != ctx->device || !d_scalars_mont) return KZG_ERR_INVALID_ARG;
+    if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!srs->d_bits) {
+        int32_t rc = srs_build_bit_tables(ctx, srs, true);
+        if (rc != KZG_OK) return rc;
+        if (!srs->d_bits) { ctx->last_error = "no per-bit tables for this SRS (memory, or KZG_NO_NAF)"; return KZG_ERR_INVALID_ARG; }
+    }
+    MsmBases b;
+    b.points = srs->d_bits + 4 * offset; b.table_stride = (uint32_t)srs->n; b.c = 7; b.W = 255; b.naf = true;
+    return msm_begin_batch(ctx, slot, b, d_scalars_mont, n, count);
+}
+int32_t kzg_msm_g1_srs_end_batch(kzg_ctx* ctx, int32_t slot, size_t count, uint64_t* out_xy_mont, uint8_t* out_is_infinity, uint64_t* out_xyzz_mont) {
+    if (!ctx || (!out_xy_mont && !out_xyzz_mont)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return msm_end_batch(ctx, slot, count, out_xy_mont, out_is_infinity, out_xyzz_mont);
+}
+
 int32_t kzg_g1_fold_partials(const uint64_t* partials_xyzz_mont, size_t count, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
     if (!out_xy_mont || (count && !partials_xyzz_mont)) return KZG_ERR_INVALID_ARG;
     kzg_host::Xyzz acc = kzg_host::xyzz_inf();

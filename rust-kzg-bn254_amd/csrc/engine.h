@@ -163,6 +163,9 @@ int32_t msm_run_batch(kzg_ctx* ctx, const uint4* d_points, const void* d_scalars
 int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs);
 int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs, bool force);
 // `polys` commitments over the first n points of one SRS in one kernel sequence (bases: the SRS's per-bit tables; msm.hip)
+size_t msm_batch_capacity(size_t n);
+int32_t msm_begin_batch(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* const* d_scalars, size_t n, size_t count);
+int32_t msm_end_batch(kzg_ctx* ctx, int slot, size_t count, uint64_t* out_xy, uint8_t* out_inf, uint64_t* out_xyzz);
 int32_t msm_run_batch_tables(kzg_ctx* ctx, const MsmBases& bases, const void* d_scalars, size_t n, size_t polys, uint64_t* out_xy, uint8_t* out_inf);
 
 // wire affine points (device memory) -> device affine format (curve.h), asynchronous on ctx->stream

@@ -254,7 +254,8 @@ static int32_t debug_check_sort(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, 
 
 // Enqueue every kernel of one MSM (or batch) plus the D2H copy of its O(100) result points on `st`, using `ws`.
 static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
-                           uint32_t batch, Pending* pend, uint32_t out_off = 0, uint32_t out_cap = MSM_MAX_OUT, uint32_t polys = 0) {
+                           uint32_t batch, Pending* pend, uint32_t out_off = 0, uint32_t out_cap = MSM_MAX_OUT, uint32_t polys = 0,
+                           const PolyPtrs* poly_ptrs = nullptr) {
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
     if (polys && (!bases.naf || n % polys != 0 || polys > MSM_BATCH_POLYS_MAX)) return KZG_ERR_INVALID_ARG;
     const Plan p = make_plan(ctx, n, bases, batch, polys);
@@ -350,12 +351,14 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_HIP_TRY(ctx, hipMemsetAsync(ccount, 0, (size_t)p.Hb * 4, st));
         uint8_t* tmpk = p.naf ? ws.sort_key.as<uint8_t>() : nullptr;
         const uint32_t poly_len = p.polys ? p.n / p.polys : 0u;
+        PolyPtrs ptrs{};
+        if (poly_ptrs) ptrs = *poly_ptrs;
         if (p.naf && ND == 32)
             hipLaunchKernelGGL(k_naf_digits<32>, dim3(p.tiles1), dim3(256), ((size_t)p.Hb + (11 + 32) * 256) * 4, st, d_scalars, p.n, p.c, p.tile1, p.Hb, ccount,
-                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), poly_len);
+                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), poly_len, ptrs);
         else if (p.naf)
             hipLaunchKernelGGL(k_naf_digits<NAF_DIGITS>, dim3(p.tiles1), dim3(256), ((size_t)p.Hb + (11 + NAF_DIGITS) * 256) * 4, st, d_scalars, p.n, p.c, p.tile1, p.Hb, ccount,
-                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), poly_len);
+                               ws.blockbase.as<uint32_t>(), ws.digits.as<uint4>(), poly_len, ptrs);
         else
         hipLaunchKernelGGL(k_sort2_scalars<false>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
                            ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, p.idx_stride, (uint32_t*)nullptr);
@@ -514,6 +517,13 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     (void)st;
     {
         RoctxRange range_wait("kzg:msm:wait");
+        static const int poll = []() { const char* e = getenv("KZG_EVENT_POLL"); return e ? atoi(e) : 0; }();
+        if (poll) {
+            hipError_t q;
+            while ((q = hipEventQuery(ws.ev_done)) == hipErrorNotReady) __builtin_ia32_pause();
+            (void)hipGetLastError();
+            KZG_HIP_TRY(ctx, q);
+        } else
         KZG_HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
     }
     RoctxRange range_epi("kzg:msm:host epilogue");
@@ -663,6 +673,7 @@ int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_s
 int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS || !ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;    // nothing in flight
     MsmPending* pend = ctx->slot_pending[slot];
+    if (pend->n_parts && pend->part[0].p.polys) return KZG_ERR_INVALID_ARG;                            // a batched launch: kzg_msm_g1_srs_end_batch collects it
     ctx->slot_pending[slot] = nullptr;
     kzg_host::Xyzz total;
     hipStream_t st = nullptr;
@@ -672,6 +683,54 @@ int32_t msm_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, ui
     if (rc != KZG_OK) return rc;
     if (out_xyzz) memcpy(out_xyzz, &total, 128);
     if (out_xy) kzg_host::xyzz_to_affine(total, out_xy, out_inf);
+    return KZG_OK;
+}
+
+// polynomials one batched launch takes (batched table mode): 2^(c-1) buckets each in one 2^16-bucket array, 2^24 pairs at most
+size_t msm_batch_capacity(size_t n) {
+    if (n == 0) return 0;
+    const int cb = batch_bucket_bits(n);
+    return std::min<size_t>(std::min<size_t>(MSM_BATCH_POLYS_MAX, (size_t)65536 >> (cb - 1)), MSM_MAX_LAUNCH / n);
+}
+
+// Asynchronous form of ONE batched launch: `count` polynomials of n scalars each (separate device buffers) over the same per-bit
+// tables on `slot`; msm_end_batch waits and returns count results (affine and / or XYZZ partials).
+int32_t msm_begin_batch(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* const* d_scalars, size_t n, size_t count) {
+    if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
+    if (!bases.naf || n == 0 || count == 0 || count > (size_t)MSM_BATCH_PTRS || count > msm_batch_capacity(n)) return KZG_ERR_INVALID_ARG;
+    hipStream_t st = nullptr;
+    { int32_t rc0 = msm_slot_stream(ctx, slot, &st); if (rc0 != KZG_OK) return rc0; }
+    MsmPending* pend = new (std::nothrow) MsmPending();
+    if (!pend) return KZG_ERR_DEVICE;
+    PolyPtrs ptrs{};
+    for (size_t k = 0; k < count; ++k) ptrs.p[k] = reinterpret_cast<const uint4*>(d_scalars[k]);
+    int32_t rc = msm_enqueue(ctx, ctx->slot_msm(slot), st, bases, ptrs.p[0], n * count, 1, &pend->part[0], 0, MSM_MAX_OUT, (uint32_t)count, &ptrs);
+    if (rc != KZG_OK) { delete pend; return rc; }
+    pend->n_parts = 1;
+    ctx->slot_pending[slot] = pend;
+    return KZG_OK;
+}
+int32_t msm_end_batch(kzg_ctx* ctx, int slot, size_t count, uint64_t* out_xy, uint8_t* out_inf, uint64_t* out_xyzz) {
+    if (slot < 0 || slot >= KZG_NUM_SLOTS || !ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
+    MsmPending* pend = ctx->slot_pending[slot];
+    if (pend->n_parts != 1 || pend->part[0].p.polys != count) return KZG_ERR_INVALID_ARG;       // (not a batched launch of that size: left in flight)
+    ctx->slot_pending[slot] = nullptr;
+    static thread_local std::vector<kzg_host::Xyzz> res;
+    res.resize(count);
+    hipStream_t st = nullptr;
+    (void)msm_slot_stream(ctx, slot, &st);
+    int32_t rc = msm_finish(ctx, ctx->slot_msm(slot), st, pend->part[0], res.data());
+    delete pend;
+    if (rc != KZG_OK) return rc;
+    if (out_xyzz) memcpy(out_xyzz, res.data(), count * 128);
+    if (out_xy) {
+        kzg_host::xyzz_batch_to_affine(res.data(), count, out_xy);
+        if (out_inf)
+            for (size_t i = 0; i < count; ++i) {
+                const uint64_t* q = out_xy + 8 * i;
+                out_inf[i] = (q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | q[6] | q[7]) == 0 ? 1 : 0;
+            }
+    }
     return KZG_OK;
 }
 

@@ -348,10 +348,14 @@ k_sort2_scalars(const uint4* __restrict__ scalars, uint32_t n, int c, int W, uin
 // scalars are `n / poly_len` polynomials of poly_len coefficients over the same bases and scalar s belongs to polynomial s / poly_len,
 // whose 64 buckets (width-8 NAF: keys < 64) are the group s / poly_len of the bucket array: one group of the first reduction level per
 // polynomial, whose seven sums k_batch_finish turns into the polynomial's commitment.
+// The polynomials of a batched launch may live in separate buffers (a stream of resident scalar sets): p[k] = polynomial k, or all null
+// = one contiguous array `scalars`.
+constexpr int MSM_BATCH_PTRS = 16;
+struct PolyPtrs { const uint4* p[MSM_BATCH_PTRS]; };
 template <int ND>
 __global__ void __launch_bounds__(256)
 k_naf_digits(const uint4* __restrict__ scalars, uint32_t n, int c, uint32_t tile_s, uint32_t Hb, uint32_t* __restrict__ ccount,
-             uint32_t* __restrict__ blockbase1, uint4* __restrict__ digs, uint32_t poly_len) {
+             uint32_t* __restrict__ blockbase1, uint4* __restrict__ digs, uint32_t poly_len, PolyPtrs ptrs) {
     latency_bound_kernel();
     extern __shared__ uint32_t lds_u32[];
     uint32_t* hist = lds_u32;                             // Hb
@@ -368,7 +372,15 @@ k_naf_digits(const uint4* __restrict__ scalars, uint32_t n, int c, uint32_t tile
         for (int m = 0; m < ND; ++m) stage[m * 256 + t] = NAF_NO_DIGIT;
         const uint32_t i = base + t;
         if (i < hi) {
-            const uint4 s_lo = scalars[2 * (size_t)i], s_hi = scalars[2 * (size_t)i + 1];
+            const uint4* sp = scalars + 2 * (size_t)i;
+            if (poly_len && ptrs.p[0]) {                  // separate buffers: a select chain over the (few) pointers, no indexed parameter access
+                const uint32_t pk = i / poly_len;
+                const uint4* base = ptrs.p[0];
+#pragma unroll
+                for (int q = 1; q < MSM_BATCH_PTRS; ++q) base = pk == (uint32_t)q ? ptrs.p[q] : base;
+                sp = base + 2 * (size_t)(i - pk * poly_len);
+            }
+            const uint4 s_lo = sp[0], s_hi = sp[1];
             uint32_t w32[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
             uint32_t k[8];
             fe_wire_to_canonical_words<FrParams>(k, w32);

@@ -233,7 +233,64 @@ class ShardedMsm:
             raise ValueError(_lib.status_message(rc))
         return part
 
-    def commit_stream(self, srs_shard, d_scalars_ptrs, depth=None, bucket=None):
+    # ---- several steps of a stream in ONE launch (the batched table mode of the MSM engine) --------------------
+    def auto_group(self):
+        """Steps of a stream this rank's library puts into one launch: shard-sized MSMs are bound by dependent-latency chains, and
+        `k` of them over the same SRS slice are one MSM problem with k x the work per kernel (k x 2^(c-1) buckets in one bucket array).
+        Derived from n // world, so that every rank groups alike (the ranks must issue the same collectives)."""
+        if os.environ.get("KZG_SHARD_GROUP"):
+            return max(1, int(os.environ["KZG_SHARD_GROUP"]))
+        if os.environ.get("KZG_SHARD_GROUP_AUTO", "0") != "1":
+            return 1        # OFF by default: see the first-launch stall in group_depth(); a stream opts in with group= or KZG_SHARD_GROUP_AUTO=1
+        per = self.n // max(1, self.world)
+        if per >= (1 << 19) or per < (1 << 13):
+            return 1
+        cap = int(_lib.load().kzg_msm_batch_capacity(per))
+        return max(1, min(cap, 4))
+
+    def group_depth(self, depth: int, group: int):
+        """Launches in flight for `group` steps per launch: two once a launch covers >= 2^19 pairs.  Such launches saturate the chip with
+        two in flight (0.62-0.75 ms per launch of 4 x 2^17 pairs at depth 2 and 3 alike).  Unresolved: the FIRST launch of a grouped
+        stream that starts on an idle GPU (after a device-wide synchronisation or 20 ms of sleep) completes after 6-7 ms instead of
+        0.7-1.3 in most runs, at depth 2 and 3, with blocking and with polling waits (tools/trace_group.py; no such gap under rocprofv3)
+        -- 0.3 ms per step of a 20-step run, where one launch per step loses 0.4 ms once.  Hence grouping is opt-in."""
+        if group > 1 and self.len * group >= (1 << 19):
+            return min(depth, 2)
+        return depth
+
+    def begin_group(self, srs_shard, d_scalars_ptrs, slot: int):
+        """Enqueue the partial MSMs of several scalar buffers as ONE launch on `slot` (one buffer: the plain begin())."""
+        if len(d_scalars_ptrs) == 1:
+            return self.begin(srs_shard, d_scalars_ptrs[0], slot)
+        arr = (C.c_void_p * len(d_scalars_ptrs))(*[C.c_void_p(int(p)) for p in d_scalars_ptrs])
+        rc = _lib.load().kzg_msm_g1_srs_device_begin_batch(self.ctx.handle, srs_shard.handle, 0, arr, self.len, len(d_scalars_ptrs), slot)
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+
+    def _end_partials(self, slot: int, count: int):
+        """Wait for the launch on `slot`: its `count` XYZZ partials, in order."""
+        if count == 1:
+            return [self._end_partial(slot)]
+        parts = np.zeros((count, 16), dtype=np.uint64)
+        rc = _lib.load().kzg_msm_g1_srs_end_batch(self.ctx.handle, slot, count, None, None, _lib.ptr(parts))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+        return [parts[j] for j in range(count)]
+
+    def _end_group(self, slot: int, count: int):
+        """world == 1: the `count` commitments of the launch on `slot`."""
+        if count == 1:
+            return [self.end(slot)]
+        out = np.zeros((count, 8), dtype=np.uint64)
+        rc = _lib.load().kzg_msm_g1_srs_end_batch(self.ctx.handle, slot, count, _lib.ptr(out), None, None)
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+        return [out[j] for j in range(count)]
+
+    def commit_stream(self, srs_shard, d_scalars_ptrs, depth=None, bucket=None, group=1):
         """Commitments of a stream of scalar buffers (device pointers to this rank's slices) with `depth` MSMs in flight
         (default: 2 for slices of >= 2^20 pairs, which saturate the GPU's integer pipes, else 3 — shard-sized MSMs are bound by
         dependent-latency chains; a fourth in flight gains or loses depending on the stream -> hardware-queue mapping).  MSM k+depth-1 is enqueued before MSM k is waited for.
@@ -247,13 +304,21 @@ class ShardedMsm:
         Failures with world > 1: a rank whose begin() / end() fails keeps issuing its collectives with a POISON partial for that step
         and does no more GPU work; every rank (the failing one included) raises ShardError at that step, after the same number of
         collectives, so nobody is left blocked in an all-gather.  A peer that dies outright shows up as ExchangeTimeout
-        (KZG_EXCHANGE_TIMEOUT_S, default 60 s): exit non-zero on it, the communicator cannot be used again."""
+        (KZG_EXCHANGE_TIMEOUT_S, default 60 s): exit non-zero on it, the communicator cannot be used again.
+        `group` consecutive steps share ONE launch (begin_group / _end_partials; `None`: auto_group(), 1: one launch per step): at
+        2^17 pairs per rank four steps per launch take 0.164 ms per step where one launch per step takes 0.22-0.24 (three in flight;
+        2^15: 0.152 -> 0.067, 2^16: 0.167 -> 0.095, 2^18 with two per launch: 0.347 -> 0.311; tools/time_shard_group.py).  The
+        group size must be the same on every rank; a failure poisons every step of its group."""
         if depth is None:
             depth = 2 if self.len >= (1 << 20) else 3
         depth = max(1, min(int(depth), _lib.NUM_SLOTS))
         if bucket is None:
             bucket = PartialGatherer.MAX_BUCKET
         bucket = max(1, min(int(bucket), PartialGatherer.MAX_BUCKET))
+        if group is None:
+            group = self.auto_group()
+        group = max(1, min(int(group), bucket))
+        depth = self.group_depth(depth, group)
         inflight = collections.deque()
         g = None
         if self.world > 1:
@@ -281,21 +346,19 @@ class ShardedMsm:
 
         def retire(flush=False):
             nonlocal exchanging, sent_first, next_step, failure
-            slot = inflight.popleft()
+            slot, count = inflight.popleft()
             if g is None:
-                return [self.end(slot)]
+                return self._end_group(slot, count)
             if slot is None:
-                part = POISON
+                parts = [POISON] * count
             else:
                 try:
-                    part = self._end_partial(slot)
+                    parts = self._end_partials(slot, count)
                 except Exception as e:                  # noqa: BLE001 -- reported to every rank through the exchange
                     failure = failure or e
-                    part = POISON
-            pending.append(part)
-            next_step += 1
+                    parts = [POISON] * count
             out = []
-            if len(pending) == bucket or (flush and not inflight):
+            if pending and len(pending) + count > bucket:   # (the groups do not divide the bucket: send what is there first)
                 if exchanging:
                     exchanging = False
                     out = collect()
@@ -303,24 +366,52 @@ class ShardedMsm:
                 g.start(np.stack(pending))
                 pending.clear()
                 exchanging = True
+            pending.extend(parts)
+            next_step += count
+            if len(pending) == bucket or (flush and not inflight):
+                if exchanging:
+                    exchanging = False
+                    out = out + collect()
+                sent_first = next_step - len(pending)
+                g.start(np.stack(pending))
+                pending.clear()
+                exchanging = True
             return out
 
+        def launch(k, ptrs):
+            slot = k % depth
+            if g is None:
+                self.begin_group(srs_shard, ptrs, slot) if len(ptrs) > 1 else self.begin(srs_shard, ptrs[0], slot)
+            elif failure is not None:
+                slot = None                             # after a failure this rank only keeps the collectives matched
+            else:
+                try:
+                    self.begin_group(srs_shard, ptrs, slot) if len(ptrs) > 1 else self.begin(srs_shard, ptrs[0], slot)
+                except Exception as e:                  # noqa: BLE001
+                    nonlocal_failure(e)
+                    slot = None
+            inflight.append((slot, len(ptrs)))
+
+        def nonlocal_failure(e):
+            nonlocal failure
+            failure = failure or e
+
         try:
-            for k, ptr in enumerate(d_scalars_ptrs):
+            k = 0
+            chunk = []
+            for ptr in d_scalars_ptrs:
+                chunk.append(ptr)
+                if len(chunk) < group:
+                    continue
                 if len(inflight) == depth:
                     yield from retire()
-                slot = k % depth
-                if g is None:
-                    self.begin(srs_shard, ptr, slot)
-                elif failure is not None:
-                    slot = None                         # after a failure this rank only keeps the collectives matched
-                else:
-                    try:
-                        self.begin(srs_shard, ptr, slot)
-                    except Exception as e:              # noqa: BLE001
-                        failure = e
-                        slot = None
-                inflight.append(slot)
+                launch(k, chunk)
+                k += 1
+                chunk = []
+            if chunk:
+                if len(inflight) == depth:
+                    yield from retire()
+                launch(k, chunk)
             while inflight:
                 yield from retire(flush=True)
             if exchanging:
@@ -329,11 +420,11 @@ class ShardedMsm:
         finally:
             # a failed begin() or a consumer that stops early must not leave slots (or an exchange) in flight
             while inflight:
-                slot = inflight.popleft()
+                slot, count = inflight.popleft()
                 if slot is None:
                     continue
                 try:
-                    self._end_partial(slot)
+                    self._end_partials(slot, count)
                 except Exception:                       # noqa: BLE001 -- draining: the slot is free again either way
                     pass
             if exchanging and g is not None and g.busy:

@@ -137,3 +137,45 @@ def test_eval_form_and_blob_batches(k, tau_srs):
     assert lib.kzg_commit_eval_form_batch(ctx.handle, tau_srs.handle, k._lib.ptr(data), 1 << 16, 2, k._lib.ptr(out), None) == k._lib.ERR_SRS_CAPACITY_EXCEEDED
     assert lib.kzg_commit_coeff_form_batch(ctx.handle, tau_srs.handle, k._lib.ptr(data), 1 << 16, 2, k._lib.ptr(out), None) == k._lib.ERR_POLY_LENGTH
     tau_srs.drop_lagrange()
+
+
+def test_grouped_stream_of_shard_sized_commitments(k, tau_srs):
+    """ShardedMsm.commit_stream with several steps per launch (kzg_msm_g1_srs_device_begin_batch / _end_batch: scalar sets in SEPARATE
+    device buffers, one batched launch): the same commitments as one launch per step, at group sizes that do and do not divide the
+    stream; the XYZZ partials of a group fold to the same points (the world > 1 path); capacity and slot misuse are errors."""
+    import torch
+    from rust_kzg_bn254_amd.sharding import ShardedMsm, fold_partials
+    n = 1 << 15
+    rnd = random.Random(11)
+    bufs = []
+    for j in range(5):
+        vals = [rnd.randrange(R_) for _ in range(64)]
+        arr = np.ascontiguousarray(np.tile(pyref.frs_to_mont(vals), (n // 64, 1)))          # 2^15 scalars with period 64
+        arr[j] = pyref.frs_to_mont([j])[0]
+        bufs.append(torch.from_numpy(arr.view(np.int64)).cuda())
+    torch.cuda.synchronize()
+    sh = ShardedMsm(tau_srs.ctx, n)
+    ptrs = [bufs[j % 5].data_ptr() for j in range(11)]
+    want = list(sh.commit_stream(tau_srs, ptrs, depth=2, group=1))
+    assert len(want) == 11 and not np.array_equal(want[0], want[1])
+    for depth, group in ((3, 4), (2, 3), (1, 2), (3, None)):            # None: auto_group(), 1 unless KZG_SHARD_GROUP_AUTO=1
+        got = list(sh.commit_stream(tau_srs, ptrs, depth=depth, group=group))
+        assert len(got) == 11 and all(np.array_equal(a, b) for a, b in zip(got, want)), (depth, group)
+    assert sh.auto_group() == 1
+    os.environ["KZG_SHARD_GROUP_AUTO"] = "1"
+    try:
+        assert sh.auto_group() == 4
+    finally:
+        del os.environ["KZG_SHARD_GROUP_AUTO"]
+    sh.begin_group(tau_srs, ptrs[:3], 1)
+    parts = sh._end_partials(1, 3)
+    for j in range(3):
+        assert np.array_equal(fold_partials(parts[j].reshape(1, 16)), want[j])
+    lib = k._lib.load()
+    assert int(lib.kzg_msm_batch_capacity(n)) == 4 and int(lib.kzg_msm_batch_capacity(512)) == 1024 and int(lib.kzg_msm_batch_capacity(1 << 18)) == 2
+    with pytest.raises(ValueError):
+        sh.begin_group(tau_srs, ptrs[:5], 0)                       # more than one launch takes
+    sh.begin_group(tau_srs, ptrs[:2], 0)
+    one = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+    assert lib.kzg_msm_g1_srs_end(tau_srs.ctx.handle, 0, k._lib.ptr(one), C.byref(inf), None) == k._lib.ERR_INVALID_ARG     # a batched launch is collected by _end_batch
+    assert all(np.array_equal(a, b) for a, b in zip(sh._end_group(0, 2), want[:2]))

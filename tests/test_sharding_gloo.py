@@ -119,6 +119,40 @@ def _worker(rank, world, port, n, q):
         outs = list(bad.commit_stream(None, [0, 1, 2], depth=depth, bucket=bucket))
         ok = ok and len(outs) == 3 and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs))
 
+    # several steps per launch (group > 1: begin_group / _end_partials; the batched table mode on a GPU): same results in order at
+    # group sizes that do and do not divide the bucket and the stream, and a failing group launch poisons every step of its group
+    class FakeG(Fake):
+        def begin_group(self, srs_shard, ptrs, slot):
+            assert slot not in self.inflight and len(ptrs) > 1
+            if 3 in ptrs and self.rank == 1 and getattr(self, "fail", False):
+                raise ValueError("injected failure")
+            self.inflight[slot] = list(ptrs)
+
+        def _end_partials(self, slot, count):
+            if count == 1:
+                return [self._end_partial(slot)]
+            js = self.inflight.pop(slot)
+            assert len(js) == count
+            return [to_partial(orc.msm_pippenger(srs[lo:hi], sets[j][lo:hi], threads=1)) for j in js]
+
+    fg = FakeG(None, n, rank, world, gather_device=None)
+    fg.inflight = {}
+    for depth, bucket, group in ((3, 8, 4), (2, 8, 3), (2, 4, 2), (1, 2, 2), (3, 3, 2), (2, 8, 8)):
+        outs = list(fg.commit_stream(None, range(len(sets)), depth=depth, bucket=bucket, group=group))
+        ok = ok and len(outs) == len(sets) and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs)) and not fg.inflight
+    fg.fail = True
+    outs, err = [], None
+    try:
+        for o in fg.commit_stream(None, range(len(sets)), depth=2, bucket=4, group=2):
+            outs.append(o)
+    except sharding.ShardError as e:
+        err = e
+    ok = ok and err is not None and err.step == 2 and err.ranks == [1] and not fg.inflight     # steps 2 and 3 share the failed launch
+    ok = ok and len(outs) <= 2 and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs))
+    fg.fail = False
+    outs = list(fg.commit_stream(None, range(len(sets)), depth=2, bucket=4, group=2))
+    ok = ok and len(outs) == len(sets) and all(np.array_equal(o, wants[j]) for j, o in enumerate(outs))
+
     # an end() that fails on one rank is reported the same way
     class FailingEnd(Fake):
         def _end_partial(self, slot):
