@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -270,6 +271,8 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
     if (p.tables && G1 > 1 && 13 * G1p > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
 
+    static const bool enq_trace = []() { const char* e = getenv("KZG_ENQ_TRACE"); return e && atoi(e) != 0; }();   // diagnostic: host time of this function's parts
+    const auto tq0 = std::chrono::steady_clock::now();
     if (!p.sort2) KZG_HIP_TRY(ctx, ws.digits.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.sorted.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.count.reserve((size_t)p.G * 4 + 16));
@@ -316,6 +319,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         ctx->lds_attr_set = true;
     }
 
+    const auto tq1 = std::chrono::steady_clock::now();
     const bool prof = ctx->profiling;
     if (prof && !ws.ev_ready) {
         for (auto& e : ws.ev) KZG_HIP_TRY(ctx, hipEventCreate(&e));
@@ -501,6 +505,11 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     if (!ws.ev_done) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
     KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_done, st));        // msm_finish waits for THIS launch, not for the stream: a later MSM may already be queued behind it
 #undef KZG_MARK
+    if (enq_trace) {
+        const auto tq2 = std::chrono::steady_clock::now();
+        const double a = std::chrono::duration<double, std::milli>(tq1 - tq0).count(), b = std::chrono::duration<double, std::milli>(tq2 - tq1).count();
+        if (a + b > 0.5) fprintf(stderr, "KZG_ENQ_TRACE: n %zu polys %u: buffers %.2f ms, launches + copies %.2f ms\n", n, p.polys, a, b);
+    }
     pend->p = p;
     pend->n_out = n_out;
     pend->batch = batch;

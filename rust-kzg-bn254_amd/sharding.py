@@ -250,10 +250,13 @@ class ShardedMsm:
 
     def group_depth(self, depth: int, group: int):
         """Launches in flight for `group` steps per launch: two once a launch covers >= 2^19 pairs.  Such launches saturate the chip with
-        two in flight (0.62-0.75 ms per launch of 4 x 2^17 pairs at depth 2 and 3 alike).  Unresolved: the FIRST launch of a grouped
-        stream that starts on an idle GPU (after a device-wide synchronisation or 20 ms of sleep) completes after 6-7 ms instead of
-        0.7-1.3 in most runs, at depth 2 and 3, with blocking and with polling waits (tools/trace_group.py; no such gap under rocprofv3)
-        -- 0.3 ms per step of a 20-step run, where one launch per step loses 0.4 ms once.  Hence grouping is opt-in."""
+        two in flight (0.62-0.75 ms per launch of 4 x 2^17 pairs at depth 2 and 3 alike).  Unresolved: when a stream of grouped launches
+        starts after a device-wide synchronisation and the slot's stream last carried a single-step launch (the tail of the previous
+        stream), the HIP runtime blocks for 5.6-6 ms inside the launch calls of that slot's first batched launch (KZG_ENQ_TRACE=1: "launches
+        + copies 5.60 ms", buffers 0.00; tools/trace_group.py).  Not the wait (polling or blocking alike), not scratch reclaim
+        (HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0, HSA_SCRATCH_SINGLE_LIMIT, HSA_NO_SCRATCH_RECLAIM: unchanged), absent with
+        GPU_MAX_HW_QUEUES=2 (which costs three-deep streams their concurrency) and under rocprofv3: 0.3 ms per step of a 20-step run.
+        Hence grouping is opt-in."""
         if group > 1 and self.len * group >= (1 << 19):
             return min(depth, 2)
         return depth
