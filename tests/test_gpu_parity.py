@@ -1007,7 +1007,7 @@ def test_g1_ifft_paths_and_lagrange_cache(k, tau_srs, ref_srs, test_srs_wire):
         assert pyref.point_from_wire(L[i]) == pyref.ec_mul(li, (1, 2)), i
     # cached Lagrange basis: same commitments as the IFFT path and the oracle's literal form
     rnd = random.Random(77)
-    for n, srs, wire in ((256, ref_srs, test_srs_wire), (2048, ref_srs, test_srs_wire), (1 << 14, tau_srs, None)):
+    for n, srs, wire in ((256, ref_srs, test_srs_wire), (2048, ref_srs, test_srs_wire), (1 << 14, tau_srs, None), (1 << 15, tau_srs, None)):   # 2^15: the Lagrange basis gets per-bit tables (NAF mode)
         poly = k.PolynomialEvalForm(pyref.frs_to_mont([rnd.randrange(R_) for _ in range(n)]))
         via_ifft = kzg.commit_eval_form(poly, srs)
         srs.cache_lagrange(n)
