@@ -33,6 +33,7 @@ struct MsmWorkspace {
     DeviceBuffer digits, sorted, count, blockbase, sort_tmp, sort_key, sort_small, offs, block_sums, bucket, chunkS, chunkTmp, chunkA, out_wire;
     DeviceBuffer head, cont;   // accumulate partials: head[g] per bucket, cont[t] per lane (36 limb planes each; msm_kernels.h section 4)
     void* pinned_out = nullptr;   // pinned host buffer for window sums
+    void* pinned_out_dev = nullptr;   // its device address: the reduction kernels store their results there directly
     // optional per-phase timing with HIP events on the launch stream (kzg_ctx_set_profiling)
     static constexpr int N_PHASES = 8;   // digits, sort (histograms + scan), scatter, (unused), accumulate, bucket sums + reduce level 1, reduce level 2, whole launch
     hipEvent_t ev[N_PHASES] = {};

@@ -305,8 +305,15 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_HIP_TRY(ctx, ws.chunkTmp.reserve((size_t)n_chunks * 36 * 4));
         KZG_HIP_TRY(ctx, ws.chunkA.reserve((size_t)n_chunks * 36 * 4));
     }
-    KZG_HIP_TRY(ctx, ws.out_wire.reserve((size_t)MSM_MAX_OUT * 32 * 4));
-    if (!ws.pinned_out) KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, (size_t)MSM_MAX_OUT * 32 * 4 + MSM_MAX_PARTS * 4, hipHostMallocDefault));   // + entry counts of profiled launches
+    if (!ws.pinned_out) {
+        KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, (size_t)MSM_MAX_OUT * 32 * 4 + MSM_MAX_PARTS * 4, hipHostMallocDefault));   // + entry counts of profiled launches
+        KZG_HIP_TRY(ctx, hipHostGetDevicePointer(&ws.pinned_out_dev, ws.pinned_out, 0));
+    }
+    // The last kernel of the sequence stores the O(200) result points straight into the pinned host buffer (coherent host memory, read
+    // after the event behind that kernel).  A device-to-host copy of them cost ~10 us per MSM -- and above ~16 KiB (208 points at 2^16
+    // buckets: every batched launch) hipMemcpyAsync takes the SDMA path, whose set-up after a device-wide synchronisation blocked the
+    // enqueueing thread for 5.6-7 ms (tools/trace_group.py with KZG_ENQ_TRACE=1; gone with HSA_ENABLE_SDMA=0).
+    uint32_t* d_out = reinterpret_cast<uint32_t*>(ws.pinned_out_dev) + (size_t)out_off * 32;
     if (!ctx->lds_attr_set) {
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
@@ -320,12 +327,20 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     }
 
     const auto tq1 = std::chrono::steady_clock::now();
+    auto tq_last = tq1;
+    auto tick = [&](int phase) {                          // KZG_ENQ_TRACE: host time of the runtime calls of one phase when they block
+        if (!enq_trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - tq_last).count();
+        if (ms > 0.3) fprintf(stderr, "KZG_ENQ_TRACE:   the calls before mark %d took %.2f ms on the host\n", phase, ms);
+        tq_last = now;
+    };
     const bool prof = ctx->profiling;
     if (prof && !ws.ev_ready) {
         for (auto& e : ws.ev) KZG_HIP_TRY(ctx, hipEventCreate(&e));
         ws.ev_ready = true;
     }
-#define KZG_MARK(i) do { if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[i], st)); } while (0)
+#define KZG_MARK(i) do { tick(i); if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[i], st)); } while (0)
 
     uint32_t* d_offs = ws.offs.as<uint32_t>();
     auto scan_counts = [&]() {
@@ -451,26 +466,26 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     if (p.tables) {
         if (fused)
             hipLaunchKernelGGL(k_msm_bucket_bits1p_fused, dim3(G1), dim3(128), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.B, p.idx_log,
-                               p.stride_adj, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, ws.out_wire.as<uint32_t>());
+                               p.stride_adj, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
         else if (pair_reduce)
             hipLaunchKernelGGL(k_msm_bucket_bits1p, dim3(G1), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
-                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, ws.out_wire.as<uint32_t>());
+                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
         else
             hipLaunchKernelGGL(k_msm_bucket_bits1, dim3((G1 * 64 + 255) / 256), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
-                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, ws.out_wire.as<uint32_t>());
+                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
         KZG_MARK(6);
         if (p.polys && p.c == 7) {
-            hipLaunchKernelGGL(k_batch_finish, dim3((p.polys + 63) / 64), dim3(64), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, ws.out_wire.as<uint32_t>());
+            hipLaunchKernelGGL(k_batch_finish, dim3((p.polys + 63) / 64), dim3(64), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, d_out);
             n_out = p.polys;
         } else if (G1 == 1) {
             n_out = 7;
         } else {
             const uint32_t waves2 = 7 * G1p;
             if (pair_reduce)
-                hipLaunchKernelGGL(k_red_bits2p, dim3((waves2 + 1) / 2), dim3(128), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, ws.out_wire.as<uint32_t>());
+                hipLaunchKernelGGL(k_red_bits2p, dim3((waves2 + 1) / 2), dim3(128), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, d_out);
             else
                 hipLaunchKernelGGL(k_red_bits2, dim3((waves2 * 64 + 255) / 256), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p,
-                                   ws.out_wire.as<uint32_t>());
+                                   d_out);
             n_out = 13 * G1p;
         }
     } else {
@@ -486,7 +501,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         hipLaunchKernelGGL(k_red_chunk_running, dim3(gc), dim3(256), 0, st, ws.bucket.as<int32_t>(), (size_t)p.G,
                            ws.chunkS.as<int32_t>(), (size_t)n_chunks, n_chunks, p.T, p.m, ws.chunkA.as<int32_t>());
         hipLaunchKernelGGL(k_red_window_sum, dim3(n_windows), dim3(p.T), 0, st, ws.chunkA.as<int32_t>(), (size_t)n_chunks, p.T,
-                           ws.out_wire.as<uint32_t>());
+                           d_out);
         n_out = n_windows;
     }
     KZG_MARK(7);
@@ -498,7 +513,6 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         ctx->last_error = "MSM result points exceed this launch's window of the result buffer";
         return KZG_ERR_INVALID_ARG;
     }
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ws.pinned_out) + (size_t)out_off * 128, ws.out_wire.p, (size_t)n_out * 128, hipMemcpyDeviceToHost, st));
     if (prof)                                             // sorted entries = mixed additions of this launch (NAF mode: data dependent)
         KZG_HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ws.pinned_out) + (size_t)MSM_MAX_OUT * 128 + (out_off / MSM_PART_OUT) * 4, d_offs + p.G, 4,
                                         hipMemcpyDeviceToHost, st));

@@ -240,8 +240,8 @@ class ShardedMsm:
         Derived from n // world, so that every rank groups alike (the ranks must issue the same collectives)."""
         if os.environ.get("KZG_SHARD_GROUP"):
             return max(1, int(os.environ["KZG_SHARD_GROUP"]))
-        if os.environ.get("KZG_SHARD_GROUP_AUTO", "0") != "1":
-            return 1        # OFF by default: see the first-launch stall in group_depth(); a stream opts in with group= or KZG_SHARD_GROUP_AUTO=1
+        if os.environ.get("KZG_SHARD_GROUP_AUTO", "1") == "0":
+            return 1
         per = self.n // max(1, self.world)
         if per >= (1 << 19) or per < (1 << 13):
             return 1
@@ -250,13 +250,7 @@ class ShardedMsm:
 
     def group_depth(self, depth: int, group: int):
         """Launches in flight for `group` steps per launch: two once a launch covers >= 2^19 pairs.  Such launches saturate the chip with
-        two in flight (0.62-0.75 ms per launch of 4 x 2^17 pairs at depth 2 and 3 alike).  Unresolved: when a stream of grouped launches
-        starts after a device-wide synchronisation and the slot's stream last carried a single-step launch (the tail of the previous
-        stream), the HIP runtime blocks for 5.6-6 ms inside the launch calls of that slot's first batched launch (KZG_ENQ_TRACE=1: "launches
-        + copies 5.60 ms", buffers 0.00; tools/trace_group.py).  Not the wait (polling or blocking alike), not scratch reclaim
-        (HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0, HSA_SCRATCH_SINGLE_LIMIT, HSA_NO_SCRATCH_RECLAIM: unchanged), absent with
-        GPU_MAX_HW_QUEUES=2 (which costs three-deep streams their concurrency) and under rocprofv3: 0.3 ms per step of a 20-step run.
-        Hence grouping is opt-in."""
+        two in flight (0.62-0.75 ms per launch of 4 x 2^17 pairs at depth 2 and 3 alike)."""
         if group > 1 and self.len * group >= (1 << 19):
             return min(depth, 2)
         return depth

@@ -158,13 +158,13 @@ def test_grouped_stream_of_shard_sized_commitments(k, tau_srs):
     ptrs = [bufs[j % 5].data_ptr() for j in range(11)]
     want = list(sh.commit_stream(tau_srs, ptrs, depth=2, group=1))
     assert len(want) == 11 and not np.array_equal(want[0], want[1])
-    for depth, group in ((3, 4), (2, 3), (1, 2), (3, None)):            # None: auto_group(), 1 unless KZG_SHARD_GROUP_AUTO=1
+    for depth, group in ((3, 4), (2, 3), (1, 2), (3, None)):            # None: auto_group()
         got = list(sh.commit_stream(tau_srs, ptrs, depth=depth, group=group))
         assert len(got) == 11 and all(np.array_equal(a, b) for a, b in zip(got, want)), (depth, group)
-    assert sh.auto_group() == 1
-    os.environ["KZG_SHARD_GROUP_AUTO"] = "1"
+    assert sh.auto_group() == 4
+    os.environ["KZG_SHARD_GROUP_AUTO"] = "0"
     try:
-        assert sh.auto_group() == 4
+        assert sh.auto_group() == 1
     finally:
         del os.environ["KZG_SHARD_GROUP_AUTO"]
     sh.begin_group(tau_srs, ptrs[:3], 1)

@@ -55,13 +55,14 @@ def test_bench_two_ranks_gloo_is_bit_exact():
     for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(key, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-secondary"]
+           "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-secondary"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bit_exact_vs_oracle"] is True
+    assert d["config"]["steps_per_launch"] == 4          # 2^17 pairs per rank: four steps of the stream per batched launch (10 = 4 + 4 + 2)
     assert d["value"] > 0 and d["value_uniform"] > 0 and d["latency_ms"] > 0
 
 
