@@ -290,6 +290,7 @@ void kzg_srs_free(kzg_srs* srs) {
     if (srs->d_points) { (void)hipSetDevice(srs->ctx->device); (void)hipFree(srs->d_points); }
     if (srs->d_small) { (void)hipSetDevice(srs->ctx->device); (void)hipFree(srs->d_small); }
     if (srs->d_bits) { (void)hipSetDevice(srs->ctx->device); (void)hipFree(srs->d_bits); }
+    if (srs->d_t3) { (void)hipSetDevice(srs->ctx->device); (void)hipFree(srs->d_t3); }
     delete srs;
 }
 

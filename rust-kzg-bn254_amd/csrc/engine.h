@@ -105,6 +105,8 @@ struct kzg_srs {
     int small_W = 0;
     // per-bit tables Bit_j[i] = 2^j P_i, j < 255, n points apart (srs.hip srs_build_bit_tables): the NAF mode of MSMs of >= SRS_NAF_MIN pairs; may be absent
     uint4* d_bits = nullptr;
+    // 3 Bit_p[j] for p < 255, j < 256 (g1fft.hip: the x3 tables of the 64..256-point g1_ifft), built on first use; a cache, hence mutable
+    mutable uint4* d_t3 = nullptr;
     // Lagrange-basis copies of the first m points (KZG::g1_ifft(m), kzg.rs:263-285), built by kzg_srs_cache_lagrange and used by
     // the eval-form commitments of exactly m evaluations instead of IFFT + MSM over the monomial basis; owned by this SRS
     std::map<size_t, kzg_srs*> lagrange;

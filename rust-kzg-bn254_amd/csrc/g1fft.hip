@@ -520,7 +520,26 @@ k_g1fft_first_tables(const uint4* __restrict__ tables, uint32_t table_stride, in
 // scalars are recoded once per size (k_g1fft_naf2); one PAIR of lanes per (output, term, slice of the digit list) adds its digits
 // (pair_madd, 5 multiplications per lane); a wave holds 32 slots of one output and leaves their sum; k_g1fft_sum_partials adds the
 // <= 32 waves of an output.  Same group elements as the staged transform.
-constexpr uint32_t NAF2_MAX = 128;                       // digits of a scalar < 2^254 in width-2 NAF: at most 254 / 2 + 1
+constexpr uint32_t NAF2_MAX = 128;                       // digit slots per scalar (width-3 NAF of a scalar < 2^254: at most 254 / 3 + 1 = 85)
+constexpr uint32_t G1FFT_T3_POINTS = 256;                // the x3 tables cover the points this path transforms
+// T3_p[j] = 3 Bit_p[j] = Bit_p[j] + Bit_(p+1)[j] for p < 254 (a digit +-3 at position 254 would exceed the scalar field), as XYZZ planes:
+// k_g1fft_to_affine turns them into the table.  65 024 points, once per SRS (kzg_srs::d_t3).
+__global__ void __launch_bounds__(256)
+k_g1fft_t3_planes(const uint4* __restrict__ bits, uint32_t stride, uint32_t total, int32_t* __restrict__ planes) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t p = t / G1FFT_T3_POINTS, j = t - p * G1FFT_T3_POINTS;
+    Affine a, b;
+    Xyzz v;
+    const bool ha = affine_load(a, bits + 4 * ((size_t)p * stride + j));
+    const bool hb = affine_load(b, bits + 4 * ((size_t)(p + 1) * stride + j));
+    if (!ha) xyzz_set_inf(v);
+    else {
+        xyzz_from_affine(v, a, 0);
+        if (hb) xyzz_madd<true>(v, b, 0);
+    }
+    xyzz_store(planes, total, t, v);
+}
 __global__ void __launch_bounds__(64)
 k_g1fft_naf2(const uint4* __restrict__ scal_canon, uint32_t n, uint16_t* __restrict__ list, uint32_t* __restrict__ cnt) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,11 +547,13 @@ k_g1fft_naf2(const uint4* __restrict__ scal_canon, uint32_t n, uint16_t* __restr
     const uint4 lo = scal_canon[2 * (size_t)e], hi = scal_canon[2 * (size_t)e + 1];
     uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint32_t m = 0;
-    naf_for_digits(k, 2, [&](uint32_t pos, uint32_t, uint32_t neg) { if (m < NAF2_MAX) list[(size_t)e * NAF2_MAX + m] = (uint16_t)(pos | (neg << 15)); ++m; });
+    // width-3 NAF: digits +-1, +-3 (key = 0 / 1), ~64 per scalar instead of the ~85 of width 2; a digit +-3 reads the x3 table
+    naf_for_digits(k, 3, [&](uint32_t pos, uint32_t key, uint32_t neg) { if (m < NAF2_MAX) list[(size_t)e * NAF2_MAX + m] = (uint16_t)(pos | (key << 14) | (neg << 15)); ++m; });
     cnt[e] = m < NAF2_MAX ? m : NAF2_MAX;
 }
 __global__ void __launch_bounds__(256)
-k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, uint32_t n, const uint16_t* __restrict__ list, const uint32_t* __restrict__ cnt,
+k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, const uint4* __restrict__ bits3 /* 3 Bit_p[j], j < G1FFT_T3_POINTS, that many points apart */,
+             uint32_t n, const uint16_t* __restrict__ list, const uint32_t* __restrict__ cnt,
              uint32_t Q, uint32_t waves_per_out, int32_t* __restrict__ partial) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, pair = lane >> 1;
     const bool odd = (t & 1u) != 0;
@@ -550,7 +571,8 @@ k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, uint32_t n, const 
     auto fetch = [&](uint32_t m, uint4& a, uint4& b, uint32_t& neg) {
         const uint32_t d = L[m < c ? m : (c ? c - 1 : 0)];
         neg = d >> 15;
-        const uint4* src = bits + 4 * ((size_t)(d & 0x7FFFu) * stride + j) + (odd ? 2 : 0);
+        const uint32_t pos = d & 0x3FFFu;
+        const uint4* src = ((d & 0x4000u) ? bits3 + 4 * ((size_t)pos * G1FFT_T3_POINTS + j) : bits + 4 * ((size_t)pos * stride + j)) + (odd ? 2 : 0);
         a = src[0]; b = src[1];
     };
     uint4 a0, b0; uint32_t neg0 = 0;
@@ -755,6 +777,21 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
         Naf2Lists nl;
         rc = get_naf2(ctx, log_n, &nl);
         if (rc != KZG_OK) return rc;
+        if (!srs->d_t3) {                                                  // x3 tables of the first 256 points, once per SRS (4 MiB)
+            const uint32_t total = 254 * G1FFT_T3_POINTS;
+            KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)total * 36 * 4));
+            KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve((size_t)total * NL * 4));
+            uint4* t3 = nullptr;
+            KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t3), (size_t)255 * G1FFT_T3_POINTS * 64));
+            KZG_HIP_TRY(ctx, hipMemsetAsync(t3, 0, (size_t)255 * G1FFT_T3_POINTS * 64, st));
+            hipLaunchKernelGGL(k_g1fft_t3_planes, dim3((total + 255) / 256), dim3(256), 0, st, srs->d_bits, (uint32_t)srs->n, total, ctx->poly[0].c.as<int32_t>());
+            const size_t lanes = (total + AFF_PER - 1) / AFF_PER;
+            hipLaunchKernelGGL(k_g1fft_to_affine, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, ctx->poly[0].c.as<int32_t>(), total, t3, 0, ctx->poly[0].a.as<int32_t>());
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { (void)hipFree(t3); return set_error(ctx, e, "building the x3 tables of g1_ifft"); }
+            srs->d_t3 = t3;
+        }
         // slices per term: two waves per SIMD in all (n^2 Q / 32 = 2048 waves) -- more waves only add tree additions (every wave ends in a
         // 5-level tree: a third of the work at 21 digits per pair), fewer leave lone waves at half the issue rate.  Measured: 256 points
         // 0.71 ms with Q = 4, 0.66 with Q = 1; 128 points 0.28 -> 0.26 (tools/time_g1ifft.py).  The floor is the additions themselves:
@@ -762,7 +799,7 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
         const uint32_t Q = (uint32_t)std::max<size_t>(1, 65536 / (n * n)), wpo = (uint32_t)(n * Q / 32);
         KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)n * wpo * 36 * 4));
         int32_t* partial = ctx->poly[0].c.as<int32_t>();
-        hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, srs->d_bits, (uint32_t)srs->n, (uint32_t)n,
+        hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, srs->d_bits, (uint32_t)srs->n, srs->d_t3, (uint32_t)n,
                            nl.list, nl.cnt, Q, wpo, partial);
         hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, wpo, (uint32_t)n, bufA);
         KZG_HIP_TRY(ctx, hipGetLastError());
