@@ -127,6 +127,11 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
                 bool other_in_flight = false;
                 for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) other_in_flight |= ctx->slot_pending[sl] != nullptr;
                 if (other_in_flight || entries < ((size_t)1 << 23)) slots = slots / 3 * 2;
+                // below 2^22 entries (2^15 .. 2^17 pairs; 2^18 is even) ONE wave per SIMD: the kernel is not throughput bound there (the same
+                // 0.20 ms at 2^17 pairs with 65 536 lanes of 30 entries as with 131 072 of 15), half the lanes leave half the partial sums
+                // to the first reduction level (0.097 -> 0.084 ms) and room for the other MSMs in flight: three in flight 2^15 0.154 ->
+                // 0.136, 2^16 0.191 -> 0.160, 2^17 0.245 -> 0.211 ms per MSM (KZG_ACC_SLOTS sweep, profiles/r03_naf.md)
+                if (entries < ((size_t)1 << 22)) slots = ctx->acc_wave_slots / 3;
             }
             lanes = std::min<size_t>(slots * 64, (entries + lmin - 1) / lmin);
         }
