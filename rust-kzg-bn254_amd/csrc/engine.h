@@ -126,11 +126,13 @@ struct MsmBases {
 };
 constexpr int SRS_SMALL_C = 15;                       // window bits of the second table set
 constexpr size_t SRS_SMALL_MAX = (size_t)1 << 13;     // MSMs of up to this many pairs use it
-constexpr size_t SRS_NAF_MIN = (size_t)1 << 15;       // MSMs of at least this many pairs use the per-bit tables (width-w NAF digits)
+constexpr size_t SRS_NAF_MIN = (size_t)1 << 15;       // an SRS of at least this many points gets per-bit tables at upload
+constexpr size_t MSM_NAF_MIN = (size_t)1 << 14;       // MSMs of at least this many pairs use them (width-w NAF digits): one at a time 2^14 0.296 -> 0.273 ms; 2^13 0.241 -> 0.273: not below
 // bucket bits (c: 2^(c-1) buckets, NAF width c + 1) of an MSM of n pairs over the per-bit tables: the window policy of srs_precompute, by MSM length
 inline int srs_naf_c(size_t n) {
     static const int forced = []() { const char* e = getenv("KZG_NAF_C"); return e ? atoi(e) : 0; }();
-    if (forced >= 15 && forced <= 17) return forced;          // (NAF_DIGITS = 16 words per scalar: width >= 16)
+    if (forced == 13 || (forced >= 15 && forced <= 17)) return forced;          // (13: 32 digit words per scalar; 15..17: 16)
+    if (n < ((size_t)1 << 15)) return 13;
     // measured (tools/time_shard_inflight.py, KZG_NAF_C = 15 / 16 / 17, two or three MSMs in flight, ms per MSM): 2^17 0.257 / 0.264 / 0.284,
     // 2^18 0.362 / 0.355 / 0.404, 2^19 0.678 / 0.631 / 0.629, 2^20 1.307 / 1.227 / 1.188 (profiles/r03_naf.md)
     return n >= ((size_t)1 << 20) ? 17 : n >= ((size_t)1 << 18) ? 16 : 15;
@@ -143,7 +145,8 @@ inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, size_t n, bool allo
         b.table_stride = (uint32_t)srs->n; b.c = srs->pre_c; b.W = srs->pre_W;
         if (srs->d_small && n <= SRS_SMALL_MAX) { b.points = srs->d_small + 4 * offset; b.c = srs->small_c; b.W = srs->small_W; }
         static const bool naf_off = []() { const char* e = getenv("KZG_NAF_OFF"); return e && atoi(e) != 0; }();   // A/B: tables built, not used
-        if (srs->d_bits && n >= SRS_NAF_MIN && !naf_off) {
+        static const size_t naf_min = []() { const char* e = getenv("KZG_NAF_MIN_LOG"); return e && atoi(e) >= 10 && atoi(e) <= 24 ? (size_t)1 << atoi(e) : MSM_NAF_MIN; }();
+        if (srs->d_bits && n >= naf_min && !naf_off) {
             b.points = srs->d_bits + 4 * offset; b.c = srs_naf_c(n); b.W = 255; b.naf = true;
         }
     }
