@@ -492,6 +492,25 @@ KZG_HD void fe_reduce(Fe<F>& a) {
     fe_mul(a, a, one);
 }
 
+// The same reduction WITHOUT a Montgomery product (no factor involved): subtract q m with q = floor(top limb / (P[8] + 1)), an
+// under-estimate of a / m by less than 1.0001, so the result lies in [0, 1.0001 m): ~70 instructions instead of the 206 of fe_mul
+// (the last pass of the Fr NTT reduces every output once).  |a| < 169 m as for fe_reduce (the top limb stays inside int32).
+template <class F>
+KZG_HD void fe_reduce_small(Fe<F>& a) {
+    fe_norm(a);
+    const int32_t D = (int32_t)F::P[NL - 1] + 1;
+    const int32_t top = a.l[NL - 1];
+    const int32_t q = (top >= 0 ? top : top - (D - 1)) / D;            // floor(top / D)
+#pragma unroll
+    for (int j = 0; j < NL - 1; ++j) {
+        const int64_t prod = (int64_t)q * (int64_t)(int32_t)F::P[j];   // |.| < 2^37
+        a.l[j] -= (int32_t)(prod & (int64_t)LMASK);
+        a.l[j + 1] -= (int32_t)(prod >> LB);
+    }
+    a.l[NL - 1] -= q * (int32_t)F::P[NL - 1];
+    fe_norm(a);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 256-bit words <-> limbs.  w[8] little-endian u32 words of a non-negative integer < 2^256.
 // ---------------------------------------------------------------------------------------------

@@ -100,7 +100,8 @@ k_ntt_build_pass_twiddles(uint4* __restrict__ tw, int log_n, int next_K, int nex
 struct NttPassArgs {
     int log_n, K, log_s;          // this pass
     int next_K, next_log_s;       // the pass after it (next_K = 0: this is the last pass)
-    int scale_log_n;              // last pass: >= 0 multiplies by (2^scale_log_n)^-1
+    int scale_log_n;              // last pass: >= 0 multiplies by (2^scale_log_n)^-1; -1: no factor left (forward transform, or the inverse's 1 / n
+                                  // folded into the twiddle array of the previous pass boundary): the outputs are only reduced (fe_reduce_small)
     uint32_t n_tiles;
 };
 
@@ -297,14 +298,14 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
             for (int l = 0; l < NL; ++l) v.l[l] = lds[l * NTT_PL + e];
             uint32_t w32[8];
             if (last) {
-                Fr kk;
-                if (a.scale_log_n >= 0) {
+                if (a.scale_log_n >= 0) {  // a single-pass inverse transform (or no twiddle array): scale by n^-1, which also reduces to (-m, 2m)
+                    Fr kk;
 #pragma unroll
                     for (int l = 0; l < NL; ++l) kk.l[l] = (int32_t)FrParams::NINV[a.scale_log_n * NL + l];
+                    fe_mul(v, v, kk);
                 } else {
-                    fe_set_one(kk);
+                    fe_reduce_small(v);    // no factor: ~70 instructions instead of a 206-instruction product by one
                 }
-                fe_mul(v, v, kk);          // reduce to (-m, 2m) (and scale by n^-1 for the inverse transform)
                 fe_canon(v);
                 fe_pack(w32, v);
             } else {
@@ -339,7 +340,8 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
 
 __global__ void __launch_bounds__(256)
 k_ntt_build_pass_twiddles(uint4* __restrict__ tw, int log_n, int next_K, int next_log_s,
-                          const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len) {
+                          const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
+                          int scale_log_n /* >= 0: every entry times (2^scale_log_n)^-1 (the inverse transform's scaling, folded in) */) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t N = 1u << log_n;
     if (idx >= N) return;
@@ -349,6 +351,13 @@ k_ntt_build_pass_twiddles(uint4* __restrict__ tw, int log_n, int next_K, int nex
     Fr w;
     if (E != 0) twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, E);
     else fe_set_one(w);
+    if (scale_log_n >= 0) {
+        Fr kk;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) kk.l[l] = (int32_t)FrParams::NINV[scale_log_n * NL + l];
+        fe_norm(w);
+        fe_mul(w, w, kk);
+    }
     fe_canon(w);
     uint32_t o[8];
     fe_pack(o, w);
@@ -385,11 +394,12 @@ int32_t ntt_get_tables(kzg_ctx* ctx, int log_n, bool inverse, NttTables* out) {
 // HBM capacity spent to remove work (like the MSM window tables): the inter-pass twiddle of every element as one 32-byte word,
 // 32 MiB per pass boundary at 2^20; kept per (device, log n, direction, boundary) for transforms of up to 2^22 elements.
 constexpr int NTT_FULL_TW_MAX_LOG = 22;
-struct PassTwKey { int dev, log_n, inverse, next_K, next_log_s; bool operator<(const PassTwKey& o) const { return std::tie(dev, log_n, inverse, next_K, next_log_s) < std::tie(o.dev, o.log_n, o.inverse, o.next_K, o.next_log_s); } };
+struct PassTwKey { int dev, log_n, inverse, next_K, next_log_s, scaled; bool operator<(const PassTwKey& o) const { return std::tie(dev, log_n, inverse, next_K, next_log_s, scaled) < std::tie(o.dev, o.log_n, o.inverse, o.next_K, o.next_log_s, o.scaled); } };
 static std::map<PassTwKey, uint4*> g_pass_tw;
-static int32_t ntt_get_pass_twiddles(kzg_ctx* ctx, int log_n, bool inverse, int next_K, int next_log_s, const NttTables& tb, int lo_bits, const uint4** out) {
+static int32_t ntt_get_pass_twiddles(kzg_ctx* ctx, int log_n, bool inverse, int next_K, int next_log_s, const NttTables& tb, int lo_bits, const uint4** out,
+                                     bool scaled) {
     std::lock_guard<std::mutex> lk(g_tables_mu);
-    PassTwKey key{ctx->device, log_n, inverse ? 1 : 0, next_K, next_log_s};
+    PassTwKey key{ctx->device, log_n, inverse ? 1 : 0, next_K, next_log_s, scaled ? 1 : 0};
     auto it = g_pass_tw.find(key);
     if (it != g_pass_tw.end()) { *out = it->second; return KZG_OK; }
     const size_t n = (size_t)1 << log_n;
@@ -397,7 +407,7 @@ static int32_t ntt_get_pass_twiddles(kzg_ctx* ctx, int log_n, bool inverse, int 
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * 32);
     if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return KZG_OK; }     // no memory: the kernel looks the twiddles up itself
     hipLaunchKernelGGL(k_ntt_build_pass_twiddles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, log_n, next_K, next_log_s,
-                       tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len);
+                       tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, scaled ? log_n : -1);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // built once; afterwards read from any stream of the device
     g_pass_tw[key] = p;
@@ -438,6 +448,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     int log_ncur = 0;
+    bool scale_folded = false;      // the inverse transform's 1 / n went into the twiddle array of the last pass boundary
     for (int pi = 0; pi < P; ++pi) {
         NttPassArgs a;
         a.log_n = log_n;
@@ -447,7 +458,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
         const bool last = pi == P - 1;
         a.next_K = last ? 0 : Ks[pi + 1];
         a.next_log_s = last ? 0 : log_n - (log_ncur + Ks[pi + 1]);
-        a.scale_log_n = (last && inverse) ? log_n : -1;
+        a.scale_log_n = (last && inverse && !scale_folded) ? log_n : -1;
         const uint32_t n_units = (uint32_t)(n >> a.K);
         const uint32_t C = 1u << (NTT_TILE_LOG - a.K);
         a.n_tiles = (n_units + C - 1) / C;
@@ -457,8 +468,10 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
         const uint32_t grid = std::min<uint32_t>(a.n_tiles, (uint32_t)cus);
         const uint4* next_tw = nullptr;
         if (!last && log_n <= NTT_FULL_TW_MAX_LOG) {
-            rc = ntt_get_pass_twiddles(ctx, log_n, inverse, a.next_K, a.next_log_s, tb, lo_bits, &next_tw);
+            const bool fold = inverse && pi == P - 2;          // the boundary in front of the last pass carries the scaling
+            rc = ntt_get_pass_twiddles(ctx, log_n, inverse, a.next_K, a.next_log_s, tb, lo_bits, &next_tw, fold);
             if (rc != KZG_OK) return rc;
+            scale_folded = fold && next_tw != nullptr;
         }
 #ifdef KZG_NTT_STAMPS
         static unsigned long long* d_stamps = nullptr;     // [pass][workgroup][8]; read back by kzg_debug_ntt_stamps

@@ -112,4 +112,17 @@ int hc_naf(const uint32_t* k_words, int w, uint32_t* pos, uint32_t* key, uint32_
     return n;
 }
 int hc_naf_max_digits(int w) { return naf_max_digits(w); }
+// fe_reduce_small on a lazy value: k doublings of +-a with normalisations in between (|value| = 2^k |a| < 169 m for k <= 7), then the
+// cheap reduction + fe_canon; out = wire words of the result (must equal +-2^k a mod m)
+void hc_reduce_small(int which, const uint32_t* a, int k, int negate, uint32_t* out) {
+    if (which == 0) {
+        Fq v; fe_from_wire(v, a); if (negate) fe_neg(v, v);
+        for (int i = 0; i < k; ++i) { fe_add(v, v, v); fe_norm(v); }
+        fe_reduce_small(v); fe_canon(v); fe_to_wire(out, v);
+    } else {
+        Fr v; fe_from_wire(v, a); if (negate) fe_neg(v, v);
+        for (int i = 0; i < k; ++i) { fe_add(v, v, v); fe_norm(v); }
+        fe_reduce_small(v); fe_canon(v); fe_to_wire(out, v);
+    }
+}
 }

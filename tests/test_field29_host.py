@@ -235,3 +235,18 @@ def test_naf_recoding(hc):
             total += n
         if w == 18:
             assert total / len(cases) < 14.2          # ~254 / 19 on the random part
+
+
+def test_reduce_small(hc):
+    """fe_reduce_small (the NTT's product-free final reduction): +-2^k a for k <= 7 (|value| up to 128 (2m)) == big-integer value."""
+    rng = random.Random(77)
+    for which, m in ((0, P), (1, R_)):
+        for a in [0, 1, m - 1, m // 2, (m - 1) // 3] + [rng.randrange(m) for _ in range(60)]:
+            aw = w32(pyref.fq_to_mont(a) if which == 0 else pyref.frs_to_mont([a])[0])
+            for k in (0, 1, 3, 6, 7):
+                for neg in (0, 1):
+                    out = np.zeros(8, np.uint32)
+                    hc.hc_reduce_small(which, aw.ctypes.data_as(u32p), k, neg, out.ctypes.data_as(u32p))
+                    want = ((-a if neg else a) << k) % m
+                    ww = pyref.fq_to_mont(want) if which == 0 else pyref.frs_to_mont([want])[0]
+                    assert np.array_equal(out.view(np.uint64), np.asarray(ww, dtype=np.uint64).reshape(-1)), (which, a, k, neg)
