@@ -228,3 +228,47 @@ def test_compute_r_powers_c_abi_matches_oracle_and_hashlib():
             r = pyref.fr_from_mont(got[1])
             assert pyref.fr_from_mont(got[n - 1]) == pow(r, n - 1, pyref.R_)
     assert len(verifier.compute_r_powers([], [], [], [], [])) == 0
+
+
+def test_pairing_known_answer_eip197_vector():
+    """An EXTERNAL known answer for the pairing predicate (the reference holds none): the first vector of Ethereum's bn256 pairing
+    precompile tests (EIP-197, go-ethereum `bn256Pairing` "jeff1": input of two (G1, G2) pairs whose pairing product is one), written
+    down from public sources; every coordinate is checked to lie on its curve by big-integer arithmetic here, so a mistyped digit
+    cannot pass.  e(P1, Q1) e(P2, Q2) == 1  <=>  pairings_verify(P1, Q1, -P2, Q2); the un-negated form and swapped G2 points must fail.
+    EIP-197 encodes an Fq2 element imaginary part first; the library's wire format is c0 (real) | c1 (imaginary), Montgomery."""
+    hexs = """1c76476f4def4bb94541d57ebba1193381ffa7aa76ada664dd31c16024c43f59 3034dd2920f673e204fee2811c678745fc819b55d3e9d294e45c9b03a76aef41
+              209dd15ebff5d46c4bd888e51a93cf99a7329636c63514396b4a452003a35bf7 04bf11ca01483bfa8b34b43561848d28905960114c8ac04049af4b6315a41678
+              2bb8324af6cfc93537a2ad1a445cfd0ca2a71acd7ac41fadbf933c2a51be344d 120a2a4cf30c1bf9845f20c6fe39e07ea2cce61f0c9bb048165fe5e4de877550
+              111e129f1cf1097710d41c4ac70fcdfa5ba2023c6ff1cbeac322de49d1b6df7c 2032c61a830e3c17286de9462bf242fca2883585b93870a73853face6a6bf411
+              198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2 1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed
+              090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b 12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa""".split()
+    v = [int(h, 16) for h in hexs]
+    P = pyref.P
+    assert all(c < P for c in v)
+    for x, y in ((v[0], v[1]), (v[6], v[7])):                             # G1: y^2 = x^3 + 3
+        assert (y * y - x ** 3 - 3) % P == 0
+
+    def fq2_mul(a, b):                                                    # (a0 + a1 i)(b0 + b1 i), i^2 = -1
+        return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+    b_twist = fq2_mul((3, 0), (pow(9 * 9 + 1, -1, P) * 9 % P, (-pow(9 * 9 + 1, -1, P)) % P))     # 3 / (9 + i)
+    for xi, xr, yi, yr in ((v[2], v[3], v[4], v[5]), (v[8], v[9], v[10], v[11])):                  # G2: y^2 = x^3 + 3 / (9 + i)
+        x, y = (xr, xi), (yr, yi)
+        x3 = fq2_mul(fq2_mul(x, x), x)
+        y2 = fq2_mul(y, y)
+        assert y2 == ((x3[0] + b_twist[0]) % P, (x3[1] + b_twist[1]) % P)
+
+    def g1(x, y):
+        return np.concatenate([pyref.fq_to_mont(x), pyref.fq_to_mont(y)]).astype(np.uint64)
+
+    def g2(xi, xr, yi, yr):
+        return np.concatenate([pyref.fq_to_mont(xr), pyref.fq_to_mont(xi), pyref.fq_to_mont(yr), pyref.fq_to_mont(yi)]).astype(np.uint64)
+
+    p1, q1 = g1(v[0], v[1]), g2(v[2], v[3], v[4], v[5])
+    p2, q2 = g1(v[6], v[7]), g2(v[8], v[9], v[10], v[11])
+    p2neg = g1(v[6], (P - v[7]) % P)
+    assert helpers.pairings_verify(p1, q1, p2neg, q2) is True
+    assert helpers.pairings_verify(p1, q1, p2, q2) is False
+    assert helpers.pairings_verify(p1, q2, p2neg, q1) is False
+    # the second pair's G2 point is the generator: the constant the library serves
+    assert np.array_equal(q2, helpers.g2_generator())
