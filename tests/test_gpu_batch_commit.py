@@ -179,3 +179,27 @@ def test_grouped_stream_of_shard_sized_commitments(k, tau_srs):
     one = np.zeros(8, np.uint64); inf = C.c_uint8(0)
     assert lib.kzg_msm_g1_srs_end(tau_srs.ctx.handle, 0, k._lib.ptr(one), C.byref(inf), None) == k._lib.ERR_INVALID_ARG     # a batched launch is collected by _end_batch
     assert all(np.array_equal(a, b) for a, b in zip(sh._end_group(0, 2), want[:2]))
+
+
+def test_naf_mode_on_ragged_sizes_and_slices(k):
+    """The NAF mode (per-bit tables) on an SRS and MSM lengths that are not powers of two, and on slices of the SRS (offset != 0: the tables
+    are srs.n points apart, the slice starts inside every one of them): against sum_i c_i tau^(offset + i) on a known-tau SRS."""
+    n_srs = 40000
+    srs = k.SRS.generate(TAU, n_srs)
+    lib = k._lib.load()
+    rnd = random.Random(21)
+    tp = [1]
+    for _ in range(n_srs - 1):
+        tp.append(tp[-1] * TAU % R_)
+    try:
+        for offset, n in ((0, 40000), (0, 33001), (5000, 30000), (7, 16384), (39999 - 16500, 16500)):
+            vals = [rnd.randrange(R_) if i % 3 else rnd.randrange(1 << 248) for i in range(n)]
+            vals[0] = 0; vals[n - 1] = R_ - 1
+            sc = np.ascontiguousarray(pyref.frs_to_mont(vals), dtype=np.uint64).reshape(-1, 4)
+            out = np.zeros(8, np.uint64); inf = C.c_uint8(7)
+            rc = lib.kzg_msm_g1_srs(srs.ctx.handle, srs.handle, offset, k._lib.ptr(sc), n, k._lib.ptr(out), C.byref(inf))
+            assert rc == 0
+            s = sum(v * tp[offset + i] for i, v in enumerate(vals)) % R_
+            assert pyref.point_from_wire(out) == pyref.ec_mul(s, (1, 2)), (offset, n)
+    finally:
+        srs.close()
