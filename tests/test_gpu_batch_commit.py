@@ -125,6 +125,10 @@ def test_eval_form_and_blob_batches(k, tau_srs):
     got = kzg.commit_eval_form_batch(polys, tau_srs)
     for p, g in zip(polys, got):
         assert np.array_equal(g, kzg.commit_eval_form(p, tau_srs))
+    for n in (1, 2, 64):                                   # tiny Lagrange bases (no window tables of their own: per-bit tables built on demand)
+        tiny = [k.PolynomialEvalForm(pyref.frs_to_mont([rnd.randrange(R_) for _ in range(n)])) for _ in range(3)]
+        for p, g in zip(tiny, kzg.commit_eval_form_batch(tiny, tau_srs)):
+            assert np.array_equal(g, kzg.commit_eval_form(p, tau_srs)), n
     blobs = [k.Blob.from_raw_data(bytes(rnd.randrange(32, 127) for _ in range(ln))) for ln in (1000, 31 * 64, 5000, 31 * 64 - 3, 20000, 999)]
     gotb = kzg.commit_blob_batch(blobs, tau_srs)
     for b, g in zip(blobs, gotb):
