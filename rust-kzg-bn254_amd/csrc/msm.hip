@@ -52,6 +52,7 @@ struct Plan {
     uint32_t nl;         // lanes of the accumulate kernel (a multiple of 256); each adds ceil(E / nl) sorted entries
     uint32_t set_len;    // digit entries per set
     uint32_t tile_len, tiles_per_set, tiles;
+    bool dual1;          // first reduction level on two groups per workgroup (k_msm_bucket_bits1p_dual): fewer instructions, longer alone -> with another MSM in flight
     bool sort2;          // two-level sort (table mode, index fits 24 bits)
     bool sort_small;     // global-atomic sort (few entries)
     uint32_t Hb, tile1, tiles1, tiles2cap;
@@ -85,6 +86,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     p.tables = bases.table_stride != 0;
     p.naf = p.tables && bases.naf;
     p.polys = p.naf ? polys : 0;
+    p.dual1 = false;
     int c;
     if (p.polys) {
         c = batch_bucket_bits(n / p.polys);                // 7: 64 buckets per polynomial (k_batch_finish); 13 / 15 / 16: whole units of 4 096 buckets (second level + host epilogue per polynomial)
@@ -123,6 +125,13 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
             // and below 2^19 pairs fewer lanes also mean fewer partial sums for the first reduction level (2^16: 0.464 -> 0.403 ms,
             // 2^17: 0.534 -> 0.486).  Alone, a 2^19 / 2^20-pair MSM is 2-3 % faster on three (0.929 / 1.474 against 0.961 / 1.496 ms).
             size_t slots = ctx->acc_wave_slots;
+            {
+                bool busy = false;
+                for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) busy |= ctx->slot_pending[sl] != nullptr;
+                static const int dual_env = []() { const char* e = getenv("KZG_BITS1_DUAL"); return e ? atoi(e) : -1; }();   // 0 / 1: never / always (A/B)
+                (void)busy;
+                p.dual1 = p.tables && p.B >= 8192 && dual_env > 0;      // off: measured no gain (same-box A/B 1.169-1.181 without, 1.174-1.179 with it whenever another MSM is in flight)
+            }
             if (!ctx->acc_slots_forced) {
                 bool other_in_flight = false;
                 for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) other_in_flight |= ctx->slot_pending[sl] != nullptr;
@@ -472,6 +481,9 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         if (fused)
             hipLaunchKernelGGL(k_msm_bucket_bits1p_fused, dim3(G1), dim3(128), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.B, p.idx_log,
                                p.stride_adj, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
+        else if (pair_reduce && p.dual1 && (G1 & 1u) == 0)
+            hipLaunchKernelGGL(k_msm_bucket_bits1p_dual, dim3(G1 / 2), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
+                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1);
         else if (pair_reduce)
             hipLaunchKernelGGL(k_msm_bucket_bits1p, dim3(G1), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);

@@ -1403,6 +1403,37 @@ __device__ __forceinline__ void group_zeta64_dual(HalfXyzz& vA, HalfXyzz& vB, ui
         half_select(vB, bit, r, vB);
     }
 }
+// Level 1 with TWO groups of 64 buckets per two-wave workgroup (groups 2 blk and 2 blk + 1; pair gp holds bucket gp of the first and
+// bucket 63 - gp of the second): the transform of both takes six additions per pair instead of twelve -- 3 of the ~8 additions per bucket
+// this level costs.  Half the waves and twice the serial work per wave: SLOWER alone (0.123 -> 0.207 ms at 2^20 pairs), but with another
+// MSM in flight the step is the sum of everybody's VALU instructions (rocprofv3 SQ_INSTS_VALU per kernel, tools/prof_valu_by_kernel.sh:
+// this level is 8 % of the accumulate kernel's count).  Measured: NO gain -- same-box A/B of the pipelined 2^20 step 1.169-1.181 ms
+// without, 1.174-1.179 with this form whenever another MSM was in flight: the level's instructions already run in issue slots the
+// accumulate waves leave empty.  Kept behind KZG_BITS1_DUAL=1 (parity-tested), off by default.  G1 even.
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
+k_msm_bucket_bits1p_dual(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
+                         const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[2 * 2 * NL * 64];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 32 + (lane >> 1);
+    const bool odd = (lane & 1u) != 0;
+    const uint32_t L = acc_seg_len(offs[B], nl);
+    HalfXyzz v[2];
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        const uint32_t bkt = (2 * blockIdx.x + which) * 64 + (which ? 63 - gp : gp);
+        BucketSpan s;
+        s.g = bkt; s.t1 = 0; s.np = 0; s.long_run = false;
+        if (bkt < B && L) s = bucket_span(offs, bkt, L);
+        bucket_sum_pairs(v[which], s, lane, odd, head, head_stride, cont, cont_stride);
+    }
+    group_zeta64_dual(v[0], v[1], lane, w, odd, lds);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int role = zeta_role(which ? 63 - gp : gp);
+        if (role >= 0) half_store(x1, x_stride, (size_t)role * G1 + 2 * blockIdx.x + which, v[which], odd);
+    }
+}
 // level 2: one two-wave workgroup per TWO jobs of k_red_bits2 (jobs 2 blk and 2 blk + 1)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
 k_red_bits2p(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
