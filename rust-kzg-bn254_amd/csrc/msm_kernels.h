@@ -1322,6 +1322,44 @@ k_msm_bucket_bits1p(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, 
 // no head / continuation partials to gather and sum -- then the zeta transform as above.  With ~2 entries per bucket the equal-split
 // accumulate kernel spent a binary search and 4 dependent one-lane mixed additions (57 us) to leave ~2 partials per bucket, which the
 // first level then added again (another ~30 us).
+// A HEAVY bucket of the fused level (more than FUSED_HEAVY entries: a short top window puts e.g. 256 of a 512-coefficient polynomial's
+// entries into one bucket of a small SRS's tables) is summed by the whole wave: pair p adds the entries hb + p, hb + p + 32, ..., a
+// five-level tree joins the 32 partial sums.  One pair walking it alone kept its wave -- and the launch -- waiting for 256 dependent
+// additions (0.93 ms for a 512-coefficient commitment on a 512-point SRS; 0.07 ms for the level otherwise).  Every lane of the wave calls.
+constexpr uint32_t FUSED_HEAVY = 24;
+__device__ __noinline__ void fused_heavy_bucket(HalfXyzz& tot, uint32_t hb, uint32_t he, uint32_t lane, const uint4* __restrict__ points,
+                                                const uint32_t* __restrict__ sorted, uint32_t idx_log, uint32_t stride_adj) {
+    const uint32_t pair = lane >> 1;
+    const bool odd = (lane & 1u) != 0;
+    HalfXyzz part;
+    half_set_inf(part);
+#pragma unroll 1
+    for (uint32_t e = hb + pair; e < he; e += 32) {     // pair-uniform trip count
+        const uint32_t cur = sorted[e];
+        const uint4* src = points + 4 * acc_point_index(cur & 0x7FFFFFFFu, idx_log, stride_adj) + (odd ? 2 : 0);
+        const uint4 q0 = src[0], q1 = src[1];
+        const uint32_t w32[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        int any = (q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w) != 0 ? 1 : 0;
+        any |= pair_swap(any);
+        if (!any) continue;
+        Fq c;
+        fe_unpack(c, w32);
+        HalfXyzz r;
+        pair_madd(r, part, c, cur >> 31, odd);
+        part = r;
+    }
+#pragma unroll 1
+    for (int d = 16; d >= 1; d >>= 1) {
+        HalfXyzz u;
+        half_shfl_down(u, part, 2 * d);
+        if (pair < (uint32_t)d) {
+            HalfXyzz r;
+            pair_add(r, part, u, odd);
+            part = r;
+        }
+    }
+    half_shfl(tot, part, odd ? 1 : 0);                  // pair 0 holds the sum
+}
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
 k_msm_bucket_bits1p_fused(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs, uint32_t B,
                           uint32_t idx_log, uint32_t stride_adj, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
@@ -1333,6 +1371,9 @@ k_msm_bucket_bits1p_fused(const uint4* __restrict__ points, const uint32_t* __re
     const uint32_t bkt = g * 64 + gp;
     uint32_t e = 0, end = 0;
     if (bkt < B) { e = offs[bkt]; end = offs[bkt + 1]; }
+    const uint32_t hb = e, he = end;
+    const bool heavy = end - e > FUSED_HEAVY;
+    if (heavy) end = e;                                 // summed by the whole wave below
     HalfXyzz v;
     half_set_inf(v);
     // two-deep software pipeline as in k_msm_accumulate: entry e + 2 and the point of entry e + 1 are in flight while entry e is added
@@ -1359,6 +1400,14 @@ k_msm_bucket_bits1p_fused(const uint4* __restrict__ points, const uint32_t* __re
         HalfXyzz r;
         pair_madd(r, v, c, cur >> 31, odd);
         v = r;
+    }
+    unsigned long long todo = __ballot(heavy && !odd);   // one bit per heavy pair (its even lane)
+    while (todo) {                                      // wave-uniform
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        HalfXyzz tot;
+        fused_heavy_bucket(tot, __shfl(hb, src_lane, 64), __shfl(he, src_lane, 64), lane, points, sorted, idx_log, stride_adj);
+        if ((int)(lane & ~1u) == src_lane) v = tot;
     }
     group_zeta64(v, lane, w, odd, lds);
     const int role = zeta_role(gp);

@@ -207,3 +207,28 @@ def test_naf_mode_on_ragged_sizes_and_slices(k):
             assert pyref.point_from_wire(out) == pyref.ec_mul(s, (1, 2)), (offset, n)
     finally:
         srs.close()
+
+
+def test_sparse_msm_with_heavy_buckets(k, test_srs_wire):
+    """The fused first reduction level (sparse MSMs: at most 2.5 entries per bucket on average) with HEAVY buckets: blob-like scalars
+    (< 2^248: the short top window of a small SRS's 13-bit tables holds one of two digits) and vectors of one repeated scalar (n
+    entries in each of ~20 buckets) on 512 / 700 / 1024 points of the reference SRS, against the oracle."""
+    lib = k._lib.load()
+    rnd = random.Random(31)
+    for n_srs in (512, 1024):
+        srs = k.SRS(test_srs_wire[:n_srs], order=n_srs)
+        try:
+            for n, kind in ((n_srs, "blob"), (n_srs, "same"), (min(700, n_srs), "blob"), (n_srs, "two")):
+                if kind == "blob":
+                    vals = [int.from_bytes(bytes([0] + [rnd.randrange(32, 127) for _ in range(31)]), "big") for _ in range(n)]
+                elif kind == "same":
+                    vals = [rnd.randrange(R_)] * n
+                else:
+                    a, b = rnd.randrange(R_), rnd.randrange(1 << 100)
+                    vals = [a if i % 3 else b for i in range(n)]
+                sc = np.ascontiguousarray(pyref.frs_to_mont(vals), dtype=np.uint64).reshape(-1, 4)
+                out = np.zeros(8, np.uint64); inf = C.c_uint8(7)
+                assert lib.kzg_msm_g1_srs(srs.ctx.handle, srs.handle, 0, k._lib.ptr(sc), n, k._lib.ptr(out), C.byref(inf)) == 0
+                assert np.array_equal(out, orc.msm_pippenger(test_srs_wire[:n], sc)), (n_srs, n, kind)
+        finally:
+            srs.close()
