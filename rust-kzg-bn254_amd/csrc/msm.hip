@@ -52,6 +52,8 @@ struct Plan {
     uint32_t nl;         // lanes of the accumulate kernel (a multiple of 256); each adds ceil(E / nl) sorted entries
     uint32_t set_len;    // digit entries per set
     uint32_t tile_len, tiles_per_set, tiles;
+    bool fused;          // sparse table-mode MSM: the first reduction level adds the sorted entries itself; its group g holds the buckets gp * G1 + g (set by msm_enqueue)
+    bool quad;           // reduction levels on lane quads (curve_quad.h): no other MSM in flight when this one was planned
     bool dual1;          // first reduction level on two groups per workgroup (k_msm_bucket_bits1p_dual): fewer instructions, longer alone -> with another MSM in flight
     bool sort2;          // two-level sort (table mode, index fits 24 bits)
     bool sort_small;     // global-atomic sort (few entries)
@@ -87,6 +89,15 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     p.naf = p.tables && bases.naf;
     p.polys = p.naf ? polys : 0;
     p.dual1 = false;
+    p.fused = false;
+    {
+        // lane quads for the two reduction levels when this MSM runs alone (0.7 of the pair form's dependent instructions, twice its lanes);
+        // with another MSM in flight the SIMDs are shared and the pair form's fewer instructions count.  KZG_QUAD_REDUCE=0 / 1: never / always.
+        static const int quad_env = []() { const char* e = getenv("KZG_QUAD_REDUCE"); return e ? atoi(e) : -1; }();
+        bool other_in_flight = false;
+        for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) other_in_flight |= ctx->slot_pending[sl] != nullptr;
+        p.quad = p.tables && (quad_env > 0 || (quad_env < 0 && !other_in_flight));
+    }
     int c;
     if (p.polys) {
         c = batch_bucket_bits(n / p.polys);                // 7: 64 buckets per polynomial (k_batch_finish); 13 / 15 / 16: whole units of 4 096 buckets (second level + host epilogue per polynomial)
@@ -273,7 +284,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
                            const PolyPtrs* poly_ptrs = nullptr) {
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
     if (polys && (!bases.naf || n % polys != 0 || polys > MSM_BATCH_POLYS_MAX)) return KZG_ERR_INVALID_ARG;
-    const Plan p = make_plan(ctx, n, bases, batch, polys);
+    Plan p = make_plan(ctx, n, bases, batch, polys);
     if (p.polys && p.B > 65536) return KZG_ERR_INVALID_ARG;
     const int ND = p.c + 1 >= 16 ? NAF_DIGITS : 32;        // digit words per scalar (width >= 16: at most 16 digits)
     const size_t entries = (size_t)p.W * n * batch;
@@ -470,6 +481,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     // 2^10 165 -> 152, 2^11 199 -> 195; at 2^12 (4.25 per bucket) 206 -> 261: a wave waits for its fullest bucket, the equal split does not.
     static const double fused_per_bucket = []() { const char* e = getenv("KZG_FUSED_PER_BUCKET"); return e ? atof(e) : 2.5; }();
     const bool fused = p.tables && !p.naf && pair_reduce && (double)entries <= fused_per_bucket * (double)p.B;
+    p.fused = fused;
     // (64- and 128-thread workgroups measured the same as 256)
     if (!fused)
         hipLaunchKernelGGL(k_msm_accumulate, dim3(p.nl / 256), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.G,
@@ -478,12 +490,21 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     phases.begin("kzg:msm:bucket reduction");
     uint32_t n_out;                       // wire XYZZ values copied to the host
     if (p.tables) {
-        if (fused)
+        if (fused && p.quad)
+            hipLaunchKernelGGL(k_msm_bucket_bits1q_fused, dim3(G1), dim3(256), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.B, p.idx_log,
+                               p.stride_adj, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
+        else if (fused)
             hipLaunchKernelGGL(k_msm_bucket_bits1p_fused, dim3(G1), dim3(128), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.B, p.idx_log,
                                p.stride_adj, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
         else if (pair_reduce && p.dual1 && (G1 & 1u) == 0)
             hipLaunchKernelGGL(k_msm_bucket_bits1p_dual, dim3(G1 / 2), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1);
+        else if (pair_reduce && p.quad && (G1 > 512 || KZG_QUAD_SMALL_WAVES == 4))
+            hipLaunchKernelGGL(k_msm_bucket_bits1q<4>, dim3(G1), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
+                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
+        else if (pair_reduce && p.quad)
+            hipLaunchKernelGGL(k_msm_bucket_bits1q<2>, dim3(G1), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
+                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
         else if (pair_reduce)
             hipLaunchKernelGGL(k_msm_bucket_bits1p, dim3(G1), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
@@ -498,7 +519,9 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
             n_out = 7;
         } else {
             const uint32_t waves2 = 7 * G1p;
-            if (pair_reduce)
+            if (pair_reduce && p.quad)
+                hipLaunchKernelGGL(k_red_bits2q, dim3(waves2), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, d_out);
+            else if (pair_reduce)
                 hipLaunchKernelGGL(k_red_bits2p, dim3((waves2 + 1) / 2), dim3(128), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, d_out);
             else
                 hipLaunchKernelGGL(k_red_bits2, dim3((waves2 * 64 + 255) / 256), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p,
@@ -624,6 +647,14 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
                 for (uint32_t g = 0; g < units; ++g) if ((g >> i) & 1u) a = kzg_host::xyzz_add(a, X2[6 * G1p + unit_lo + g]);
                 S[nbits++] = a;
             }
+        }
+        if (p.fused && G1 > 1) {                          // the fused level's group g holds the buckets gp * G1 + g: its six sums are the TOP six index bits,
+            Xyzz Sk[32];                                  // the second level's the low log2(G1)
+            const int lg = ilog2_floor(G1);
+            for (int k = 0; k < 6; ++k) Sk[lg + k] = S[k];
+            for (int j = 0; j < lg; ++j) Sk[j] = S[6 + j];
+            nbits = lg + 6;
+            for (int j = 0; j < nbits; ++j) S[j] = Sk[j];
         }
         if (p.naf) {                                      // the bucket index is the key rotated by six bits (naf.h naf_bucket)
             Xyzz Sk[32];

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve_pair.h"
+#include "curve_quad.h"
 #include "naf.h"
 
 namespace kzg {
@@ -1326,7 +1327,8 @@ k_msm_bucket_bits1p(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, 
 // entries into one bucket of a small SRS's tables) is summed by the whole wave: pair p adds the entries hb + p, hb + p + 32, ..., a
 // five-level tree joins the 32 partial sums.  One pair walking it alone kept its wave -- and the launch -- waiting for 256 dependent
 // additions (0.93 ms for a 512-coefficient commitment on a 512-point SRS; 0.07 ms for the level otherwise).  Every lane of the wave calls.
-constexpr uint32_t FUSED_HEAVY = 24;
+constexpr uint32_t FUSED_HEAVY = 12;        // (24 while the groups held neighbouring buckets: the ~100 heavy buckets of a blob's top window then sat in two workgroups)
+constexpr uint32_t FUSED_HEAVY_QUADS = 8;   // lane-quad form: 16 quads share a heavy bucket
 __device__ __noinline__ void fused_heavy_bucket(HalfXyzz& tot, uint32_t hb, uint32_t he, uint32_t lane, const uint4* __restrict__ points,
                                                 const uint32_t* __restrict__ sorted, uint32_t idx_log, uint32_t stride_adj) {
     const uint32_t pair = lane >> 1;
@@ -1368,7 +1370,7 @@ k_msm_bucket_bits1p_fused(const uint4* __restrict__ points, const uint32_t* __re
     __shared__ int32_t lds[2 * NL * 64];
     const uint32_t g = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 32 + (lane >> 1);
     const bool odd = (lane & 1u) != 0;
-    const uint32_t bkt = g * 64 + gp;
+    const uint32_t bkt = gp * G1 + g;                   // strided: neighbouring buckets (the few heavy ones of a short top window) go to different workgroups
     uint32_t e = 0, end = 0;
     if (bkt < B) { e = offs[bkt]; end = offs[bkt + 1]; }
     const uint32_t hb = e, he = end;
@@ -1517,6 +1519,242 @@ k_red_bits2p(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint3
             const int role = zeta_role(idx);
             if (role >= 0) half_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + grp[which], v[which], odd);
         }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 6d. the same two reduction levels on LANE QUADS (curve_quad.h): one point per four lanes, four multiplications per lane and addition
+//     instead of seven; 64 values = one workgroup of four waves (16 quads each).  ~0.7 of the pair form's dependent instructions at
+//     twice its lanes: used when no other MSM is in flight (then latency is everything and the SIMDs are idle anyway).
+//     Same inputs, same X1 / out_wire layout, the same group elements (KZG_QUAD_REDUCE=0: always the pair kernels).
+// -------------------------------------------------------------------------------------------------
+#ifndef KZG_QUAD_SMALL_WAVES
+#define KZG_QUAD_SMALL_WAVES 4     // waves per SIMD the small quad launches are compiled for (128 VGPRs with a few spills; 2 = no spills measured the same or 5 % slower)
+#endif
+__device__ __forceinline__ void bucket_partial_quad(QuadXyzz& v, const BucketSpan& s, uint32_t k, const int32_t* __restrict__ head, size_t head_stride,
+                                                    const int32_t* __restrict__ cont, size_t cont_stride, uint32_t q) {
+    if (k == 0) { quad_load(v, head, head_stride, s.g, q); return; }
+    const uint32_t first = s.t1 + 1;
+    const uint32_t t = !s.long_run ? s.t1 + k : (k == 1 ? first : (first / 64 + (k - 1)) * 64);
+    quad_load(v, cont, cont_stride, t, q);
+}
+// a heavy bucket, summed by the 16 quads of the wave: quad p takes the partials p, p + 16, ..; then a 4-step tree
+__device__ __noinline__ void bucket_sum_heavy_quads(QuadXyzz& tot, uint32_t g, uint32_t t1, uint32_t np, uint32_t long_run, uint32_t lane,
+                                                    const int32_t* __restrict__ head, size_t head_stride, const int32_t* __restrict__ cont, size_t cont_stride) {
+    const uint32_t quad = lane >> 2, q = lane & 3u;
+    BucketSpan h;
+    h.g = g; h.t1 = t1; h.np = np; h.long_run = long_run != 0;
+    QuadXyzz part;
+    quad_set_inf(part);
+    const uint32_t loads = (np + 15) / 16;
+#pragma unroll 1
+    for (uint32_t step = 0; step < loads + 4; ++step) {
+        QuadXyzz u;
+        bool on;
+        if (step < loads) {
+            const uint32_t k = quad + 16 * step;
+            on = k < np;
+            if (on) bucket_partial_quad(u, h, k, head, head_stride, cont, cont_stride, q);
+        } else {
+            const uint32_t d = 8u >> (step - loads);
+            quad_shfl_down(u, part, (int)(4 * d));
+            on = quad < d;
+        }
+        if (on) {
+            QuadXyzz r;
+            quad_add(r, part, u, q);
+            part = r;
+        }
+    }
+    quad_shfl(tot, part, (int)q);                      // quad 0 holds the sum
+}
+// Sum of all partials of this QUAD's bucket (s is the same in the four lanes).  Every lane of the wave must call this.
+__device__ __forceinline__ void bucket_sum_quads(QuadXyzz& acc, const BucketSpan& s, uint32_t lane, uint32_t q, const int32_t* __restrict__ head,
+                                                 size_t head_stride, const int32_t* __restrict__ cont, size_t cont_stride) {
+    quad_set_inf(acc);
+    const bool heavy = s.np > NP_SERIAL;
+    if (!heavy) {
+#pragma unroll 1
+        for (uint32_t k = 0; k < s.np; ++k) {
+            QuadXyzz v, r;
+            bucket_partial_quad(v, s, k, head, head_stride, cont, cont_stride, q);
+            quad_add(r, acc, v, q);
+            acc = r;
+        }
+    }
+    unsigned long long todo = __ballot(heavy && q == 0);   // one bit per heavy quad (its lane 0)
+    while (todo) {                                     // wave-uniform
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        QuadXyzz tot;
+        bucket_sum_heavy_quads(tot, __shfl(s.g, src, 64), __shfl(s.t1, src, 64), __shfl(s.np, src, 64), (uint32_t)__shfl((int)s.long_run, src, 64), lane,
+                               head, head_stride, cont, cont_stride);
+        if ((int)(lane & ~3u) == src) acc = tot;
+    }
+}
+// Superset-sum transform over the 64 values of a four-wave group, value gp = 16 w + quad: afterwards gp = 0 holds the total and
+// gp = 2^k the sum over the values whose index has bit k set.  Steps 0..3 inside the wave, steps 4 and 5 through LDS (the waves whose
+// index has the bit set publish, the others add).  Called by every lane of the four waves (four barriers inside).
+__device__ __forceinline__ void group_zeta64q(QuadXyzz& v, uint32_t lane, uint32_t w, uint32_t q, int32_t* __restrict__ lds /* (NL + 1) x 256 words */) {
+    const uint32_t quad = lane >> 2, tid = w * 64 + lane;
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {                      // one addition site for the six steps
+        QuadXyzz u;
+        bool on;
+        if (k < 4) {
+            quad_shfl_down(u, v, 4 << k);
+            on = ((quad >> k) & 1u) == 0;
+        } else {
+            const uint32_t bit = 1u << (k - 4);
+            if (k == 5) __syncthreads();               // step 4's readers are done
+            if (w & bit) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) lds[j * 256 + tid] = v.c.l[j];
+                lds[NL * 256 + tid] = v.inf ? 1 : 0;
+            }
+            __syncthreads();
+            on = (w & bit) == 0;
+            const uint32_t src = tid + 64 * bit;
+            if (on) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) u.c.l[j] = lds[j * 256 + src];
+                u.inf = lds[NL * 256 + src] != 0;
+            }
+        }
+        if (on) {
+            QuadXyzz r;
+            quad_add(r, v, u, q);
+            v = r;
+        }
+    }
+}
+template <int WAVES>      // 4: up to 1 024 workgroups in one round (128 VGPRs, some spills); 2: all the registers the additions want
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+k_msm_bucket_bits1q(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
+                    const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
+                    uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[(NL + 1) * 256];
+    const uint32_t g = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 16 + (lane >> 2), q = lane & 3u;
+    const uint32_t L = acc_seg_len(offs[B], nl);
+    const uint32_t bkt = g * 64 + gp;
+    BucketSpan s;
+    s.g = bkt; s.t1 = 0; s.np = 0; s.long_run = false;
+    if (bkt < B && L) s = bucket_span(offs, bkt, L);
+    QuadXyzz v;
+    bucket_sum_quads(v, s, lane, q, head, head_stride, cont, cont_stride);
+    group_zeta64q(v, lane, w, q, lds);
+    const int role = zeta_role(gp);
+    if (role < 0) return;
+    if (G1 == 1) quad_store_wire(out_wire, (size_t)role, v, q);
+    else quad_store(x1, x_stride, (size_t)role * G1 + g, v, q);
+}
+// level 1 FUSED with the accumulation (sparse MSMs; see k_msm_bucket_bits1p_fused): quad = bucket, entries added with quad_madd
+__device__ __noinline__ void fused_heavy_bucket_quads(QuadXyzz& tot, uint32_t hb, uint32_t he, uint32_t lane, const uint4* __restrict__ points,
+                                                      const uint32_t* __restrict__ sorted, uint32_t idx_log, uint32_t stride_adj) {
+    const uint32_t quad = lane >> 2, q = lane & 3u;
+    QuadXyzz part;
+    quad_set_inf(part);
+#pragma unroll 1
+    for (uint32_t e = hb + quad; e < he; e += 16) {     // quad-uniform trip count
+        const uint32_t cur = sorted[e];
+        const uint4* src = points + 4 * acc_point_index(cur & 0x7FFFFFFFu, idx_log, stride_adj) + ((q & 1u) ? 2 : 0);
+        const uint4 q0 = src[0], q1 = src[1];
+        const uint32_t w32[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        int any = (q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w) != 0 ? 1 : 0;
+        any |= pair_swap(any);
+        if (!any) continue;
+        Fq c;
+        fe_unpack(c, w32);
+        QuadXyzz r;
+        quad_madd(r, part, c, cur >> 31, q);
+        part = r;
+    }
+#pragma unroll 1
+    for (int d = 8; d >= 1; d >>= 1) {
+        QuadXyzz u;
+        quad_shfl_down(u, part, 4 * d);
+        if (quad < (uint32_t)d) {
+            QuadXyzz r;
+            quad_add(r, part, u, q);
+            part = r;
+        }
+    }
+    quad_shfl(tot, part, (int)q);                       // quad 0 holds the sum
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KZG_QUAD_SMALL_WAVES, KZG_QUAD_SMALL_WAVES)))      // (sparse MSMs: at most 256 workgroups)
+k_msm_bucket_bits1q_fused(const uint4* __restrict__ points, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs, uint32_t B,
+                          uint32_t idx_log, uint32_t stride_adj, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
+                          uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[(NL + 1) * 256];
+    const uint32_t g = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 16 + (lane >> 2), q = lane & 3u;
+    const uint32_t bkt = gp * G1 + g;                   // strided, as in k_msm_bucket_bits1p_fused
+    uint32_t e = 0, end = 0;
+    if (bkt < B) { e = offs[bkt]; end = offs[bkt + 1]; }
+    const uint32_t hb = e, he = end;
+    const bool heavy = end - e > FUSED_HEAVY_QUADS;
+    if (heavy) end = e;                                 // summed by the whole wave below
+    QuadXyzz v;
+    quad_set_inf(v);
+    const uint32_t half = (q & 1u) ? 2 : 0;             // lanes 0, 2: x; lanes 1, 3: y
+    const uint32_t last = end ? end - 1 : 0;
+    uint32_t ent = e < end ? sorted[e] : 0u;
+    uint32_t ent1 = e < end ? sorted[e + 1 < end ? e + 1 : last] : 0u;
+    const uint4* src = points + 4 * acc_point_index(ent & 0x7FFFFFFFu, idx_log, stride_adj) + half;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    if (e < end) { q0 = src[0]; q1 = src[1]; }
+#pragma unroll 1
+    for (; e < end; ++e) {                              // quad-uniform trip count
+        const uint32_t cur = ent;
+        const uint32_t w32[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        int any = (q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w) != 0 ? 1 : 0;
+        ent = ent1;
+        src = points + 4 * acc_point_index(ent & 0x7FFFFFFFu, idx_log, stride_adj) + half;
+        q0 = src[0]; q1 = src[1];
+        ent1 = sorted[e + 2 < end ? e + 2 : last];
+        any |= pair_swap(any);
+        if (!any) continue;                             // identity base (quad-uniform)
+        Fq c;
+        fe_unpack(c, w32);
+        QuadXyzz r;
+        quad_madd(r, v, c, cur >> 31, q);
+        v = r;
+    }
+    unsigned long long todo = __ballot(heavy && q == 0);
+    while (todo) {                                      // wave-uniform
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        QuadXyzz tot;
+        fused_heavy_bucket_quads(tot, __shfl(hb, src_lane, 64), __shfl(he, src_lane, 64), lane, points, sorted, idx_log, stride_adj);
+        if ((int)(lane & ~3u) == src_lane) v = tot;
+    }
+    group_zeta64q(v, lane, w, q, lds);
+    const int role = zeta_role(gp);
+    if (role < 0) return;
+    if (G1 == 1) quad_store_wire(out_wire, (size_t)role, v, q);
+    else quad_store(x1, x_stride, (size_t)role * G1 + g, v, q);
+}
+// level 2: one four-wave workgroup per job of k_red_bits2
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KZG_QUAD_SMALL_WAVES, KZG_QUAD_SMALL_WAVES)))      // (at most 7 x 16 workgroups)
+k_red_bits2q(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[(NL + 1) * 256];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 16 + (lane >> 2), q = lane & 3u;
+    const uint32_t job = blockIdx.x;                   // < 7 G1p
+    const bool sum_job = job < 6u * G1p;
+    const uint32_t a = sum_job ? job / G1p : 6u;
+    const uint32_t grp = sum_job ? job % G1p : job - 6u * G1p;
+    const uint32_t cnt = G1 - grp * 64 < 64 ? G1 - grp * 64 : 64;
+    QuadXyzz v;
+    if (gp < cnt) quad_load(v, x1, x_stride, (size_t)a * G1 + (size_t)grp * 64 + gp, q);
+    else quad_set_inf(v);
+    group_zeta64q(v, lane, w, q, lds);
+    if (sum_job) {
+        if (gp == 0) quad_store_wire(out_wire, job, v, q);
+    } else {
+        const int role = zeta_role(gp);
+        if (role >= 0) quad_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + grp, v, q);
     }
 }
 
