@@ -66,6 +66,9 @@ const char* kzg_ctx_last_error(const kzg_ctx* ctx);
 /* Tunables (0 = automatic): MSM window bits c in [2,16]; accumulate segment length.  A non-zero c also forces the
  * generic (no precomputed tables) mode for SRS-based calls. */
 int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len);
+/* Lanes per point of the table-mode bucket-reduction kernels: 0 = automatic (lane quads for an MSM that runs alone, lane pairs
+ * beside another MSM in flight), 2 = always pairs, 4 = always quads.  Results are identical; a test / measurement hook. */
+int32_t kzg_ctx_set_reduction_lanes(kzg_ctx* ctx, int32_t lanes);
 /* Measurement aid: when enabled, every MSM launch is bracketed phase by phase with HIP events on the
  * context's launch stream.  phase_ms_out[0..7] = accumulated milliseconds of: digits, bucket scan, scatter,
  * segment map, bucket ACCUMULATE (the dominant kernel), bucket finalise, window reduction, whole device span;

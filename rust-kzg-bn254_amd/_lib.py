@@ -51,6 +51,7 @@ PROTOTYPES = {
     "kzg_ctx_destroy": (None, [vp]),
     "kzg_ctx_last_error": (C.c_char_p, [vp]),
     "kzg_ctx_set_msm_window": (i32, [vp, i32, i32]),
+    "kzg_ctx_set_reduction_lanes": (i32, [vp, i32]),
     "kzg_srs_upload": (i32, [vp, u64p, sz, C.POINTER(vp)]),
     "kzg_srs_load_compressed_be": (i32, [vp, u8p, sz, C.POINTER(vp), C.POINTER(C.c_uint64)]),
     "kzg_srs_generate": (i32, [vp, u64p, C.c_uint64, sz, C.POINTER(vp)]),
@@ -191,6 +192,11 @@ class Context:
         rc = load().kzg_ctx_set_msm_window(self.handle, c_bits, segment_len)
         if rc != OK:
             raise ValueError("window bits must be 0 (auto) or in [2,16]")
+
+    def set_reduction_lanes(self, lanes=0):
+        """Lanes per point of the bucket-reduction kernels: 0 automatic, 2 pairs, 4 quads (same results; test / measurement hook)."""
+        if load().kzg_ctx_set_reduction_lanes(self.handle, lanes) != OK:
+            raise ValueError("lanes must be 0, 2 or 4")
 
     def close(self):
         if self.handle:

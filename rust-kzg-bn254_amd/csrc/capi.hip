@@ -152,6 +152,13 @@ int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len
     return KZG_OK;
 }
 
+int32_t kzg_ctx_set_reduction_lanes(kzg_ctx* ctx, int32_t lanes) {
+    if (!ctx || (lanes != 0 && lanes != 2 && lanes != 4)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->reduction_lanes = lanes;
+    return KZG_OK;
+}
+
 int32_t kzg_ctx_set_profiling(kzg_ctx* ctx, int32_t enable) {
     if (!ctx) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);

@@ -35,18 +35,9 @@ __device__ __forceinline__ void half_set_inf(HalfXyzz& h) { fe_set_zero(h.u); fe
 
 // value of the other lane of the pair (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
 __device__ __forceinline__ int32_t pair_swap(int32_t x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true); }
-// A DPP operand written by a VALU instruction needs two wait states before the DPP instruction reads it.  hipcc inserts them for
-// its own instructions but does not look INTO inline asm: when the last instructions of fe_mul_asm (fe_asm.h) write the limbs a DPP move
-// reads next, the move saw the OLD register contents (found with tools/ubench/quad_check.hip: quad_add's Y wrong in every generic case,
-// right again as soon as unrelated code was scheduled in between).  The guard routes the limbs through an asm statement that waits.
-__device__ __forceinline__ void fe_dpp_guard(Fq& a) {
-    asm("s_nop 1" : "+v"(a.l[0]), "+v"(a.l[1]), "+v"(a.l[2]), "+v"(a.l[3]), "+v"(a.l[4]), "+v"(a.l[5]), "+v"(a.l[6]), "+v"(a.l[7]), "+v"(a.l[8]));
-}
 __device__ __forceinline__ void fe_pair_swap(Fq& r, const Fq& a) {
-    Fq t = a;
-    fe_dpp_guard(t);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) r.l[j] = pair_swap(t.l[j]);
+    for (int j = 0; j < NL; ++j) r.l[j] = pair_swap(a.l[j]);
 }
 
 // r = 2 a (dbl-2008-s-1), a not the identity:

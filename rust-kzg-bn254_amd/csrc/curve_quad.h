@@ -43,10 +43,8 @@ __device__ __forceinline__ int32_t quad_mov(int32_t x) {
 }
 template <int CTRL>
 __device__ __forceinline__ void fe_quad_mov(Fq& r, const Fq& a) {
-    Fq t = a;
-    fe_dpp_guard(t);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) r.l[j] = quad_mov<CTRL>(t.l[j]);
+    for (int j = 0; j < NL; ++j) r.l[j] = quad_mov<CTRL>(a.l[j]);
 }
 // the whole point of the quad, in every lane
 __device__ __forceinline__ void quad_gather(Xyzz& p, const QuadXyzz& h) {

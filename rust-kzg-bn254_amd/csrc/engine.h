@@ -73,6 +73,7 @@ struct kzg_ctx {
     std::string last_error;
     int msm_c_override = 0;
     int msm_seg_override = 0;
+    int reduction_lanes = 0;               // kzg_ctx_set_reduction_lanes: 0 automatic, 2 lane pairs, 4 lane quads
     bool profiling = false;
     bool lds_attr_set = false;
     bool poly_lds_attr_set = false;

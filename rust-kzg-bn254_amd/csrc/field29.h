@@ -154,6 +154,52 @@ KZG_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
     for (int j = 0; j < NL; ++j) r.l[j] = out[j];
 }
 
+// The same product for the LATENCY-bound kernels (a lone wave per SIMD: bucket reductions, G1 FFT, small polynomial kernels).  A lone
+// wave issues a DEPENDENT instruction only every ~8 cycles, an independent one every 4: fe_mul above is one chain of ~206.  Here the 17
+// column sums of a b are 17 independent chains (product scanning, no reduction inside), and the Montgomery reduction walks the columns
+// afterwards: its own chain is ~half as long and the product chains fill the issue slots beside it.  Same value, same output range.
+template <class F>
+KZG_HD void fe_mul_ilp(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
+    KZG_CHECK_MUL(a, b, "fe_mul_ilp");
+    int32_t al[NL], bl[NL];
+    fe_opaque_limbs(al, a);
+    fe_opaque_limbs(bl, b);
+    int64_t T[2 * NL - 1];
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; ++k) {
+        int64_t t = 0;
+#pragma unroll
+        for (int j = (k < NL ? 0 : k - NL + 1); j <= (k < NL ? k : NL - 1); ++j) t += (int64_t)al[j] * (int64_t)bl[k - j];
+        T[k] = t;
+    }
+    int64_t acc = 0;
+    int32_t m[NL];
+    int32_t out[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        int64_t mp = 0;                                  // the terms of the earlier m: off the critical path
+#pragma unroll
+        for (int j = 0; j + 1 < k; ++j) mp += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        acc += T[k] + mp;
+        if (k >= 1) acc += (int64_t)m[k - 1] * (int64_t)(int32_t)F::P[1];
+        m[k] = (int32_t)(((uint32_t)acc * F::INV) & LMASK);
+        acc += (int64_t)m[k] * (int64_t)(int32_t)F::P[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+        int64_t mp = 0;                                  // all m known: independent of the carry chain
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; ++j) mp += (int64_t)m[j] * (int64_t)(int32_t)F::P[k - j];
+        acc += T[k] + mp;
+        out[k - NL] = (int32_t)((uint32_t)acc & LMASK);
+        acc >>= LB;
+    }
+    out[NL - 1] = (int32_t)acc;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.l[j] = out[j];
+}
+
 // ---------------------------------------------------------------------------------------------
 // TWO independent Montgomery products with their column sums interleaved statement by statement (used by xyzz_madd, curve.h):
 // with the chain barrier of fe_mac on BOTH accumulators every column is one chain of mads that starts from the carry (no 64-bit

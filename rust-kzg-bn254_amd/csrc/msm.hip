@@ -97,6 +97,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         bool other_in_flight = false;
         for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) other_in_flight |= ctx->slot_pending[sl] != nullptr;
         p.quad = p.tables && (quad_env > 0 || (quad_env < 0 && !other_in_flight));
+        if (ctx->reduction_lanes) p.quad = p.tables && ctx->reduction_lanes == 4;
     }
     int c;
     if (p.polys) {

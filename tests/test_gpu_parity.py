@@ -894,6 +894,42 @@ def test_msm_adversarial_digit_patterns(k, tau_srs):
     big.close()
 
 
+def test_reduction_kernels_on_lane_pairs_and_lane_quads(k, ref_srs, test_srs_wire, tau_srs):
+    """The two forms of the table-mode reduction kernels (curve_pair.h: one point per two lanes, used beside another MSM in flight;
+    curve_quad.h: per four lanes, used by an MSM that runs alone) forced one after the other over the same inputs: sparse MSMs (the
+    fused first level, with its heavy-bucket path: equal scalars), mid-size ones (accumulate kernel + both levels), the NAF mode, and the
+    boundary digit patterns.  Each against the oracle or the known-tau closed form."""
+    ctx = ref_srs.ctx
+    assert tau_srs.ctx is ctx
+    def tau_check(vals):
+        ptau, cur = 0, 1
+        for v in vals:
+            ptau = (ptau + v * cur) % R_
+            cur = cur * TAU % R_
+        return pyref.ec_mul(ptau, (1, 2))
+    rnd = random.Random(77)
+    try:
+        for lanes in (2, 4):
+            ctx.set_reduction_lanes(lanes)
+            for n in (1, 2, 33, 700, 3000):
+                sc = rand_scalars(n, 400 + n)
+                assert np.array_equal(msm_srs(k, ref_srs, sc), orc.msm_pippenger(test_srs_wire[:n], sc)), (lanes, n)
+            same = np.ascontiguousarray(np.broadcast_to(rand_scalars(1, 5), (600, 4))).copy()      # 600 entries in one bucket per window
+            assert np.array_equal(msm_srs(k, ref_srs, same), orc.msm_pippenger(test_srs_wire[:600], same)), lanes
+            for n in (5000, (1 << 14) + 5, 1 << 16):
+                vals = [rnd.randrange(R_) for _ in range(n)]
+                vals[::7] = [R_ - 1] * len(vals[::7])
+                vals[3::11] = [(1 << 253) - 1] * len(vals[3::11])
+                assert pyref.point_from_wire(msm_srs(k, tau_srs, pyref.frs_to_mont(vals))) == tau_check(vals), (lanes, n)
+            few = [rnd.randrange(R_) for _ in range(3)]
+            vals = [few[i % 3] for i in range(40000)]                                              # three heavy buckets per window, NAF mode
+            assert pyref.point_from_wire(msm_srs(k, tau_srs, pyref.frs_to_mont(vals))) == tau_check(vals), lanes
+    finally:
+        ctx.set_reduction_lanes(0)
+    with pytest.raises(ValueError):
+        ctx.set_reduction_lanes(3)
+
+
 @pytest.mark.parametrize("log_n", [14, 20, 22])
 def test_ntt_extreme_values(k, log_n):
     """Magnitude corner cases of the lazy-reduction NTT (values grow by 2m per butterfly stage before the next multiply):
