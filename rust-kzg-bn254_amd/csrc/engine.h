@@ -84,6 +84,7 @@ struct kzg_ctx {
     hipStream_t stream_x[KZG_NUM_SLOTS - 1] = {}; // one stream per slot (slot 0: `stream`), created on first use
     kzg::MsmPending* slot_pending[KZG_NUM_SLOTS] = {};   // what each slot of the asynchronous calls has in flight
     kzg::NttWorkspace ntt;
+    int32_t* ondomain_inv[13] = {};      // [log n] -> 1 / (w^k - 1), k < n <= 4096 (limb planes): proofs at a known domain point (poly.hip)
     kzg::NttWorkspace ntt_x[KZG_NUM_SLOTS - 1];   // slots 1.. of the asynchronous commitment / proof calls
     void* vb_pinned = nullptr;           // pinned staging of the packed blobs of one batch verification (capi.hip), grown on demand
     size_t vb_pinned_bytes = 0;

@@ -393,6 +393,71 @@ k_poly_quotient_on_domain(uint32_t n, NttTables tb, const int32_t* __restrict__ 
     wire_store(q_out, m, q);
 }
 
+// ---- K3' / K4': z = w^m with m known on the host (compute_proof_with_known_z_fr_index, kzg.rs:237-260), n <= POLY_SMALL_MAX ---------
+// The denominators of an on-domain point are the SAME set for every m:  w^i - w^m = w^m (w^(i-m) - 1), so with the per-domain table
+// t1[k] = 1 / (w^k - 1) (built once per domain size by the inversion chain above at z = 1) the inverse is w^(n-m) t1[(i - m) mod n]: no
+// inversion chain, no barycentric sum (y = f_m, helpers.rs:497-504): three kernels (46 + 15 + 6 us for 2 048 evaluations) less per proof.
+__global__ void __launch_bounds__(POLY_THREADS)
+k_poly_quotient_table(const uint4* __restrict__ evals, uint32_t n, NttTables tb, const int32_t* __restrict__ t1, uint32_t m,
+                      uint4* __restrict__ q_out, int32_t* __restrict__ partial) {
+    __shared__ int32_t lds[NL * POLY_THREADS];
+    const uint32_t T = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr y, zinv;
+    wire_load(y, evals, m);
+    fe_reduce(y);
+    domain_elem(zinv, tb, (n - m) & (n - 1));             // w^-m
+    Fr sum;
+    fe_set_zero(sum);
+    uint32_t cnt = 0;
+    for (uint32_t i = t; i < n; i += T, ++cnt) {
+        if (i == m) continue;
+        Fr f, iv, q, w, term;
+        wire_load(f, evals, i);
+        pl_load(iv, t1, n, (i - m) & (n - 1));
+        fe_mul(iv, iv, zinv);                             // 1 / (w^i - w^m)
+        fe_sub(f, f, y);                                  // (-3m, 3m)
+        fe_mul(q, f, iv);
+        wire_store(q_out, i, q);
+        domain_elem(w, tb, i);
+        fe_mul(term, q, w);
+        fe_add(sum, sum, term);
+        fe_norm(sum);
+        if (cnt % 32 == 31) fe_reduce(sum);
+    }
+    fe_reduce(sum);
+    block_sum(sum, lds);
+    if (threadIdx.x == 0) pl_store(partial, gridDim.x, blockIdx.x, sum);
+}
+// as K4, and y = f_m for the read-back
+__global__ void __launch_bounds__(POLY_THREADS)
+k_poly_quotient_on_domain_known(const uint4* __restrict__ evals, uint32_t n, NttTables tb, const int32_t* __restrict__ partial, uint32_t n_partial,
+                                uint32_t m, ProofScalars* __restrict__ ps, uint4* __restrict__ q_out) {
+    __shared__ int32_t lds[NL * POLY_THREADS];
+    Fr sum;
+    fe_set_zero(sum);
+    for (uint32_t i = threadIdx.x; i < n_partial; i += POLY_THREADS) {
+        Fr v;
+        pl_load(v, partial, n_partial, i);
+        fe_add(sum, sum, v);
+        fe_norm(sum);
+        if ((i / POLY_THREADS) % 32 == 31) fe_reduce(sum);
+    }
+    fe_reduce(sum);
+    block_sum(sum, lds);
+    if (threadIdx.x != 0) return;
+    Fr zinv, q, y;
+    domain_elem(zinv, tb, (n - m) & (n - 1));
+    fe_mul(q, sum, zinv);
+    fe_neg(q, q);
+    fe_norm(q);
+    wire_store(q_out, m, q);
+    wire_load(y, evals, m);
+    ps->on_domain_index = m;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) ps->y[j] = y.l[j];
+    fe_to_wire(ps->y_wire, y);
+}
+
 // ---- blob bytes -> Fr (helpers::to_fr_array, primitives/src/helpers.rs:40-57) ---------------------------------------
 // element i = the 32 big-endian bytes [32 i, 32 i + 32) (the last chunk right-padded with zeros) mod r, emitted in wire
 // (Montgomery, radix 2^256) form; elements i >= n_elems (power-of-two padding of PolynomialEvalForm::new,
@@ -741,6 +806,53 @@ const uint64_t* h_on_domain_constants() {
     } init;
     return init.c;
 }
+// w_(2^k) and its inverse in wire form, k <= 28: arkworks' roots of unity are the powers of g = 5^((r-1)/2^28)
+struct HRoots { uint64_t w[29][4], winv[29][4]; };
+const HRoots& h_roots() {
+    static const struct Init {
+        HRoots r;
+        Init() {
+            const uint64_t one_int[4] = {1, 0, 0, 0}, five_int[4] = {5, 0, 0, 0};
+            uint64_t acc[4], base[4];
+            h_fr_mul(H_FR_R2, one_int, acc);
+            h_fr_mul(H_FR_R2, five_int, base);
+            uint64_t e[4] = {H_FR[0] - 1, H_FR[1], H_FR[2], H_FR[3]};            // (r - 1) >> 28
+            for (int i = 0; i < 4; ++i) e[i] = (e[i] >> 28) | (i < 3 ? e[i + 1] << 36 : 0);
+            for (int i = 0; i < 254; ++i) {
+                if ((e[i >> 6] >> (i & 63)) & 1) h_fr_mul(acc, base, acc);
+                h_fr_mul(base, base, base);
+            }
+            memcpy(r.w[28], acc, 32);
+            for (int k = 27; k >= 0; --k) h_fr_mul(r.w[k + 1], r.w[k + 1], r.w[k]);
+            h_fr_inv(r.w[28], r.winv[28]);
+            for (int k = 27; k >= 0; --k) h_fr_mul(r.winv[k + 1], r.winv[k + 1], r.winv[k]);
+        }
+    } init;
+    return init.r;
+}
+// m with w_n^m = z for a z of the n-point domain (n = 2^log_n, z^n = 1): one bit per step, lowest first (Pohlig-Hellman in a group of
+// order 2^k: ~k^2 / 2 host multiplications, 3 us at k = 11).  Returns false if z turns out not to be a power of w_n.
+bool h_domain_index(const uint64_t z[4], int log_n, uint32_t* m_out) {
+    const HRoots& R = h_roots();
+    uint64_t one_w[4];
+    const uint64_t one_int[4] = {1, 0, 0, 0};
+    h_fr_mul(H_FR_R2, one_int, one_w);
+    uint64_t h[4];
+    memcpy(h, z, 32);
+    uint32_t m = 0;
+    for (int b = 0; b < log_n; ++b) {
+        uint64_t t[4];
+        memcpy(t, h, 32);
+        for (int q = 0; q < log_n - 1 - b; ++q) h_fr_mul(t, t, t);      // h^(2^(k-1-b)) = (-1)^(bit b of m)
+        if (memcmp(t, one_w, 32) != 0) {
+            m |= 1u << b;
+            h_fr_mul(h, R.winv[log_n - b], h);                         // h *= w_n^-(2^b) = w_(n / 2^b)^-1
+        }
+    }
+    if (memcmp(h, one_w, 32) != 0) return false;
+    *m_out = m;
+    return true;
+}
 }  // namespace
 
 // Enqueue the O(n) part of a proof on `st` with the buffers of `ps_set`, without waiting: upload, denominators + batch
@@ -778,6 +890,7 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     ProofScalars* init = reinterpret_cast<ProofScalars*>(pin);
     memset(init, 0, sizeof *init);
     init->on_domain_index = NO_INDEX;
+    bool z_on_domain = false;
     {
         uint64_t* zt = reinterpret_cast<uint64_t*>(pin + 1024);
         memcpy(zt, z, 32);
@@ -790,6 +903,7 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         uint64_t* zit = zt + 4 * (log_n + 2);                // z^-(2^a), a <= log_n: only read when z is on the domain
         uint64_t* cst = zt + 4 * (2 * log_n + 3);            // 1/(i - 1), -1/2, 1/(-i - 1), i = w^(n/4) = 5^((r-1)/4)
         if ((den[0] | den[1] | den[2] | den[3]) == 0) {
+            z_on_domain = true;
             memset(top, 0, 32);
             h_fr_inv(zt, zit);
             for (int a = 1; a <= log_n; ++a) h_fr_mul(zit + 4 * (a - 1), zit + 4 * (a - 1), zit + 4 * a);
@@ -799,6 +913,47 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         }
         memcpy(cst, h_on_domain_constants(), 96);
     }
+    if (!ctx->poly_lds_attr_set) {
+        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_poly_inv_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(NL * POLY_SMALL_MAX * 4)));
+        ctx->poly_lds_attr_set = true;
+    }
+    // z = w^m on a domain of at most 4 096 points (compute_proof_with_known_z_fr_index at the reference's bench sizes): the host finds m,
+    // the inverses come from the domain's table 1 / (w^k - 1) -- no inversion chain, no barycentric sum (KZG_ONDOMAIN_TABLE=0: the chain)
+    static const bool table_path = []() { const char* e = getenv("KZG_ONDOMAIN_TABLE"); return !(e && atoi(e) == 0); }();
+    uint32_t m_known = NO_INDEX;
+    if (table_path && want_proof && z_on_domain && n >= 2 && n <= POLY_SMALL_MAX && h_domain_index(z, log_n, &m_known)) {
+        int32_t*& t1 = ctx->ondomain_inv[log_n];
+        if (!t1) {                                           // once per domain size: the chain below at z = 1
+            std::vector<uint64_t> z1((size_t)(2 * log_n + 6) * 4, 0);
+            const uint64_t one_int[4] = {1, 0, 0, 0};
+            uint64_t one_w[4];
+            h_fr_mul(H_FR_R2, one_int, one_w);
+            for (int a = 0; a <= log_n; ++a) { memcpy(&z1[4 * (size_t)a], one_w, 32); memcpy(&z1[4 * (size_t)(log_n + 2 + a)], one_w, 32); }
+            memcpy(&z1[4 * (size_t)(2 * log_n + 3)], h_on_domain_constants(), 96);
+            uint4* d_z1 = nullptr;
+            KZG_HIP_TRY(ctx, hipMalloc(&d_z1, z1.size() * 8));
+            hipError_t e1 = hipMalloc(&t1, (size_t)NL * n * 4);
+            if (e1 == hipSuccess) e1 = hipMemcpy(d_z1, z1.data(), z1.size() * 8, hipMemcpyHostToDevice);
+            if (e1 == hipSuccess) {
+                hipLaunchKernelGGL(k_poly_inv_small, dim3(1), dim3(POLY_SMALL_THREADS), (size_t)NL * n * 4, st, d_z1, log_n, log_n, tb, t1);
+                e1 = hipGetLastError();
+                if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+            }
+            (void)hipFree(d_z1);
+            if (e1 != hipSuccess) { if (t1) { (void)hipFree(t1); t1 = nullptr; } KZG_HIP_TRY(ctx, e1); }
+        }
+        init->on_domain_index = m_known;
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
+        if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_poly_quotient_table, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, t1, m_known,
+                           set.c.as<uint4>(), partial);
+        hipLaunchKernelGGL(k_poly_quotient_on_domain_known, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, partial, blocks,
+                           m_known, ps, set.c.as<uint4>());
+        KZG_HIP_TRY(ctx, hipGetLastError());
+        KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + 3072, ps, sizeof(ProofScalars), hipMemcpyDeviceToHost, st));
+        return ntt_run(ctx, set.c.p, n, true, st, nttws);
+    }
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zt, pin + 1024, (size_t)(2 * log_n + 6) * 32, hipMemcpyHostToDevice, st));
     if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));   // nullptr: set.a already holds the n evaluations (blob proofs)
@@ -806,11 +961,6 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     // the chain of smaller domains, coarsest first: small kernel (<= 4096 points, in LDS), then x4 levels, then the last level
     const int32_t* next = nullptr;
     int direct = 0;
-    if (!ctx->poly_lds_attr_set) {
-        KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_poly_inv_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)(NL * POLY_SMALL_MAX * 4)));
-        ctx->poly_lds_attr_set = true;
-    }
     if (n <= POLY_SMALL_MAX) {
         hipLaunchKernelGGL(k_poly_inv_small, dim3(1), dim3(POLY_SMALL_THREADS), (size_t)NL * n * 4, st, d_zt, log_n, log_n, tb, d_inv);
         next = d_inv; direct = 1;

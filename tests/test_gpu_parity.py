@@ -372,7 +372,8 @@ def test_random_blob_commit_and_proof_2_12(k, tau_srs):
 def test_proofs_every_inversion_chain_shape(k, tau_srs, log_n):
     """compute_proof_impl (kzg.rs:128-178, :237-260) on domains of 1 .. 2^15 points: the batch inversion of the denominators is a
     chain of levels whose shape depends on n (small kernel only / + the fused x4 last level / + x4 middle levels), off the domain
-    and ON it (first, middle, last index: the zero denominator sits in a different lane and level each time).  Expected values by
+    and ON it (first, second, middle, last and three random indices: the zero denominator sits in a different lane and level each time;
+    up to 4 096 points the host finds the index and the inverses come from the domain's table 1 / (w^k - 1)).  Expected values by
     big integers on the known-tau SRS: y = f^(z), proof = ((f^(tau) - y) / (tau - z)) G1 with f^ from the barycentric formula."""
     n = 1 << log_n
     rnd = random.Random(0xC0DE + log_n)
@@ -402,7 +403,7 @@ def test_proofs_every_inversion_chain_shape(k, tau_srs, log_n):
     poly = k.PolynomialEvalForm(pyref.frs_to_mont(evals))
     kzg = k.KZG.new(); kzg.calculate_and_store_roots_of_unity(n * 32)
     z_off = rnd.randrange(R_)
-    cases = [(z_off, bary(z_off))] + [(roots[m], evals[m]) for m in sorted({0, n // 2, n - 1})]
+    cases = [(z_off, bary(z_off))] + [(roots[m], evals[m]) for m in sorted({0, n // 2, n - 1, 1 % n, rnd.randrange(n), rnd.randrange(n), rnd.randrange(n)})]
     for z, y_want in cases:
         proof, y = kzg._compute_proof_impl(poly, pyref.fr_to_mont(z), tau_srs, want_y=True)
         assert pyref.fr_from_mont(y) == y_want, (log_n, z == z_off)
