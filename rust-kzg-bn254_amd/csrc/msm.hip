@@ -500,11 +500,9 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         else if (pair_reduce && p.dual1 && (G1 & 1u) == 0)
             hipLaunchKernelGGL(k_msm_bucket_bits1p_dual, dim3(G1 / 2), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1);
-        else if (pair_reduce && p.quad && (G1 > 512 || KZG_QUAD_SMALL_WAVES == 4))
-            hipLaunchKernelGGL(k_msm_bucket_bits1q<4>, dim3(G1), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
-                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
-        else if (pair_reduce && p.quad)
-            hipLaunchKernelGGL(k_msm_bucket_bits1q<2>, dim3(G1), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
+        else if (pair_reduce && p.quad && (G1 <= 512 || ctx->reduction_lanes == 4))
+            // (at 2^16 buckets the level is 4 096 quad waves of ~11 000 instructions: throughput bound, 0.121 against 0.114 ms on pairs)
+            hipLaunchKernelGGL(k_msm_bucket_bits1q, dim3(G1), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
         else if (pair_reduce)
             hipLaunchKernelGGL(k_msm_bucket_bits1p, dim3(G1), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,

@@ -1628,8 +1628,7 @@ __device__ __forceinline__ void group_zeta64q(QuadXyzz& v, uint32_t lane, uint32
         }
     }
 }
-template <int WAVES>      // 4: up to 1 024 workgroups in one round (128 VGPRs, some spills); 2: all the registers the additions want
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KZG_QUAD_SMALL_WAVES, KZG_QUAD_SMALL_WAVES)))
 k_msm_bucket_bits1q(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
                     const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
                     uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
