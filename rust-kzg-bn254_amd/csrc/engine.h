@@ -32,6 +32,8 @@ struct MsmWorkspace {
     DeviceBuffer bases_wire;   // staging for ad-hoc bases in wire format
     DeviceBuffer digits, sorted, count, blockbase, sort_tmp, sort_key, sort_small, offs, block_sums, bucket, chunkS, chunkTmp, chunkA, out_wire;
     DeviceBuffer head, cont;   // accumulate partials: head[g] per bucket, cont[t] per lane (36 limb planes each; msm_kernels.h section 4)
+    const void* count_zero_ptr = nullptr;   // `count` at this address holds zeros in its first count_zero_g words once the stream gets here (small table-mode sort: the scan clears what it read)
+    uint32_t count_zero_g = 0;
     void* pinned_out = nullptr;   // pinned host buffer for window sums
     void* pinned_out_dev = nullptr;   // its device address: the reduction kernels store their results there directly
     // optional per-phase timing with HIP events on the launch stream (kzg_ctx_set_profiling)

@@ -40,7 +40,8 @@ constexpr int RED_T = 512;          // chunks (= threads of the per-window scan 
 // digits[w * n + i] = (|d| - 1) | (d < 0) << 31, or DIGIT_NONE for d == 0.
 // `n_total` scalars = batch * n; scalar j belongs to MSM j / n, whose digit rows are (j / n) * W + w.
 __global__ void __launch_bounds__(256)
-k_msm_digits(const uint4* __restrict__ scalars, uint32_t n_total, uint32_t n, int c, int W, uint32_t* __restrict__ digits) {
+k_msm_digits(const uint4* __restrict__ scalars, uint32_t n_total, uint32_t n, int c, int W, uint32_t* __restrict__ digits,
+             uint32_t* __restrict__ count = nullptr /* one bucket set (table mode, one MSM): the histogram of k_sort_small_hist in the same pass */) {
     latency_bound_kernel();
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_total) return;
@@ -60,7 +61,10 @@ k_msm_digits(const uint4* __restrict__ scalars, uint32_t n_total, uint32_t n, in
         uint32_t mag = neg ? (1u << c) - raw : raw;          // |digit| in [0, 2^(c-1)]
         carry = neg;
         uint32_t v = DIGIT_NONE;
-        if (mag != 0) v = (mag - 1) | (neg << 31);
+        if (mag != 0) {
+            v = (mag - 1) | (neg << 31);
+            if (count) atomicAdd(&count[mag - 1], 1u);
+        }
         digits[((size_t)msm * W + w) * n + i] = v;
     }
 }
@@ -104,8 +108,11 @@ __device__ __forceinline__ uint4 scan1_load(const uint32_t* __restrict__ count, 
     if (g + 2 < hi) v.z = count[g + 2];
     return v;
 }
+// LEAN (small table-mode sort): also leaves cursor[g] = offs[g] for the scatter's atomics and CLEARS the counters it has read, so the
+// next MSM on this workspace needs neither memset (msm.hip keeps track: MsmWorkspace::count_zero_g).
+template <bool LEAN>
 __global__ void __launch_bounds__(SCAN1_THREADS)
-k_scan_counts_1wg(const uint32_t* __restrict__ count, uint32_t G, uint32_t* __restrict__ offs /* G + 1 */) {
+k_scan_counts_1wg(uint32_t* __restrict__ count, uint32_t G, uint32_t* __restrict__ offs /* G + 1 */, uint32_t* __restrict__ cursor /* LEAN: G */) {
     latency_bound_kernel();
     __shared__ uint32_t wave_total[SCAN1_THREADS / 64];
     const uint32_t t = threadIdx.x, w = t >> 6, lane = t & 63;
@@ -134,8 +141,14 @@ k_scan_counts_1wg(const uint32_t* __restrict__ count, uint32_t G, uint32_t* __re
             for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += x; }
             uint4 o;
             o.x = run + incl - sum4; o.y = o.x + v[k].x; o.z = o.y + v[k].y; o.w = o.z + v[k].z;
-            if (g + 4 <= hi) *reinterpret_cast<uint4*>(offs + g) = o;
-            else { if (g < hi) offs[g] = o.x; if (g + 1 < hi) offs[g + 1] = o.y; if (g + 2 < hi) offs[g + 2] = o.z; }
+            if (g + 4 <= hi) {
+                *reinterpret_cast<uint4*>(offs + g) = o;
+                if (LEAN) { *reinterpret_cast<uint4*>(cursor + g) = o; *reinterpret_cast<uint4*>(count + g) = make_uint4(0, 0, 0, 0); }
+            } else {
+                if (g < hi) { offs[g] = o.x; if (LEAN) { cursor[g] = o.x; count[g] = 0; } }
+                if (g + 1 < hi) { offs[g + 1] = o.y; if (LEAN) { cursor[g + 1] = o.y; count[g + 1] = 0; } }
+                if (g + 2 < hi) { offs[g + 2] = o.z; if (LEAN) { cursor[g + 2] = o.z; count[g + 2] = 0; } }
+            }
             run += __shfl(incl, 63, 64);
         }
     }
@@ -251,8 +264,8 @@ k_sort_small_hist(const uint32_t* __restrict__ digits, uint32_t n_entries, uint3
 }
 __global__ void __launch_bounds__(256)
 k_sort_small_scatter(const uint32_t* __restrict__ digits, uint32_t n_entries, uint32_t n, uint32_t set_len, uint32_t B,
-                     const uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor /* G zeros */, uint32_t table_stride,
-                     uint32_t windows_per_msm, uint32_t* __restrict__ sorted) {
+                     const uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor /* G zeros, or a copy of offs (cursor_is_offs) */, uint32_t table_stride,
+                     uint32_t windows_per_msm, uint32_t* __restrict__ sorted, int cursor_is_offs = 0) {
     latency_bound_kernel();
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) return;
@@ -260,7 +273,7 @@ k_sort_small_scatter(const uint32_t* __restrict__ digits, uint32_t n_entries, ui
     if (v == DIGIT_NONE) return;
     const uint32_t set = e / set_len, es = e - set * set_len;
     const size_t gb = (size_t)set * B + (v & 0x7FFFFFFFu);
-    const uint32_t pos = offs[gb] + atomicAdd(&cursor[gb], 1u);
+    const uint32_t pos = (cursor_is_offs ? 0u : offs[gb]) + atomicAdd(&cursor[gb], 1u);
     uint32_t idx;
     if (table_stride) { const uint32_t w = es / n; idx = w * table_stride + (es - w * n); }
     else idx = (set / windows_per_msm) * n + es;
