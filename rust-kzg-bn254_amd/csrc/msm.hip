@@ -52,6 +52,7 @@ struct Plan {
     uint32_t nl;         // lanes of the accumulate kernel (a multiple of 256); each adds ceil(E / nl) sorted entries
     uint32_t set_len;    // digit entries per set
     uint32_t tile_len, tiles_per_set, tiles;
+    bool bitsum;         // tiny MSM over the per-bit tables as a plain sum: one result point (k_bitsum_level1 / 2)
     bool fused;          // sparse table-mode MSM: the first reduction level adds the sorted entries itself; its group g holds the buckets gp * G1 + g (set by msm_enqueue)
     bool quad;           // reduction levels on lane quads (curve_quad.h): no other MSM in flight when this one was planned
     bool dual1;          // first reduction level on two groups per workgroup (k_msm_bucket_bits1p_dual): fewer instructions, longer alone -> with another MSM in flight
@@ -90,6 +91,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     p.polys = p.naf ? polys : 0;
     p.dual1 = false;
     p.fused = false;
+    p.bitsum = false;
     {
         // lane quads for the two reduction levels when this MSM runs alone (0.7 of the pair form's dependent instructions, twice its lanes);
         // with another MSM in flight the SIMDs are shared and the pair form's fewer instructions count.  KZG_QUAD_REDUCE=0 / 1: never / always.
@@ -285,6 +287,50 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
                            const PolyPtrs* poly_ptrs = nullptr) {
     if (batch == 0 || (batch > 1 && bases.table_stride != 0)) return KZG_ERR_INVALID_ARG;
     if (polys && (!bases.naf || n % polys != 0 || polys > MSM_BATCH_POLYS_MAX)) return KZG_ERR_INVALID_ARG;
+    if (bases.bitsum && batch == 1 && !polys && n <= BITSUM_MAX_N) {
+        // tiny MSM: two launches, one result point (msm_kernels.h section 6e)
+        RoctxRange range_bs("kzg:msm:bit sums");
+        Plan p{};
+        p.n = (uint32_t)n; p.batch = 1; p.tables = true; p.bitsum = true; p.B = 64; p.G = 64; p.W = 255; p.c = 7;
+        const int chunk = n <= 512 ? 8 : n <= 2048 ? 16 : 32;                     // positions per quad: one wave per SIMD at 512 / 1 024 scalars (the six-step tree of every workgroup is what the launch costs: 2^9 30 us with 8, 38 with 4; 2^11 63 with 16, 77 with 8)
+        const uint32_t n_wg = (uint32_t)((n * (size_t)(256 / chunk) + 63) / 64);
+        KZG_HIP_TRY(ctx, ws.chunkS.reserve((size_t)n_wg * 36 * 4));
+        if (!ws.pinned_out) {
+            KZG_HIP_TRY(ctx, hipHostMalloc(&ws.pinned_out, (size_t)MSM_MAX_OUT * 32 * 4 + MSM_MAX_PARTS * 4, hipHostMallocDefault));
+            KZG_HIP_TRY(ctx, hipHostGetDevicePointer(&ws.pinned_out_dev, ws.pinned_out, 0));
+        }
+        const uint32_t n_res = (n_wg + 63) / 64;                 // <= 8 points for the host to add
+        if (out_cap < n_res || out_off + n_res > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
+        uint32_t* d_out = reinterpret_cast<uint32_t*>(ws.pinned_out_dev) + (size_t)out_off * 32;
+        const bool prof = ctx->profiling;
+        if (prof && !ws.ev_ready) {
+            for (auto& e : ws.ev) KZG_HIP_TRY(ctx, hipEventCreate(&e));
+            ws.ev_ready = true;
+        }
+        if (prof) {
+            reinterpret_cast<uint32_t*>(static_cast<char*>(ws.pinned_out) + (size_t)MSM_MAX_OUT * 128)[out_off / MSM_PART_OUT] = 0;
+            for (int i = 0; i <= 5; ++i) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[i], st));
+        }
+        if (chunk == 8)
+            hipLaunchKernelGGL(k_bitsum_level1<8>, dim3(n_wg), dim3(256), 0, st, bases.points, bases.table_stride, d_scalars, (uint32_t)n, ws.chunkS.as<int32_t>());
+        else if (chunk == 16)
+            hipLaunchKernelGGL(k_bitsum_level1<16>, dim3(n_wg), dim3(256), 0, st, bases.points, bases.table_stride, d_scalars, (uint32_t)n, ws.chunkS.as<int32_t>());
+        else
+            hipLaunchKernelGGL(k_bitsum_level1<32>, dim3(n_wg), dim3(256), 0, st, bases.points, bases.table_stride, d_scalars, (uint32_t)n, ws.chunkS.as<int32_t>());
+        if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[6], st));
+        hipLaunchKernelGGL(k_bitsum_level2, dim3(n_res), dim3(256), 0, st, ws.chunkS.as<int32_t>(), n_wg, d_out);
+        if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[7], st));
+        KZG_HIP_TRY(ctx, hipGetLastError());
+        if (!ws.ev_done) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
+        KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_done, st));
+        pend->p = p;
+        pend->n_out = n_res;
+        pend->batch = 1;
+        pend->n = n;
+        pend->out_off = out_off;
+        pend->profiled = true;
+        return KZG_OK;
+    }
     Plan p = make_plan(ctx, n, bases, batch, polys);
     if (p.polys && p.B > 65536) return KZG_ERR_INVALID_ARG;
     const int ND = p.c + 1 >= 16 ? NAF_DIGITS : 32;        // digit words per scalar (width >= 16: at most 16 digits)
@@ -632,6 +678,12 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     if (!p.tables) {
         for (uint32_t b = 0; b < batch; ++b)
             result[b] = kzg_host::horner_windows(vals + (size_t)b * p.W, p.W, p.c);   // sum_w 2^(c w) S_w: <= 255 doublings
+        return KZG_OK;
+    }
+    if (p.bitsum) {
+        Xyzz acc = vals[0];
+        for (uint32_t i = 1; i < n_out; ++i) acc = kzg_host::xyzz_add(acc, vals[i]);
+        result[0] = acc;
         return KZG_OK;
     }
     if (p.polys && p.c == 7) {                             // batched table mode, 64 buckets per polynomial: k_batch_finish left one commitment each

@@ -1770,6 +1770,89 @@ k_red_bits2q(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint3
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// 6e. TINY MSMs over the per-bit tables as plain SUMS (n <= BITSUM_MAX_N pairs): sum_i s_i P_i = sum_i sum_p naf_p(s_i) Bit_p[i] with
+//     the plain non-adjacent form of s_i (digits 0, +-1: ~85 table points per scalar).  No buckets, so no sort and no bit-weighted
+//     transform: a quad takes 8 / 16 positions of one scalar (at most 4 / 8 non-zero digits: that many dependent mixed additions),
+//     the 64 quads of a workgroup are summed by a six-step tree, a second launch sums 64 partial sums per workgroup, the host adds the <= 8 results.  A 512-coefficient
+//     commitment is then ~19 dependent point additions deep instead of ~35 (bucket walk + two six-step transforms + the host's 14-bit
+//     double-and-add), and two launches instead of five.
+// -------------------------------------------------------------------------------------------------
+constexpr uint32_t BITSUM_MAX_N = 8192;     // what the kernels take; the default policy (engine.h srs_bases) uses them up to 4 096
+// CHUNK = bit positions per quad (8 / 16 / 32: 32 / 16 / 8 quads per scalar, at most 4 / 8 / 16 dependent mixed additions): chosen by n (msm.hip)
+template <int CHUNK>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KZG_QUAD_SMALL_WAVES, KZG_QUAD_SMALL_WAVES)))
+k_bitsum_level1(const uint4* __restrict__ bits /* Bit_p[i] at (p stride + i) x 64 B */, uint32_t stride, const uint4* __restrict__ scalars, uint32_t n,
+                int32_t* __restrict__ part /* gridDim.x partial sums, limb planes */) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[(NL + 1) * 256];
+    constexpr uint32_t PER = 256 / CHUNK, MASK = CHUNK == 32 ? 0xFFFFFFFFu : (1u << (CHUNK & 31)) - 1u;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 16 + (lane >> 2), q = lane & 3u;
+    const uint32_t job = blockIdx.x * 64 + gp;          // (scalar, chunk of positions)
+    const uint32_t i = job / PER, chunk = job % PER;
+    QuadXyzz v;
+    quad_set_inf(v);
+    uint32_t digits = 0, negs = 0;                      // bit b: position CHUNK chunk + b carries a digit / the digit is -1
+    if (i < n) {
+        const uint4 lo = scalars[2 * (size_t)i], hi = scalars[2 * (size_t)i + 1];
+        const uint32_t w32[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t k[8];
+        fe_wire_to_canonical_words<FrParams>(k, w32);
+        // plain NAF: digit_p = bit_(p+1)(3k) - bit_(p+1)(k).  Only the two words around this chunk's positions are needed.
+        uint32_t h[9];
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { c += (uint64_t)k[j] * 3u; h[j] = (uint32_t)c; c >>= 32; }
+        h[8] = (uint32_t)c;
+        const uint32_t bit0 = (uint32_t)CHUNK * chunk + 1u;             // first bit of (3k, k) this chunk looks at
+        const uint32_t wd = bit0 >> 5, sh = bit0 & 31u;
+        uint32_t hw = 0, hw1 = 0, kw = 0, kw1 = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if ((uint32_t)j == wd) { hw = h[j]; kw = j < 8 ? k[j] : 0u; }
+            if ((uint32_t)j == wd + 1) { hw1 = h[j]; kw1 = j < 8 ? k[j] : 0u; }
+        }
+        const uint32_t hs = (uint32_t)((((uint64_t)hw1 << 32) | hw) >> sh) & MASK;
+        const uint32_t ks = (uint32_t)((((uint64_t)kw1 << 32) | kw) >> sh) & MASK;
+        digits = hs ^ ks;
+        negs = ks & ~hs;
+    }
+    // (the same for the four lanes of the quad: quad-uniform trip count)
+    uint32_t todo = digits;
+#pragma unroll 1
+    while (todo) {
+        const uint32_t b = (uint32_t)__ffs((int)todo) - 1u;
+        todo &= todo - 1u;
+        const uint32_t pos = (uint32_t)CHUNK * chunk + b;
+        const uint4* src = bits + 4 * ((size_t)pos * stride + i) + ((q & 1u) ? 2 : 0);
+        const uint4 q0 = src[0], q1 = src[1];
+        const uint32_t w32[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        int any = (q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w) != 0 ? 1 : 0;
+        any |= pair_swap(any);
+        if (!any) continue;                             // identity base
+        Fq cxy;
+        fe_unpack(cxy, w32);
+        QuadXyzz r;
+        quad_madd(r, v, cxy, (negs >> b) & 1u, q);
+        v = r;
+    }
+    group_zeta64q(v, lane, w, q, lds);                  // value 0 of the transform = the sum of the 64 quads
+    if (gp == 0) quad_store(part, gridDim.x, blockIdx.x, v, q);
+}
+// workgroup b: the sum of the partial sums [64 b, 64 b + 64) -> out_wire[b] (at most 8 points, added on the host)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KZG_QUAD_SMALL_WAVES, KZG_QUAD_SMALL_WAVES)))
+k_bitsum_level2(const int32_t* __restrict__ part, uint32_t n_part, uint32_t* __restrict__ out_wire) {
+    latency_bound_kernel();
+    __shared__ int32_t lds[(NL + 1) * 256];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 16 + (lane >> 2), q = lane & 3u;
+    const uint32_t j = blockIdx.x * 64 + gp;
+    QuadXyzz v;
+    if (j < n_part) quad_load(v, part, n_part, j, q);
+    else quad_set_inf(v);
+    group_zeta64q(v, lane, w, q, lds);
+    if (gp == 0) quad_store_wire(out_wire, blockIdx.x, v, q);
+}
+
 // Batched table mode (k_naf_digits with poly_len != 0): group g of the first reduction level IS polynomial g.  Its seven sums
 // (x1[role * G1 + g]: S_0 .. S_5 over the key bits, T the total) give the commitment sum_key (2 key + 1) V_key = 2 sum_j 2^j S_j + T:
 // six doublings and six additions on one lane per polynomial, XYZZ wire words out.

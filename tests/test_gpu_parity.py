@@ -895,6 +895,38 @@ def test_msm_adversarial_digit_patterns(k, tau_srs):
     big.close()
 
 
+def test_tiny_msm_as_sums_of_per_bit_table_points(k, tau_srs):
+    """MSMs of up to 4 096 pairs on an SRS with per-bit tables run as plain sums of table points (k_bitsum_level1 / 2: the non-adjacent
+    form of every scalar, 8 / 16 / 32 positions per lane quad by length): every length around the workgroup / chunk boundaries, offsets into the SRS,
+    and scalars that stress the recoding -- 0, 1, r - 1, 2^253, runs of ones (carries through every position), 0101.. / 1010.. / 0011..
+    patterns, 3 k for such k -- against the closed form on the known-tau SRS."""
+    rnd = random.Random(2048)
+    def tau_check(vals, off=0):
+        ptau, cur = 0, pow(TAU, off, R_)
+        for v in vals:
+            ptau = (ptau + v * cur) % R_
+            cur = cur * TAU % R_
+        return pyref.ec_mul(ptau, (1, 2)) if ptau else None
+    ones = (1 << 253) - 1
+    a5 = int("5" * 63, 16) % R_
+    aa = int("a" * 62, 16) % R_
+    c3 = int("3" * 63, 16) % R_
+    special = [0, 1, 2, 3, R_ - 1, R_ - 2, 1 << 253, ones, ones - 1, (1 << 200) - 1, a5, aa, c3, 3 * a5 % R_, 3 * aa % R_, (R_ - 1) // 2, (R_ + 1) // 2,
+               (1 << 8) - 1, 1 << 8, (1 << 248) + (1 << 247), sum(1 << (8 * j + 7) for j in range(31)), sum(3 << (8 * j + 6) for j in range(31))]
+    for n in (1, 2, 3, 31, 32, 33, 63, 64, 65, 500, 512, 513, 1024, 1025, 2047, 2048, 2049, 4095, 4096):
+        vals = [rnd.randrange(R_) for _ in range(n)]
+        for j, sp in enumerate(special):
+            if j < n:
+                vals[(j * 7) % n] = sp
+        got = msm_srs(k, tau_srs, pyref.frs_to_mont(vals))
+        assert pyref.point_from_wire(got) == tau_check(vals), n
+    for n, off in ((100, 1), (777, 5000), (2048, (1 << 16) - 2048), (4096, (1 << 16) - 4096), (1, (1 << 16) - 1)):
+        vals = [rnd.randrange(R_) for _ in range(n)]
+        assert pyref.point_from_wire(msm_srs(k, tau_srs, pyref.frs_to_mont(vals), offset=off)) == tau_check(vals, off), (n, off)
+    for vals in ([0] * 300, [special[7]] * 2048, [R_ - 1] * 1000, [special[10]] * 4096):            # all zero (identity), all-ones scalars, r - 1 everywhere
+        assert pyref.point_from_wire(msm_srs(k, tau_srs, pyref.frs_to_mont(vals))) == tau_check(vals)
+
+
 def test_reduction_kernels_on_lane_pairs_and_lane_quads(k, ref_srs, test_srs_wire, tau_srs):
     """The two forms of the table-mode reduction kernels (curve_pair.h: one point per two lanes, used beside another MSM in flight;
     curve_quad.h: per four lanes, used by an MSM that runs alone) forced one after the other over the same inputs: sparse MSMs (the
