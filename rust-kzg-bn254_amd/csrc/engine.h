@@ -131,7 +131,7 @@ struct MsmBases {
 };
 constexpr int SRS_SMALL_C = 15;                       // window bits of the second table set
 constexpr size_t SRS_SMALL_MAX = (size_t)1 << 13;     // MSMs of up to this many pairs use it
-constexpr size_t SRS_NAF_MIN = (size_t)1 << 15;       // an SRS of at least this many points gets per-bit tables at upload
+constexpr size_t SRS_NAF_MIN = (size_t)1 << 11;       // an SRS of at least this many points gets per-bit tables at upload (16 KiB per point; from 2^15 points for the NAF mode of large MSMs, below for the bit sums of tiny ones)
 constexpr size_t MSM_NAF_MIN = (size_t)1 << 14;       // MSMs of at least this many pairs use them (width-w NAF digits): one at a time 2^14 0.296 -> 0.273 ms; 2^13 0.241 -> 0.273: not below
 // bucket bits (c: 2^(c-1) buckets, NAF width c + 1) of an MSM of n pairs over the per-bit tables: the window policy of srs_precompute, by MSM length
 inline int srs_naf_c(size_t n) {

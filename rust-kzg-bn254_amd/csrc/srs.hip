@@ -406,7 +406,7 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
 // Per-bit tables Bit_j[i] = 2^j P_i, j < 255 (msm_kernels.h "NAF mode"): 255 x 64 B per point -- 15.9 GiB for a 2^20-point SRS, of
 // the 288 GB this GPU has -- so that MSMs of >= SRS_NAF_MIN pairs recode their scalars in width-w NAF: 254 / (w + 1) mixed additions
 // per scalar instead of 255 / c into the same 2^(c-1) buckets (13.4 instead of 15 at 2^16 buckets; measured in DESIGN.md section 4c).
-// Built for SRS of 2^15 .. 2^22 points when they fit beside a quarter of the free memory; KZG_NO_NAF=1: never.
+// Built for SRS of 2^11 .. 2^22 points when they fit beside a quarter of the free memory; KZG_NO_NAF=1: never.
 // force: also for an SRS below SRS_NAF_MIN points (the batched commitments build them on first use: 16 KiB per point)
 int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs, bool force) {
     const char* env = getenv("KZG_NO_NAF");

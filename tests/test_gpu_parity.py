@@ -55,6 +55,18 @@ def test_msm_matches_oracle_on_reference_srs(k, ref_srs, test_srs_wire, n):
     assert np.array_equal(got, orc.msm_pippenger(test_srs_wire[:n], sc))
 
 
+@pytest.fixture(scope="module")
+def small_srs(k, test_srs_wire):
+    """1 500 points: below 2^11, so WITHOUT per-bit tables -- its small MSMs run through the sort / buckets / fused first level."""
+    return k.SRS(test_srs_wire[:1500], order=1500)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 64, 255, 1000, 1500])
+def test_msm_matches_oracle_through_the_buckets(k, small_srs, test_srs_wire, n):
+    sc = rand_scalars(n, 7000 + n)
+    assert np.array_equal(msm_srs(k, small_srs, sc), orc.msm_pippenger(test_srs_wire[:n], sc))
+
+
 @pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
 def test_msm_every_window_size(k, ref_srs, test_srs_wire, c):
     n = 700
@@ -927,13 +939,14 @@ def test_tiny_msm_as_sums_of_per_bit_table_points(k, tau_srs):
         assert pyref.point_from_wire(msm_srs(k, tau_srs, pyref.frs_to_mont(vals))) == tau_check(vals)
 
 
-def test_reduction_kernels_on_lane_pairs_and_lane_quads(k, ref_srs, test_srs_wire, tau_srs):
+def test_reduction_kernels_on_lane_pairs_and_lane_quads(k, ref_srs, small_srs, test_srs_wire, tau_srs):
     """The two forms of the table-mode reduction kernels (curve_pair.h: one point per two lanes, used beside another MSM in flight;
     curve_quad.h: per four lanes, used by an MSM that runs alone) forced one after the other over the same inputs: sparse MSMs (the
     fused first level, with its heavy-bucket path: equal scalars), mid-size ones (accumulate kernel + both levels), the NAF mode, and the
     boundary digit patterns.  Each against the oracle or the known-tau closed form."""
     ctx = ref_srs.ctx
     assert tau_srs.ctx is ctx
+    assert small_srs.ctx is ctx
     def tau_check(vals):
         ptau, cur = 0, 1
         for v in vals:
@@ -944,11 +957,13 @@ def test_reduction_kernels_on_lane_pairs_and_lane_quads(k, ref_srs, test_srs_wir
     try:
         for lanes in (2, 4):
             ctx.set_reduction_lanes(lanes)
-            for n in (1, 2, 33, 700, 3000):
+            for n in (1, 2, 33, 700, 1500):                     # (an SRS below 2^11 points has no per-bit tables: these go through the buckets)
                 sc = rand_scalars(n, 400 + n)
-                assert np.array_equal(msm_srs(k, ref_srs, sc), orc.msm_pippenger(test_srs_wire[:n], sc)), (lanes, n)
+                assert np.array_equal(msm_srs(k, small_srs, sc), orc.msm_pippenger(test_srs_wire[:n], sc)), (lanes, n)
             same = np.ascontiguousarray(np.broadcast_to(rand_scalars(1, 5), (600, 4))).copy()      # 600 entries in one bucket per window
-            assert np.array_equal(msm_srs(k, ref_srs, same), orc.msm_pippenger(test_srs_wire[:600], same)), lanes
+            assert np.array_equal(msm_srs(k, small_srs, same), orc.msm_pippenger(test_srs_wire[:600], same)), lanes
+            sc = rand_scalars(3000, 3400)                       # (bit sums on the 3 000-point SRS: the same result under either setting)
+            assert np.array_equal(msm_srs(k, ref_srs, sc), orc.msm_pippenger(test_srs_wire[:3000], sc)), lanes
             for n in (5000, (1 << 14) + 5, 1 << 16):
                 vals = [rnd.randrange(R_) for _ in range(n)]
                 vals[::7] = [R_ - 1] * len(vals[::7])
