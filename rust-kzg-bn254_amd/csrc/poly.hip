@@ -399,7 +399,7 @@ k_poly_quotient_on_domain(uint32_t n, NttTables tb, const int32_t* __restrict__ 
 // inversion chain, no barycentric sum (y = f_m, helpers.rs:497-504): three kernels (46 + 15 + 6 us for 2 048 evaluations) less per proof.
 __global__ void __launch_bounds__(POLY_THREADS)
 k_poly_quotient_table(const uint4* __restrict__ evals, uint32_t n, NttTables tb, const int32_t* __restrict__ t1, uint32_t m,
-                      uint4* __restrict__ q_out, int32_t* __restrict__ partial) {
+                      uint4* __restrict__ q_out, int32_t* __restrict__ partial, ProofScalars* __restrict__ ps /* one workgroup: it also finishes q_m and y */) {
     __shared__ int32_t lds[NL * POLY_THREADS];
     const uint32_t T = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     Fr y, zinv;
@@ -426,7 +426,17 @@ k_poly_quotient_table(const uint4* __restrict__ evals, uint32_t n, NttTables tb,
     }
     fe_reduce(sum);
     block_sum(sum, lds);
-    if (threadIdx.x == 0) pl_store(partial, gridDim.x, blockIdx.x, sum);
+    if (threadIdx.x != 0) return;
+    if (gridDim.x > 1) { pl_store(partial, gridDim.x, blockIdx.x, sum); return; }
+    Fr q;                                                 // n <= 1 024: the only workgroup -- what k_poly_quotient_on_domain_known would do
+    fe_mul(q, sum, zinv);
+    fe_neg(q, q);
+    fe_norm(q);
+    wire_store(q_out, m, q);
+    ps->on_domain_index = m;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) ps->y[j] = y.l[j];
+    fe_to_wire(ps->y_wire, y);
 }
 // as K4, and y = f_m for the read-back
 __global__ void __launch_bounds__(POLY_THREADS)
@@ -947,9 +957,10 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
         if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_poly_quotient_table, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, t1, m_known,
-                           set.c.as<uint4>(), partial);
-        hipLaunchKernelGGL(k_poly_quotient_on_domain_known, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, partial, blocks,
-                           m_known, ps, set.c.as<uint4>());
+                           set.c.as<uint4>(), partial, ps);
+        if (blocks > 1)
+            hipLaunchKernelGGL(k_poly_quotient_on_domain_known, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, partial, blocks,
+                               m_known, ps, set.c.as<uint4>());
         KZG_HIP_TRY(ctx, hipGetLastError());
         KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + 3072, ps, sizeof(ProofScalars), hipMemcpyDeviceToHost, st));
         return ntt_run(ctx, set.c.p, n, true, st, nttws);
