@@ -953,16 +953,17 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
             (void)hipFree(d_z1);
             if (e1 != hipSuccess) { if (t1) { (void)hipFree(t1); t1 = nullptr; } KZG_HIP_TRY(ctx, e1); }
         }
-        init->on_domain_index = m_known;
-        KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
+        // (no upload of the ProofScalars image and no copy back: the kernels below only WRITE it, straight into the pinned read-back slot)
+        void* ps_host_dev = nullptr;
+        KZG_HIP_TRY(ctx, hipHostGetDevicePointer(&ps_host_dev, pin + 3072, 0));
+        ProofScalars* ps_out = static_cast<ProofScalars*>(ps_host_dev);
         if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_poly_quotient_table, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, t1, m_known,
-                           set.c.as<uint4>(), partial, ps);
+                           set.c.as<uint4>(), partial, ps_out);
         if (blocks > 1)
             hipLaunchKernelGGL(k_poly_quotient_on_domain_known, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, partial, blocks,
-                               m_known, ps, set.c.as<uint4>());
+                               m_known, ps_out, set.c.as<uint4>());
         KZG_HIP_TRY(ctx, hipGetLastError());
-        KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + 3072, ps, sizeof(ProofScalars), hipMemcpyDeviceToHost, st));
         return ntt_run(ctx, set.c.p, n, true, st, nttws);
     }
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
