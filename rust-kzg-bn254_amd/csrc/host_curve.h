@@ -62,7 +62,7 @@ inline Fq mul(const Fq& a, const Fq& b) {
     return r;
 }
 inline Fq sqr(const Fq& a) { return mul(a, a); }
-inline Fq inv(const Fq& a) {            // a^(p-2)
+inline Fq inv_fermat(const Fq& a) {     // a^(p-2): 381 Montgomery products, ~11 us (kept as the cross-check of inv below)
     Fq e = FQ_P; e.l[0] -= 2;
     Fq acc = FQ_ONE, base = a;
     for (int i = 0; i < 254; ++i) {
@@ -70,6 +70,43 @@ inline Fq inv(const Fq& a) {            // a^(p-2)
         base = sqr(base);
     }
     return acc;
+}
+// plain 256-bit helpers of the binary inversion
+inline bool geq(const Fq& a, const Fq& b) {
+    for (int i = 3; i >= 0; --i) { if (a.l[i] > b.l[i]) return true; if (a.l[i] < b.l[i]) return false; }
+    return true;
+}
+inline void sub_raw(Fq& a, const Fq& b) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)a.l[i] - b.l[i] - br; a.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+}
+inline void shr1(Fq& a) {
+    for (int i = 0; i < 3; ++i) a.l[i] = (a.l[i] >> 1) | (a.l[i + 1] << 63);
+    a.l[3] >>= 1;
+}
+inline void half_mod_p(Fq& x) {         // x / 2 mod p, x < p < 2^254 (x + p does not overflow)
+    if (x.l[0] & 1) { u128 c = 0; for (int i = 0; i < 4; ++i) { c += (u128)x.l[i] + FQ_P.l[i]; x.l[i] = (uint64_t)c; c >>= 64; } }
+    shr1(x);
+}
+// Inverse of a Montgomery-form element (a R -> a^-1 R), a != 0: binary extended Euclid on the plain integers (at most 2 x 254 shift /
+// subtract steps on four words, ~2-3 us) and two Montgomery products by R^2 to get back into the form.  `into_affine()` is on the
+// critical path of every commitment: the Fermat form above was 11 of the ~70 us of a 512-coefficient commitment.
+inline const Fq& fq_r2() {
+    static const Fq r2 = []() { Fq v = FQ_ONE; for (int i = 0; i < 256; ++i) v = add(v, v); return v; }();     // R * 2^256 = R^2 mod p
+    return r2;
+}
+inline Fq inv(const Fq& a) {
+    if (is_zero(a)) return a;           // (as a^(p-2) would: 0)
+    Fq u = a, v = FQ_P, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+    const Fq one = {{1, 0, 0, 0}};
+    while (!eq(u, one) && !eq(v, one)) {
+        while ((u.l[0] & 1) == 0) { shr1(u); half_mod_p(x1); }
+        while ((v.l[0] & 1) == 0) { shr1(v); half_mod_p(x2); }
+        if (geq(u, v)) { sub_raw(u, v); x1 = sub(x1, x2); }
+        else { sub_raw(v, u); x2 = sub(x2, x1); }
+    }
+    const Fq b = eq(u, one) ? x1 : x2;  // (a R)^-1 = a^-1 R^-1 as a plain integer < p
+    return mul(mul(b, fq_r2()), fq_r2());       // . R^2 R^-1 . R^2 R^-1 = a^-1 R
 }
 
 struct Xyzz { Fq x, y, zz, zzz; };          // identity: zz == 0

@@ -11,6 +11,24 @@ static bool fq12_eq(const Fq12& a, const Fq12& b) { for (int i = 0; i < 12; ++i)
 int main() {
     G1 g; g.x = FQ_ONE; g.y = FQ_TWO; g.inf = false;
     G2 h = g2_generator();
+    {   // binary-Euclid inversion (host_curve.h inv) against a^(p-2) and against a * a^-1 = 1: edge values and 20 000 pseudo-random ones
+        bool ok = true;
+        Fq pm1 = FQ_P; pm1.l[0] -= 1;
+        Fq edge[6] = {FQ_ONE, FQ_TWO, pm1, {{1, 0, 0, 0}}, {{2, 0, 0, 0}}, {{0, 0, 0, 1ULL << 61}}};
+        for (const Fq& a : edge) ok = ok && eq(inv(a), inv_fermat(a)) && eq(mul(a, inv(a)), FQ_ONE);
+        uint64_t s = 88172645463325252ULL;
+        Fq a = FQ_TWO;
+        for (int i = 0; i < 20000 && ok; ++i) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            Fq t = {{s, s * 0x9E3779B97F4A7C15ULL, ~s, s >> 3}};
+            t.l[3] &= (1ULL << 61) - 1;                    // < 2^253 < p
+            a = mul(add(a, t), FQ_TWO);
+            if (is_zero(a)) continue;
+            const Fq b = inv(a);
+            ok = eq(mul(a, b), FQ_ONE) && (i % 64 != 0 || eq(b, inv_fermat(a)));
+        }
+        printf("binary_inverse %d\n", (int)(ok && is_zero(inv(fq_zero()))));
+    }
     printf("g1_on_curve %d\n", (int)g1_on_curve(g));
     printf("g2_gen_on_curve %d\n", (int)g2_on_curve(h));
     printf("g2_tau_on_curve %d\n", (int)g2_on_curve(g2_tau_mainnet()));
