@@ -798,10 +798,29 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
     bool is_cont = false, long_run = false;
     if (active) {
         uint32_t lo = 0, hi = G;                       // invariant: offs[lo] <= begin < offs[hi]
+#ifdef KZG_ACC_BINARY_SEARCH                           // (A/B: one dependent load per step, 16 steps at 2^16 buckets)
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (offs[mid] <= begin) lo = mid; else hi = mid;
         }
+#else
+        // 16-ary: fifteen INDEPENDENT probes per round, four dependent rounds instead of sixteen at 2^16 buckets (offs is L2 resident and
+        // neighbouring lanes probe the same words); the prologue of a lane is ~10 us of dependent loads otherwise -- nothing at 2^20 pairs
+        // (73 entries per lane), a tenth of the kernel at 2^12 .. 2^16
+        while (hi - lo > 1) {
+            const uint32_t s = (hi - lo + 15) >> 4;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (uint32_t j = 1; j < 16; ++j) {
+                const uint32_t p = lo + j * s;
+                const uint32_t v = p < hi ? offs[p] : 0xFFFFFFFFu;
+                cnt += v <= begin ? 1u : 0u;       // offs is non-decreasing: the probes that are <= begin form a prefix
+            }
+            const uint32_t nlo = lo + cnt * s, nhi = lo + (cnt + 1) * s;
+            if (cnt < 15 && nhi < hi) hi = nhi;
+            lo = nlo;
+        }
+#endif
         g = lo;
         const uint32_t o0 = offs[g];
         next = offs[g + 1];
