@@ -512,8 +512,14 @@ def main():
             for nn in (512, 1024, 2048):
                 sc_s = np.ascontiguousarray(scalars[:nn]); zq_s = np.ascontiguousarray(scalars_b[77])
                 small["commit_coeff_%d_ms" % nn] = avg_ms(lambda: lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(sc_s), nn, _lib.ptr(o8), C.byref(oi)), reps=30, warm=5)
-                small["compute_proof_%d_ms" % nn] = avg_ms(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(sc_s), nn, None, nn, _lib.ptr(zq_s), _lib.ptr(o8),
+                # bench_kzg_proof.rs:17-58 proves at a DOMAIN point (compute_proof_with_known_z_fr_index): z = w^idx; the off-domain figure beside it
+                roots_s = np.zeros((nn, 4), np.uint64); n_roots = C.c_size_t(0)
+                assert lib.kzg_calculate_roots_of_unity(ctx.handle, nn * 32, _lib.ptr(roots_s), nn, C.byref(n_roots)) == 0 and n_roots.value == nn
+                zq_on = np.ascontiguousarray(roots_s[(nn * 3) // 7])
+                small["compute_proof_%d_ms" % nn] = avg_ms(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(sc_s), nn, None, nn, _lib.ptr(zq_on), _lib.ptr(o8),
                                                                                            C.byref(oi), _lib.ptr(o4)), reps=30, warm=5)
+                small["compute_proof_off_domain_%d_ms" % nn] = avg_ms(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(sc_s), nn, None, nn, _lib.ptr(zq_s),
+                                                                                                      _lib.ptr(o8), C.byref(oi), _lib.ptr(o4)), reps=30, warm=5)
             # the same shapes as ONE batched call over 512 polynomials (resident scalars): microseconds per commitment, checked against a single call
             for nn in (512, 2048):
                 cnt_b = min(512, n // nn)

@@ -882,7 +882,12 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     if (blocks == 0) blocks = 1;
     KZG_HIP_TRY(ctx, set.a.reserve(n * 32));                 // evaluations (wire)
     // inverses (planes) | level scratch: the smaller domains' inverses, two ping-pong plane sets of the small kernel
-    const size_t n1 = n > POLY_SMALL_MAX ? n / 4 : 0;        // the level above the last one (0: the small kernel gives all n inverses)
+    // The one-workgroup kernel takes the chain up to 2^chain_small_log points, x4 levels on the whole chip go on from there: its late levels
+    // keep all 16 waves of one CU busy, a x4 launch over many CUs costs about one of them.  KZG_POLY_SMALL_LOG (2..12), off-domain proofs of
+    // 2^11 / 2^12 / 2^14 evaluations (tools/time_proof_sizes.py, same box): 12 -> 0.231 / 0.295 / 0.426 ms, 9 -> 0.226 / 0.281 / 0.414, 7 -> 0.230 / 0.286 / 0.422
+    static const int chain_small_log = []() { const char* e = getenv("KZG_POLY_SMALL_LOG"); const int v = e ? atoi(e) : 9; return v >= 2 && v <= (int)POLY_SMALL_MAX_LOG ? v : 9; }();
+    const size_t chain_small_max = (size_t)1 << chain_small_log;
+    const size_t n1 = n > chain_small_max ? n / 4 : 0;       // the level above the last one (0: the small kernel gives all n inverses)
     const size_t lvl_words = n1 ? (n1 + n1 / 2) * NL + 64 : 0;          // sum over n/4, n/16, ... < n1 * 4/3
     KZG_HIP_TRY(ctx, set.b.reserve((n * NL + lvl_words) * 4));
     KZG_HIP_TRY(ctx, set.c.reserve(n * 32));                 // quotient (wire)
@@ -973,13 +978,13 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     // the chain of smaller domains, coarsest first: small kernel (<= 4096 points, in LDS), then x4 levels, then the last level
     const int32_t* next = nullptr;
     int direct = 0;
-    if (n <= POLY_SMALL_MAX) {
+    if (n <= chain_small_max) {
         hipLaunchKernelGGL(k_poly_inv_small, dim3(1), dim3(POLY_SMALL_THREADS), (size_t)NL * n * 4, st, d_zt, log_n, log_n, tb, d_inv);
         next = d_inv; direct = 1;
     } else {
         int log_l = log_n - 2;                               // sizes n/4, n/16, .. down to the first one <= 4096
         std::vector<int> logs;
-        while (log_l > (int)POLY_SMALL_MAX_LOG) { logs.push_back(log_l); log_l -= 2; }
+        while (log_l > chain_small_log) { logs.push_back(log_l); log_l -= 2; }
         std::vector<int32_t*> bufs;                          // level buffers inside d_lvl: size 2^logs[0] first
         int32_t* cursor = d_lvl;
         for (int l : logs) { bufs.push_back(cursor); cursor += ((size_t)NL << l); }
