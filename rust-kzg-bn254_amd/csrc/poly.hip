@@ -971,8 +971,10 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         KZG_HIP_TRY(ctx, hipGetLastError());
         return ntt_run(ctx, set.c.p, n, true, st, nttws);
     }
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(ps, init, sizeof *init, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zt, pin + 1024, (size_t)(2 * log_n + 6) * 32, hipMemcpyHostToDevice, st));
+    // one upload for the scalar image (pin[0, 1024) -> small[0, 1024)) and the chain's scalars right behind it (pin + 1024 -> small + 1024)
+    static_assert(sizeof(ProofScalars) <= 1024, "the ProofScalars image and the zt table are uploaded as one block");
+    memset(pin + sizeof(ProofScalars), 0, 1024 - sizeof(ProofScalars));
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(small, pin, 1024 + (size_t)(2 * log_n + 6) * 32, hipMemcpyHostToDevice, st));
     if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));   // nullptr: set.a already holds the n evaluations (blob proofs)
 
     // the chain of smaller domains, coarsest first: small kernel (<= 4096 points, in LDS), then x4 levels, then the last level
