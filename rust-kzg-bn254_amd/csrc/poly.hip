@@ -229,6 +229,23 @@ k_poly_inv_level(const uint4* __restrict__ zt, int log_n, int log_nl, NttTables 
     for (uint32_t k = 0; k < 4; ++k) pl_store(out, N, t + k * T, inv[k]);
 }
 
+// y = (z^n - 1) / n * sum  for z off the domain (helpers.rs:529-532), into the proof's scalar image; one thread
+__device__ __forceinline__ void poly_store_y_off_domain(const Fr& sum, int log_n, const uint4* __restrict__ z_wire, ProofScalars* __restrict__ ps) {
+    Fr y, z, zn, one, ninv;
+    wire_load(z, z_wire, 0);
+    zn = z;
+    for (int k = 0; k < log_n; ++k) fe_sqr(zn, zn);          // z^n, n = 2^log_n
+    fe_set_one(one);
+    fe_sub(zn, zn, one);                           // in (-3m, 2m)
+#pragma unroll
+    for (int j = 0; j < NL; ++j) ninv.l[j] = (int32_t)FrParams::NINV[log_n * NL + j];
+    fe_mul(y, sum, zn);
+    fe_mul(y, y, ninv);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) ps->y[j] = y.l[j];
+    fe_to_wire(ps->y_wire, y);
+}
+
 // ---- K1: the last level (inverses of all n denominators) + barycentric partial sums ---------------------------------------
 // lane t owns elements i = k * T + t.  inv[i] = 1 / (w^i - z)  (1 for the on-domain index).
 //   direct != 0: next[i] already is that inverse (n <= 4096: K0 produced all of them); any number of lanes
@@ -236,7 +253,7 @@ k_poly_inv_level(const uint4* __restrict__ zt, int log_n, int log_nl, NttTables 
 __global__ void __launch_bounds__(POLY_THREADS)
 k_poly_inverses(const uint4* __restrict__ evals, uint32_t n, int log_n, NttTables tb, const uint4* __restrict__ z_wire,
                 const int32_t* __restrict__ next, int direct, int32_t* __restrict__ inv, int32_t* __restrict__ partial /* NL x gridDim */,
-                ProofScalars* __restrict__ ps) {
+                ProofScalars* __restrict__ ps, int finish_y /* one workgroup, z off the domain: it also does what k_poly_finish_y would */) {
     __shared__ int32_t lds[NL * POLY_THREADS];
     const uint32_t T = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     Fr z;
@@ -289,7 +306,9 @@ k_poly_inverses(const uint4* __restrict__ evals, uint32_t n, int log_n, NttTable
     }
     fe_reduce(sum);
     block_sum(sum, lds);
-    if (threadIdx.x == 0) pl_store(partial, gridDim.x, blockIdx.x, sum);
+    if (threadIdx.x != 0) return;
+    if (finish_y) poly_store_y_off_domain(sum, log_n, z_wire, ps);
+    else pl_store(partial, gridDim.x, blockIdx.x, sum);
 }
 
 // ---- K2: y ---------------------------------------------------------------------------------------------
@@ -314,16 +333,8 @@ k_poly_finish_y(const uint4* __restrict__ evals, uint32_t n, int log_n, const ui
     if (m != NO_INDEX) {
         wire_load(y, evals, m);                   // helpers.rs:497-504
     } else {
-        Fr z, zn, one, ninv;
-        wire_load(z, z_wire, 0);
-        zn = z;
-        for (int k = 0; k < log_n; ++k) fe_sqr(zn, zn);      // z^n, n = 2^log_n
-        fe_set_one(one);
-        fe_sub(zn, zn, one);                       // in (-3m, 2m)
-#pragma unroll
-        for (int j = 0; j < NL; ++j) ninv.l[j] = (int32_t)FrParams::NINV[log_n * NL + j];
-        fe_mul(y, sum, zn);
-        fe_mul(y, y, ninv);                        // helpers.rs:529-532
+        poly_store_y_off_domain(sum, log_n, z_wire, ps);
+        return;
     }
 #pragma unroll
     for (int j = 0; j < NL; ++j) ps->y[j] = y.l[j];
@@ -1001,17 +1012,20 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         }
         next = prev;
     }
+    const int fused_y = blocks == 1 && !z_on_domain;         // one workgroup holds the whole barycentric sum: no second launch for y
     hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, tb, d_z,
-                       next, direct, d_inv, partial, ps);
-    hipLaunchKernelGGL(k_poly_finish_y, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, d_z,
-                       partial, blocks, ps);
+                       next, direct, d_inv, partial, ps, fused_y);
+    if (!fused_y)
+        hipLaunchKernelGGL(k_poly_finish_y, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, d_z,
+                           partial, blocks, ps);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + 3072, ps, sizeof(ProofScalars), hipMemcpyDeviceToHost, st));
     if (!want_proof) return KZG_OK;
     hipLaunchKernelGGL(k_poly_quotient, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, d_inv,
                        ps, set.c.as<uint4>(), partial);
-    hipLaunchKernelGGL(k_poly_quotient_on_domain, dim3(1), dim3(POLY_THREADS), 0, st, (uint32_t)n, tb, partial, blocks, ps,
-                       set.c.as<uint4>());
+    if (z_on_domain)                                         // (z off the domain: the kernel would return at once)
+        hipLaunchKernelGGL(k_poly_quotient_on_domain, dim3(1), dim3(POLY_THREADS), 0, st, (uint32_t)n, tb, partial, blocks, ps,
+                           set.c.as<uint4>());
     KZG_HIP_TRY(ctx, hipGetLastError());
     // commit_eval_form(quotient): coefficients = IFFT(q), then MSM over the monomial SRS (kzg.rs:176-177)
     return ntt_run(ctx, set.c.p, n, true, st, nttws);
