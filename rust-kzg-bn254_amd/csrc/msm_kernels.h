@@ -747,7 +747,10 @@ k_sort2_bin(const uint32_t* __restrict__ tmp1, const uint32_t* __restrict__ csta
 // Runs of more than RUN_SERIAL continuation lanes (heavy buckets: skewed or repeated scalars, the short top window) are folded
 // inside each wave by a segmented suffix scan over ds_bpermute shuffles first, so that only the first lane of the run and the
 // lanes 0 of the following waves hold a partial: bucket_partial() below enumerates them.
-constexpr uint32_t RUN_SERIAL = 8;        // continuation lanes a bucket's owner adds one by one
+#ifndef KZG_RUN_SERIAL
+#define KZG_RUN_SERIAL 8
+#endif
+constexpr uint32_t RUN_SERIAL = KZG_RUN_SERIAL;        // continuation lanes a bucket's owner adds one by one
 constexpr uint32_t NP_SERIAL = 10;        // partials (head included) above which a wave sums a bucket cooperatively
 
 __device__ __forceinline__ void xyzz_shfl_down(Xyzz& r, const Xyzz& v, int d) {
