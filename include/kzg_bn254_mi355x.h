@@ -102,6 +102,23 @@ int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t firs
 int32_t kzg_srs_download(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, size_t n, uint64_t* out_xy_mont);
 void    kzg_srs_free(kzg_srs* srs);
 size_t  kzg_srs_len(const kzg_srs* srs);
+/* The same loader for the "native" format of SRS::parallel_read_g1_points_native(.., is_native = true) (prover/src/srs.rs:205-251 ->
+ * primitives/src/traits.rs:34-36: G1Affine::deserialize_compressed of ark-serialize 0.5): x as 32 little-endian bytes, flags in the top
+ * two bits of the LAST byte (0x80 = the larger y, 0x40 = infinity; both set, or x >= p -> KZG_ERR_DESERIALIZE).  RESTATED from
+ * ark-serialize, not pinned by a reference vector: the reference tree holds no file in this format and calls the function nowhere. */
+int32_t kzg_srs_load_compressed_ark_le(kzg_ctx* ctx, const uint8_t* bytes, size_t n_points, kzg_srs** out, uint64_t* bad_index);
+/* 1 when the SRS carries its per-bit tables Bit_p[i] = 2^p P_i (the NAF mode of MSMs of >= 2^14 pairs and the batched launches need
+ * them; absent with KZG_NO_NAF=1, above 2^22 points, or when HBM is short).  build != 0: try to build them first (once, on the SRS's
+ * own context).
+ *
+ * THREADS.  An SRS handle may be used from any number of host threads and by every context of its GPU at once, as the reference shares
+ * one `SRS` across threads (prover/tests/kzg_test.rs:9-17, primitives/tests/blob_test.rs:83-94).  Tables that are built after upload
+ * -- these per-bit tables on the first batched call of a small SRS, the x3 tables of kzg_g1_ifft(64..256), the bases attached by
+ * kzg_srs_cache_lagrange -- are built under a lock of the SRS and published only when complete; calls on ONE context are serialised by
+ * the context's own lock, so N threads sharing a context see N serial calls; threads that need to overlap use one context each
+ * (contexts of one GPU share the SRS).  kzg_srs_free / kzg_srs_drop_lagrange must not race with calls that use the handle.
+ * tests/test_gpu_concurrency.py exercises exactly this contract. */
+int32_t kzg_srs_has_bit_tables(kzg_srs* srs, int32_t build);
 
 /* ---- arkworks boundary 1: <G1Projective as VariableBaseMSM>::msm(bases, scalars).into_affine() -- */
 /* Call sites: prover/src/kzg.rs:100, :121; primitives/src/helpers.rs:332 (g1_lincomb).
@@ -269,7 +286,12 @@ int32_t kzg_multi_scalars_upload(kzg_multi* m, int32_t buffer_id, const uint64_t
 int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids, size_t count, uint64_t* out_xy_mont,
                                          uint8_t* out_is_infinity);
 
-/* helpers::compute_challenge (primitives/src/helpers.rs:411-472): the Fiat-Shamir evaluation point of a blob,
+/* NOTE on the two Fiat-Shamir transcripts below (kzg_compute_challenge, kzg_compute_r_powers): their byte layout follows the reference
+ * line by line, but the 32-byte compressed G1 encoding inside them (x little-endian, 0x80 = larger y, 0x40 = infinity) is ark-serialize's
+ * `serialize_compressed`, RESTATED here and in oracle/ alike and pinned by NO vector the reference holds -- its own tests only check that the
+ * functions are deterministic (primitives/tests/helpers_test.rs:846-949).  Everything else in this header is pinned by reference fixtures.
+ *
+ * helpers::compute_challenge (primitives/src/helpers.rs:411-472): the Fiat-Shamir evaluation point of a blob,
  *   z = SHA-256( "EIGENDA_FSBLOBVERIFY_V1_" || u64be(n) || n x 32 B evaluations (big-endian, canonical) || commitment ) mod r,
  * n = next_pow2(ceil(len / 32)); evaluations = the blob's 32-byte big-endian chunks mod r (Blob::to_polynomial_eval_form, last
  * chunk right-padded with zeros, zero elements up to n); commitment = ark-serialize compressed G1Affine (32 B, x little-endian,
@@ -319,6 +341,11 @@ int32_t kzg_pairings_verify(const uint64_t a1_xy_mont[8], const uint64_t a2_g2_m
 int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t proof_xy_mont[8],
                          const uint64_t value_mont[4], const uint64_t z_mont[4],
                          const uint64_t* g2_tau_mont, int32_t* out_ok);
+/* verify::verify_blob_kzg_proof (verifier/src/verify.rs:76-98) in one call: both points validated (KZG_ERR_G1_NOT_ON_CURVE), the blob's
+ * challenge z = compute_challenge(blob, commitment) (helpers.rs:411-472, host SHA-256), y = p(z) (helpers.rs:475-535, GPU), then
+ * verify_proof above.  blob_bytes = the padded bytes of the blob (Blob::data()); an empty blob -> KZG_ERR_ZERO_LENGTH. */
+int32_t kzg_verify_blob_kzg_proof(kzg_ctx* ctx, const uint8_t* blob_bytes, size_t len, const uint64_t commitment_xy_mont[8],
+                                  const uint64_t proof_xy_mont[8], const uint64_t* g2_tau_mont, int32_t* out_ok);
 /* batch::verify_kzg_proof_batch (verifier/src/batch.rs:185-256) after the caller has derived r_powers from its
  * transcript (compute_r_powers, batch.rs:76-168): point validation, the three g1_lincomb calls as one batched GPU MSM,
  * the final 2-pairing check. */

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "kzg_ctx_set_reduction_lanes": (i32, [vp, i32]),
     "kzg_srs_upload": (i32, [vp, u64p, sz, C.POINTER(vp)]),
     "kzg_srs_load_compressed_be": (i32, [vp, u8p, sz, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+    "kzg_srs_load_compressed_ark_le": (i32, [vp, u8p, sz, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+    "kzg_srs_has_bit_tables": (i32, [vp, i32]),
     "kzg_srs_generate": (i32, [vp, u64p, C.c_uint64, sz, C.POINTER(vp)]),
     "kzg_ctx_set_profiling": (i32, [vp, i32]),
     "kzg_ctx_get_msm_profile": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -121,6 +123,7 @@ PROTOTYPES = {
     "kzg_compute_r_powers": (i32, [u64p, u64p, u64p, u64p, u64p, sz, u64p]),
     "kzg_compute_challenges_and_evaluate_polynomial": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, sz, u64p, u64p]),
     "kzg_evaluate_blobs_in_evaluation_form_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, sz, u64p]),
+    "kzg_verify_blob_kzg_proof": (i32, [vp, u8p, sz, u64p, u64p, u64p, C.POINTER(i32)]),
     "kzg_verify_blob_kzg_proof_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, u64p, sz, u64p, C.POINTER(i32)]),
 }
 

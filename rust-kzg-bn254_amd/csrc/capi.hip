@@ -257,7 +257,14 @@ int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t firs
     return KZG_OK;
 }
 
+static int32_t srs_load_compressed(kzg_ctx* ctx, const uint8_t* bytes, size_t n_points, kzg_srs** out, uint64_t* bad_index, bool ark_le);
 int32_t kzg_srs_load_compressed_be(kzg_ctx* ctx, const uint8_t* bytes, size_t n_points, kzg_srs** out, uint64_t* bad_index) {
+    return srs_load_compressed(ctx, bytes, n_points, out, bad_index, false);
+}
+int32_t kzg_srs_load_compressed_ark_le(kzg_ctx* ctx, const uint8_t* bytes, size_t n_points, kzg_srs** out, uint64_t* bad_index) {
+    return srs_load_compressed(ctx, bytes, n_points, out, bad_index, true);
+}
+static int32_t srs_load_compressed(kzg_ctx* ctx, const uint8_t* bytes, size_t n_points, kzg_srs** out, uint64_t* bad_index, bool ark_le) {
     if (!ctx || !out || (n_points && !bytes)) return KZG_ERR_INVALID_ARG;
     *out = nullptr;
     if (n_points > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
@@ -271,7 +278,7 @@ int32_t kzg_srs_load_compressed_be(kzg_ctx* ctx, const uint8_t* bytes, size_t n_
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
         if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
         uint32_t kind = 0, idx = 0;
-        int32_t rc = srs_decompress(ctx, bytes, n_points, s->d_points, &kind, &idx);
+        int32_t rc = srs_decompress(ctx, bytes, n_points, s->d_points, &kind, &idx, ark_le);
         if (rc == KZG_OK && kind != 0) {
             if (bad_index) *bad_index = idx;
             rc = kind == 1 ? KZG_ERR_DESERIALIZE : KZG_ERR_NOT_ON_CURVE;
@@ -303,6 +310,15 @@ void kzg_srs_free(kzg_srs* srs) {
 }
 
 size_t kzg_srs_len(const kzg_srs* srs) { return srs ? srs->n : 0; }
+int32_t kzg_srs_has_bit_tables(kzg_srs* srs, int32_t build) {
+    if (!srs) return 0;
+    if (srs_bits(srs)) return 1;
+    if (!build || !srs->ctx) return 0;
+    std::lock_guard<std::mutex> lk(srs->ctx->mu);
+    if (hipSetDevice(srs->ctx->device) != hipSuccess) return 0;
+    (void)srs_build_bit_tables(srs->ctx, srs, true);
+    return srs_bits(srs) ? 1 : 0;
+}
 
 // Lagrange basis of the first n points as an SRS of its own (device resident, with its window tables)
 static int32_t build_lagrange(kzg_ctx* ctx, const kzg_srs* srs, size_t n, kzg_srs** out) {
@@ -336,10 +352,11 @@ int32_t kzg_srs_cache_lagrange(kzg_ctx* ctx, kzg_srs* srs, size_t n) {
     if (!ctx || !srs || srs->ctx != ctx) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (srs->lagrange.count(n)) return KZG_OK;
+    if (srs_cached_lagrange(srs, n)) return KZG_OK;
     kzg_srs* l = nullptr;
-    int32_t rc = build_lagrange(ctx, srs, n, &l);
+    int32_t rc = build_lagrange(ctx, srs, n, &l);           // (under ctx->mu: one builder at a time; complete and synchronised on return)
     if (rc != KZG_OK) return rc;
+    std::lock_guard<std::mutex> lazy(srs->lazy_mu);
     srs->lagrange[n] = l;
     return KZG_OK;
 }
@@ -347,6 +364,7 @@ int32_t kzg_srs_cache_lagrange(kzg_ctx* ctx, kzg_srs* srs, size_t n) {
 int32_t kzg_srs_drop_lagrange(kzg_ctx* ctx, kzg_srs* srs) {
     if (!ctx || !srs || srs->ctx != ctx) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lazy(srs->lazy_mu);
     for (auto& kv : srs->lagrange) kzg_srs_free(kv.second);
     srs->lagrange.clear();
     return KZG_OK;
@@ -483,13 +501,15 @@ int32_t kzg_msm_g1_srs_device_begin_batch(kzg_ctx* ctx, kzg_srs* srs, size_t off
     if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!srs->d_bits) {
+    uint4* bits = srs_bits(srs);
+    if (!bits) {
         int32_t rc = srs_build_bit_tables(ctx, srs, true);
         if (rc != KZG_OK) return rc;
-        if (!srs->d_bits) { ctx->last_error = "no per-bit tables for this SRS (memory, or KZG_NO_NAF)"; return KZG_ERR_INVALID_ARG; }
+        bits = srs_bits(srs);
+        if (!bits) { ctx->last_error = "no per-bit tables for this SRS (memory, or KZG_NO_NAF)"; return KZG_ERR_INVALID_ARG; }
     }
     MsmBases b;
-    b.points = srs->d_bits + 4 * offset; b.table_stride = (uint32_t)srs->n; b.c = 7; b.W = 255; b.naf = true;
+    b.points = bits + 4 * offset; b.table_stride = (uint32_t)srs->n; b.c = 7; b.W = 255; b.naf = true;
     return msm_begin_batch(ctx, slot, b, d_scalars_mont, n, count);
 }
 int32_t kzg_msm_g1_srs_end_batch(kzg_ctx* ctx, int32_t slot, size_t count, uint64_t* out_xy_mont, uint8_t* out_is_infinity, uint64_t* out_xyzz_mont) {
@@ -658,9 +678,8 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    auto cached = srs->lagrange.find(n);
-    if (cached != srs->lagrange.end())                                   // the reference's literal form: MSM over the Lagrange basis (kzg.rs:98-100)
-        return msm_run(ctx, srs_bases(cached->second, 0, n, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
+    if (const kzg_srs* cached = srs_cached_lagrange(srs, n))            // the reference's literal form: MSM over the Lagrange basis (kzg.rs:98-100)
+        return msm_run(ctx, srs_bases(cached, 0, n, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
     int32_t rc = ntt_run(ctx, ctx->poly[0].a.p, n, true);               // coefficients = IFFT(evaluations)
     if (rc != KZG_OK) return rc;
     return msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
@@ -672,11 +691,13 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
 // bases, so they are one MSM problem: width-8 NAF digits over the SRS's per-bit tables, 64 buckets per polynomial in one bucket
 // array (msm.hip msm_run_batch_tables).  An SRS without per-bit tables (fewer than 2^15 points) gets them on the first batched call.
 static int32_t commit_batch_device(kzg_ctx* ctx, kzg_srs* basis, const void* d_scalars, size_t n, size_t count, uint64_t* out_xy, uint8_t* out_inf) {
-    if (!basis->d_bits) {
+    uint4* bits = srs_bits(basis);
+    if (!bits) {
         int32_t rc = srs_build_bit_tables(ctx, basis, true);
         if (rc != KZG_OK) return rc;
+        bits = srs_bits(basis);
     }
-    if (!basis->d_bits) {                                  // no room for tables (or KZG_NO_NAF): one commitment after the other
+    if (!bits) {                                  // no room for tables (or KZG_NO_NAF): one commitment after the other
         for (size_t k = 0; k < count; ++k) {
             int32_t rc = msm_run(ctx, srs_bases(basis, 0, n, ctx->msm_c_override == 0), static_cast<const char*>(d_scalars) + k * n * 32, n,
                                  out_xy + 8 * k, out_inf ? out_inf + k : nullptr, nullptr);
@@ -685,7 +706,7 @@ static int32_t commit_batch_device(kzg_ctx* ctx, kzg_srs* basis, const void* d_s
         return KZG_OK;
     }
     MsmBases b;
-    b.points = basis->d_bits; b.table_stride = (uint32_t)basis->n; b.c = 7; b.W = 255; b.naf = true;
+    b.points = bits; b.table_stride = (uint32_t)basis->n; b.c = 7; b.W = 255; b.naf = true;
     return msm_run_batch_tables(ctx, b, d_scalars, n, count, out_xy, out_inf);
 }
 static int32_t commit_batch_common(kzg_ctx* ctx, kzg_srs* srs, const void* scalars, bool on_device, bool eval_form, size_t n, size_t count,
@@ -700,7 +721,8 @@ static int32_t commit_batch_common(kzg_ctx* ctx, kzg_srs* srs, const void* scala
     if (eval_form) {                                       // the reference's literal form: MSM over the Lagrange basis of n points, kept with the SRS
         int32_t rc = kzg_srs_cache_lagrange(ctx, srs, n);
         if (rc != KZG_OK) return rc;
-        basis = srs->lagrange[n];
+        basis = srs_cached_lagrange(srs, n);
+        if (!basis) return KZG_ERR_INVALID_ARG;             // dropped by another thread between the two calls
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1344,6 +1366,21 @@ int32_t kzg_compute_r_powers(const uint64_t* commitments_xy_mont, const uint64_t
     if (!commitments_xy_mont || !zs_mont || !ys_mont || !proofs_xy_mont || !blobs_as_field_elements_length || !out_r_powers_mont) return KZG_ERR_INVALID_ARG;
     r_powers_host(commitments_xy_mont, zs_mont, ys_mont, proofs_xy_mont, blobs_as_field_elements_length, n, out_r_powers_mont);
     return KZG_OK;
+}
+
+// verify::verify_blob_kzg_proof (verifier/src/verify.rs:76-98) in one call: validate both points, z = compute_challenge(blob, commitment),
+// y = p(z) (one batched-evaluation launch of one blob), then verify::verify_proof (verify.rs:10-72) on the host.
+int32_t kzg_verify_blob_kzg_proof(kzg_ctx* ctx, const uint8_t* blob_bytes, size_t len, const uint64_t commitment_xy_mont[8],
+                                  const uint64_t proof_xy_mont[8], const uint64_t* g2_tau_mont, int32_t* out_ok) {
+    if (!ctx || !out_ok || !commitment_xy_mont || !proof_xy_mont || (len && !blob_bytes)) return KZG_ERR_INVALID_ARG;
+    using namespace kzg_host;
+    if (!g1_on_curve(g1_from_wire(commitment_xy_mont)) || !g1_on_curve(g1_from_wire(proof_xy_mont))) return KZG_ERR_G1_NOT_ON_CURVE;   // verify.rs:82,85
+    uint64_t z[4], y[4];
+    const uint8_t* blobs[1] = {blob_bytes};
+    const size_t lens[1] = {len};
+    int32_t rc = challenges_and_evaluations(ctx, blobs, lens, commitment_xy_mont, 1, true, z, y);     // verify.rs:88-94
+    if (rc != KZG_OK) return rc;
+    return kzg_verify_proof(commitment_xy_mont, proof_xy_mont, y, z, g2_tau_mont, out_ok);            // verify.rs:97
 }
 
 int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blobs, const size_t* blob_lens, const uint64_t* commitments_xy_mont,

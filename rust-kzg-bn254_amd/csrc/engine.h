@@ -97,6 +97,11 @@ struct kzg_ctx {
 
 struct kzg_srs {
     kzg_ctx* ctx = nullptr;
+    // An SRS may be used by several host threads and by every context of its GPU at once (the reference shares one SRS across threads:
+    // prover/tests/kzg_test.rs:9-17).  Everything below that is built AFTER the handle was returned -- per-bit tables on the first batched
+    // call, the x3 tables of g1_ifft, cached Lagrange bases -- is built and published under lazy_mu, fully synchronised before the pointer
+    // is stored, and read through the accessors below (a reader sees "absent" or "complete", never a table under construction).
+    mutable std::mutex lazy_mu;
     // device affine format (curve.h), 64 B per point.  Without precomputation: n points.  With precomputed
     // window tables (pre_W > 0): pre_W x n points, table w holds T_w[i] = 2^(pre_c * w) * P_i (table 0 = the SRS).
     uint4* d_points = nullptr;
@@ -143,8 +148,16 @@ inline int srs_naf_c(size_t n) {
     return n >= ((size_t)1 << 20) ? 17 : n >= ((size_t)1 << 18) ? 16 : 15;
 }
 // bases of an MSM of n pairs over srs[offset .. offset + n)
+inline uint4* srs_bits(const kzg_srs* srs) { std::lock_guard<std::mutex> lk(srs->lazy_mu); return srs->d_bits; }
+inline uint4* srs_t3(const kzg_srs* srs) { std::lock_guard<std::mutex> lk(srs->lazy_mu); return srs->d_t3; }
+inline kzg_srs* srs_cached_lagrange(const kzg_srs* srs, size_t n) {
+    std::lock_guard<std::mutex> lk(srs->lazy_mu);
+    auto it = srs->lagrange.find(n);
+    return it == srs->lagrange.end() ? nullptr : it->second;
+}
 inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, size_t n, bool allow_tables) {
     MsmBases b;
+    std::lock_guard<std::mutex> lk(srs->lazy_mu);
     b.points = srs->d_points + 4 * offset;
     if (allow_tables && srs->pre_W > 0) {
         b.table_stride = (uint32_t)srs->n; b.c = srs->pre_c; b.W = srs->pre_W;
@@ -203,7 +216,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
 // synthetic SRS P_i = tau^i * G1 written to d_points (device format); device SRS -> wire on the host
 int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_power, size_t n, uint4* d_points);
 int32_t srs_download(kzg_ctx* ctx, const uint4* d_points, size_t n, uint64_t* out_xy);
-int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_points, uint32_t* err_kind, uint32_t* err_index);
+int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_points, uint32_t* err_kind, uint32_t* err_index, bool ark_le = false);
 
 // KZG::g1_ifft: Lagrange-basis SRS of size n (n a power of two <= srs->n), affine wire points to the host / left on the device
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy);

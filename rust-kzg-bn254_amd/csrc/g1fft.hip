@@ -773,10 +773,12 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
     const int32_t* result = bufA;
     // 64 .. 256 points of an SRS with per-bit tables: the whole transform as sums of table points (k_g1fft_bits; KZG_G1FFT_BITS=0: off)
     static const bool use_bits = []() { const char* e = getenv("KZG_G1FFT_BITS"); return !(e && atoi(e) == 0); }();
-    if (use_bits && srs->d_bits && srs->lagrange_of == 0 && n >= 64 && n <= 256) {     // (512 points: 2.1 ms here, 1.85 ms staged)
+    if (use_bits && srs_bits(srs) && srs->lagrange_of == 0 && n >= 64 && n <= 256) {     // (512 points: 2.1 ms here, 1.85 ms staged)
         Naf2Lists nl;
         rc = get_naf2(ctx, log_n, &nl);
         if (rc != KZG_OK) return rc;
+        uint4* const d_bits = srs_bits(srs);
+        std::unique_lock<std::mutex> lazy(srs->lazy_mu);
         if (!srs->d_t3) {                                                  // x3 tables of the first 256 points, once per SRS (4 MiB)
             const uint32_t total = 254 * G1FFT_T3_POINTS;
             KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)total * 36 * 4));
@@ -784,7 +786,7 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
             uint4* t3 = nullptr;
             KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t3), (size_t)255 * G1FFT_T3_POINTS * 64));
             KZG_HIP_TRY(ctx, hipMemsetAsync(t3, 0, (size_t)255 * G1FFT_T3_POINTS * 64, st));
-            hipLaunchKernelGGL(k_g1fft_t3_planes, dim3((total + 255) / 256), dim3(256), 0, st, srs->d_bits, (uint32_t)srs->n, total, ctx->poly[0].c.as<int32_t>());
+            hipLaunchKernelGGL(k_g1fft_t3_planes, dim3((total + 255) / 256), dim3(256), 0, st, d_bits, (uint32_t)srs->n, total, ctx->poly[0].c.as<int32_t>());
             const size_t lanes = (total + AFF_PER - 1) / AFF_PER;
             hipLaunchKernelGGL(k_g1fft_to_affine, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, ctx->poly[0].c.as<int32_t>(), total, t3, 0, ctx->poly[0].a.as<int32_t>());
             hipError_t e = hipGetLastError();
@@ -792,6 +794,8 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
             if (e != hipSuccess) { (void)hipFree(t3); return set_error(ctx, e, "building the x3 tables of g1_ifft"); }
             srs->d_t3 = t3;
         }
+        uint4* const d_t3 = srs->d_t3;
+        lazy.unlock();
         // slices per term: two waves per SIMD in all (n^2 Q / 32 = 2048 waves) -- more waves only add tree additions (every wave ends in a
         // 5-level tree: a third of the work at 21 digits per pair), fewer leave lone waves at half the issue rate.  Measured: 256 points
         // 0.71 ms with Q = 4, 0.66 with Q = 1; 128 points 0.28 -> 0.26 (tools/time_g1ifft.py).  The floor is the additions themselves:
@@ -799,7 +803,7 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
         const uint32_t Q = (uint32_t)std::max<size_t>(1, 65536 / (n * n)), wpo = (uint32_t)(n * Q / 32);
         KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)n * wpo * 36 * 4));
         int32_t* partial = ctx->poly[0].c.as<int32_t>();
-        hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, srs->d_bits, (uint32_t)srs->n, srs->d_t3, (uint32_t)n,
+        hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, d_bits, (uint32_t)srs->n, d_t3, (uint32_t)n,
                            nl.list, nl.cnt, Q, wpo, partial);
         hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, wpo, (uint32_t)n, bufA);
         KZG_HIP_TRY(ctx, hipGetLastError());
@@ -929,12 +933,15 @@ static int32_t g1_ifft_as_batched_msm(kzg_ctx* ctx, const kzg_srs* srs, size_t n
         else {
             KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&exp), n * n * 32));
             hipLaunchKernelGGL(k_g1fft_expand_scalars, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, tabw, (uint32_t)n, exp);
-            KZG_HIP_TRY(ctx, hipGetLastError());
+            hipError_t e = hipGetLastError();
+            // the cache is shared by every context (and stream) of the device: complete before anyone else can find it
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { (void)hipFree(exp); return set_error(ctx, e, "expanding the scalars of g1_ifft"); }
             g_expanded[key] = exp;
         }
     }
     MsmBases b;
-    b.points = srs->d_bits; b.table_stride = (uint32_t)srs->n; b.c = 7; b.W = 255; b.naf = true;
+    b.points = srs_bits(srs); b.table_stride = (uint32_t)srs->n; b.c = 7; b.W = 255; b.naf = true;
     return msm_run_batch_tables(ctx, b, exp, n, n, out_xy, nullptr);
 }
 
@@ -945,7 +952,7 @@ int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy
         if (const char* e = getenv("KZG_G1FFT_BATCH")) { unsigned long a = 0, b2 = 0; int k = sscanf(e, "%lu,%lu", &a, &b2); lo = a; hi = k == 2 ? b2 : a; if (a == 0) { lo = 1; hi = 0; } }
         return std::make_pair(lo, hi);
     }();
-    if (srs->d_bits && srs->lagrange_of == 0 && n >= batch_range.first && n <= batch_range.second && n <= 1024 && !ctx->slot_pending[0])
+    if (srs_bits(srs) && srs->lagrange_of == 0 && n >= batch_range.first && n <= batch_range.second && n <= 1024 && !ctx->slot_pending[0])
         return g1_ifft_as_batched_msm(ctx, srs, n, out_xy);
     if (n <= G1FFT_HOST_AFFINE_MAX) {
         const int32_t* result = nullptr;

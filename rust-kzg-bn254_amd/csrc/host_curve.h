@@ -95,11 +95,15 @@ inline const Fq& fq_r2() {
     static const Fq r2 = []() { Fq v = FQ_ONE; for (int i = 0; i < 256; ++i) v = add(v, v); return v; }();     // R * 2^256 = R^2 mod p
     return r2;
 }
-inline Fq inv(const Fq& a) {
+inline Fq inv(const Fq& a_in) {
+    // caller-supplied words (kzg_g1_fold_partials takes XYZZ partials from the wire) may be any 256-bit value: canonicalise first.  A
+    // non-zero multiple of p would otherwise reach u == v == p, u = 0, and the halving loop below would never end
+    Fq a = a_in;
+    for (int i = 0; i < 6 && geq(a, FQ_P); ++i) sub_raw(a, FQ_P);     // 2^256 / p < 6
     if (is_zero(a)) return a;           // (as a^(p-2) would: 0)
     Fq u = a, v = FQ_P, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
     const Fq one = {{1, 0, 0, 0}};
-    while (!eq(u, one) && !eq(v, one)) {
+    for (int guard = 0; guard < 1024 && !eq(u, one) && !eq(v, one); ++guard) {     // gcd(a, p) = 1: at most 2 x 254 rounds
         while ((u.l[0] & 1) == 0) { shr1(u); half_mod_p(x1); }
         while ((v.l[0] & 1) == 0) { shr1(v); half_mod_p(x2); }
         if (geq(u, v)) { sub_raw(u, v); x1 = sub(x1, x2); }

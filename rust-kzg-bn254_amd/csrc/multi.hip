@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 constexpr int KZG_MULTI_BUFFERS = 16;    // resident scalar buffers per handle (kzg_multi_scalars_upload)
@@ -191,20 +192,24 @@ int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids
         // this device's software pipeline: MSM k + depth - 1 is enqueued before MSM k is waited for (engine.h slots)
         const size_t shard_len = m->lo[g + 1] - m->lo[g];
         const int depth = shard_len >= ((size_t)1 << 20) ? 2 : 3;
-        std::vector<size_t> inflight;                                                 // step indices, oldest first
+        // (step, slot) pairs, oldest first.  Slots come from this device's own LAUNCH counter, not from the step index: steps whose
+        // buffer does not reach this device's shard start nothing here, and k % depth would then hand a busy slot to a later step
+        std::vector<std::pair<size_t, int32_t>> inflight;
+        size_t launches = 0;
         auto retire = [&]() -> int32_t {
-            const size_t k = inflight.front();
+            const auto [k, slot] = inflight.front();
             inflight.erase(inflight.begin());
-            return kzg_msm_g1_srs_end(m->ctx[g], (int32_t)(k % (size_t)depth), nullptr, nullptr, parts.data() + 16 * (k * G + g));
+            return kzg_msm_g1_srs_end(m->ctx[g], slot, nullptr, nullptr, parts.data() + 16 * (k * G + g));
         };
         int32_t r = KZG_OK;
         for (size_t k = 0; k < count && r == KZG_OK; ++k) {
             const size_t n = m->buf_n[buffer_ids[k]], lo = m->lo[g], hi = std::min(m->lo[g + 1], n);
             if (lo >= hi) continue;                                                   // identity partial (zeros)
-            if (inflight.size() == (size_t)depth) r = retire();
+            if (inflight.size() == (size_t)depth) r = retire();                       // frees exactly the slot launch `launches` maps to
             if (r != KZG_OK) break;
-            r = kzg_msm_g1_srs_device_begin(m->ctx[g], m->shard[g], 0, m->dbuf[g][(size_t)buffer_ids[k]], hi - lo, (int32_t)(k % (size_t)depth));
-            if (r == KZG_OK) inflight.push_back(k);
+            const int32_t slot = (int32_t)(launches % (size_t)depth);
+            r = kzg_msm_g1_srs_device_begin(m->ctx[g], m->shard[g], 0, m->dbuf[g][(size_t)buffer_ids[k]], hi - lo, slot);
+            if (r == KZG_OK) { inflight.emplace_back(k, slot); ++launches; }
         }
         while (!inflight.empty()) { const int32_t r2 = retire(); if (r == KZG_OK) r = r2; }   // drain whatever is in flight, also after an error
         return r;

@@ -1099,22 +1099,27 @@ int32_t vb_evaluate_setup(kzg_ctx* ctx, size_t packed_len, size_t nb) {
     KZG_HIP_TRY(ctx, set.b.reserve(nb * (sizeof(VbBlob) + sizeof(VbPrep)) + 64));
     KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vb_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NL * 2 * VB_THREADS * 4)));
     KZG_HIP_TRY(ctx, hipMemsetAsync(set.a.as<uint4>() + 2 * nb, 0, nb * 32, ctx->stream));
-    return KZG_OK;
+    // slot 1's stream carries the blob bytes: created HERE, on the calling thread under ctx->mu -- vb_evaluate_enqueue runs on the
+    // caller's worker threads, which must not create context state (two chunks finishing together raced on stream_x[0])
+    hipStream_t st_copy = nullptr;
+    return msm_slot_stream(ctx, 1, &st_copy);
 }
 // `small_pinned`: pinned staging of at least nb x 48 bytes for the chunk's challenges and descriptors (a copy from pageable memory would
 // make this call wait for everything queued on the stream before it)
 int32_t vb_evaluate_enqueue(kzg_ctx* ctx, const uint8_t* packed, const void* meta_host, size_t nb, size_t b0, size_t b1, const uint64_t* zs,
                             uint8_t* small_pinned) {
     if (b1 <= b0) return KZG_OK;
-    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));                                       // (worker threads of the caller's pool)
+    // worker threads of the caller's pool: errors travel in the return code only (ctx->last_error belongs to the thread holding ctx->mu)
+    hipEvent_t up = nullptr;
+#define VB_TRY(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); if (up) (void)hipEventDestroy(up); return KZG_ERR_DEVICE; } } while (0)
+    VB_TRY(hipSetDevice(ctx->device));
     PolySet& set = ctx->poly[0];
-    hipStream_t st = ctx->stream, st_copy = nullptr;
+    hipStream_t st = ctx->stream, st_copy = ctx->stream_x[0];                          // both exist since vb_evaluate_setup
+    if (!st_copy) return KZG_ERR_INVALID_ARG;
     // the blob bytes go up on a second stream (slot 1's): k_vb_prep is one inversion deep (~0.2 ms on a few lone waves, whatever the
     // chunk size) and needs the challenges only, so it runs while the chunk's bytes are still on the bus; k_vb_eval waits for them
-    int32_t rc = msm_slot_stream(ctx, 1, &st_copy);
-    if (rc != KZG_OK) return rc;
     NttTables tb;
-    rc = ntt_get_tables(ctx, VB_MAX_LOG, false, &tb);
+    int32_t rc = ntt_get_tables(ctx, VB_MAX_LOG, false, &tb);                          // cached by vb_evaluate_setup: a look-up
     if (rc != KZG_OK) return rc;
     const VbBlob* meta = static_cast<const VbBlob*>(meta_host);
     uint4* d_zs = set.a.as<uint4>();
@@ -1131,25 +1136,25 @@ int32_t vb_evaluate_enqueue(kzg_ctx* ctx, const uint8_t* packed, const void* met
     }
     const uint32_t max_lf = std::min<uint32_t>(1u << max_log, (uint32_t)VB_THREADS);
     const size_t lds = std::max<size_t>((size_t)NL * 2 * max_lf, (size_t)NL * VB_THREADS) * 4;
-    hipEvent_t up = nullptr;
     if (hi > lo) {
-        KZG_HIP_TRY(ctx, hipMemcpyAsync(set.c.as<uint8_t>() + lo, packed + lo, hi - lo, hipMemcpyHostToDevice, st_copy));
-        KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&up, hipEventDisableTiming));
-        KZG_HIP_TRY(ctx, hipEventRecord(up, st_copy));
+        VB_TRY(hipMemcpyAsync(set.c.as<uint8_t>() + lo, packed + lo, hi - lo, hipMemcpyHostToDevice, st_copy));
+        VB_TRY(hipEventCreateWithFlags(&up, hipEventDisableTiming));
+        VB_TRY(hipEventRecord(up, st_copy));
     }
     uint8_t* pz = small_pinned + b0 * 32;
     uint8_t* pm = small_pinned + nb * 32 + b0 * sizeof(VbBlob);
     memcpy(pz, zs + 4 * b0, (b1 - b0) * 32);
     memcpy(pm, meta + b0, (b1 - b0) * sizeof(VbBlob));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_zs + 2 * b0, pz, (b1 - b0) * 32, hipMemcpyHostToDevice, st));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(d_meta + b0, pm, (b1 - b0) * sizeof(VbBlob), hipMemcpyHostToDevice, st));
+    VB_TRY(hipMemcpyAsync(d_zs + 2 * b0, pz, (b1 - b0) * 32, hipMemcpyHostToDevice, st));
+    VB_TRY(hipMemcpyAsync(d_meta + b0, pm, (b1 - b0) * sizeof(VbBlob), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_vb_prep, dim3((unsigned)((b1 - b0 + 63) / 64)), dim3(64), 0, st, d_zs + 2 * b0, d_meta + b0, (uint32_t)(b1 - b0), d_prep + b0);
     if (up) {
-        KZG_HIP_TRY(ctx, hipStreamWaitEvent(st, up, 0));
+        VB_TRY(hipStreamWaitEvent(st, up, 0));
         (void)hipEventDestroy(up);                                                     // released by the runtime once the wait has been satisfied
     }
     hipLaunchKernelGGL(k_vb_eval, dim3((unsigned)(b1 - b0)), dim3(VB_THREADS), lds, st, set.c.as<uint8_t>(), d_meta + b0, d_prep + b0, tb, d_ys + 2 * b0);
-    KZG_HIP_TRY(ctx, hipGetLastError());
+    VB_TRY(hipGetLastError());
+#undef VB_TRY
     return KZG_OK;
 }
 int32_t vb_evaluate_finish(kzg_ctx* ctx, size_t nb, uint64_t* ys_out, uint8_t* fallback_out) {

@@ -215,33 +215,46 @@ k_srs_double_batch(const uint4* __restrict__ prev, uint4* __restrict__ next, siz
 // lexicographically_largest (helpers.rs:151-173: y > (p-1)/2 on the canonical integer).  The subgroup check of the
 // reference is vacuous on BN254 G1 (cofactor 1).  One lane per point; status[0] = first error (0 ok, 1 bad infinity
 // encoding, 2 not on curve), status[1] = its index.
+//
+// ARK_LE = true: the "native" format of SRS::parallel_read_g1_points_native(is_native = true) (prover/src/srs.rs:205-251 ->
+// primitives/src/traits.rs:34-36, G1Affine::deserialize_compressed of ark-serialize 0.5, restated -- the reference holds no file in this
+// format): x as 32 LITTLE-endian bytes, flags in the top two bits of the LAST byte: 0x80 = y is the larger root (SWFlags::YIsNegative),
+// 0x40 = the point at infinity, both = rejected; x must be canonical (< p), else the element does not deserialise (status 1).
+template <bool ARK_LE>
 __global__ void __launch_bounds__(256)
-k_srs_decompress_be(const uint8_t* __restrict__ bytes, uint4* __restrict__ out, uint32_t n, uint32_t* __restrict__ status) {
+k_srs_decompress(const uint8_t* __restrict__ bytes, uint4* __restrict__ out, uint32_t n, uint32_t* __restrict__ status) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* b = bytes + (size_t)i * 32;
-    const uint32_t flag = b[0] & 0xC0u;
+    const uint32_t flag = (ARK_LE ? b[31] : b[0]) & 0xC0u;
+    constexpr uint32_t FLAG_SMALLEST = ARK_LE ? 0x00u : 0x80u, FLAG_LARGEST = ARK_LE ? 0x80u : 0xC0u;
     uint32_t o[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[j] = 0;
     uint32_t err = 0;
-    if (flag == 0x40u) {
-        uint32_t rest = b[0] & 0x3Fu;
-        for (int k = 1; k < 32; ++k) rest |= b[k];
-        if (rest) err = 1;                               // "point at infinity not coded properly for g1"
-    } else {
-        uint32_t w32[8];
+    uint32_t w32[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {                    // little-endian word k = big-endian bytes 28-4k .. 31-4k
-            uint32_t w = 0;
+    for (int k = 0; k < 8; ++k) {                        // little-endian word k = big-endian bytes 28-4k .. 31-4k (gnark) / bytes 4k .. 4k+3 (ark)
+        uint32_t w = 0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                uint32_t byte = b[28 - 4 * k + t];
-                if (k == 7 && t == 0) byte &= 0x3Fu;
-                w = (w << 8) | byte;
-            }
-            w32[k] = w;
+        for (int t = 0; t < 4; ++t) {
+            uint32_t byte = ARK_LE ? b[4 * k + 3 - t] : b[28 - 4 * k + t];
+            if (k == 7 && t == 0) byte &= 0x3Fu;
+            w = (w << 8) | byte;
         }
+        w32[k] = w;
+    }
+    bool x_canonical = false;                            // x < p ?
+    for (int k = 7; k >= 0; --k) {
+        if (w32[k] != FqParams::P32[k]) { x_canonical = w32[k] < FqParams::P32[k]; break; }
+    }
+    if (ARK_LE && (flag == 0xC0u || !x_canonical)) {
+        err = 1;                                         // ark-serialize: UnexpectedFlags / a field element >= the modulus
+    } else if (flag == 0x40u) {
+        uint32_t rest = 0;
+        for (int k = 0; k < 8; ++k) rest |= w32[k];
+        if (rest && !ARK_LE) err = 1;                    // "point at infinity not coded properly for g1" (ark returns the identity whatever x)
+    } else {
         Fq x, y2, y, t, kin, b3;
         fe_unpack(x, w32);
 #pragma unroll
@@ -284,7 +297,7 @@ k_srs_decompress_be(const uint8_t* __restrict__ bytes, uint4* __restrict__ out, 
             for (int k = 7; k >= 0; --k) {
                 if (yw[k] != FqParams::HALF_UP32[k]) { ge = yw[k] > FqParams::HALF_UP32[k]; break; }
             }
-            const bool negate = ge ? (flag == 0x80u) : (flag == 0xC0u);
+            const bool negate = ge ? (flag == FLAG_SMALLEST) : (flag == FLAG_LARGEST);
             Fq ys;
             fe_canon(y);                                 // [0, m) before the sign flip so that -y stays inside (-m, 2m)
             fe_cneg(ys, y, negate ? 1u : 0u);
@@ -412,6 +425,7 @@ int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs, bool force) {
     const char* env = getenv("KZG_NO_NAF");
     if (env && atoi(env) != 0) return KZG_OK;
     const size_t n = srs->n;
+    std::lock_guard<std::mutex> lazy(srs->lazy_mu);           // two contexts asking at once: the second finds the tables built
     if (n == 0 || (n < SRS_NAF_MIN && !force) || n > ((size_t)1 << 22) || srs->d_bits) return KZG_OK;
     const size_t bytes = (size_t)255 * n * 64;
     size_t free_b = 0, total_b = 0;
@@ -432,7 +446,7 @@ int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs, bool force) {
 }
 
 // compressed big-endian points (host bytes) -> d_points (device format); *err_kind / *err_index describe the first bad point
-int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_points, uint32_t* err_kind, uint32_t* err_index) {
+int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_points, uint32_t* err_kind, uint32_t* err_index, bool ark_le) {
     *err_kind = 0;
     *err_index = 0;
     if (n == 0) return KZG_OK;
@@ -441,8 +455,12 @@ int32_t srs_decompress(kzg_ctx* ctx, const uint8_t* bytes, size_t n, uint4* d_po
     uint32_t* d_status = ctx->poly[0].small.as<uint32_t>();
     KZG_HIP_TRY(ctx, hipMemsetAsync(d_status, 0, 8, ctx->stream));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].c.p, bytes, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_srs_decompress_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly[0].c.as<uint8_t>(), d_points,
-                       (uint32_t)n, d_status);
+    if (ark_le)
+        hipLaunchKernelGGL(k_srs_decompress<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly[0].c.as<uint8_t>(), d_points,
+                           (uint32_t)n, d_status);
+    else
+        hipLaunchKernelGGL(k_srs_decompress<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->poly[0].c.as<uint8_t>(), d_points,
+                           (uint32_t)n, d_status);
     KZG_HIP_TRY(ctx, hipGetLastError());
     uint32_t st[2] = {0, 0};
     KZG_HIP_TRY(ctx, hipMemcpyAsync(st, d_status, 8, hipMemcpyDeviceToHost, ctx->stream));

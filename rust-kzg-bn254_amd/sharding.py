@@ -234,7 +234,7 @@ class ShardedMsm:
         return part
 
     # ---- several steps of a stream in ONE launch (the batched table mode of the MSM engine) --------------------
-    def auto_group(self):
+    def auto_group(self, srs_shard=None):
         """Steps of a stream this rank's library puts into one launch: shard-sized MSMs are bound by dependent-latency chains, and
         `k` of them over the same SRS slice are one MSM problem with k x the work per kernel (k x 2^(c-1) buckets in one bucket array).
         Derived from n // world, so that every rank groups alike (the ranks must issue the same collectives)."""
@@ -245,7 +245,12 @@ class ShardedMsm:
         per = self.n // max(1, self.world)
         if per >= (1 << 19) or per < (1 << 13):
             return 1
-        cap = int(_lib.load().kzg_msm_batch_capacity(per))
+        # the batched launch needs the per-bit tables of the shard (absent with KZG_NO_NAF=1, when memory is short, above 2^22 points):
+        # without them one launch per step (every grouped launch failed instead).  Ranks that may disagree (memory) must agree
+        # on the minimum before streaming -- bench.py all-reduces it.
+        if srs_shard is not None and not _lib.load().kzg_srs_has_bit_tables(srs_shard.handle, 1):
+            return 1
+        cap = int(_lib.load().kzg_msm_batch_capacity(per))             # per = the smallest shard
         return max(1, min(cap, 4))
 
     def group_depth(self, depth: int, group: int):

@@ -26,9 +26,10 @@ class SRS:
         self._n = pts.shape[0]
 
     @classmethod
-    def new(cls, path_to_g1_points, order, points_to_load, ctx=None):
+    def new(cls, path_to_g1_points, order, points_to_load, ctx=None, is_native=False):
         """SRS::new (srs.rs:35-49): read `points_to_load` compressed points (32 bytes each, gnark big-endian flags) and
-        decompress them on the GPU (`kzg_srs_load_compressed_be`)."""
+        decompress them on the GPU (`kzg_srs_load_compressed_be`).  is_native=True: the arkworks little-endian compressed
+        format of `parallel_read_g1_points_native(.., is_native = true)` (srs.rs:205-251; `kzg_srs_load_compressed_ark_le`)."""
         if points_to_load > order:
             raise GenericError("Number of points to load exceeds SRS order.")               # srs.rs:36-40
         with open(path_to_g1_points, "rb") as f:
@@ -41,9 +42,10 @@ class SRS:
         h = C.c_void_p()
         bad = C.c_uint64(0)
         buf = np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, np.uint8)
-        rc = _lib.load().kzg_srs_load_compressed_be(self.ctx.handle, buf.ctypes.data_as(_lib.u8p), points_to_load, C.byref(h), C.byref(bad))
+        load = _lib.load().kzg_srs_load_compressed_ark_le if is_native else _lib.load().kzg_srs_load_compressed_be
+        rc = load(self.ctx.handle, buf.ctypes.data_as(_lib.u8p), points_to_load, C.byref(h), C.byref(bad))
         if rc == _lib.ERR_DESERIALIZE:
-            raise DeserializationError("point at infinity not coded properly for g1")
+            raise DeserializationError("Deserialization failed" if is_native else "point at infinity not coded properly for g1")   # traits.rs:17 / helpers.rs:191-195
         if rc == _lib.ERR_NOT_ON_CURVE:
             chunk = list(data[32 * bad.value:32 * bad.value + 32])
             raise NotOnCurveError(f"compressed g1 point not on curve: {chunk}")

@@ -44,7 +44,21 @@ def verify_proof(commitment, proof, value_fr, z_fr, g2_tau=None) -> bool:
 
 
 def verify_blob_kzg_proof(blob, commitment, proof, g2_tau=None, ctx=None) -> bool:
-    """verify.rs:76-98."""
+    """verify.rs:76-98 as ONE call of the C-ABI (`kzg_verify_blob_kzg_proof`)."""
+    ctx = ctx or _lib.default_context()
+    data = np.frombuffer(bytes(blob.data()), dtype=np.uint8) if len(blob.data()) else np.zeros(1, np.uint8)
+    ok = _lib.i32(0)
+    tau = None if g2_tau is None else _lib.as_u64(g2_tau, 0).reshape(16)
+    rc = _lib.load().kzg_verify_blob_kzg_proof(ctx.handle, data.ctypes.data_as(_lib.u8p), len(blob.data()),
+                                               _lib.ptr(_lib.as_u64(commitment, 0).reshape(8)), _lib.ptr(_lib.as_u64(proof, 0).reshape(8)),
+                                               None if tau is None else _lib.ptr(tau), C.byref(ok))
+    ctx.check_device(rc)
+    _raise_for(rc)
+    return bool(ok.value)
+
+
+def verify_blob_kzg_proof_composed(blob, commitment, proof, g2_tau=None, ctx=None) -> bool:
+    """verify.rs:76-98 composed from the reference's own steps (three calls); the one-call form above must agree with it."""
     helpers.validate_g1_point(commitment)
     helpers.validate_g1_point(proof)
     polynomial = blob.to_polynomial_eval_form()

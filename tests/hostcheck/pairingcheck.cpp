@@ -28,6 +28,12 @@ int main() {
             ok = eq(mul(a, b), FQ_ONE) && (i % 64 != 0 || eq(b, inv_fermat(a)));
         }
         printf("binary_inverse %d\n", (int)(ok && is_zero(inv(fq_zero()))));
+        // non-canonical input: p, 2p, 5p invert to 0 like the literal zero, a + p inverts like a -- and none of them hangs
+        Fq k2 = FQ_P, k5 = FQ_P, ap = FQ_TWO;
+        { unsigned __int128 c = 0; for (int i = 0; i < 4; ++i) { c += (unsigned __int128)k2.l[i] + FQ_P.l[i]; k2.l[i] = (uint64_t)c; c >>= 64; } }
+        for (int r = 0; r < 4; ++r) { unsigned __int128 c = 0; for (int i = 0; i < 4; ++i) { c += (unsigned __int128)k5.l[i] + FQ_P.l[i]; k5.l[i] = (uint64_t)c; c >>= 64; } }
+        { unsigned __int128 c = 0; for (int i = 0; i < 4; ++i) { c += (unsigned __int128)ap.l[i] + FQ_P.l[i]; ap.l[i] = (uint64_t)c; c >>= 64; } }
+        printf("inverse_noncanonical %d\n", (int)(is_zero(inv(FQ_P)) && is_zero(inv(k2)) && is_zero(inv(k5)) && eq(inv(ap), inv(FQ_TWO))));
     }
     printf("g1_on_curve %d\n", (int)g1_on_curve(g));
     printf("g2_gen_on_curve %d\n", (int)g2_on_curve(h));

@@ -39,13 +39,48 @@ def test_bench_emits_the_contract_line():
     assert "phases_ms_per_launch" in d and "phases_ms_per_launch_pipelined" in d
 
 
-def test_bench_refuses_n_gpus_without_launcher():
-    """`bench.py --gpus 2` without torchrun must not silently measure one GPU."""
+def test_bench_n_gpus_without_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (no WORLD_SIZE) must produce the line: bench.py starts the two
+    ranks itself before anything touches the GPU (one child process per rank, RANK / WORLD_SIZE / MASTER_* set), relays rank 0's JSON
+    line and exits with the children's worst code.  On this one-GPU box the exchange is rehearsed over gloo, both ranks on GPU 0."""
+    env = dict(os.environ, KZG_BENCH_LOG_N="16", KZG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-secondary"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 6 and d["config"]["bit_exact_vs_oracle"] is True
+    assert len(d["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in d["ms_per_step_per_rank"])
+    assert abs(max(d["ms_per_step_per_rank"]) - d["ms_per_step"]) < 1e-9            # MAX over ranks
+    assert d["launched_by"].startswith("bench.py itself")
+
+
+def test_bench_without_launcher_refuses_more_ranks_than_gpus_over_rccl():
+    """One rank per GPU over RCCL needs N devices: on a box with fewer, `--gpus N` fails loudly BEFORE starting ranks (it must not
+    measure N ranks on one GPU and call it N GPUs) unless the gloo rehearsal switch is set."""
+    import torch
+    n = torch.cuda.device_count() + 1
     env = dict(os.environ, KZG_BENCH_LOG_N="12")
-    env.pop("WORLD_SIZE", None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KZG_BENCH_BACKEND"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
                          capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
-    assert res.returncode != 0 and "torch.distributed.run" in (res.stderr + res.stdout)
+    assert res.returncode != 0 and "GPU(s) visible" in (res.stderr + res.stdout)
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """A rank that exits non-zero makes the launcher-less bench exit non-zero, and the surviving rank (waiting in the rendezvous for
+    its peer) is ended after the grace period instead of hanging the run."""
+    env = dict(os.environ, KZG_BENCH_LOG_N="12", KZG_BENCH_BACKEND="gloo", KZG_BENCH_RANK_GRACE_S="5", KZG_BENCH_FAIL_RANK="1")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-secondary"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 7, (res.returncode, res.stderr[-1500:])
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_bench_two_ranks_gloo_is_bit_exact():

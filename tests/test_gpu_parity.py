@@ -1171,3 +1171,23 @@ def test_multi_device_handle_three_contexts_on_one_gpu(k, test_srs_wire, tau_srs
     ptau = sum(v * pow(TAU, i, R_) for i, v in enumerate(vals)) % R_
     assert pyref.point_from_wire(m.commit_coeff_form(pyref.frs_to_mont(vals))) == pyref.ec_mul(ptau, (1, 2))
     m.close()
+
+
+def test_multi_device_stream_of_mixed_lengths_keeps_its_slots(k, test_srs_wire):
+    """ADVICE r3 (csrc/multi.hip): a resident stream that mixes polynomials too short to reach a device's shard with full-length ones.
+    Slots used to be k % depth of the STEP index; after a skipped step two MSMs in flight on one device could map to the same slot and
+    the whole stream failed with INVALID_ARG.  Three contexts on GPU 0, shards [0,1000) [1000,2000) [2000,3000): buffer 1 (600
+    coefficients) only reaches device 0, buffer 2 (1500) devices 0 and 1; every commitment against the oracle."""
+    from rust_kzg_bn254_amd.sharding import MultiKzg
+    m = MultiKzg([0, 0, 0])
+    m.srs_upload(test_srs_wire)
+    lens = {0: 3000, 1: 600, 2: 1500, 3: 2999, 4: 1}
+    sc = {b: rand_scalars(n, 900 + b) for b, n in lens.items()}
+    want = {b: orc.msm_pippenger(test_srs_wire[:n], sc[b]) for b, n in lens.items()}
+    for b in lens:
+        m.scalars_upload(b, sc[b])
+    order = [0, 1, 0, 3, 1, 1, 2, 0, 4, 3, 2, 1, 0, 0, 4, 4, 3, 1, 2, 0, 3]
+    got = m.commit_resident_stream(order)
+    for i, b in enumerate(order):
+        assert np.array_equal(got[i], want[b]), (i, b)
+    m.close()

@@ -31,7 +31,7 @@ def test_pairing_properties_host_build(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + CSRC, os.path.join(HERE, "hostcheck", "pairingcheck.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split("\n")
     rows = dict(line.split() for line in out if line.strip())
-    assert len(rows) == 36
+    assert len(rows) == 37
     assert all(v == "1" for v in rows.values()), rows
 
 
