@@ -36,13 +36,12 @@ DEPTH = int(os.environ["KZG_BENCH_DEPTH"]) if os.environ.get("KZG_BENCH_DEPTH") 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 BYTES_PER_PAIR = 96            # 64 B packed affine point + 32 B scalar, each read once
 PMC_JSON = os.path.join(ROOT, "profiles", "r03d_pmc_summary.json")
-MADS_PER_MIXED_ADD = 1467      # v_mad_i64_i32 per xyzz_madd (8 x 162 + 2 x 126 - 81 for the fused Y3; DESIGN.md section 4)
-# The whole instruction stream of one mixed addition in the accumulate loop, by class, from the ISA of the round-3 kernel (the Montgomery
-# products are single asm statements: generated csrc/fe_asm.h; loop body of k_msm_accumulate, `hipcc -S`: 2 088 instructions + ~70 of
-# loop control, index / address arithmetic and the prefetch in the blocks around it): v_mad_i64_i32, v_mul_lo_u32, v_ashrrev_i64,
-# v_and_b32, other 32-bit VALU / SALU, s_nop.  Priced with the issue rates of THIS box, measured in set-up at the kernel's occupancy
-# (kzg_ctx_measure_valu_rates, three waves per SIMD); the constants below are only the fallback for world > 1.
-VALU_MIX_COUNTS = (1467, 81, 153, 179, 273, 5)
+MADS_PER_MIXED_ADD = 1467      # v_mad_i64_i32 per xyzz_madd (8 x 162 + 2 x 126 - 81 for the fused Y3)
+# The instruction stream of one mixed addition on the fast path of k_msm_accumulate's loop, by class: v_mad_i64_i32, v_mul_lo_u32, 64-bit
+# shifts, v_and_b32, every other instruction (32-bit VALU / SALU / loads), s_nop.  REGENERATED from the compiler's listing by
+# tools/count_isa.py (`hipcc -S` of csrc/msm.hip); tests/test_isa_counts.py fails when these constants and the listing disagree.  Priced
+# with the issue rates of THIS box, measured in set-up at the kernel's occupancy (kzg_ctx_measure_valu_rates, three waves per SIMD).
+VALU_MIX_COUNTS = (1467, 81, 154, 179, 227, 5)
 VALU_RATES_FALLBACK_NS = (2.13, 2.03, 1.85, 1.24, 1.24, 0.42)     # profiles/r01_valu_rates_mi355x.txt, four waves per SIMD
 N_SIMDS = 1024
 N_BUFFERS = 8                  # distinct resident scalar buffers the timed steps rotate through
