@@ -609,6 +609,38 @@ def main():
                     st = stats_ms(lambda: lib.kzg_g1_ifft(ctx.handle, srs.handle, nn, _lib.ptr(lag)), reps=9, warm=2)
                     small["g1_ifft_%d_ms" % nn] = st["median"]; small_stats["g1_ifft_%d" % nn] = st
             small["statistic"] = "median of the per-call wall times (60 calls per commit / proof shape, 9 per g1_ifft size); mean / p99 / min / max under reference_bench_shapes_stats"
+            # sizes beyond the tables (parity: tests/test_gpu_large_sizes.py): the 2^20 step WITHOUT the 15.9 GiB of per-bit
+            # tables (KZG_NO_NAF=1: fixed 17-bit windows over the 1 GiB window tables), a commitment over a 2^23-point SRS (window tables
+            # only: per-bit tables stop at 2^22 points), and the Fr NTT at 2^25 / 2^26 (three passes, lookup twiddles), all device-resident
+            beyond = {}
+            if LOG_N == 20:
+                os.environ["KZG_NO_NAF"] = "1"
+                srs_nonaf = k.SRS.generate(tau, n, ctx=ctx)
+                del os.environ["KZG_NO_NAF"]
+                sh1 = ShardedMsm(ctx, n, 0, 1, gather_device=None)
+                list(sh1.commit_stream(srs_nonaf, [rot_ptrs[i % N_BUFFERS] for i in range(24)], depth=2))
+                torch.cuda.synchronize(); t = time.perf_counter()
+                res_nn = list(sh1.commit_stream(srs_nonaf, [rot_ptrs[i % N_BUFFERS] for i in range(24)], depth=2))
+                torch.cuda.synchronize()
+                beyond["step_2_20_without_per_bit_tables_ms"] = (time.perf_counter() - t) / 24 * 1e3
+                assert all(np.array_equal(r, wants[i % N_BUFFERS]) for i, r in enumerate(res_nn)), "commitment without per-bit tables differs"
+                beyond["step_2_20_with_per_bit_tables_ms"] = ms_per_step
+                beyond["srs_memory_GiB"] = {"window_tables_c17": 15 * n * 64 / 2.0 ** 30, "small_msm_tables_c15": 17 * n * 64 / 2.0 ** 30, "per_bit_tables": 255 * n * 64 / 2.0 ** 30}
+                srs_nonaf.close()
+                n23 = 1 << 23
+                srs23 = k.SRS.generate(tau, n23, ctx=ctx)
+                d23 = torch.cat([d_sets[i % N_BUFFERS] for i in range(8)])               # 2^23 resident scalars (the eight buffers back to back)
+                st23 = stats_ms(lambda: lib.kzg_msm_g1_srs_device(ctx.handle, srs23.handle, 0, C.c_void_p(d23.data_ptr()), n23, _lib.ptr(o8), C.byref(oi)), reps=7, warm=2)
+                beyond["commit_2_23_pairs_over_2_23_srs_ms"] = st23["median"]; beyond["commit_2_23_pairs_stats"] = st23
+                beyond["commit_2_23_pairs_per_s"] = n23 / (st23["median"] * 1e-3)
+                srs23.close(); del d23
+                for lg in (25, 26):
+                    big_n = torch.zeros((1 << lg, 4), dtype=torch.int64, device="cuda")
+                    big_n[:, 0] = torch.arange(1 << lg, device="cuda")
+                    stn = stats_ms(lambda: (lib.kzg_fr_ntt_device(ctx.handle, C.c_void_p(big_n.data_ptr()), 1 << lg, 0), torch.cuda.synchronize()), reps=5, warm=1)
+                    beyond["fr_ntt_2_%d_ms" % lg] = stn["median"]
+                    beyond["fr_ntt_2_%d_algorithmic_GBps" % lg] = 64.0 * (1 << lg) / (stn["median"] * 1e-3) / 1e9
+                    del big_n
             # measured copy ceiling of this box (device-to-device, 1 GiB): read + write bytes per second
             big = torch.empty(1 << 28, dtype=torch.int32, device="cuda"); big2 = torch.empty_like(big)
             copy_ms = avg_ms(lambda: big2.copy_(big), reps=10)
@@ -622,7 +654,7 @@ def main():
                 "batch_verify_4096_core_ms": bv_ms, "batch_verify_4096_three_msms_ms": m3_ms,
                 "batch_verify_4096_end_to_end_ms": e2e_ms, "batch_verify_4096_end_to_end_stats": e2e_stats, "batch_verify_4096_end_to_end_blob_MiB": e2e_bytes / 2.0 ** 20,
                 "batch_verify_4096_end_to_end_host_threads": min(32, os.cpu_count() or 1),
-                "reference_bench_shapes": small, "reference_bench_shapes_stats": small_stats,
+                "reference_bench_shapes": small, "reference_bench_shapes_stats": small_stats, "beyond_the_tables": beyond,
                 "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,
                 "fr_ntt_algorithmic_GBps": 64.0 * n / (ntt_ms * 1e-3) / 1e9, "fr_ntt_frac_of_hbm_peak": 64.0 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -116,6 +116,7 @@ struct kzg_srs {
     uint4* d_bits = nullptr;
     // 3 Bit_p[j] for p < 255, j < 256 (g1fft.hip: the x3 tables of the 64..256-point g1_ifft), built on first use; a cache, hence mutable
     mutable uint4* d_t3 = nullptr;
+    mutable uint32_t t3_n = 0;           // points covered by d_t3: min(n, 2048)
     // Lagrange-basis copies of the first m points (KZG::g1_ifft(m), kzg.rs:263-285), built by kzg_srs_cache_lagrange and used by
     // the eval-form commitments of exactly m evaluations instead of IFFT + MSM over the monomial basis; owned by this SRS
     std::map<size_t, kzg_srs*> lagrange;

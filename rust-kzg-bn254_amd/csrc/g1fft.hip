@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <vector>
 
@@ -521,14 +522,14 @@ k_g1fft_first_tables(const uint4* __restrict__ tables, uint32_t table_stride, in
 // (pair_madd, 5 multiplications per lane); a wave holds 32 slots of one output and leaves their sum; k_g1fft_sum_partials adds the
 // <= 32 waves of an output.  Same group elements as the staged transform.
 constexpr uint32_t NAF2_MAX = 128;                       // digit slots per scalar (width-3 NAF of a scalar < 2^254: at most 254 / 3 + 1 = 85)
-constexpr uint32_t G1FFT_T3_POINTS = 256;                // the x3 tables cover the points this path transforms
+constexpr uint32_t G1FFT_T3_MAX = 2048;                  // the x3 tables cover the first min(SRS length, 2048) points: every point the table paths transform
 // T3_p[j] = 3 Bit_p[j] = Bit_p[j] + Bit_(p+1)[j] for p < 254 (a digit +-3 at position 254 would exceed the scalar field), as XYZZ planes:
-// k_g1fft_to_affine turns them into the table.  65 024 points, once per SRS (kzg_srs::d_t3).
+// k_g1fft_to_affine turns them into the table.  254 x t3_points points (33 MB at 2 048), once per SRS (kzg_srs::d_t3, ::t3_n).
 __global__ void __launch_bounds__(256)
-k_g1fft_t3_planes(const uint4* __restrict__ bits, uint32_t stride, uint32_t total, int32_t* __restrict__ planes) {
+k_g1fft_t3_planes(const uint4* __restrict__ bits, uint32_t stride, uint32_t t3_points, uint32_t total, int32_t* __restrict__ planes) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
-    const uint32_t p = t / G1FFT_T3_POINTS, j = t - p * G1FFT_T3_POINTS;
+    const uint32_t p = t / t3_points, j = t - p * t3_points;          // t3_points <= stride: every read stays inside its bit plane
     Affine a, b;
     Xyzz v;
     const bool ha = affine_load(a, bits + 4 * ((size_t)p * stride + j));
@@ -551,18 +552,22 @@ k_g1fft_naf2(const uint4* __restrict__ scal_canon, uint32_t n, uint16_t* __restr
     naf_for_digits(k, 3, [&](uint32_t pos, uint32_t key, uint32_t neg) { if (m < NAF2_MAX) list[(size_t)e * NAF2_MAX + m] = (uint16_t)(pos | (key << 14) | (neg << 15)); ++m; });
     cnt[e] = m < NAF2_MAX ? m : NAF2_MAX;
 }
+// K < log n: the same kernel as the FIRST STAGE of a staged transform of radix R = 2^K (the index rule of k_g1fft_first_tables: output o
+// sums the R inputs u + (n / R) j' with the scalars w^-(n / R . j . j'), u = o mod n / R, j = o / (n / R)); K = log n is the whole transform.
 __global__ void __launch_bounds__(256)
-k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, const uint4* __restrict__ bits3 /* 3 Bit_p[j], j < G1FFT_T3_POINTS, that many points apart */,
-             uint32_t n, const uint16_t* __restrict__ list, const uint32_t* __restrict__ cnt,
+k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, const uint4* __restrict__ bits3 /* 3 Bit_p[i], i < t3_points, that many points apart */,
+             uint32_t t3_points, uint32_t n, int log_n, int K, const uint16_t* __restrict__ list, const uint32_t* __restrict__ cnt,
              uint32_t Q, uint32_t waves_per_out, int32_t* __restrict__ partial) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, pair = lane >> 1;
     const bool odd = (t & 1u) != 0;
     const uint32_t gw = t >> 6;
     const uint32_t o = gw / waves_per_out, wv = gw - o * waves_per_out;
     if (o >= n) return;                                           // wave-uniform
-    const uint32_t slot = wv * 32 + pair;                         // < n Q (the host makes n Q a multiple of 32)
-    const uint32_t j = slot / Q, q = slot - j * Q;
-    const uint32_t e = (uint32_t)((unsigned long long)o * j) & (n - 1);
+    const uint32_t slot = wv * 32 + pair;                         // < R Q (the host makes R Q a multiple of 32)
+    const uint32_t jp = slot / Q, q = slot - jp * Q;
+    const uint32_t nr = n >> K, u = o & (nr - 1), jo = o >> (log_n - K);
+    const uint32_t j = u + nr * jp;                               // the input point
+    const uint32_t e = (uint32_t)((unsigned long long)nr * jo * jp) & (n - 1);
     const uint16_t* L = list + (size_t)e * NAF2_MAX;
     const uint32_t c = cnt[e];
     HalfXyzz acc;
@@ -572,7 +577,7 @@ k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, const uint4* __res
         const uint32_t d = L[m < c ? m : (c ? c - 1 : 0)];
         neg = d >> 15;
         const uint32_t pos = d & 0x3FFFu;
-        const uint4* src = ((d & 0x4000u) ? bits3 + 4 * ((size_t)pos * G1FFT_T3_POINTS + j) : bits + 4 * ((size_t)pos * stride + j)) + (odd ? 2 : 0);
+        const uint4* src = ((d & 0x4000u) ? bits3 + 4 * ((size_t)pos * t3_points + j) : bits + 4 * ((size_t)pos * stride + j)) + (odd ? 2 : 0);
         a = src[0]; b = src[1];
     };
     uint4 a0, b0; uint32_t neg0 = 0;
@@ -720,24 +725,27 @@ static int32_t get_scalars(kzg_ctx* ctx, int log_n, bool scaled, const uint4** o
     return KZG_OK;
 }
 
-// width-2 NAF digit lists of the n scalars w^-e / n (k_g1fft_naf2), cached per (device, log n)
+// width-3 NAF digit lists of the n scalars w^-e / n (scaled: the whole transform) or w^-e (a first stage), k_g1fft_naf2; cached per (device, log n, scaled)
 struct Naf2Lists { uint16_t* list = nullptr; uint32_t* cnt = nullptr; };
-static std::map<std::pair<int, int>, Naf2Lists> g_naf2;
-static int32_t get_naf2(kzg_ctx* ctx, int log_n, Naf2Lists* out) {
+static std::map<std::tuple<int, int, int>, Naf2Lists> g_naf2;
+static int32_t get_naf2(kzg_ctx* ctx, int log_n, bool scaled, Naf2Lists* out) {
     const uint4* sc = nullptr;
-    int32_t rc = get_scalars(ctx, log_n, true, &sc, 1);              // canonical integers of w^-e / n
+    int32_t rc = get_scalars(ctx, log_n, scaled, &sc, 1);            // canonical integers
     if (rc != KZG_OK) return rc;
     std::lock_guard<std::mutex> lk(g_scal_mu);
-    auto key = std::make_pair(ctx->device, log_n);
+    auto key = std::make_tuple(ctx->device, log_n, scaled ? 1 : 0);
     auto it = g_naf2.find(key);
     if (it != g_naf2.end()) { *out = it->second; return KZG_OK; }
     const size_t n = (size_t)1 << log_n;
     Naf2Lists l;
     KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&l.list), n * NAF2_MAX * 2));
-    KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&l.cnt), n * 4));
-    hipLaunchKernelGGL(k_g1fft_naf2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, sc, (uint32_t)n, l.list, l.cnt);
-    KZG_HIP_TRY(ctx, hipGetLastError());
-    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&l.cnt), n * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_g1fft_naf2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, sc, (uint32_t)n, l.list, l.cnt);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // shared by every context of the device: complete before it is published
+    if (e != hipSuccess) { (void)hipFree(l.list); if (l.cnt) (void)hipFree(l.cnt); return set_error(ctx, e, "recoding the scalars of g1_ifft"); }
     g_naf2[key] = l;
     *out = l;
     return KZG_OK;
@@ -771,31 +779,44 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
     if (rc == KZG_OK) rc = get_scalars(ctx, log_n, true, &scal_n);
     if (rc != KZG_OK) return rc;
     const int32_t* result = bufA;
-    // 64 .. 256 points of an SRS with per-bit tables: the whole transform as sums of table points (k_g1fft_bits; KZG_G1FFT_BITS=0: off)
+    // 64 .. 256 points of an SRS with per-bit tables: the whole transform as sums of table points (k_g1fft_bits; KZG_G1FFT_BITS=0: off);
+    // 512 .. 2048 points: the FIRST STAGE that way (radix 2^K0 over the SRS points: n 2^K0 x 64 mixed additions at the chip's throughput
+    // instead of a 127-step scalar-multiplication chain), the rest as one direct stage on lane pairs (KZG_G1FFT_BITS_FIRST=0: off)
     static const bool use_bits = []() { const char* e = getenv("KZG_G1FFT_BITS"); return !(e && atoi(e) == 0); }();
-    if (use_bits && srs_bits(srs) && srs->lagrange_of == 0 && n >= 64 && n <= 256) {     // (512 points: 2.1 ms here, 1.85 ms staged)
-        Naf2Lists nl;
-        rc = get_naf2(ctx, log_n, &nl);
-        if (rc != KZG_OK) return rc;
-        uint4* const d_bits = srs_bits(srs);
+    static const bool use_bits_first = []() { const char* e = getenv("KZG_G1FFT_BITS_FIRST"); return !(e && atoi(e) == 0); }();
+    uint4* const d_bits = srs_bits(srs);
+    const bool whole_by_bits = use_bits && d_bits && srs->lagrange_of == 0 && n >= 64 && n <= 256;
+    const bool first_by_bits = use_bits && use_bits_first && d_bits && srs->lagrange_of == 0 && n >= 512 && n <= G1FFT_T3_MAX;
+    uint4* d_t3 = nullptr;
+    uint32_t t3_points = 0;
+    if (whole_by_bits || first_by_bits) {
         std::unique_lock<std::mutex> lazy(srs->lazy_mu);
-        if (!srs->d_t3) {                                                  // x3 tables of the first 256 points, once per SRS (4 MiB)
-            const uint32_t total = 254 * G1FFT_T3_POINTS;
+        if (!srs->d_t3) {                                                  // x3 tables of the first min(SRS length, 2048) points, once per SRS (<= 33 MB)
+            const uint32_t pts = (uint32_t)std::min<size_t>(srs->n, G1FFT_T3_MAX);
+            const uint32_t total = 254 * pts;
             KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)total * 36 * 4));
             KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve((size_t)total * NL * 4));
             uint4* t3 = nullptr;
-            KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t3), (size_t)255 * G1FFT_T3_POINTS * 64));
-            KZG_HIP_TRY(ctx, hipMemsetAsync(t3, 0, (size_t)255 * G1FFT_T3_POINTS * 64, st));
-            hipLaunchKernelGGL(k_g1fft_t3_planes, dim3((total + 255) / 256), dim3(256), 0, st, d_bits, (uint32_t)srs->n, total, ctx->poly[0].c.as<int32_t>());
-            const size_t lanes = (total + AFF_PER - 1) / AFF_PER;
-            hipLaunchKernelGGL(k_g1fft_to_affine, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, ctx->poly[0].c.as<int32_t>(), total, t3, 0, ctx->poly[0].a.as<int32_t>());
-            hipError_t e = hipGetLastError();
+            KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t3), (size_t)255 * pts * 64));
+            hipError_t e = hipMemsetAsync(t3, 0, (size_t)255 * pts * 64, st);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_g1fft_t3_planes, dim3((total + 255) / 256), dim3(256), 0, st, d_bits, (uint32_t)srs->n, pts, total, ctx->poly[0].c.as<int32_t>());
+                const size_t lanes = (total + AFF_PER - 1) / AFF_PER;
+                hipLaunchKernelGGL(k_g1fft_to_affine, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, ctx->poly[0].c.as<int32_t>(), total, t3, 0, ctx->poly[0].a.as<int32_t>());
+                e = hipGetLastError();
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) { (void)hipFree(t3); return set_error(ctx, e, "building the x3 tables of g1_ifft"); }
             srs->d_t3 = t3;
+            srs->t3_n = pts;
         }
-        uint4* const d_t3 = srs->d_t3;
-        lazy.unlock();
+        d_t3 = srs->d_t3;
+        t3_points = srs->t3_n;
+    }
+    if (whole_by_bits) {
+        Naf2Lists nl;
+        rc = get_naf2(ctx, log_n, true, &nl);
+        if (rc != KZG_OK) return rc;
         // slices per term: two waves per SIMD in all (n^2 Q / 32 = 2048 waves) -- more waves only add tree additions (every wave ends in a
         // 5-level tree: a third of the work at 21 digits per pair), fewer leave lone waves at half the issue rate.  Measured: 256 points
         // 0.71 ms with Q = 4, 0.66 with Q = 1; 128 points 0.28 -> 0.26 (tools/time_g1ifft.py).  The floor is the additions themselves:
@@ -803,9 +824,29 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
         const uint32_t Q = (uint32_t)std::max<size_t>(1, 65536 / (n * n)), wpo = (uint32_t)(n * Q / 32);
         KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)n * wpo * 36 * 4));
         int32_t* partial = ctx->poly[0].c.as<int32_t>();
-        hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, d_bits, (uint32_t)srs->n, d_t3, (uint32_t)n,
-                           nl.list, nl.cnt, Q, wpo, partial);
+        hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, d_bits, (uint32_t)srs->n, d_t3, t3_points, (uint32_t)n,
+                           log_n, log_n, nl.list, nl.cnt, Q, wpo, partial);
         hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, wpo, (uint32_t)n, bufA);
+        KZG_HIP_TRY(ctx, hipGetLastError());
+        *result_out = bufA;
+        return KZG_OK;
+    }
+    if (first_by_bits) {
+        // K0 + K1 = log n with K1 <= 5 (a wave of the direct stage holds whole outputs): 512 = 2^4 . 2^5, 1024 = 2^5 . 2^5, 2048 = 2^6 . 2^5.
+        // Stage 1: n 2^K0 (output, term) pairs x ~64 digits (0.5 / 2.1 / 8.4 M mixed additions); stage 2: n 2^5 scalar multiplications on lane pairs
+        const int K1 = std::min(5, log_n - 1), K0 = log_n - K1;
+        Naf2Lists nl;
+        rc = get_naf2(ctx, log_n, false, &nl);
+        if (rc != KZG_OK) return rc;
+        const size_t R0 = (size_t)1 << K0;
+        const uint32_t Q = (uint32_t)std::max<size_t>(std::max<size_t>(1, 32 / R0), 65536 / (n * R0)), wpo = (uint32_t)(R0 * Q / 32);
+        KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)n * wpo * 36 * 4));
+        int32_t* partial = ctx->poly[0].c.as<int32_t>();
+        hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, d_bits, (uint32_t)srs->n, d_t3, t3_points, (uint32_t)n,
+                           log_n, K0, nl.list, nl.cnt, Q, wpo, partial);
+        hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, wpo, (uint32_t)n, bufB);
+        const size_t lanes = n << K1;
+        hipLaunchKernelGGL(k_g1fft_direct_pairs, dim3((unsigned)((2 * lanes + 255) / 256)), dim3(256), 0, st, bufB, bufA, (uint32_t)n, log_n, K1, 0, scal_n, 1);
         KZG_HIP_TRY(ctx, hipGetLastError());
         *result_out = bufA;
         return KZG_OK;

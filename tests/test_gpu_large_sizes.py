@@ -1,0 +1,129 @@
+"""-m gpu: sizes beyond the tables.  The reference accepts polynomials of up to 2^28 elements
+(primitives/src/polynomial.rs:42, :170) and SRS files of up to 2^28 points (primitives/src/consts.rs:66); the GPU path had been
+oracle-checked to 2^24 (NTT) and a 2^21-point SRS (MSM).
+
+* Fr NTT at 2^25 and 2^26 (1 / 2 GiB of data; three passes, the lookup-twiddle path): forward transform bit for bit against the
+  oracle, exact round trip, the inverse against the oracle at 2^25, and the definition F[i] = sum_j a_j w^(ij) at sparse indices.
+* commitments over a 2^23-point SRS (window tables, NO per-bit tables: the table-less side of srs_build_bit_tables' 2^22 limit) and a
+  2^24-point SRS (16 launches of 2^20 pairs: the cap of the asynchronous calls), checked against (sum_i c_i tau^i mod r) G1 by big
+  integers -- never against another run of the HIP path.  Step times are printed (pytest -s) and reported by bench.py `secondary`.
+Host memory: ~7 GiB at the peak (2^26 elements = 2 GiB per array)."""
+import ctypes as C
+import hashlib
+import time
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import pyref
+from pyref import R_
+
+pytestmark = pytest.mark.gpu
+TAU = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % R_
+MONT = (1 << 256) % R_
+
+
+@pytest.fixture(scope="module")
+def k():
+    import rust_kzg_bn254_amd as k
+    k.load()
+    k.default_context()
+    return k
+
+
+def random_canonical(n, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    return a
+
+
+@pytest.mark.parametrize("log_n", [25, 26])
+def test_ntt_2_25_and_2_26_match_the_oracle(k, log_n):
+    n = 1 << log_n
+    a = random_canonical(n, 9100 + log_n)
+    ctx = k.default_context(); lib = k._lib.load()
+    f = a.copy()
+    t0 = time.perf_counter()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(f), n, 0) == 0
+    t_gpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want = orc.fr_ntt_mt(a, inverse=False)
+    t_cpu = time.perf_counter() - t0
+    print("2^%d forward NTT: GPU incl. PCIe both ways %.3f s, oracle (all host cores) %.1f s" % (log_n, t_gpu, t_cpu))
+    assert np.array_equal(f, want), log_n
+    del want
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(f), n, 1) == 0            # round trip
+    assert np.array_equal(f, a)
+    if log_n == 25:
+        assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(f), n, 1) == 0
+        assert np.array_equal(f, orc.fr_ntt_mt(a, inverse=True))
+    del f
+    a[:] = 0
+    idxs, vals = [0, 1, 5_000_001, n - 1], [3, 5, 7, 11]
+    for j, v in zip(idxs, vals):
+        a[j] = pyref.fr_to_mont(v)
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(a), n, 0) == 0
+    w = pyref.root_of_unity(log_n)
+    for i in (0, 1, 2, 1234567, n // 2, n // 2 + 1, n - 1):
+        assert pyref.fr_from_mont(a[i]) == sum(v * pow(w, i * j, R_) for j, v in zip(idxs, vals)) % R_, (log_n, i)
+
+
+def _blob_like(n, seed):
+    """canonical values < 2^248 (31 payload bytes behind a zero byte, helpers.rs:823-840) as python ints + wire array"""
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(32, 127, size=(n, 31), dtype=np.uint8)
+    be = np.zeros((n, 32), np.uint8); be[:, 1:] = raw
+    vals = [int.from_bytes(be[i].tobytes(), "big") for i in range(n)]
+    return vals
+
+
+def _to_wire(vals):
+    return np.frombuffer(b"".join((v * MONT % R_).to_bytes(32, "little") for v in vals), dtype=np.uint64).reshape(-1, 4).copy()
+
+
+def _expected(vals, offset=0):
+    acc, tp = 0, pow(TAU, offset, R_)
+    for v in vals:
+        acc = (acc + v * tp) % R_
+        tp = tp * TAU % R_
+    return pyref.ec_mul(acc, (1, 2))
+
+
+@pytest.mark.parametrize("log_srs", [23, 24])
+def test_commitments_over_2_23_and_2_24_point_srs(k, log_srs):
+    ctx = k.default_context(); lib = k._lib.load()
+    n_srs = 1 << log_srs
+    t0 = time.perf_counter()
+    srs = k.SRS.generate(TAU, n_srs)
+    print("SRS 2^%d: generated + tables in %.2f s; per-bit tables: %d" % (log_srs, time.perf_counter() - t0, lib.kzg_srs_has_bit_tables(srs.handle, 0)))
+    try:
+        assert lib.kzg_srs_has_bit_tables(srs.handle, 0) == 0          # above 2^22 points: window tables only
+        out = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+        # the whole SRS; a ragged length that ends inside a launch; one 2^20 launch at an offset straddling launch boundaries; a small MSM at the far end
+        cases = [(0, n_srs), (0, 5 * (1 << 20) + 4321), ((3 << 20) - 1000, 1 << 20), (n_srs - 3000, 2048)]
+        whole = None
+        for ci, (offset, n) in enumerate(cases):
+            # the whole SRS with 62-bit scalars (every point and every launch takes part; the big-integer expectation stays cheap);
+            # the other cases use full-width blob-like scalars
+            vals = _blob_like(n, 50 + ci + log_srs) if ci else [int(v) for v in np.random.default_rng(log_srs).integers(1, 1 << 62, size=n)]
+            wire = _to_wire(vals)
+            want = _expected(vals, offset)
+            if ci == 0:
+                whole = (wire, want, _expected(vals[:1 << 20]))
+            t0 = time.perf_counter()
+            assert lib.kzg_msm_g1_srs(ctx.handle, srs.handle, offset, k._lib.ptr(wire), n, k._lib.ptr(out), C.byref(inf)) == 0
+            dt = time.perf_counter() - t0
+            print("  SRS 2^%d, MSM of %d pairs at offset %d from host scalars: %.2f ms" % (log_srs, n, offset, dt * 1e3))
+            assert pyref.point_from_wire(out) == want, (log_srs, offset, n)
+        # asynchronous form on the whole SRS (16 launches at 2^24: the documented cap) beside a second slot
+        wire, want, want_first = whole
+        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n_srs, 0) == 0
+        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(wire), 1 << 20, 1) == 0
+        o2 = np.zeros(8, np.uint64)
+        assert lib.kzg_msm_g1_srs_end(ctx.handle, 0, k._lib.ptr(out), C.byref(inf), None) == 0
+        assert lib.kzg_msm_g1_srs_end(ctx.handle, 1, k._lib.ptr(o2), C.byref(inf), None) == 0
+        assert pyref.point_from_wire(out) == want and pyref.point_from_wire(o2) == want_first
+    finally:
+        srs.close()

@@ -1113,10 +1113,11 @@ def test_g1_ifft_paths_and_lagrange_cache(k, tau_srs, ref_srs, test_srs_wire):
         ref_srs.cache_lagrange(48)
 
 
-@pytest.mark.parametrize("log_n", [6, 7, 8, 9])
+@pytest.mark.parametrize("log_n", [6, 7, 8, 9, 10, 11])
 def test_g1_ifft_through_the_per_bit_tables(k, tau_srs, log_n):
-    """g1_ifft of 64 .. 512 points of an SRS that carries per-bit tables (>= 2^15 points): the whole transform as sums of table points
-    (k_g1fft_bits: plain-NAF digit lists of the n scalars w^-e / n).  EVERY output against the known-tau value L_i = l_i(tau) G by
+    """g1_ifft of 64 .. 2048 points of an SRS that carries per-bit tables (>= 2^15 points): up to 256 points the whole transform as sums
+    of table points (k_g1fft_bits: NAF digit lists of the n scalars w^-e / n); 512 points as batched MSMs; 1024 / 2048 (round 4) with the
+    FIRST STAGE as sums of table points and one direct stage behind it.  Outputs against the known-tau value L_i = l_i(tau) G by
     big-integer arithmetic, and the same transform through the staged kernels (a copy of the first n points as an SRS of its own,
     which is too small for per-bit tables)."""
     kzg = k.KZG.new()
