@@ -127,3 +127,44 @@ def test_commitments_over_2_23_and_2_24_point_srs(k, log_srs):
         assert pyref.point_from_wire(out) == want and pyref.point_from_wire(o2) == want_first
     finally:
         srs.close()
+
+
+@pytest.mark.parametrize("log_srs", [25, 26])
+def test_commitment_over_2_25_and_2_26_point_srs_periodic_scalars(k, log_srs):
+    """A commitment over EVERY point of a 2^25-point SRS (window tables, 32 launches of 2^20 pairs) and of a 2^26-point SRS (its window
+    tables would take 64 GiB: above the 48 GiB cap of srs_precompute, so this is the table-less generic mode: 19 windows of 2^13
+    buckets, Horner on the host).  Scalars: 4 096 full-width random constants repeated with period 4 096, so that the expected value
+    has a closed form -- sum_m k_m tau^m (tau^(4096 Q) - 1) / (tau^4096 - 1) -- and 2^26 big-integer products are not needed on the host;
+    4 096 x 15 distinct (window, digit) pairs keep the buckets evenly filled."""
+    ctx = k.default_context(); lib = k._lib.load()
+    n = 1 << log_srs
+    period = 4096
+    rng = np.random.default_rng(100 + log_srs)
+    ks = [int.from_bytes(rng.bytes(40), "little") % R_ for _ in range(period)]
+    block = _to_wire(ks)
+    wire = np.ascontiguousarray(np.tile(block, (n // period, 1)))
+    q = n // period
+    geo = (pow(TAU, period * q, R_) - 1) * pow(pow(TAU, period, R_) - 1, -1, R_) % R_
+    acc, tp = 0, 1
+    for v in ks:
+        acc = (acc + v * tp) % R_
+        tp = tp * TAU % R_
+    want = pyref.ec_mul(acc * geo % R_, (1, 2))
+    t0 = time.perf_counter()
+    srs = k.SRS.generate(TAU, n)
+    t_srs = time.perf_counter() - t0
+    try:
+        out = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+        t0 = time.perf_counter()
+        assert lib.kzg_msm_g1_srs(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n, k._lib.ptr(out), C.byref(inf)) == 0
+        dt = time.perf_counter() - t0
+        print("SRS 2^%d (set-up %.1f s): commitment over all %d points from host scalars: %.1f ms (%.2f ms per 2^20 pairs)" % (log_srs, t_srs, n, dt * 1e3, dt * 1e3 / (n >> 20)))
+        assert pyref.point_from_wire(out) == want, log_srs
+        # the asynchronous calls are documented to stop at 2^24 pairs: beyond it they must refuse, not misbehave
+        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n, 0) != 0
+        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 5, k._lib.ptr(wire), 1 << 24, 0) == 0
+        assert lib.kzg_msm_g1_srs_end(ctx.handle, 0, k._lib.ptr(out), C.byref(inf), None) == 0
+        geo24 = (pow(TAU, 1 << 24, R_) - 1) * pow(pow(TAU, period, R_) - 1, -1, R_) % R_
+        assert pyref.point_from_wire(out) == pyref.ec_mul(acc * geo24 % R_ * pow(TAU, 5, R_) % R_, (1, 2))
+    finally:
+        srs.close()
