@@ -149,6 +149,56 @@ __device__ __forceinline__ void quad_madd(QuadXyzz& r, const QuadXyzz& acc, cons
     if (acc.inf) r = from;
 }
 
+// r = 2 a (dbl-2008-s-1), a finite.  The nine products of the one-lane form have a dependency depth of THREE, and the quad reaches it:
+//     round   lane 0 (X)                lane 1 (Y)              lane 2 (ZZ)           lane 3 (ZZZ)
+//       1     XX = X^2                  V = U^2  (U = 2 Y)      V = U^2               V = U^2
+//             M = 3 XX
+//       2     S = X V                   W = U V                 ZZ3 = ZZ V            MM = M^2   (M from lane 0)
+//             X3 = MM - 2 S
+//       3     D = M (3 S - MM)          WY = W Y                --                    ZZZ3 = ZZZ W   (W from lane 1)
+//                                       Y3 = D - WY                                                   (S - X3 = 3 S - MM)
+// (the pair form is five products deep).  Ranges as curve.h: X3 in (-5m, 4m), Y3 in (-3m, 3m), ZZ3 / ZZZ3 in (-m, 2m).
+__device__ __forceinline__ void quad_dbl(QuadXyzz& r, const QuadXyzz& a, uint32_t q) {
+    Fq y, u, s1, t1;
+    fe_quad_mov<QUAD_BCAST1>(y, a.c);
+    fe_dbl(u, y); fe_norm(u);                  // U = 2 Y, |U| < 6m
+    fe_select(s1, q == 0u, a.c, u);
+    fe_sqr(t1, s1);                            // XX (49 m^2) | V | V | V (36 m^2)
+    Fq m, m0, v1;
+    fe_add(m, t1, t1); fe_add(m, m, t1); fe_norm(m);     // lane 0: M = 3 XX, |M| < 6m
+    fe_quad_mov<QUAD_BCAST0>(m0, m);
+    fe_quad_mov<QUAD_BCAST1>(v1, t1);          // V in every lane
+    Fq a2, b2, t2;
+    fe_select(a2, q == 1u, u, a.c);            // X | U | ZZ | (ZZZ)
+    fe_select(a2, q == 3u, m0, a2);            // X | U | ZZ | M
+    fe_select(b2, q == 3u, m0, v1);            // V | V | V | M
+    fe_mul(t2, a2, b2);                        // S = X V (7m * 2m) | W = U V | ZZ3 = ZZ V | MM = M^2 (36 m^2)
+    Fq mm, w1, x3, tq;
+    fe_quad_mov<QUAD_BCAST3>(mm, t2);
+    fe_quad_mov<QUAD_BCAST1>(w1, t2);
+    fe_sub(x3, mm, t2); fe_sub(x3, x3, t2); fe_norm(x3);         // lane 0: X3 = MM - 2 S in (-5m, 4m)
+    fe_add(tq, t2, t2); fe_add(tq, tq, t2); fe_sub(tq, tq, mm); fe_norm(tq);      // lane 0: 3 S - MM in (-5m, 7m)
+    Fq a3, b3, t3;
+    fe_select(a3, q == 0u, m, w1);             // M | W | W | W
+    fe_select(b3, q == 0u, tq, a.c);           // 3 S - MM | Y | (ZZ) | ZZZ
+    fe_mul(t3, a3, b3);                        // D = M (3 S - MM) (42 m^2) | WY = W Y | (unused) | ZZZ3 = W ZZZ
+    Fq d0, y3;
+    fe_quad_mov<QUAD_BCAST0>(d0, t3);
+    fe_sub(y3, d0, t3); fe_norm(y3);           // lane 1: Y3 = D - WY in (-3m, 3m)      (dpp(t) - t: see quad_add_tail on v_subrev_u32_dpp)
+    Fq lo, hi;
+    fe_select(lo, q == 1u, y3, x3);
+    fe_select(hi, q == 3u, t3, t2);
+    fe_select(r.c, q >= 2u, hi, lo);
+    r.inf = false;
+}
+// a may be the identity (quad-uniform flag)
+__device__ __forceinline__ void quad_dbl_any(QuadXyzz& r, const QuadXyzz& a, uint32_t q) {
+    if (__all(a.inf)) { r = a; return; }
+    QuadXyzz d;
+    quad_dbl(d, a, q);
+    if (a.inf) r = a; else r = d;
+}
+
 // ---- memory: the struct-of-arrays XYZZ layout of curve.h (36 limb planes), each lane touching its coordinate ---------------------
 __device__ __forceinline__ void quad_load(QuadXyzz& h, const int32_t* __restrict__ base, size_t stride, size_t i, uint32_t q) {
 #pragma unroll

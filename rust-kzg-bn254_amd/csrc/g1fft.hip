@@ -17,6 +17,8 @@
 //   * Jacobian -> affine by Montgomery's trick (one inversion per lane for 16 points) when there are many points.
 #include "engine.h"
 #include "curve_pair.h"
+#include "curve_quad.h"
+#include "fe_invert.h"
 #include "naf.h"
 #include "host_curve.h"
 
@@ -30,8 +32,13 @@
 
 namespace kzg {
 
+// the ONE inversion behind every batched affine conversion: Bernstein-Yang division steps (fe_invert.h: ~20 us on a lone lane) instead of
+// a^(m-2) (381 dependent products, ~175 us).  -DKZG_INVERT_FERMAT restores the exponentiation (A/B).
 template <class F>
 __device__ __forceinline__ void fe_inverse_fermat(Fe<F>& out, const Fe<F>& a) {
+#if !defined(KZG_INVERT_FERMAT)
+    fe_inverse_safegcd(out, a);
+#else
     Fe<F> acc, base = a;
     fe_set_one(acc);
     uint32_t e[8];
@@ -48,6 +55,7 @@ __device__ __forceinline__ void fe_inverse_fermat(Fe<F>& out, const Fe<F>& a) {
         }
     }
     out = acc;
+#endif
 }
 
 // ---- GLV: k P = k1 P + k2 phi(P), phi(x, y) = (beta x, y) = [lambda] P on BN254 G1, |k1|, |k2| < 2^127 ---------------------------
@@ -397,6 +405,81 @@ k_g1fft_direct_pairs(const int32_t* __restrict__ x, int32_t* __restrict__ y, uin
         }
     }
     if (active && jp == 0) half_store(y, n, o, term, odd);
+}
+
+// ---- the direct stage on LANE QUADS (curve_quad.h; round 4) -------------------------------------------------------------------------
+// One step of the GLV chain is a doubling and an addition one after the other: 5 + 7 products deep on a lane pair, 3 + 4 on a quad.  A stage
+// that fits one wave per SIMD is pure latency, so the quad form takes 7 / 12 of the pair form's time (measured: 0.83 -> ~0.5 ms); the products
+// [k] x of all (output, term) slots go to a partial array and k_g1fft_sum_partials adds the R = 2^K terms of an output (a wave holds 16 quads,
+// so the tree no longer fits the multiplying wave for R = 32).  r = [k] p, k as its GLV halves; every lane of a quad holds the same k.
+__device__ __forceinline__ void quad_scalar_mul(QuadXyzz& r, const QuadXyzz& p, const uint32_t kk[8], uint32_t q) {
+    const uint32_t s1 = kk[3] >> 31, s2 = kk[7] >> 31;
+    Fq beta, kin, bx, y1, y2;
+    {
+        uint32_t bw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bw[j] = GLV_BETA[j];
+        fe_unpack(beta, bw);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) kin.l[j] = (int32_t)FqParams::K_PLAIN_IN[j];
+        fe_mul(beta, beta, kin);                                   // plain integer -> internal form
+    }
+    fe_mul(bx, p.c, beta);                                         // lane 0: beta X
+    fe_cneg(y1, p.c, s1); fe_norm(y1);                             // lane 1: +-Y
+    fe_cneg(y2, p.c, s2); fe_norm(y2);
+    QuadXyzz P1 = p, P2 = p, S;
+    fe_select(P1.c, q == 1u, y1, p.c);
+    fe_select(P2.c, q == 1u, y2, p.c);
+    fe_select(P2.c, q == 0u, bx, P2.c);
+    quad_add(S, P1, P2, q);
+    QuadXyzz acc;
+    quad_set_inf(acc);
+#pragma unroll 1
+    for (int i = 126; i >= 0; --i) {
+        QuadXyzz t;
+        quad_dbl_any(t, acc, q);
+        acc = t;
+        const uint32_t b1 = (kk[i >> 5] >> (i & 31)) & 1u, b2 = (kk[4 + (i >> 5)] >> (i & 31)) & 1u;
+        QuadXyzz op;
+        const bool both = b1 & b2;
+        fe_select(op.c, both, S.c, b1 ? P1.c : P2.c);
+        op.inf = p.inf || (both ? S.inf : !(b1 | b2));
+        quad_add(t, acc, op, q);
+        acc = t;
+    }
+    r = acc;
+}
+
+// slot (o, j') of a direct stage of radix R = 2^K (the index rule of k_g1fft_direct_pairs): partial[o R + j'] = [w^-e (/ n)] x[input]
+__global__ void __launch_bounds__(256)
+k_g1fft_mul_quads(const int32_t* __restrict__ x, int32_t* __restrict__ partial, uint32_t n, int log_n, int K, int log_s,
+                  const uint4* __restrict__ scal, int last) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, q = t & 3u, quad = t >> 2;
+    const uint32_t R = 1u << K;
+    const uint32_t o = quad >> K, jp = quad & (R - 1);
+    const bool active = o < n;
+    QuadXyzz term;
+    quad_set_inf(term);
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool plain = true;                                            // the term is the input itself (scalar 1)
+    if (active) {
+        const uint32_t nr = n >> K;
+        const uint32_t u = o & (nr - 1), j = o >> (log_n - K);
+        const uint32_t qq = u & ((1u << log_s) - 1), p = u >> log_s;
+        const uint32_t e = (uint32_t)(((unsigned long long)p * jp << log_s) + (unsigned long long)nr * j * jp) & (n - 1);
+        quad_load(term, x, n, (size_t)qq + ((size_t)(R * p + jp) << log_s), q);
+        if (!(e == 0 && !last)) {
+            const uint4 lo = scal[2 * (size_t)e], hi = scal[2 * (size_t)e + 1];
+            k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+            plain = false;
+        }
+    }
+    if (!__all(plain)) {                                          // wave-uniform: the multiplication runs for the whole wave or not at all
+        QuadXyzz m;
+        quad_scalar_mul(m, term, k, q);
+        if (!plain) term = m;
+    }
+    if (active) quad_store(partial, (size_t)n * R, (size_t)o * R + jp, term, q);
 }
 
 __global__ void __launch_bounds__(256)
@@ -832,23 +915,59 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
         return KZG_OK;
     }
     if (first_by_bits) {
-        // K0 + K1 = log n with K1 <= 5 (a wave of the direct stage holds whole outputs): 512 = 2^4 . 2^5, 1024 = 2^5 . 2^5, 2048 = 2^6 . 2^5.
-        // Stage 1: n 2^K0 (output, term) pairs x ~64 digits (0.5 / 2.1 / 8.4 M mixed additions); stage 2: n 2^5 scalar multiplications on lane pairs
-        const int K1 = std::min(5, log_n - 1), K0 = log_n - K1;
+        // Plan (bits of the stages, first one through the per-bit tables): the later stages are one 127-step GLV chain deep each, pure latency
+        // while they fit one wave per SIMD (65 536 lanes = 16 384 quads = n 2^K <= 16 384).  512 = 2^4 . 2^5, 1024 = 2^6 . 2^4, 2048 = 2^5 . 2^3 . 2^3
+        // (measured, tools/time_g1ifft.py; KZG_G1FFT_PLAN="k0,k1[,k2]" overrides, KZG_G1FFT_QUADS=0: the later stages on lane pairs, K <= 5).
+        int plan[4] = {0, 0, 0, 0}, np = 0;
+        static const bool use_quads = []() { const char* e = getenv("KZG_G1FFT_QUADS"); return !(e && atoi(e) == 0); }();
+        if (const char* e = getenv("KZG_G1FFT_PLAN")) {
+            int a0 = 0, a1 = 0, a2 = 0;
+            const int got = sscanf(e, "%d,%d,%d", &a0, &a1, &a2);
+            if (got >= 2 && a0 >= 1 && a0 <= 7 && a1 >= 1 && a1 <= 5 && (got < 3 || (a2 >= 1 && a2 <= 5)) && a0 + a1 + (got == 3 ? a2 : 0) == log_n) {
+                plan[0] = a0; plan[1] = a1; np = 2;
+                if (got == 3) { plan[2] = a2; np = 3; }
+            }
+        }
+        if (np == 0) {
+            if (!use_quads) { plan[1] = std::min(5, log_n - 1); plan[0] = log_n - plan[1]; np = 2; }
+            else if (log_n == 9) { plan[0] = 4; plan[1] = 5; np = 2; }
+            else if (log_n == 10) { plan[0] = 6; plan[1] = 4; np = 2; }
+            else { plan[0] = 5; plan[1] = 3; plan[2] = 3; np = 3; }
+        }
+        const int K0 = plan[0];
         Naf2Lists nl;
         rc = get_naf2(ctx, log_n, false, &nl);
         if (rc != KZG_OK) return rc;
         const size_t R0 = (size_t)1 << K0;
         const uint32_t Q = (uint32_t)std::max<size_t>(std::max<size_t>(1, 32 / R0), 65536 / (n * R0)), wpo = (uint32_t)(R0 * Q / 32);
-        KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)n * wpo * 36 * 4));
+        size_t part_points = (size_t)n * wpo;
+        for (int i = 1; i < np; ++i) part_points = std::max(part_points, n << plan[i]);
+        KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve(part_points * 36 * 4));
         int32_t* partial = ctx->poly[0].c.as<int32_t>();
+        int32_t* src = bufB;
+        int32_t* dst = bufA;
         hipLaunchKernelGGL(k_g1fft_bits, dim3((unsigned)((n * (size_t)wpo * 64 + 255) / 256)), dim3(256), 0, st, d_bits, (uint32_t)srs->n, d_t3, t3_points, (uint32_t)n,
                            log_n, K0, nl.list, nl.cnt, Q, wpo, partial);
-        hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, wpo, (uint32_t)n, bufB);
-        const size_t lanes = n << K1;
-        hipLaunchKernelGGL(k_g1fft_direct_pairs, dim3((unsigned)((2 * lanes + 255) / 256)), dim3(256), 0, st, bufB, bufA, (uint32_t)n, log_n, K1, 0, scal_n, 1);
+        hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, wpo, (uint32_t)n, src);
+        int done = K0;
+        for (int i = 1; i < np; ++i) {
+            const int K = plan[i];
+            done += K;
+            const int log_s = log_n - done;
+            const bool last = i == np - 1;
+            const size_t slots = n << K;
+            if (use_quads) {
+                hipLaunchKernelGGL(k_g1fft_mul_quads, dim3((unsigned)((4 * slots + 255) / 256)), dim3(256), 0, st, src, partial, (uint32_t)n, log_n, K, log_s,
+                                   last ? scal_n : scal, last ? 1 : 0);
+                hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, (uint32_t)1 << K, (uint32_t)n, dst);
+            } else {
+                hipLaunchKernelGGL(k_g1fft_direct_pairs, dim3((unsigned)((2 * slots + 255) / 256)), dim3(256), 0, st, src, dst, (uint32_t)n, log_n, K, log_s,
+                                   last ? scal_n : scal, last ? 1 : 0);
+            }
+            std::swap(src, dst);
+        }
         KZG_HIP_TRY(ctx, hipGetLastError());
-        *result_out = bufA;
+        *result_out = src;
         return KZG_OK;
     }
     // Stage plan.  A stage is one scalar multiplication deep whatever it computes, so the plan minimises (number of stages) x (time of a
@@ -989,7 +1108,9 @@ static int32_t g1_ifft_as_batched_msm(kzg_ctx* ctx, const kzg_srs* srs, size_t n
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy) {
     // sizes the batched MSM wins at (measured, tools/time_g1ifft.py): KZG_G1FFT_BATCH="lo,hi" overrides, "0" switches it off
     static const std::pair<size_t, size_t> batch_range = []() {
-        size_t lo = 512, hi = 512;     // 64 / 128 / 256 / 512 / 1024 points: 0.49 / 0.55 / 0.70 / 1.15 / 3.0 ms this way, 0.19 / 0.26 / 0.68 / 1.84 / 1.96 ms otherwise
+        // 64 / 128 / 256 / 512 / 1024 points: 0.49 / 0.55 / 0.70 / 1.08 / 3.0 ms this way.  Round 3 took it at 512 points (staged: 1.84 ms); since
+        // round 4 the table first stage + one quad stage does 512 points in 0.86 ms, so the default range is empty (KZG_G1FFT_BATCH=512 restores it)
+        size_t lo = 1, hi = 0;
         if (const char* e = getenv("KZG_G1FFT_BATCH")) { unsigned long a = 0, b2 = 0; int k = sscanf(e, "%lu,%lu", &a, &b2); lo = a; hi = k == 2 ? b2 : a; if (a == 0) { lo = 1; hi = 0; } }
         return std::make_pair(lo, hi);
     }();

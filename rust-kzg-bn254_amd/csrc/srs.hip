@@ -6,13 +6,17 @@
 //   k_points_device_to_wire: read a device-resident SRS back in wire format (for parity checks).
 #include "engine.h"
 #include "curve.h"
+#include "fe_invert.h"
 
 #include <cstdlib>
 
 namespace kzg {
 
 template <class F>
-__device__ __forceinline__ void fe_inverse(Fe<F>& out, const Fe<F>& a) {     // a^(m-2)
+__device__ __forceinline__ void fe_inverse(Fe<F>& out, const Fe<F>& a) {     // a^-1 (0 -> 0): division steps, fe_invert.h (round 4; was a^(m-2))
+#if !defined(KZG_INVERT_FERMAT)
+    fe_inverse_safegcd(out, a);
+#else
     Fe<F> acc, base = a;
     fe_set_one(acc);
     uint32_t e[8];
@@ -29,6 +33,7 @@ __device__ __forceinline__ void fe_inverse(Fe<F>& out, const Fe<F>& a) {     // 
         }
     }
     out = acc;
+#endif
 }
 
 // scalars: n canonical 256-bit integers k_i (device, 8 u32 each); out: device affine format

@@ -7,6 +7,7 @@
 #include "field29.h"
 #include "curve.h"
 #include "naf.h"
+#include "fe_invert.h"
 
 using namespace kzg;
 
@@ -54,6 +55,19 @@ int hc_paired_vs_single(const int32_t* a1, const int32_t* b1, const int32_t* a2,
     int bad = 0;
     for (int j = 0; j < NL; ++j) bad |= (p1.l[j] != q1.l[j]) | (p2.l[j] != q2.l[j]) << 1 | (s1.l[j] != t1.l[j]) << 2 | (s2.l[j] != t2.l[j]) << 3;
     return bad;
+}
+// wire a -> wire a^-1 by the safegcd division steps of fe_invert.h (0 -> 0); lazy != 0: the input is first made a lazy value in (-m, 2m)
+// that is NOT canonical (a + m or a - m where that stays inside the range) to exercise the canonicalisation at the entry
+void hc_inverse_safegcd(int which, const uint32_t* a, uint32_t* out, int lazy) {
+    if (which == 0) {
+        Fq x, r; fe_from_wire(x, a);
+        if (lazy) { Fq one; fe_set_one(one); fe_mul(x, x, one); }       // another representative of the same residue, still in (-m, 2m)
+        fe_inverse_safegcd(r, x); fe_to_wire(out, r);
+    } else {
+        Fr x, r; fe_from_wire(x, a);
+        if (lazy) { Fr one; fe_set_one(one); fe_mul(x, x, one); }
+        fe_inverse_safegcd(r, x); fe_to_wire(out, r);
+    }
 }
 void hc_wire_to_canonical(int which, const uint32_t* a, uint32_t* out) {
     if (which == 0) fe_wire_to_canonical_words<FqParams>(out, a);

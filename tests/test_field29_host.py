@@ -29,7 +29,7 @@ u8p = C.POINTER(C.c_uint8)
 
 @pytest.fixture(scope="module")
 def hc():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("field29.h", "curve.h", "field_constants.h", "naf.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("field29.h", "curve.h", "field_constants.h", "naf.h", "fe_invert.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-DKZG_BOUND_CHECK", "-Wno-unknown-pragmas", "-fPIC",
                                "-shared", "-I" + CSRC, "-o", SO, SRC])
@@ -250,3 +250,22 @@ def test_reduce_small(hc):
                     want = ((-a if neg else a) << k) % m
                     ww = pyref.fq_to_mont(want) if which == 0 else pyref.frs_to_mont([want])[0]
                     assert np.array_equal(out.view(np.uint64), np.asarray(ww, dtype=np.uint64).reshape(-1)), (which, a, k, neg)
+
+
+def test_safegcd_inverse(hc):
+    """fe_inverse_safegcd (csrc/fe_invert.h, round 4: Bernstein-Yang division steps instead of a^(m-2) on the device) against big-integer
+    inverses: edge values (0 -> 0, 1, m - 1, 2, (m +- 1) / 2, powers of two, values whose low limbs are all ones) and 3 000 random ones per
+    field, canonical and lazy representatives; the bound-checked build asserts fe_mul's operand bounds at the exit products."""
+    rng = random.Random(4242)
+    for which, m in ((0, P), (1, R_)):
+        edge = [0, 1, 2, 3, m - 1, m - 2, (m - 1) // 2, (m + 1) // 2, (1 << 29) - 1, 1 << 29, (1 << 58) - 1, (1 << 253) % m, (1 << 253) - 1,
+                (1 << 261) % m, pow(5, (m - 1) // 3, m)]
+        vals = edge + [rng.randrange(m) for _ in range(3000)] + [rng.randrange(1 << 64) for _ in range(200)]
+        for a in vals:
+            aw = w32(pyref.fq_to_mont(a) if which == 0 else pyref.frs_to_mont([a])[0])
+            want = pow(a, -1, m) if a else 0
+            ww = np.asarray(pyref.fq_to_mont(want) if which == 0 else pyref.frs_to_mont([want])[0], dtype=np.uint64).reshape(-1)
+            for lazy in (0, 1):
+                out = np.zeros(8, np.uint32)
+                hc.hc_inverse_safegcd(which, aw.ctypes.data_as(u32p), out.ctypes.data_as(u32p), lazy)
+                assert np.array_equal(out.view(np.uint64), ww), (which, a, lazy)

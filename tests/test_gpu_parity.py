@@ -14,6 +14,7 @@ from pyref import P, R_
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAU = int.from_bytes(__import__("hashlib").sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % R_
 
 
@@ -1116,8 +1117,8 @@ def test_g1_ifft_paths_and_lagrange_cache(k, tau_srs, ref_srs, test_srs_wire):
 @pytest.mark.parametrize("log_n", [6, 7, 8, 9, 10, 11])
 def test_g1_ifft_through_the_per_bit_tables(k, tau_srs, log_n):
     """g1_ifft of 64 .. 2048 points of an SRS that carries per-bit tables (>= 2^15 points): up to 256 points the whole transform as sums
-    of table points (k_g1fft_bits: NAF digit lists of the n scalars w^-e / n); 512 points as batched MSMs; 1024 / 2048 (round 4) with the
-    FIRST STAGE as sums of table points and one direct stage behind it.  Outputs against the known-tau value L_i = l_i(tau) G by
+    of table points (k_g1fft_bits: NAF digit lists of the n scalars w^-e / n); 512 / 1024 / 2048 (round 4) with the FIRST STAGE as sums of
+    table points and one or two direct stages on lane quads behind it.  Outputs against the known-tau value L_i = l_i(tau) G by
     big-integer arithmetic, and the same transform through the staged kernels (a copy of the first n points as an SRS of its own,
     which is too small for per-bit tables)."""
     kzg = k.KZG.new()
@@ -1192,3 +1193,34 @@ def test_multi_device_stream_of_mixed_lengths_keeps_its_slots(k, test_srs_wire):
     for i, b in enumerate(order):
         assert np.array_equal(got[i], want[b]), (i, b)
     m.close()
+
+
+def test_g1_ifft_alternative_paths_agree_with_the_default(k, tau_srs):
+    """The paths g1_ifft no longer takes by default stay correct: 512 points as batched MSMs (KZG_G1FFT_BATCH=512, round 3's default), the
+    later stages on lane pairs (KZG_G1FFT_QUADS=0), other stage plans (KZG_G1FFT_PLAN), the staged kernels without the table first stage
+    (KZG_G1FFT_BITS_FIRST=0) and the exponentiation form of the batched inversion are selected per PROCESS (the switches are read
+    once), so each runs in a child process on the same known-tau SRS and must print the digest of the default path's output."""
+    import hashlib
+    import subprocess
+    import sys
+    kzg = k.KZG.new()
+    want = {n: hashlib.sha256(kzg.g1_ifft(n, tau_srs).tobytes()).hexdigest() for n in (512, 1024, 2048)}
+    code = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, rust_kzg_bn254_amd as k\n"
+        "srs = k.SRS.generate(%d, %d); kz = k.KZG.new()\n"
+        "print(' '.join(hashlib.sha256(kz.g1_ifft(n, srs).tobytes()).hexdigest() for n in (512, 1024, 2048)))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), TAU, len(tau_srs))
+    for env_add in ({"KZG_G1FFT_BATCH": "512"}, {"KZG_G1FFT_QUADS": "0"}, {"KZG_G1FFT_BITS_FIRST": "0"}):
+        env = dict(os.environ, **env_add)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, (env_add, res.stderr[-1500:])
+        got = res.stdout.strip().splitlines()[-1].split()
+        assert got == [want[512], want[1024], want[2048]], env_add
+    for plan, n in (("5,4", 512), ("3,3,3", 512), ("5,5", 1024), ("4,3,3", 1024), ("6,5", 2048), ("7,4", 2048)):
+        env = dict(os.environ, KZG_G1FFT_PLAN=plan)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, (plan, res.stderr[-1500:])
+        got = dict(zip((512, 1024, 2048), res.stdout.strip().splitlines()[-1].split()))
+        assert got[n] == want[n], (plan, n)

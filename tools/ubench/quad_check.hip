@@ -1,6 +1,6 @@
 // Device check of the lane-quad point arithmetic (csrc/curve_quad.h) against the one-lane formulas (csrc/curve.h): quad_add and quad_madd on
 // random field values (the formulas are rational maps: the operands need not be curve points), with the identity, doubling and
-// cancellation cases mixed into every wave.
+// cancellation cases mixed into every wave; round 4: quad_dbl against xyzz_dbl.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 quad_check.hip -o quad_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -29,7 +29,12 @@ __global__ void __launch_bounds__(64) k_check(const uint32_t* __restrict__ a_w, 
     quad_gather(A, a);
     quad_gather(B, b);
     QuadXyzz r;
-    if (!madd) {
+    if (madd == 2) {                           // doubling (round 4: quad_dbl); kind 6 / 7: X at the wide end of its range (3 x in (-3m, 6m))
+        if ((kind == 6 || kind == 7) && q == 0) { Fq t; fe_add(t, a.c, a.c); fe_add(t, t, a.c); fe_norm(t); a.c = t; }
+        quad_gather(A, a);
+        quad_dbl_any(r, a, q);
+        xyzz_dbl(R, A);
+    } else if (!madd) {
         quad_add(r, a, b, q);
         xyzz_add<false>(R, A, B);
     } else {
@@ -67,7 +72,7 @@ int main() {
     CHECK(hipMemcpy(d_a, a.data(), a.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_b, b.data(), a.size() * 4, hipMemcpyHostToDevice));
     int bad_total = 0;
-    for (int madd = 0; madd < 2; ++madd) {
+    for (int madd = 0; madd < 3; ++madd) {
         CHECK(hipMemset(d_q, 0xEE, a.size() * 4)); CHECK(hipMemset(d_r, 0xDD, a.size() * 4));
         hipLaunchKernelGGL(k_check, dim3(n / 16), dim3(64), 0, 0, d_a, d_b, n, madd, d_q, d_r);
         CHECK(hipDeviceSynchronize());
@@ -81,7 +86,7 @@ int main() {
                 if (memcmp(&hq[(size_t)i * 32 + c * 8], &hr[(size_t)i * 32 + c * 8], 32) != 0) { ++bad_coord[c]; any = true; }
             if (any) { ++bad; ++bad_kind[i % 8]; }
         }
-        printf("%s: %d of %u cases differ; by kind:", madd ? "quad_madd" : "quad_add", bad, n);
+        printf("%s: %d of %u cases differ; by kind:", madd == 2 ? "quad_dbl" : madd ? "quad_madd" : "quad_add", bad, n);
         for (int k = 0; k < 8; ++k) printf(" %d", bad_kind[k]);
         printf("; by coordinate X Y ZZ ZZZ: %d %d %d %d\n", bad_coord[0], bad_coord[1], bad_coord[2], bad_coord[3]);
         bad_total += bad;
