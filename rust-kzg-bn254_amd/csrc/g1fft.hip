@@ -409,7 +409,8 @@ k_g1fft_direct_pairs(const int32_t* __restrict__ x, int32_t* __restrict__ y, uin
 
 // ---- the direct stage on LANE QUADS (curve_quad.h; round 4) -------------------------------------------------------------------------
 // One step of the GLV chain is a doubling and an addition one after the other: 5 + 7 products deep on a lane pair, 3 + 4 on a quad.  A stage
-// that fits one wave per SIMD is pure latency, so the quad form takes 7 / 12 of the pair form's time (measured: 0.83 -> ~0.5 ms); the products
+// that fits one wave per SIMD is pure latency, so the quad form takes 7 / 12 of the pair form's time (measured: 0.83 -> 0.60 ms; with two bits
+// per step 3 + 3 + 4 per two bits); the products
 // [k] x of all (output, term) slots go to a partial array and k_g1fft_sum_partials adds the R = 2^K terms of an output (a wave holds 16 quads,
 // so the tree no longer fits the multiplying wave for R = 32).  r = [k] p, k as its GLV halves; every lane of a quad holds the same k.
 __device__ __forceinline__ void quad_scalar_mul(QuadXyzz& r, const QuadXyzz& p, const uint32_t kk[8], uint32_t q) {
@@ -427,10 +428,13 @@ __device__ __forceinline__ void quad_scalar_mul(QuadXyzz& r, const QuadXyzz& p, 
     fe_mul(bx, p.c, beta);                                         // lane 0: beta X
     fe_cneg(y1, p.c, s1); fe_norm(y1);                             // lane 1: +-Y
     fe_cneg(y2, p.c, s2); fe_norm(y2);
-    QuadXyzz P1 = p, P2 = p, S;
+    QuadXyzz P1 = p, P2 = p;
     fe_select(P1.c, q == 1u, y1, p.c);
     fe_select(P2.c, q == 1u, y2, p.c);
     fe_select(P2.c, q == 0u, bx, P2.c);
+#if defined(KZG_G1FFT_QUAD_W1)
+    // one bit of each half per step: a doubling and an addition of P1, P2 or P1 + P2 (7 products deep per bit)
+    QuadXyzz S;
     quad_add(S, P1, P2, q);
     QuadXyzz acc;
     quad_set_inf(acc);
@@ -448,6 +452,52 @@ __device__ __forceinline__ void quad_scalar_mul(QuadXyzz& r, const QuadXyzz& p, 
         acc = t;
     }
     r = acc;
+#else
+    // TWO bits of each half per step: two doublings and ONE addition of T[a + 4 b] = a P1 + b P2, a, b < 4 (3 + 3 + 4 = 10 products deep per two
+    // bits instead of 14).  On a quad a point is nine VGPRs per lane, so the fifteen table points stay in registers (135 VGPRs); the entry
+    // is picked with a v_cndmask tree.  No entry is the identity unless p is (a + b lambda != 0 mod r for these a, b): one flag for all.
+    Fq T[16];                                                      // T[0] unused
+    QuadXyzz t, u;
+    T[1] = P1.c; T[4] = P2.c;
+    quad_dbl_any(t, P1, q); T[2] = t.c;
+    quad_add(u, t, P1, q); T[3] = u.c;
+    quad_dbl_any(t, P2, q); T[8] = t.c;
+    quad_add(u, t, P2, q); T[12] = u.c;
+#pragma unroll
+    for (int bb = 1; bb < 4; ++bb)
+#pragma unroll
+        for (int aa = 1; aa < 4; ++aa) {
+            QuadXyzz x, y;
+            x.c = T[aa]; x.inf = p.inf; y.c = T[4 * bb]; y.inf = p.inf;
+            quad_add(t, x, y, q);
+            T[aa + 4 * bb] = t.c;
+        }
+    QuadXyzz acc;
+    quad_set_inf(acc);
+#pragma unroll 1
+    for (int i = 63; i >= 0; --i) {                                // bits 2 i + 1, 2 i of both halves (bit 127 is the sign: masked)
+        quad_dbl_any(t, acc, q);
+        quad_dbl_any(acc, t, q);
+        const uint32_t w = (uint32_t)i >> 4, sh = ((uint32_t)i & 15u) * 2u;
+        uint32_t a = (kk[w] >> sh) & 3u, b = (kk[4 + w] >> sh) & 3u;
+        if (i == 63) { a &= 1u; b &= 1u; }
+        const uint32_t idx = a | (b << 2);
+        // 16-way select as a binary tree over the index bits (entry 0 never used as a point: op.inf covers it)
+        Fq s8[8], s4[4], s2[2];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) fe_select(s8[m], (idx & 1u) != 0, T[2 * m + 1], T[m == 0 ? 1 : 2 * m]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fe_select(s4[m], (idx & 2u) != 0, s8[2 * m + 1], s8[2 * m]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) fe_select(s2[m], (idx & 4u) != 0, s4[2 * m + 1], s4[2 * m]);
+        QuadXyzz op;
+        fe_select(op.c, (idx & 8u) != 0, s2[1], s2[0]);
+        op.inf = p.inf || idx == 0u;
+        quad_add(t, acc, op, q);
+        acc = t;
+    }
+    r = acc;
+#endif
 }
 
 // slot (o, j') of a direct stage of radix R = 2^K (the index rule of k_g1fft_direct_pairs): partial[o R + j'] = [w^-e (/ n)] x[input]
