@@ -803,7 +803,7 @@ __device__ __forceinline__ void affine_emit(uint4* __restrict__ out, size_t i, c
 }
 // lane t converts the points i = t, t + T, t + 2T, ... (T = number of lanes) with ONE inversion (Montgomery's trick): prefix
 // products of the denominators ZZ ZZZ go through `scratch` (9 limb planes, stride n).  per lane <= AFF_PER points.
-constexpr uint32_t AFF_PER = 16;
+constexpr uint32_t AFF_PER = 4;        // 16 while the lane's inversion was a 381-product chain; with division steps (fe_invert.h) shorter chains on more lanes win: 84 -> ~45 us at 1 024 points
 __global__ void __launch_bounds__(256)
 k_g1fft_to_affine(const int32_t* __restrict__ planes, uint32_t n, uint4* __restrict__ out, int wire, int32_t* __restrict__ scratch) {
     const uint32_t T = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
