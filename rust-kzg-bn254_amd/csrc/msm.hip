@@ -791,6 +791,10 @@ int32_t msm_slot_stream(kzg_ctx* ctx, int slot, hipStream_t* out) {
     // queues (4 by default, shared with every other stream of the process): at 2^17 pairs per MSM, depth 2 gives 0.43-0.45 ms per
     // MSM, depth 3 0.37-0.38 (0.5 in one mapping), depth 4 anything from 0.34 to 0.46.  Sharing streams between slots (2 or 3
     // streams for 4 slots, any assignment) made depth 4 mapping-independent but no faster than depth 2-3 (tools/queue_probe.py).
+    // KZG_SLOT_STREAMS=k (experiment, default = one stream per slot): slot s runs on stream s mod k, so that with more slots than streams the
+    // next MSM of a stream is already enqueued behind the one in flight (no host round trip between them) while only k MSMs compete for the chip
+    static const int n_streams = []() { const char* e = getenv("KZG_SLOT_STREAMS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= KZG_NUM_SLOTS ? v : KZG_NUM_SLOTS; }();
+    slot %= n_streams;
     if (slot == 0) { *out = ctx->stream; return KZG_OK; }
     if (!ctx->stream_x[slot - 1]) KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_x[slot - 1], hipStreamNonBlocking));
     *out = ctx->stream_x[slot - 1];
