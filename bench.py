@@ -176,28 +176,45 @@ def self_launch(args):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("KZG_BENCH_TEST_CHILD_CMD"):        # test hook (tests/test_host_logic.py): stand-in ranks, to test the launcher without a GPU
+        cmd = os.environ["KZG_BENCH_TEST_CHILD_CMD"].split()
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                  MASTER_PORT=str(port), KZG_BENCH_SELF_LAUNCHED="1")
         procs.append(subprocess.Popen(cmd, env=e, stdout=None if r == 0 else subprocess.DEVNULL))      # rank 0 prints the line; stderr is shared
+    import signal
+
+    def stop_ranks(signum, _frame):                       # the launcher is told to stop (driver time-out, Ctrl-C): take the ranks along
+        for p in procs:                                   # exactly the PIDs started above
+            if p.poll() is None:
+                p.terminate()
+        raise SystemExit(128 + signum)
+    old_handlers = {sig: signal.signal(sig, stop_ranks) for sig in (signal.SIGTERM, signal.SIGINT)}
     worst, failed_at = 0, None
     grace = float(os.environ.get("KZG_BENCH_RANK_GRACE_S", "60"))
     live = list(procs)
-    while live:
-        time.sleep(0.2)
-        for p in list(live):
-            rc = p.poll()
-            if rc is None:
-                continue
-            live.remove(p)
-            if rc != 0:
-                worst = worst or (rc if rc > 0 else 128 - rc)
-                failed_at = failed_at or time.monotonic()
-        if failed_at and live and time.monotonic() - failed_at > grace:
-            for p in live:                                # exactly the PIDs started above
+    try:
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0:
+                    worst = worst or (rc if rc > 0 else 128 - rc)
+                    failed_at = failed_at or time.monotonic()
+            if failed_at and live and time.monotonic() - failed_at > grace:
+                for p in live:
+                    p.kill()
+                failed_at = time.monotonic() + 1e9
+    finally:
+        for p in procs:                                   # never leave a rank behind on the GPUs
+            if p.poll() is None:
                 p.kill()
-            failed_at = time.monotonic() + 1e9
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
     if worst:
         raise SystemExit(worst)
 

@@ -137,3 +137,31 @@ def test_srs_order_guard(k):
         k.SRS.new("tests/test-files/g1.point", 3000, 3001)
     with pytest.raises(k.errors.GenericError, match="Expected 3001 points"):
         k.SRS.new(os.path.join(ROOT, "tests", "golden", "g1.point"), 4000, 3001)
+
+
+def test_bench_self_launch_takes_its_ranks_along_when_stopped():
+    """`bench.py --gpus N` without a launcher is the parent of its ranks: when it is told to stop (the driver's time-out sends SIGTERM) no rank
+    may stay behind.  CPU-only: the ranks are replaced by sleepers through KZG_BENCH_TEST_CHILD_CMD."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KZG_BENCH_BACKEND="gloo", KZG_BENCH_TEST_CHILD_CMD="sleep 300")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 60
+    kids = []
+    while time.time() < deadline and len(kids) < 2:
+        time.sleep(0.3)
+        out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], capture_output=True, text=True).stdout.split()
+        kids = [int(x) for x in out]
+    assert len(kids) == 2, kids
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=30)
+    assert rc == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in kids:
+        alive = subprocess.run(["ps", "-p", str(pid), "-o", "stat="], capture_output=True, text=True).stdout.strip()
+        assert alive == "" or alive.startswith("Z"), (pid, alive)
