@@ -654,23 +654,29 @@ k_g1fft_first_tables(const uint4* __restrict__ tables, uint32_t table_stride, in
 // scalars are recoded once per size (k_g1fft_naf2); one PAIR of lanes per (output, term, slice of the digit list) adds its digits
 // (pair_madd, 5 multiplications per lane); a wave holds 32 slots of one output and leaves their sum; k_g1fft_sum_partials adds the
 // <= 32 waves of an output.  Same group elements as the staged transform.
-constexpr uint32_t NAF2_MAX = 128;                       // digit slots per scalar (width-3 NAF of a scalar < 2^254: at most 254 / 3 + 1 = 85)
+constexpr uint32_t NAF2_MAX = 128;                       // digit slots per scalar (width-4 NAF of a scalar < 2^254: at most 254 / 4 + 1 = 64)
 constexpr uint32_t G1FFT_T3_MAX = 2048;                  // the x3 tables cover the first min(SRS length, 2048) points: every point the table paths transform
-// T3_p[j] = 3 Bit_p[j] = Bit_p[j] + Bit_(p+1)[j] for p < 254 (a digit +-3 at position 254 would exceed the scalar field), as XYZZ planes:
-// k_g1fft_to_affine turns them into the table.  254 x t3_points points (33 MB at 2 048), once per SRS (kzg_srs::d_t3, ::t3_n).
+// The odd multiples 3, 5, 7 of Bit_p[j] as XYZZ planes: k_g1fft_to_affine turns them into the tables.  3 x 255 x t3_points points (100 MB at
+// 2 048), once per SRS (kzg_srs::d_t3, ::t3_n).
 __global__ void __launch_bounds__(256)
 k_g1fft_t3_planes(const uint4* __restrict__ bits, uint32_t stride, uint32_t t3_points, uint32_t total, int32_t* __restrict__ planes) {
+    // slot t = ((key - 1) 255 + p) t3_points + j, key = 1, 2, 3: (2 key + 1) Bit_p[j] = Bit_p + Bit_(p+1) | Bit_p + Bit_(p+2) | Bit_(p+3) - Bit_p
+    // (round 4: width-4 digits +-1, +-3, +-5, +-7).  A slot whose second plane would be beyond bit 254 stays the identity: no scalar
+    // below the group order has such a digit (5 2^252 and 7 2^251 exceed it even with every lower digit negative).
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
-    const uint32_t p = t / t3_points, j = t - p * t3_points;          // t3_points <= stride: every read stays inside its bit plane
-    Affine a, b;
+    const uint32_t row = t / t3_points, j = t - row * t3_points;          // t3_points <= stride: every read stays inside its bit plane
+    const uint32_t key = row / 255u + 1u, p = row - (key - 1u) * 255u;
     Xyzz v;
-    const bool ha = affine_load(a, bits + 4 * ((size_t)p * stride + j));
-    const bool hb = affine_load(b, bits + 4 * ((size_t)(p + 1) * stride + j));
-    if (!ha) xyzz_set_inf(v);
-    else {
-        xyzz_from_affine(v, a, 0);
-        if (hb) xyzz_madd<true>(v, b, 0);
+    xyzz_set_inf(v);
+    if (p + key <= 254u) {
+        Affine a, b;
+        const bool ha = affine_load(a, bits + 4 * ((size_t)p * stride + j));
+        const bool hb = affine_load(b, bits + 4 * ((size_t)(p + key) * stride + j));
+        if (ha && hb) {
+            if (key < 3u) { xyzz_from_affine(v, a, 0); xyzz_madd<true>(v, b, 0); }
+            else { xyzz_from_affine(v, b, 0); xyzz_madd<true>(v, a, 1); }
+        }
     }
     xyzz_store(planes, total, t, v);
 }
@@ -681,8 +687,9 @@ k_g1fft_naf2(const uint4* __restrict__ scal_canon, uint32_t n, uint16_t* __restr
     const uint4 lo = scal_canon[2 * (size_t)e], hi = scal_canon[2 * (size_t)e + 1];
     uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint32_t m = 0;
-    // width-3 NAF: digits +-1, +-3 (key = 0 / 1), ~64 per scalar instead of the ~85 of width 2; a digit +-3 reads the x3 table
-    naf_for_digits(k, 3, [&](uint32_t pos, uint32_t key, uint32_t neg) { if (m < NAF2_MAX) list[(size_t)e * NAF2_MAX + m] = (uint16_t)(pos | (key << 14) | (neg << 15)); ++m; });
+    // width-4 NAF (round 4; width 3 before): digits +-1, +-3, +-5, +-7 (key = 0 .. 3), ~51 per scalar instead of ~64; a digit with key > 0
+    // reads the table of that odd multiple.  Entry: position (8 bits) | key << 8 | sign << 15
+    naf_for_digits(k, 4, [&](uint32_t pos, uint32_t key, uint32_t neg) { if (m < NAF2_MAX) list[(size_t)e * NAF2_MAX + m] = (uint16_t)(pos | (key << 8) | (neg << 15)); ++m; });
     cnt[e] = m < NAF2_MAX ? m : NAF2_MAX;
 }
 // K < log n: the same kernel as the FIRST STAGE of a staged transform of radix R = 2^K (the index rule of k_g1fft_first_tables: output o
@@ -709,8 +716,8 @@ k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, const uint4* __res
     auto fetch = [&](uint32_t m, uint4& a, uint4& b, uint32_t& neg) {
         const uint32_t d = L[m < c ? m : (c ? c - 1 : 0)];
         neg = d >> 15;
-        const uint32_t pos = d & 0x3FFFu;
-        const uint4* src = ((d & 0x4000u) ? bits3 + 4 * ((size_t)pos * t3_points + j) : bits + 4 * ((size_t)pos * stride + j)) + (odd ? 2 : 0);
+        const uint32_t pos = d & 0xFFu, key = (d >> 8) & 3u;
+        const uint4* src = (key ? bits3 + 4 * ((size_t)((key - 1u) * 255u + pos) * t3_points + j) : bits + 4 * ((size_t)pos * stride + j)) + (odd ? 2 : 0);
         a = src[0]; b = src[1];
     };
     uint4 a0, b0; uint32_t neg0 = 0;
@@ -926,12 +933,12 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
         std::unique_lock<std::mutex> lazy(srs->lazy_mu);
         if (!srs->d_t3) {                                                  // x3 tables of the first min(SRS length, 2048) points, once per SRS (<= 33 MB)
             const uint32_t pts = (uint32_t)std::min<size_t>(srs->n, G1FFT_T3_MAX);
-            const uint32_t total = 254 * pts;
+            const uint32_t total = 3 * 255 * pts;                              // the x3, x5, x7 tables (100 MB at 2 048 points)
             KZG_HIP_TRY(ctx, ctx->poly[0].c.reserve((size_t)total * 36 * 4));
             KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve((size_t)total * NL * 4));
             uint4* t3 = nullptr;
-            KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t3), (size_t)255 * pts * 64));
-            hipError_t e = hipMemsetAsync(t3, 0, (size_t)255 * pts * 64, st);
+            KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t3), (size_t)total * 64));
+            hipError_t e = hipMemsetAsync(t3, 0, (size_t)total * 64, st);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_g1fft_t3_planes, dim3((total + 255) / 256), dim3(256), 0, st, d_bits, (uint32_t)srs->n, pts, total, ctx->poly[0].c.as<int32_t>());
                 const size_t lanes = (total + AFF_PER - 1) / AFF_PER;
