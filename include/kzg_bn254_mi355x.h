@@ -113,7 +113,7 @@ int32_t kzg_srs_load_compressed_ark_le(kzg_ctx* ctx, const uint8_t* bytes, size_
  *
  * THREADS.  An SRS handle may be used from any number of host threads and by every context of its GPU at once, as the reference shares
  * one `SRS` across threads (prover/tests/kzg_test.rs:9-17, primitives/tests/blob_test.rs:83-94).  Tables that are built after upload
- * -- these per-bit tables on the first batched call of a small SRS, the x3 tables of kzg_g1_ifft(64..256), the bases attached by
+ * -- these per-bit tables on the first batched call of a small SRS, the x3 / x5 / x7 tables of kzg_g1_ifft(64..2048) (<= 100 MB, built on the first such call), the bases attached by
  * kzg_srs_cache_lagrange -- are built under a lock of the SRS and published only when complete; calls on ONE context are serialised by
  * the context's own lock, so N threads sharing a context see N serial calls; threads that need to overlap use one context each
  * (contexts of one GPU share the SRS).  kzg_srs_free / kzg_srs_drop_lagrange must not race with calls that use the handle.
