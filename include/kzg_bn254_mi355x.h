@@ -286,6 +286,22 @@ int32_t kzg_multi_scalars_upload(kzg_multi* m, int32_t buffer_id, const uint64_t
 int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids, size_t count, uint64_t* out_xy_mont,
                                          uint8_t* out_is_infinity);
 
+/* ---- one process per GPU: the exchange of the partial sums over RCCL, behind the C-ABI (BASELINE north_star) ------------
+ * The MSM shards by scalar index: rank g holds the SRS powers and coefficients [g n / G, (g+1) n / G) and computes one XYZZ partial
+ * (kzg_msm_g1_srs_partial[_device]).  RCCL has no reduction operator for elliptic-curve addition, so the "all-reduce" of the G partial
+ * sums is ONE all-gather of G x 128 bytes over xGMI and a fold of G points on every rank:
+ *   kzg_rccl_allgather_fold      partial in -> the same folded affine point on every rank; the collective runs on the context's stream
+ *   kzg_commit_coeff_form_rccl   KZG::commit_coeff_form (prover/src/kzg.rs:107-125) of this rank's resident coefficient slice over its
+ *                                SRS shard + the exchange + the fold, in one call
+ * nccl_comm = the caller's ncclComm_t for this context's device (the host creates it: ncclGetUniqueId / ncclCommInitRank of the RCCL that
+ * belongs to /opt/rocm -- librccl.so is dlopen'ed on first use, KZG_RCCL_LIB overrides the path; no link-time dependency).  Every rank of
+ * the communicator must make the call (it is a collective).  Python hosts use torch.distributed instead (sharding.py: the same
+ * all-gather through PyTorch's communicator, several steps per collective); one process driving all GPUs uses kzg_multi_* (no collective). */
+int32_t kzg_rccl_allgather_fold(kzg_ctx* ctx, void* nccl_comm, int32_t world, const uint64_t partial_xyzz_mont[16],
+                                uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+int32_t kzg_commit_coeff_form_rccl(kzg_ctx* ctx, const kzg_srs* srs_shard, const void* d_coeffs_shard_mont, size_t n_shard, void* nccl_comm,
+                                   int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+
 /* NOTE on the two Fiat-Shamir transcripts below (kzg_compute_challenge, kzg_compute_r_powers): their byte layout follows the reference
  * line by line, but the 32-byte compressed G1 encoding inside them (x little-endian, 0x80 = larger y, 0x40 = infinity) is ark-serialize's
  * `serialize_compressed`, RESTATED here and in oracle/ alike and pinned by NO vector the reference holds -- its own tests only check that the

@@ -123,6 +123,8 @@ PROTOTYPES = {
     "kzg_compute_r_powers": (i32, [u64p, u64p, u64p, u64p, u64p, sz, u64p]),
     "kzg_compute_challenges_and_evaluate_polynomial": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, sz, u64p, u64p]),
     "kzg_evaluate_blobs_in_evaluation_form_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, sz, u64p]),
+    "kzg_rccl_allgather_fold": (i32, [vp, vp, i32, u64p, u64p, u8p]),
+    "kzg_commit_coeff_form_rccl": (i32, [vp, vp, vp, sz, vp, i32, u64p, u8p]),
     "kzg_verify_blob_kzg_proof": (i32, [vp, u8p, sz, u64p, u64p, u64p, C.POINTER(i32)]),
     "kzg_verify_blob_kzg_proof_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, u64p, sz, u64p, C.POINTER(i32)]),
 }

@@ -137,6 +137,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     ctx->ntt.release();
     for (auto& w : ctx->ntt_x) w.release();
     for (auto& ps : ctx->poly) ps.release();
+    ctx->rccl_buf.release();
     if (ctx->vb_pinned) { (void)hipHostFree(ctx->vb_pinned); ctx->vb_pinned = nullptr; ctx->vb_pinned_bytes = 0; }
     for (auto& t : ctx->ondomain_inv) if (t) { (void)hipFree(t); t = nullptr; }
     (void)hipStreamDestroy(ctx->stream);

@@ -90,6 +90,7 @@ struct kzg_ctx {
     kzg::NttWorkspace ntt_x[KZG_NUM_SLOTS - 1];   // slots 1.. of the asynchronous commitment / proof calls
     void* vb_pinned = nullptr;           // pinned staging of the packed blobs of one batch verification (capi.hip), grown on demand
     size_t vb_pinned_bytes = 0;
+    kzg::DeviceBuffer rccl_buf;          // this rank's partial + the gathered partials of kzg_rccl_allgather_fold (multi.hip)
     kzg::PolySet poly[KZG_NUM_SLOTS];   // polynomial / proof pipeline scratch, one set per slot ([0] also serves the synchronous calls)
     kzg::MsmWorkspace& slot_msm(int slot) { return slot ? msm_x[slot - 1] : msm; }
     kzg::NttWorkspace& slot_ntt(int slot) { return slot ? ntt_x[slot - 1] : ntt; }

@@ -8,6 +8,9 @@
 #include "host_curve.h"
 
 #include <cstring>
+#include <dlfcn.h>
+#include <cstdlib>
+#include <string>
 #include <new>
 #include <thread>
 #include <utility>
@@ -220,6 +223,78 @@ int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids
         if (rc != KZG_OK) return rc;
     }
     return KZG_OK;
+}
+
+// ---- the exchange of the partial sums over RCCL, behind the C-ABI (one process per GPU; north_star's "single RCCL all-reduce") ----------
+// RCCL has no reduction operator for elliptic-curve addition, so the all-reduce of G partial sums is an all-gather of G x 128 bytes and a
+// fold of G points on every rank.  The communicator belongs to the HOST (a Rust host creates it with its own RCCL binding:
+// ncclGetUniqueId on rank 0, the id handed to the other ranks by whatever channel it has, ncclCommInitRank on this context's device);
+// the library only issues the collective on its own stream.  librccl is dlopen'ed on first use -- /opt/rocm/lib/librccl.so, the build
+// that belongs to the HIP runtime this library links (KZG_RCCL_LIB overrides; a process that also holds PyTorch's bundled copy keeps
+// the two apart) -- so there is no link-time dependency and single-GPU users never load it.
+}  // extern "C"
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+struct Rccl { void* lib = nullptr; nccl_allgather_fn all_gather = nullptr; nccl_errstr_fn err = nullptr; bool tried = false; };
+Rccl& rccl() {
+    static Rccl r;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!r.tried) {
+        r.tried = true;
+        const char* env = getenv("KZG_RCCL_LIB");
+        const char* names[] = {env, "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            r.all_gather = reinterpret_cast<nccl_allgather_fn>(dlsym(r.lib, "ncclAllGather"));
+            r.err = reinterpret_cast<nccl_errstr_fn>(dlsym(r.lib, "ncclGetErrorString"));
+        }
+    }
+    return r;
+}
+}  // namespace
+extern "C" {
+
+int32_t kzg_rccl_allgather_fold(kzg_ctx* ctx, void* nccl_comm, int32_t world, const uint64_t partial_xyzz_mont[16],
+                                uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!ctx || !nccl_comm || world < 1 || world > 4096 || !partial_xyzz_mont || !out_xy_mont) return KZG_ERR_INVALID_ARG;
+    Rccl& r = rccl();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!r.all_gather) { ctx->last_error = "librccl.so could not be loaded (KZG_RCCL_LIB, /opt/rocm/lib/librccl.so)"; return KZG_ERR_DEVICE; }
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // device staging: this rank's 128 bytes | world x 128 gathered bytes (grown on demand, kept with the context)
+    const size_t need = 128 + 128 * (size_t)world;
+    static thread_local std::vector<uint64_t> gathered;
+    gathered.resize(16 * (size_t)world);
+    kzg::DeviceBuffer& d = ctx->rccl_buf;
+    KZG_HIP_TRY(ctx, d.reserve(need + 256));
+    char* dev = d.as<char>();
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(dev, partial_xyzz_mont, 128, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = r.all_gather(dev, dev + 128, 128, /* ncclUint8 */ 1, nccl_comm, ctx->stream);
+    if (rc != 0) {
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->last_error = std::string("ncclAllGather: ") + (r.err ? r.err(rc) : "error");
+        return KZG_ERR_DEVICE;
+    }
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(gathered.data(), dev + 128, 128 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return kzg_g1_fold_partials(gathered.data(), (size_t)world, out_xy_mont, out_is_infinity);
+}
+
+int32_t kzg_commit_coeff_form_rccl(kzg_ctx* ctx, const kzg_srs* srs_shard, const void* d_coeffs_shard_mont, size_t n_shard, void* nccl_comm,
+                                   int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!ctx || !srs_shard || !nccl_comm || !out_xy_mont || (n_shard && !d_coeffs_shard_mont)) return KZG_ERR_INVALID_ARG;
+    uint64_t part[16] = {0};                                         // an empty shard contributes the identity (ZZ = 0)
+    if (n_shard) {
+        const int32_t rc = kzg_msm_g1_srs_partial_device(ctx, srs_shard, 0, d_coeffs_shard_mont, n_shard, part);
+        if (rc != KZG_OK) return rc;                                 // (the caller's ranks must then agree to stop: the collective has not been issued)
+    }
+    return kzg_rccl_allgather_fold(ctx, nccl_comm, world, part, out_xy_mont, out_is_infinity);
 }
 
 }  // extern "C"

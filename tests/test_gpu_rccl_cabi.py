@@ -1,0 +1,86 @@
+"""-m gpu: the RCCL exchange BEHIND the C-ABI (kzg_rccl_allgather_fold, kzg_commit_coeff_form_rccl; BASELINE north_star: "a single RCCL
+all-reduce of the per-GPU partial G1 sums ... behind a thin C-ABI").  The communicator belongs to the host: here a child process WITHOUT
+torch (the library and /opt/rocm's librccl share one HIP runtime; PyTorch bundles its own) creates a communicator with ctypes -- one
+rank on this one-GPU box (RCCL refuses two ranks on one device) -- and checks
+
+* partial -> all-gather over the communicator -> fold == the plain commitment of the same coefficients (and == sum_i c_i tau^i G1);
+* the one-call form kzg_commit_coeff_form_rccl on resident coefficients, an empty shard (identity partial), and the error path of a bad
+  communicator argument.
+With N ranks the same two calls run once per process; the N-rank exchange itself is exercised through torch.distributed by bench.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import ctypes as C, hashlib, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import pyref
+from pyref import R_
+import rust_kzg_bn254_amd as k
+from rust_kzg_bn254_amd import _lib
+assert "torch" not in sys.modules
+lib = _lib.load()
+ctx = k.Context(0)
+TAU = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") %% R_
+n = 1 << 15
+srs = k.SRS.generate(TAU, n, ctx=ctx)
+rng = np.random.default_rng(3)
+vals = [int.from_bytes(rng.bytes(40), "little") %% R_ for _ in range(n)]
+wire = pyref.frs_to_mont(vals)
+
+rccl = C.CDLL(os.environ.get("KZG_RCCL_LIB", "/opt/rocm/lib/librccl.so"))
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+uid = UniqueId()
+assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+comm = C.c_void_p()
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0, "ncclCommInitRank"
+
+want = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+assert lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(wire), n, _lib.ptr(want), C.byref(inf)) == 0
+acc, tp = 0, 1
+for v in vals:
+    acc = (acc + v * tp) %% R_; tp = tp * TAU %% R_
+assert pyref.point_from_wire(want) == pyref.ec_mul(acc, (1, 2))
+
+part = np.zeros(16, np.uint64)
+assert lib.kzg_msm_g1_srs_partial(ctx.handle, srs.handle, 0, _lib.ptr(wire), n, _lib.ptr(part)) == 0
+got = np.zeros(8, np.uint64)
+rc = lib.kzg_rccl_allgather_fold(ctx.handle, comm, 1, _lib.ptr(part), _lib.ptr(got), C.byref(inf))
+assert rc == 0, (rc, lib.kzg_ctx_last_error(ctx.handle))
+assert np.array_equal(got, want), "fold of the gathered partial differs from the commitment"
+
+# the one-call form on resident coefficients (hipMalloc + hipMemcpy through the runtime the library links)
+hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+d = C.c_void_p()
+assert hip.hipMalloc(C.byref(d), C.c_size_t(n * 32)) == 0
+assert hip.hipMemcpy(d, wire.ctypes.data_as(C.c_void_p), C.c_size_t(n * 32), 1) == 0
+got2 = np.zeros(8, np.uint64)
+rc = lib.kzg_commit_coeff_form_rccl(ctx.handle, srs.handle, d, n, comm, 1, _lib.ptr(got2), C.byref(inf))
+assert rc == 0, (rc, lib.kzg_ctx_last_error(ctx.handle))
+assert np.array_equal(got2, want)
+# an empty shard contributes the identity
+got3 = np.ones(8, np.uint64)
+assert lib.kzg_commit_coeff_form_rccl(ctx.handle, srs.handle, None, 0, comm, 1, _lib.ptr(got3), C.byref(inf)) == 0
+assert inf.value == 1 and not got3.any()
+# argument errors
+assert lib.kzg_rccl_allgather_fold(ctx.handle, None, 1, _lib.ptr(part), _lib.ptr(got), C.byref(inf)) == -1
+assert lib.kzg_rccl_allgather_fold(ctx.handle, comm, 0, _lib.ptr(part), _lib.ptr(got), C.byref(inf)) == -1
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+print("rccl c-abi ok")
+'''
+
+
+def test_rccl_exchange_behind_the_c_abi_one_rank():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-800:], res.stderr[-2500:])
+    assert "rccl c-abi ok" in res.stdout
