@@ -30,3 +30,19 @@ def test_multi_device_c_example(tmp_path):
     res = subprocess.run([exe, "0", "0", "0"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
     assert "3 device context(s)" in res.stdout and "== the single-device one" in res.stdout
+
+
+def test_rccl_c_example_one_rank(tmp_path):
+    """examples/rccl_commit.c: kzg_commit_coeff_form_rccl from plain C with a communicator the program creates itself (one rank on this
+    one-GPU box): the RCCL path behind the C-ABI == the plain commitment."""
+    exe = str(tmp_path / "rccl_commit")
+    libdir = os.path.join(ROOT, "rust-kzg-bn254_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "rccl_commit.c"), "-L" + libdir, "-lkzg_bn254_mi355x", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(key, None)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr[-1500:])
+    assert "one-rank RCCL commitment == the plain commitment" in res.stdout
