@@ -4,6 +4,9 @@ C-ABI / the HIP kernels for every commitment, transform, evaluation and proof). 
     prover/tests/kzg_test.rs            (all 6 tests)
     primitives/tests/polynomial_test.rs (all 5)
     primitives/tests/blob_test.rs       (all 4; the 1 000 x 16 MiB rayon loop of test_convert_by_padding_empty_byte runs 4 x 1 MiB per thread)
+    primitives/tests/helpers_test.rs    (the 9 calculate_roots_of_unity tests -- the roots are generated on the GPU -- and the 5 G1 curve /
+                                         validation tests; its fixture tests (to_fr_array, pad_payload, PRIMITIVE_ROOTS_OF_UNITY ...) are
+                                         in tests/test_oracle.py and tests/test_host_logic.py)
     verifier/tests/tests.rs             (the 4 tests not already in tests/test_gpu_verifier.py: identity points, intermediate point
                                          validation, zero commitment, random inputs)
 
@@ -24,7 +27,8 @@ from pyref import R_
 pytestmark = pytest.mark.gpu
 
 TAU = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % R_
-MAINNET_SRS_G1_SIZE = 131072                                          # primitives/src/consts.rs
+SRS_POINTS = 131072                                                   # kzg_test.rs:11-16 loads 131 072 points
+MAINNET_SRS_G1_SIZE = 268435456                                       # primitives/src/consts.rs:66
 GETTYSBURG_PREFIX = b"Fourscore and seven years ago our fathers brought forth, on this continent, a new nation, conceived in liberty"
 
 
@@ -39,7 +43,7 @@ def k():
 @pytest.fixture(scope="module")
 def srs(k):
     """SRS_INSTANCE (kzg_test.rs:11-16: 131 072 mainnet points) -- here 131 072 known-tau points."""
-    return k.SRS.generate(TAU, MAINNET_SRS_G1_SIZE)
+    return k.SRS.generate(TAU, SRS_POINTS)
 
 
 @pytest.fixture(scope="module")
@@ -270,3 +274,111 @@ def test_verify_proof_edge_cases_with_valid_inputs(k, g2_tau):
     # and the positive control the reference's loop lacks: p(X) = a + b X, proof = [b] G1, value = a + b z
     a, b, z = rng.randrange(R_), rng.randrange(R_), rng.randrange(R_)
     assert k.verify_proof(g1(a + b * TAU), g1(b), fr(k, (a + b * z) % R_), fr(k, z), g2_tau) is True
+
+
+# ---- primitives/tests/helpers_test.rs: calculate_roots_of_unity (generated on the GPU) and the G1 point checks -------------------------
+def _ints(roots):
+    return pyref.frs_from_mont(np.asarray(roots))
+
+
+def test_calculate_roots_of_unity_error_zero_length(k):
+    """helpers_test.rs:28-42"""
+    with pytest.raises(k.errors.GenericError, match="Length of data after padding is 0"):
+        k.helpers.calculate_roots_of_unity(0)
+
+
+def test_calculate_roots_of_unity_error_oversized_input(k):
+    """helpers_test.rs:44-60"""
+    with pytest.raises(k.errors.GenericError, match="the length of data after padding is not valid with respect to the SRS"):
+        k.helpers.calculate_roots_of_unity((MAINNET_SRS_G1_SIZE + 1) * 32)
+
+
+def test_calculate_roots_of_unity_basic_functionality(k):
+    """helpers_test.rs:62-89"""
+    r32 = k.helpers.calculate_roots_of_unity(32)
+    assert len(r32) == 1 and _ints(r32) == [1]
+    assert len(k.helpers.calculate_roots_of_unity(64)) == 2
+    r96 = k.helpers.calculate_roots_of_unity(96)
+    assert len(r96) == 4 and _ints(r96)[0] == 1
+
+
+def test_calculate_roots_of_unity_mathematical_properties(k):
+    """helpers_test.rs:91-130"""
+    for length, n in ((3 * 32, 4), (5 * 32, 8)):
+        roots = _ints(k.helpers.calculate_roots_of_unity(length))
+        assert len(roots) == n and roots[0] == 1
+        assert all(pow(w, n, R_) == 1 for w in roots)
+
+
+def test_calculate_roots_of_unity_powers_of_two(k):
+    """helpers_test.rs:132-178"""
+    for count in (1, 2, 4, 8, 16, 32):
+        roots = _ints(k.helpers.calculate_roots_of_unity(count * 32))
+        assert len(roots) == count and roots[0] == 1 and len(set(roots)) == count
+
+
+def test_calculate_roots_of_unity_boundary_conditions(k):
+    """helpers_test.rs:180-222 (the largest accepted length, 2^28 elements = 8 GiB of roots, is only checked for its status here: the
+    reference's own test accepts either outcome there)"""
+    assert len(k.helpers.calculate_roots_of_unity(1)) == 1
+    assert len(k.helpers.calculate_roots_of_unity(32)) == 1
+    n_out = __import__("ctypes").c_size_t(0)
+    rc = k._lib.load().kzg_calculate_roots_of_unity(k.default_context().handle, MAINNET_SRS_G1_SIZE * 32, None, 0, __import__("ctypes").byref(n_out))
+    assert n_out.value == MAINNET_SRS_G1_SIZE and rc == k._lib.ERR_INVALID_ARG          # size query: accepted length, no buffer given
+
+
+def test_calculate_roots_of_unity_consistency(k):
+    """helpers_test.rs:224-243"""
+    a, b, c = (k.helpers.calculate_roots_of_unity(100) for _ in range(3))
+    assert np.array_equal(a, b) and np.array_equal(b, c)
+
+
+def test_calculate_roots_of_unity_large_valid_inputs(k):
+    """helpers_test.rs:245-283: w^n == 1 for EVERY root at 1 kB .. 1 MB of data."""
+    for length in (1000, 10000, 100000, 1000000):
+        roots = _ints(k.helpers.calculate_roots_of_unity(length))
+        n = len(roots)
+        assert n > 0 and roots[0] == 1
+        assert all(pow(w, n, R_) == 1 for w in roots)
+        assert roots[1] == pyref.root_of_unity(n.bit_length() - 1) and all(roots[i + 1] == roots[i] * roots[1] % R_ for i in range(0, n - 1, 97))
+
+
+def test_calculate_roots_of_unity_specific_error_conditions(k):
+    """helpers_test.rs:285-322: a large valid length (2^23 elements here: 256 MiB of roots) succeeds."""
+    roots = k.helpers.calculate_roots_of_unity((1 << 23) * 32)
+    assert len(roots) == 1 << 23 and pyref.fr_from_mont(roots[0]) == 1
+    w = pyref.fr_from_mont(roots[1])
+    assert pow(w, 1 << 23, R_) == 1 and pow(w, 1 << 22, R_) == R_ - 1
+    assert pyref.fr_from_mont(roots[(1 << 23) - 1]) == pow(w, (1 << 23) - 1, R_)
+
+
+def test_g1_is_on_curve(k):
+    """helpers_test.rs:324-336"""
+    rng = random.Random(324)
+    for _ in range(200):
+        x, y = pyref.ec_mul(rng.randrange(1, R_), (1, 2))
+        assert k.helpers.is_on_curve_g1(np.array(pyref.point_to_wire((x, y)), dtype=np.uint64))
+        assert not k.helpers.is_on_curve_g1(np.array(pyref.point_to_wire(((x + 1) % pyref.P, y)), dtype=np.uint64))
+
+
+def test_validate_g1_point_valid_point(k):
+    """helpers_test.rs:622-634"""
+    rng = random.Random(622)
+    for _ in range(10):
+        k.helpers.validate_g1_point(g1(rng.randrange(1, R_)))
+
+
+def test_validate_g1_point_identity_point(k):
+    """helpers_test.rs:636-641"""
+    k.helpers.validate_g1_point(np.zeros(8, dtype=np.uint64))
+
+
+def test_validate_g1_point_invalid_curve_point(k):
+    """helpers_test.rs:643-672"""
+    with pytest.raises(k.errors.NotOnCurveError, match="G1 point not on curve"):
+        k.helpers.validate_g1_point(np.array(pyref.point_to_wire((1, 1)), dtype=np.uint64))
+
+
+def test_validate_g1_point_generator(k):
+    """helpers_test.rs:674-679"""
+    k.helpers.validate_g1_point(np.array(pyref.point_to_wire((1, 2)), dtype=np.uint64))
