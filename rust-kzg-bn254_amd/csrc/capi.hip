@@ -103,6 +103,11 @@ int32_t kzg_device_count(void) {
     return n;
 }
 
+// live contexts per device: the caches of ntt.hip / g1fft.hip outlive a context (they are shared by the contexts of a device) and are
+// freed with the last one (they were never freed)
+static std::mutex g_ctx_count_mu;
+static std::map<int, int> g_ctx_count;
+
 int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out) {
     if (!out) return KZG_ERR_INVALID_ARG;
     *out = nullptr;
@@ -121,6 +126,7 @@ int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out) {
         if (env && atoi(env) > 0) { ctx->acc_wave_slots = (uint32_t)atoi(env); ctx->acc_slots_forced = true; }
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete ctx; return KZG_ERR_DEVICE; }
+    { std::lock_guard<std::mutex> lk(g_ctx_count_mu); ++g_ctx_count[device_id]; }
     *out = ctx;
     return KZG_OK;
 }
@@ -141,7 +147,11 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     if (ctx->vb_pinned) { (void)hipHostFree(ctx->vb_pinned); ctx->vb_pinned = nullptr; ctx->vb_pinned_bytes = 0; }
     for (auto& t : ctx->ondomain_inv) if (t) { (void)hipFree(t); t = nullptr; }
     (void)hipStreamDestroy(ctx->stream);
+    const int dev = ctx->device;
     delete ctx;
+    bool last = false;
+    { std::lock_guard<std::mutex> lk(g_ctx_count_mu); last = --g_ctx_count[dev] <= 0; if (last) g_ctx_count.erase(dev); }
+    if (last) { kzg::ntt_release_device_caches(dev); kzg::g1fft_release_device_caches(dev); }
 }
 
 const char* kzg_ctx_last_error(const kzg_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }

@@ -226,6 +226,10 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
 
 int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);
 
+// process-wide caches keyed by device (NTT twiddles, g1_ifft scalar sets): released when the LAST context of a device is destroyed
+void ntt_release_device_caches(int dev);
+void g1fft_release_device_caches(int dev);
+
 }  // namespace kzg
 
 // ---- roctx phase ranges (tracing) ------------------------------------------------------------------------

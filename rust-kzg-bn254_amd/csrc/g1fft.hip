@@ -1162,6 +1162,20 @@ static int32_t g1_ifft_as_batched_msm(kzg_ctx* ctx, const kzg_srs* srs, size_t n
     return msm_run_batch_tables(ctx, b, exp, n, n, out_xy, nullptr);
 }
 
+// the last context of device `dev` is gone: free the scalar tables, digit lists and expanded scalar sets g1_ifft cached for it
+void g1fft_release_device_caches(int dev) {
+    std::lock_guard<std::mutex> lk(g_scal_mu);
+    for (auto it = g_scal.begin(); it != g_scal.end();) {
+        if (it->first.dev == dev) { (void)hipFree(it->second); it = g_scal.erase(it); } else ++it;
+    }
+    for (auto it = g_naf2.begin(); it != g_naf2.end();) {
+        if (std::get<0>(it->first) == dev) { (void)hipFree(it->second.list); (void)hipFree(it->second.cnt); it = g_naf2.erase(it); } else ++it;
+    }
+    for (auto it = g_expanded.begin(); it != g_expanded.end();) {
+        if (it->first.first == dev) { (void)hipFree(it->second); it = g_expanded.erase(it); } else ++it;
+    }
+}
+
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy) {
     // sizes the batched MSM wins at (measured, tools/time_g1ifft.py): KZG_G1FFT_BATCH="lo,hi" overrides, "0" switches it off
     static const std::pair<size_t, size_t> batch_range = []() {

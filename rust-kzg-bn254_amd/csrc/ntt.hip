@@ -415,6 +415,17 @@ static int32_t ntt_get_pass_twiddles(kzg_ctx* ctx, int log_n, bool inverse, int 
     return KZG_OK;
 }
 
+// the last context of device `dev` is gone: free what the transforms cached for it (twiddle tables, per-element twiddle arrays)
+void ntt_release_device_caches(int dev) {
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    for (auto it = g_tables.begin(); it != g_tables.end();) {
+        if (it->first.dev == dev) { (void)hipFree(it->second.lo); (void)hipFree(it->second.hi); it = g_tables.erase(it); } else ++it;
+    }
+    for (auto it = g_pass_tw.begin(); it != g_pass_tw.end();) {
+        if (it->first.dev == dev) { (void)hipFree(it->second); it = g_pass_tw.erase(it); } else ++it;
+    }
+}
+
 #ifdef KZG_NTT_STAMPS
 static unsigned long long* g_ntt_stamps = nullptr;
 }  // namespace kzg

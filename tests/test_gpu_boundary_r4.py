@@ -5,6 +5,8 @@
 * `kzg_srs_load_compressed_ark_le` -- the `is_native = true` format of SRS::parallel_read_g1_points_native
   (prover/src/srs.rs:205-251, primitives/src/traits.rs:34-36): the reference's 3000 test points re-encoded in ark-serialize's compressed
   form must decode to srs.g1.points.string; malformed encodings are rejected."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,7 @@ from pyref import R_
 
 pytestmark = pytest.mark.gpu
 TAU = int.from_bytes(__import__("hashlib").sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % R_
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -133,3 +136,34 @@ def test_srs_load_ark_le_rejects_malformed_points(k, tmp_path, test_srs_points):
     xw, yw = pyref.point_from_wire(s.g1[0])
     assert (xw, yw) == (test_srs_points[2][0], pyref.P - test_srs_points[2][1])
     s.close()
+
+
+def test_device_caches_are_rebuilt_after_the_last_context_is_destroyed(k):
+    """The twiddle tables of the NTT and the scalar / digit lists of g1_ifft are process-wide caches keyed by device; they are released
+    when the LAST context of the device is destroyed and rebuilt by the next one: same results before and after.  Runs in a
+    child process so that no other context of this test session keeps the caches alive."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, rust_kzg_bn254_amd as k\n"
+        "from rust_kzg_bn254_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "def run():\n"
+        "    ctx = k.Context(0)\n"
+        "    srs = k.SRS.generate(%d, 1 << 12, ctx=ctx)\n"
+        "    a = np.arange(4 << 14, dtype=np.uint64).reshape(-1, 4) %% 251\n"
+        "    assert lib.kzg_fr_ntt(ctx.handle, _lib.ptr(a), 1 << 14, 0) == 0\n"
+        "    lag = np.zeros((1024, 8), np.uint64)\n"
+        "    assert lib.kzg_g1_ifft(ctx.handle, srs.handle, 1024, _lib.ptr(lag)) == 0\n"
+        "    d = hashlib.sha256(a.tobytes() + lag.tobytes()).hexdigest()\n"
+        "    srs.close(); lib.kzg_ctx_destroy(ctx.handle); ctx.handle = None\n"
+        "    return d\n"
+        "first = run(); second = run(); third = run()\n"
+        "assert first == second == third, (first, second, third)\n"
+        "print('caches ok', first[:16])\n"
+    ) % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"), TAU)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2000:])
+    assert "caches ok" in res.stdout
