@@ -293,6 +293,8 @@ int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids
  *   kzg_rccl_allgather_fold      partial in -> the same folded affine point on every rank; the collective runs on the context's stream
  *   kzg_commit_coeff_form_rccl   KZG::commit_coeff_form (prover/src/kzg.rs:107-125) of this rank's resident coefficient slice over its
  *                                SRS shard + the exchange + the fold, in one call
+ * Eval-form commitments and proofs shard the same way (BASELINE config 4): kzg_commit_eval_form_partial / kzg_compute_proof_partial give
+ * this rank's partial, kzg_rccl_allgather_fold exchanges and folds it.
  * nccl_comm = the caller's ncclComm_t for this context's device (the host creates it: ncclGetUniqueId / ncclCommInitRank of the RCCL that
  * belongs to /opt/rocm -- librccl.so is dlopen'ed on first use, KZG_RCCL_LIB overrides the path; no link-time dependency).  Every rank of
  * the communicator must make the call (it is a collective).  Python hosts use torch.distributed instead (sharding.py: the same

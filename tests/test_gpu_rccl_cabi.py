@@ -5,7 +5,8 @@ rank on this one-GPU box (RCCL refuses two ranks on one device) -- and checks
 
 * partial -> all-gather over the communicator -> fold == the plain commitment of the same coefficients (and == sum_i c_i tau^i G1);
 * the one-call form kzg_commit_coeff_form_rccl on resident coefficients, an empty shard (identity partial), and the error path of a bad
-  communicator argument.
+  communicator argument;
+* BASELINE config 4's shape: kzg_commit_eval_form_partial / kzg_compute_proof_partial + the exchange == the single-GPU commitment, proof and y.
 With N ranks the same two calls run once per process; the N-rank exchange itself is exercised through torch.distributed by bench.py."""
 import os
 import subprocess
@@ -70,6 +71,19 @@ assert np.array_equal(got2, want)
 got3 = np.ones(8, np.uint64)
 assert lib.kzg_commit_coeff_form_rccl(ctx.handle, srs.handle, None, 0, comm, 1, _lib.ptr(got3), C.byref(inf)) == 0
 assert inf.value == 1 and not got3.any()
+# BASELINE config 4 through the same exchange: eval-form commitment and proof of one polynomial, this rank's shard = the whole SRS here
+ev = pyref.frs_to_mont([int.from_bytes(rng.bytes(40), "little") %% R_ for _ in range(n)])
+z = pyref.fr_to_mont(0x1234567)
+want_c = np.zeros(8, np.uint64); want_p = np.zeros(8, np.uint64); want_y = np.zeros(4, np.uint64)
+assert lib.kzg_commit_eval_form(ctx.handle, srs.handle, _lib.ptr(ev), n, _lib.ptr(want_c), C.byref(inf)) == 0
+assert lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(ev), n, None, n, _lib.ptr(z), _lib.ptr(want_p), C.byref(inf), _lib.ptr(want_y)) == 0
+pc = np.zeros(16, np.uint64); pp = np.zeros(16, np.uint64); y = np.zeros(4, np.uint64)
+assert lib.kzg_commit_eval_form_partial(ctx.handle, srs.handle, 0, _lib.ptr(ev), n, _lib.ptr(pc)) == 0
+assert lib.kzg_compute_proof_partial(ctx.handle, srs.handle, 0, _lib.ptr(ev), n, None, n, _lib.ptr(z), _lib.ptr(pp), _lib.ptr(y)) == 0
+gc = np.zeros(8, np.uint64); gp = np.zeros(8, np.uint64)
+assert lib.kzg_rccl_allgather_fold(ctx.handle, comm, 1, _lib.ptr(pc), _lib.ptr(gc), C.byref(inf)) == 0
+assert lib.kzg_rccl_allgather_fold(ctx.handle, comm, 1, _lib.ptr(pp), _lib.ptr(gp), C.byref(inf)) == 0
+assert np.array_equal(gc, want_c) and np.array_equal(gp, want_p) and np.array_equal(y, want_y)
 # argument errors
 assert lib.kzg_rccl_allgather_fold(ctx.handle, None, 1, _lib.ptr(part), _lib.ptr(got), C.byref(inf)) == -1
 assert lib.kzg_rccl_allgather_fold(ctx.handle, comm, 0, _lib.ptr(part), _lib.ptr(got), C.byref(inf)) == -1
