@@ -413,7 +413,7 @@ k_g1fft_direct_pairs(const int32_t* __restrict__ x, int32_t* __restrict__ y, uin
 // per step 3 + 3 + 4 per two bits); the products
 // [k] x of all (output, term) slots go to a partial array and k_g1fft_sum_partials adds the R = 2^K terms of an output (a wave holds 16 quads,
 // so the tree no longer fits the multiplying wave for R = 32).  r = [k] p, k as its GLV halves; every lane of a quad holds the same k.
-__device__ __forceinline__ void quad_scalar_mul(QuadXyzz& r, const QuadXyzz& p, const uint32_t kk[8], uint32_t q) {
+__device__ __forceinline__ void quad_scalar_mul(QuadXyzz& r, const QuadXyzz& p, const uint32_t kk[8], uint32_t q, int32_t* __restrict__ tab /* this lane's LDS column: word (entry 9 + limb) 256 */) {
     const uint32_t s1 = kk[3] >> 31, s2 = kk[7] >> 31;
     Fq beta, kin, bx, y1, y2;
     {
@@ -454,34 +454,57 @@ __device__ __forceinline__ void quad_scalar_mul(QuadXyzz& r, const QuadXyzz& p, 
     r = acc;
 #else
     // TWO bits of each half per step: two doublings and ONE addition of T[a + 4 b] = a P1 + b P2, a, b < 4 (3 + 3 + 4 = 10 products deep per two
-    // bits instead of 14).  On a quad a point is nine VGPRs per lane, so the fifteen table points stay in registers (135 VGPRs); the entry
-    // is picked with a v_cndmask tree.  No entry is the identity unless p is (a + b lambda != 0 mod r for these a, b): one flag for all.
-    Fq T[16];                                                      // T[0] unused
+    // bits instead of 14).  On a quad a point is nine words per lane, so the fifteen table points of a lane stay in registers (135 VGPRs)
+    // and the entry is picked with a v_cndmask tree.  -DKZG_G1FFT_QUAD_LDS keeps them in a 540-byte LDS column per lane instead (144 KiB per
+    // workgroup, nine ds_read_b32 per step issued ahead of the doublings): 195 instead of 288 VGPRs, the SAME time per stage (measured:
+    // 0.728 / 0.975 / 1.428 ms against 0.729 / 0.978 / 1.441 ms at 512 / 1 024 / 2 048 points) -- the selects are not what a stage waits for.
+    // No entry is the identity unless p is (a + b lambda != 0 mod r for these a, b): one flag for all.
     QuadXyzz t, u;
-    T[1] = P1.c; T[4] = P2.c;
-    quad_dbl_any(t, P1, q); T[2] = t.c;
-    quad_add(u, t, P1, q); T[3] = u.c;
-    quad_dbl_any(t, P2, q); T[8] = t.c;
-    quad_add(u, t, P2, q); T[12] = u.c;
+#if !defined(KZG_G1FFT_QUAD_LDS)
+    Fq T[16];                                                      // T[0] unused
+#define QTAB_PUT(e, v) T[e] = (v)
+#define QTAB_GET(dst, e) dst = T[e]
+#else
+    auto tab_put = [&](int e, const Fq& v) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) tab[(e * NL + j) * 256] = v.l[j];
+    };
+    auto tab_get = [&](Fq& v, uint32_t e) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) v.l[j] = tab[(e * NL + j) * 256];
+    };
+#define QTAB_PUT(e, v) tab_put(e, v)
+#define QTAB_GET(dst, e) tab_get(dst, e)
+#endif
+    QTAB_PUT(1, P1.c); QTAB_PUT(4, P2.c);
+    Fq p1x2, p1x3, p2x2, p2x3;
+    quad_dbl_any(t, P1, q); p1x2 = t.c; QTAB_PUT(2, t.c);
+    quad_add(u, t, P1, q); p1x3 = u.c; QTAB_PUT(3, u.c);
+    quad_dbl_any(t, P2, q); p2x2 = t.c; QTAB_PUT(8, t.c);
+    quad_add(u, t, P2, q); p2x3 = u.c; QTAB_PUT(12, u.c);
 #pragma unroll
     for (int bb = 1; bb < 4; ++bb)
 #pragma unroll
         for (int aa = 1; aa < 4; ++aa) {
             QuadXyzz x, y;
-            x.c = T[aa]; x.inf = p.inf; y.c = T[4 * bb]; y.inf = p.inf;
+            x.c = aa == 1 ? P1.c : aa == 2 ? p1x2 : p1x3; x.inf = p.inf;
+            y.c = bb == 1 ? P2.c : bb == 2 ? p2x2 : p2x3; y.inf = p.inf;
             quad_add(t, x, y, q);
-            T[aa + 4 * bb] = t.c;
+            QTAB_PUT(aa + 4 * bb, t.c);
         }
     QuadXyzz acc;
     quad_set_inf(acc);
+    // the two 127-bit halves as shift registers (a dynamically indexed kk[] would live in scratch memory): the window is the top two bits
+    uint32_t h1[4] = {kk[0], kk[1], kk[2], kk[3] & 0x7FFFFFFFu}, h2[4] = {kk[4], kk[5], kk[6], kk[7] & 0x7FFFFFFFu};   // bit 127 is the sign
 #pragma unroll 1
-    for (int i = 63; i >= 0; --i) {                                // bits 2 i + 1, 2 i of both halves (bit 127 is the sign: masked)
-        quad_dbl_any(t, acc, q);
-        quad_dbl_any(acc, t, q);
-        const uint32_t w = (uint32_t)i >> 4, sh = ((uint32_t)i & 15u) * 2u;
-        uint32_t a = (kk[w] >> sh) & 3u, b = (kk[4 + w] >> sh) & 3u;
-        if (i == 63) { a &= 1u; b &= 1u; }
+    for (int i = 63; i >= 0; --i) {                                // bits 2 i + 1, 2 i of both halves
+        const uint32_t a = h1[3] >> 30, b = h2[3] >> 30;
+#pragma unroll
+        for (int j = 3; j > 0; --j) { h1[j] = (h1[j] << 2) | (h1[j - 1] >> 30); h2[j] = (h2[j] << 2) | (h2[j - 1] >> 30); }
+        h1[0] <<= 2; h2[0] <<= 2;
         const uint32_t idx = a | (b << 2);
+        QuadXyzz op;
+#if !defined(KZG_G1FFT_QUAD_LDS)
         // 16-way select as a binary tree over the index bits (entry 0 never used as a point: op.inf covers it)
         Fq s8[8], s4[4], s2[2];
 #pragma unroll
@@ -490,12 +513,18 @@ __device__ __forceinline__ void quad_scalar_mul(QuadXyzz& r, const QuadXyzz& p, 
         for (int m = 0; m < 4; ++m) fe_select(s4[m], (idx & 2u) != 0, s8[2 * m + 1], s8[2 * m]);
 #pragma unroll
         for (int m = 0; m < 2; ++m) fe_select(s2[m], (idx & 4u) != 0, s4[2 * m + 1], s4[2 * m]);
-        QuadXyzz op;
         fe_select(op.c, (idx & 8u) != 0, s2[1], s2[0]);
+#else
+        QTAB_GET(op.c, idx ? idx : 1u);                            // issued before the doublings: the reads are back when the addition needs them
+#endif
         op.inf = p.inf || idx == 0u;
+        quad_dbl_any(t, acc, q);
+        quad_dbl_any(acc, t, q);
         quad_add(t, acc, op, q);
         acc = t;
     }
+#undef QTAB_PUT
+#undef QTAB_GET
     r = acc;
 #endif
 }
@@ -524,9 +553,10 @@ k_g1fft_mul_quads(const int32_t* __restrict__ x, int32_t* __restrict__ partial, 
             plain = false;
         }
     }
+    extern __shared__ int32_t qtab[];                             // -DKZG_G1FFT_QUAD_LDS: 16 entries x 9 words x 256 lanes; unused (size 0) otherwise
     if (!__all(plain)) {                                          // wave-uniform: the multiplication runs for the whole wave or not at all
         QuadXyzz m;
-        quad_scalar_mul(m, term, k, q);
+        quad_scalar_mul(m, term, k, q, qtab + threadIdx.x);
         if (!plain) term = m;
     }
     if (active) quad_store(partial, (size_t)n * R, (size_t)o * R + jp, term, q);
@@ -992,6 +1022,16 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
             else { plan[0] = 5; plan[1] = 3; plan[2] = 3; np = 3; }
         }
         const int K0 = plan[0];
+#if !defined(KZG_G1FFT_QUAD_LDS) || defined(KZG_G1FFT_QUAD_W1)
+        constexpr size_t QUAD_TAB_LDS = 0;
+#else
+        constexpr size_t QUAD_TAB_LDS = (size_t)16 * NL * 256 * 4;     // entries 1 .. 15 of every lane (entry 0 unused): 144 KiB of the CU's 160
+        static bool quad_attr_set = false;
+        if (use_quads && !quad_attr_set) {
+            KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1fft_mul_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUAD_TAB_LDS));
+            quad_attr_set = true;
+        }
+#endif
         Naf2Lists nl;
         rc = get_naf2(ctx, log_n, false, &nl);
         if (rc != KZG_OK) return rc;
@@ -1014,7 +1054,7 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
             const bool last = i == np - 1;
             const size_t slots = n << K;
             if (use_quads) {
-                hipLaunchKernelGGL(k_g1fft_mul_quads, dim3((unsigned)((4 * slots + 255) / 256)), dim3(256), 0, st, src, partial, (uint32_t)n, log_n, K, log_s,
+                hipLaunchKernelGGL(k_g1fft_mul_quads, dim3((unsigned)((4 * slots + 255) / 256)), dim3(256), QUAD_TAB_LDS, st, src, partial, (uint32_t)n, log_n, K, log_s,
                                    last ? scal_n : scal, last ? 1 : 0);
                 hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, (uint32_t)1 << K, (uint32_t)n, dst);
             } else {
