@@ -153,8 +153,9 @@ int32_t kzg_msm_g1_srs_partial(kzg_ctx* ctx, const kzg_srs* srs, size_t offset,
  * (out_xy_mont / out_is_infinity) and/or the unconverted partial sum (out_xyzz_mont, 16 u64); either may be NULL.
  * With begin(k+1) issued before end(k), the sort / bucket-reduction phases of one MSM run beside the accumulation of the
  * other and the host epilogue leaves the critical path.  d_scalars_mont must be complete before `begin` and stay
- * untouched until `end`.  1 <= n <= 2^24 (and at most 16 launches: over an SRS of more than 2^20 points, whose MSMs run as launches
- * of 2^20 pairs, that is n <= 2^24 as well; the synchronous calls have no such cap); a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG.
+ * untouched until `end`.  1 <= n <= 2^26 (at most 64 launches: an SRS of more than 2^20 points is served in launches of 2^20 pairs;
+ * the synchronous calls have no cap; the asynchronous commit_eval_form / commit_blob / compute_proof forms below stop at 2^24);
+ * a slot that is still in flight (or, for `end`, idle) -> KZG_ERR_INVALID_ARG.
  * The synchronous MSM / commit / proof calls use slot 0's workspace: while slot 0 is in flight they return
  * KZG_ERR_INVALID_ARG (text in kzg_ctx_last_error); the other slots may be in flight beside them.  Two slots hide the latency-bound
  * phases of a 2^20-pair MSM; shard-sized MSMs (2^17 .. 2^18 pairs per GPU) keep gaining up to four. */

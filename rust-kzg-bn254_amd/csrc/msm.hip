@@ -24,7 +24,7 @@
 namespace kzg {
 
 constexpr uint32_t MSM_BATCH_POLYS_MAX = 1024;  // polynomials of one batched table-mode launch (64 buckets each: 2^16 buckets)
-constexpr uint32_t MSM_MAX_OUT = 4096;         // XYZZ values one launch may hand to the host epilogue (generic mode: W * batch window sums)
+constexpr uint32_t MSM_MAX_OUT = 16384;        // XYZZ values one launch may hand to the host epilogue (generic mode: W * batch window sums)
 constexpr size_t SORT1_MAX_LDS = 131072;       // single-pass sort: one LDS counter per bucket (<= 2^15 buckets)
 
 void MsmWorkspace::release() {
@@ -219,7 +219,7 @@ struct Pending {
 };
 // One asynchronous MSM = up to MSM_MAX_PARTS launches back to back on the slot's stream, sharing its workspace (stream order keeps
 // them apart); each copies its O(200) result points to its own MSM_PART_OUT-point window of the pinned buffer.
-constexpr uint32_t MSM_MAX_PARTS = 16;
+constexpr uint32_t MSM_MAX_PARTS = 64;       // round 4: 64 launches (2^26 pairs over a table-mode SRS of more than 2^20 points); 16 before
 constexpr uint32_t MSM_PART_OUT = MSM_MAX_OUT / MSM_MAX_PARTS;
 struct MsmPending {
     Pending part[MSM_MAX_PARTS];
@@ -804,7 +804,7 @@ int32_t msm_slot_stream(kzg_ctx* ctx, int slot, hipStream_t* out) {
 int32_t msm_begin(kzg_ctx* ctx, int slot, const MsmBases& bases, const void* d_scalars, size_t n) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;     // slot still in flight
     if (n == 0) return KZG_ERR_INVALID_ARG;
-    if (n > MSM_MAX_LAUNCH) return KZG_ERR_TOO_LARGE;
+    if (n > 4 * MSM_MAX_LAUNCH) return KZG_ERR_TOO_LARGE;             // 2^26 pairs: MSM_MAX_PARTS launches of 2^20 (table mode) or four of 2^24
     hipStream_t st = nullptr;
     { int32_t rc0 = msm_slot_stream(ctx, slot, &st); if (rc0 != KZG_OK) return rc0; }
     MsmPending* pend = new (std::nothrow) MsmPending();

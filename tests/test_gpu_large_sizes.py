@@ -160,11 +160,16 @@ def test_commitment_over_2_25_and_2_26_point_srs_periodic_scalars(k, log_srs):
         dt = time.perf_counter() - t0
         print("SRS 2^%d (set-up %.1f s): commitment over all %d points from host scalars: %.1f ms (%.2f ms per 2^20 pairs)" % (log_srs, t_srs, n, dt * 1e3, dt * 1e3 / (n >> 20)))
         assert pyref.point_from_wire(out) == want, log_srs
-        # the asynchronous calls are documented to stop at 2^24 pairs: beyond it they must refuse, not misbehave
-        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n, 0) != 0
-        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 5, k._lib.ptr(wire), 1 << 24, 0) == 0
+        # the asynchronous form reaches 2^26 pairs since round 4 (64 launches of 2^20 over the 2^25-point tables, four of 2^24 in generic mode);
+        # beside it a 2^24-pair MSM at an offset on a second slot
+        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n, 0) == 0
+        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 5, k._lib.ptr(wire), 1 << 24, 1) == 0
+        o2 = np.zeros(8, np.uint64)
         assert lib.kzg_msm_g1_srs_end(ctx.handle, 0, k._lib.ptr(out), C.byref(inf), None) == 0
+        assert lib.kzg_msm_g1_srs_end(ctx.handle, 1, k._lib.ptr(o2), C.byref(inf), None) == 0
+        assert pyref.point_from_wire(out) == want
         geo24 = (pow(TAU, 1 << 24, R_) - 1) * pow(pow(TAU, period, R_) - 1, -1, R_) % R_
-        assert pyref.point_from_wire(out) == pyref.ec_mul(acc * geo24 % R_ * pow(TAU, 5, R_) % R_, (1, 2))
+        assert pyref.point_from_wire(o2) == pyref.ec_mul(acc * geo24 % R_ * pow(TAU, 5, R_) % R_, (1, 2))
+        assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n, 7) != 0            # not a slot
     finally:
         srs.close()
