@@ -173,3 +173,46 @@ def test_commitment_over_2_25_and_2_26_point_srs_periodic_scalars(k, log_srs):
         assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n, 7) != 0            # not a slot
     finally:
         srs.close()
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_eval_form_commitment_and_proofs_at_2_22_and_2_24(k, log_n):
+    """commit_eval_form (kzg.rs:84-104) and compute_proof (kzg.rs:128-178, :237-260), off the domain and on it, at 2^22 and 2^24
+    evaluations (the reference accepts 2^28; the proof pipeline had been checked to 2^20).  The polynomial has 2 000 random coefficients at
+    random degrees (degree n - 1 among them), so f(tau), f(z) and the quotient's value at tau are cheap big-integer sums; its n evaluations
+    -- dense -- come from the GPU NTT, which tests/test_gpu_ntt_sizes.py and the test above pin against the oracle up to 2^26."""
+    n = 1 << log_n
+    ctx = k.default_context(); lib = k._lib.load()
+    rng = np.random.default_rng(2200 + log_n)
+    idx = sorted(set([0, 1, n - 1] + [int(v) for v in rng.integers(0, n, size=2000)]))
+    cs = [int.from_bytes(rng.bytes(40), "little") % R_ for _ in idx]
+    f = lambda x: sum(c * pow(x, j, R_) for c, j in zip(cs, idx)) % R_          # noqa: E731
+    coeffs = np.zeros((n, 4), np.uint64)
+    coeffs[idx] = pyref.frs_to_mont(cs)
+    evals = coeffs.copy()
+    assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(evals), n, 0) == 0
+    w = pyref.root_of_unity(log_n)
+    for m in (0, 1, 12345, n - 1):
+        assert pyref.fr_from_mont(evals[m]) == f(pow(w, m, R_)), m                # the NTT's output is the evaluation vector
+    srs = k.SRS.generate(TAU, n)
+    try:
+        out = np.zeros(8, np.uint64); inf = C.c_uint8(0); y = np.zeros(4, np.uint64)
+        ftau = f(TAU)
+        t0 = time.perf_counter()
+        assert lib.kzg_commit_eval_form(ctx.handle, srs.handle, k._lib.ptr(evals), n, k._lib.ptr(out), C.byref(inf)) == 0
+        t_commit = time.perf_counter() - t0
+        assert pyref.point_from_wire(out) == pyref.ec_mul(ftau, (1, 2)), log_n
+        assert lib.kzg_commit_coeff_form(ctx.handle, srs.handle, k._lib.ptr(coeffs), n, k._lib.ptr(out), C.byref(inf)) == 0
+        assert pyref.point_from_wire(out) == pyref.ec_mul(ftau, (1, 2)), log_n
+        z_off = int.from_bytes(rng.bytes(40), "little") % R_
+        for z, which in ((z_off, "off the domain"), (pow(w, 3 * n // 7, R_), "on the domain"), (1, "z = 1")):
+            zw = pyref.fr_to_mont(z)
+            t0 = time.perf_counter()
+            assert lib.kzg_compute_proof(ctx.handle, srs.handle, k._lib.ptr(evals), n, None, n, k._lib.ptr(zw), k._lib.ptr(out), C.byref(inf), k._lib.ptr(y)) == 0
+            dt = time.perf_counter() - t0
+            fz = f(z)
+            assert pyref.fr_from_mont(y) == fz, (log_n, which)
+            assert pyref.point_from_wire(out) == pyref.ec_mul((ftau - fz) * pow(TAU - z, -1, R_) % R_, (1, 2)), (log_n, which)
+            print("  2^%d evaluations: commit_eval_form %.1f ms, compute_proof %s %.1f ms (host buffers)" % (log_n, t_commit * 1e3, which, dt * 1e3))
+    finally:
+        srs.close()
