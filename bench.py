@@ -246,8 +246,17 @@ def main():
     if backend != "nccl":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # KZG_BENCH_FORCE_EXCHANGE=1: a ONE-rank run takes the N > 1 path end to end -- process group, the per-step all-gather of the partials
+    # (RCCL with one rank), fold, every collective below.  What a one-GPU box can rehearse of the driver's multi-GPU run over real RCCL;
+    # the line says so ("rccl_ranks": 1, "exchange_backend": "nccl") and its value includes the exchange a single GPU does not need.
+    multi = world > 1 or os.environ.get("KZG_BENCH_FORCE_EXCHANGE") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                 # (only the one-rank rehearsal gets here without a launcher's port)
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -263,7 +272,7 @@ def main():
     tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % FR
 
     # ---- inputs: this rank's shard of the SRS (resident) and of the scalars (resident) ---------------------------
-    sh = ShardedMsm(ctx, n, rank, world, gather_device="cuda" if backend == "nccl" else None)
+    sh = ShardedMsm(ctx, n, rank, world, gather_device="cuda" if backend == "nccl" else None, force_exchange=multi)
     srs = k.SRS.generate(tau, sh.len, ctx=ctx, first_power=sh.lo)
     seed0 = 0x4B5A472D424E3235 & 0x7FFFFFFF
     # Scalars-A, identical on every rank (seeded).  The timed steps ROTATE through N_BUFFERS distinct resident buffers (a commitment
@@ -286,7 +295,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -300,7 +309,7 @@ def main():
     # computed, exchanged, folded and checked.  2^17 pairs per rank: 0.164 against 0.22-0.24 ms per step in steady state, 0.19-0.20 against 0.25
     # in a 20-step run
     GROUP = sh.auto_group(srs) if pipelined else 1
-    if world > 1:                                                       # every rank must batch alike (the exchanges are collectives)
+    if multi:                                                           # every rank must batch alike (the exchanges are collectives)
         g = torch.tensor([GROUP], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(g, op=dist.ReduceOp.MIN)
         GROUP = int(g.item())
@@ -312,6 +321,8 @@ def main():
         t_prev = time.perf_counter()
         marks = []
         ptrs = [ptr[i % len(ptr)] for i in range(count)] if isinstance(ptr, list) else [ptr] * count
+        if bucket is None and os.environ.get("KZG_BENCH_EXCHANGE_BUCKET"):          # diagnostics: partials per exchange (default 8)
+            bucket = int(os.environ["KZG_BENCH_EXCHANGE_BUCKET"])
         for res in sh.commit_stream(srs, ptrs, depth=depth, bucket=bucket, group=(GROUP if depth > 1 else 1)):
             if keep is not None:
                 keep.append(res)
@@ -329,7 +340,7 @@ def main():
         res = run_steps(count, ptr, depth, bucket, keep)
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             every = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(every, t)
@@ -346,6 +357,16 @@ def main():
     # the stall sat INSIDE the timed region -- 0.23 ms per step at --steps 20.  (2) The host spent seconds preparing the inputs
     # above with the GPU idle; the clock needs ~30 steps to settle (per-step times 1.45 -> 1.15 ms).
     # The same step count on every rank (the exchange is a collective); none of this is timed, the W warm-up steps follow.
+    # (3) Python's cyclic collector is switched off from here to the end of the measurements (KZG_BENCH_GC=1 leaves it on): with torch
+    # imported a full collection takes ~5 ms on the host thread that feeds the GPU, and the container allocations of the exchange path
+    # (N > 1) trigger one ~40 steps into a region -- the GPU drains (depth 2: 1.1 ms of queued work), idles 4 ms and then spends ~15
+    # steps regaining its clock: 5.6-5.9 ms lost once per region, = 30 shard steps at 8 ranks (profiles/r04_exchange_gc_stall.txt).
+    # A service would gc.freeze() after set-up for the same reason.  Nothing of the measured path runs in the collector.
+    import gc
+    gc_off = os.environ.get("KZG_BENCH_GC", "0") == "0"
+    if gc_off:
+        gc.collect()
+        gc.disable()
     barrier()
     spinup_steps = int(os.environ.get("KZG_BENCH_SPINUP_STEPS", str(min(48 * world, 384))))
     run_steps(spinup_steps, rot_ptrs, depth_used)
@@ -353,8 +374,8 @@ def main():
     timed_results = []
     elapsed, result = timed(args.steps, rot_ptrs, depth_used, keep=timed_results)    # THE timed region: exactly --steps steps, step k on buffer k mod N_BUFFERS
     per_rank_ms = [e / args.steps * 1e3 for e in rank_elapsed]
-    comm_ranks = dist.get_world_size() if world > 1 else 1
-    if world > 1:
+    comm_ranks = dist.get_world_size() if multi else 1
+    if multi:
         # every rank must hold the same folded commitment
         chk = torch.from_numpy(result.view(np.int64).copy())
         if backend == "nccl":
@@ -388,6 +409,8 @@ def main():
     lib.kzg_ctx_get_msm_profile(ctx.handle, phase, C.byref(launches), C.byref(pairs))
     lib.kzg_ctx_set_profiling(ctx.handle, 0)
     phase_piped = [phase[i] / max(1, launches.value) for i in range(8)]
+    if gc_off:
+        gc.enable()
 
     exit_code = 0
     if rank == 0:
@@ -415,7 +438,7 @@ def main():
             "value_uniform": n * side_steps / elapsed_b,
             "latency_ms": elapsed_lat / side_steps * 1e3,
             "n_gpus": world,
-            "rccl_ranks": comm_ranks, "exchange_backend": (backend if world > 1 else None),
+            "rccl_ranks": comm_ranks, "exchange_backend": (backend if multi else None),
             "ms_per_step_per_rank": per_rank_ms,
             "launched_by": "bench.py itself (N child ranks)" if os.environ.get("KZG_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process"),
             "steps": args.steps,
@@ -430,6 +453,7 @@ def main():
             "config": {"workload": "G1 MSM 2^%d scalars (KZG::commit_coeff_form), scalars resident in HBM; step k commits buffer k mod %d "
                                    "(%d distinct resident scalar sets, %d MiB)" % (LOG_N, N_BUFFERS, N_BUFFERS, N_BUFFERS * 32 * n >> 20),
                        "sharding": "by scalar index over %d GPU(s); all-gather of XYZZ partials + host fold" % world,
+                       "host_gc_in_timed_region": os.environ.get("KZG_BENCH_GC", "0") != "0",
                        "pipeline_depth": sh.group_depth(depth_used, GROUP), "steps_per_launch": GROUP,
                        "untimed_before_warmup": "set-up: %d steps (workspaces), the first device-wide synchronisation, %d steps (clock ramp); then the %d warm-up steps" % (depth_used, spinup_steps, args.warmup),
                        "latency_ms_is": "one commitment at a time (depth 1, one exchange per step), %d steps" % side_steps,
@@ -714,7 +738,7 @@ def main():
                                                          "sample": "one forward 2^18 NTT, 1 thread, %.3f s wall" % ntt_1_s},
                                        "gpu_bit_exact_vs_oracle": ntt_exact}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         code = torch.tensor([exit_code], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.broadcast(code, src=0)
         exit_code = int(code.item())

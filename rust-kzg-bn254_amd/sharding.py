@@ -168,12 +168,17 @@ def fold_partials(parts):
 class ShardedMsm:
     """MSM of n (scalar, point) pairs sharded over `world` ranks."""
 
-    def __init__(self, ctx, n: int, rank: int = 0, world: int = 1, gather_device="cuda"):
+    def __init__(self, ctx, n: int, rank: int = 0, world: int = 1, gather_device="cuda", force_exchange=None):
         self.ctx, self.n, self.rank, self.world = ctx, n, rank, world
         self.lo, self.hi = shard_bounds(n, rank, world)
         self.len = self.hi - self.lo
         self.gather_device = gather_device
         self._gatherer = None
+        # one rank normally folds its own result; `force_exchange` (KZG_SHARD_FORCE_EXCHANGE=1) sends it through the collective all the
+        # same -- the N > 1 code path on a one-GPU box (needs an initialised process group of one rank)
+        if force_exchange is None:
+            force_exchange = os.environ.get("KZG_SHARD_FORCE_EXCHANGE") == "1"
+        self.exchange = world > 1 or bool(force_exchange)
 
     def _gather(self, part):
         if self._gatherer is None:
@@ -191,7 +196,7 @@ class ShardedMsm:
         return out
 
     def commit_device(self, srs_shard, d_scalars_ptr: int):
-        if self.world == 1:
+        if not self.exchange:
             out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
             rc = _lib.load().kzg_msm_g1_srs_device(self.ctx.handle, srs_shard.handle, 0, C.c_void_p(d_scalars_ptr), self.len,
                                                    _lib.ptr(out), C.byref(inf))
@@ -212,7 +217,7 @@ class ShardedMsm:
 
     def end(self, slot: int):
         """Wait for `slot`; returns the folded commitment (all-gather of the partials + host fold when world > 1)."""
-        if self.world == 1:
+        if not self.exchange:
             out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)
             rc = _lib.load().kzg_msm_g1_srs_end(self.ctx.handle, slot, _lib.ptr(out), C.byref(inf), None)
         else:
@@ -221,7 +226,7 @@ class ShardedMsm:
         self.ctx.check_device(rc)
         if rc != _lib.OK:
             raise ValueError(_lib.status_message(rc))
-        if self.world == 1:
+        if not self.exchange:
             return out
         return fold_partials(self._gather(part))
 
@@ -307,6 +312,8 @@ class ShardedMsm:
         and does no more GPU work; every rank (the failing one included) raises ShardError at that step, after the same number of
         collectives, so nobody is left blocked in an all-gather.  A peer that dies outright shows up as ExchangeTimeout
         (KZG_EXCHANGE_TIMEOUT_S, default 60 s): exit non-zero on it, the communicator cannot be used again.
+        (A Python host should `gc.freeze()` or disable the cyclic collector around a stream: with torch imported one full collection
+        takes ~5 ms on this thread, 30 shard steps at 8 ranks, and the GPU then needs ~15 steps to regain its clock -- bench.py does.)
         `group` consecutive steps share ONE launch (begin_group / _end_partials; `None`: auto_group(), 1: one launch per step): at
         2^17 pairs per rank four steps per launch take 0.164 ms per step where one launch per step takes 0.22-0.24 (three in flight;
         2^15: 0.152 -> 0.067, 2^16: 0.167 -> 0.095, 2^18 with two per launch: 0.347 -> 0.311; tools/time_shard_group.py).  The
@@ -323,7 +330,7 @@ class ShardedMsm:
         depth = self.group_depth(depth, group)
         inflight = collections.deque()
         g = None
-        if self.world > 1:
+        if self.exchange:
             if self._gatherer is None:
                 self._gatherer = PartialGatherer(self.world, self.gather_device)
             g = self._gatherer

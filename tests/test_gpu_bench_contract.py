@@ -64,7 +64,7 @@ def test_bench_without_launcher_refuses_more_ranks_than_gpus_over_rccl():
     import torch
     n = torch.cuda.device_count() + 1
     env = dict(os.environ, KZG_BENCH_LOG_N="12")
-    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KZG_BENCH_BACKEND"):
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KZG_BENCH_BACKEND", "MASTER_PORT"):
         env.pop(key, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
                          capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
@@ -98,6 +98,25 @@ def test_bench_two_ranks_gloo_is_bit_exact():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bit_exact_vs_oracle"] is True
     assert d["config"]["steps_per_launch"] == 4          # 2^17 pairs per rank: four steps of the stream per batched launch (10 = 4 + 4 + 2)
+    assert d["value"] > 0 and d["value_uniform"] > 0 and d["latency_ms"] > 0
+
+
+def test_bench_one_rank_through_rccl_takes_the_multi_gpu_path():
+    """What a one-GPU box can run of the driver's N > 1 bench over REAL RCCL (two ranks on one device are refused by RCCL): one rank with
+    KZG_BENCH_FORCE_EXCHANGE=1 initialises the nccl process group and sends every step through the N > 1 code -- grouped launches
+    (2^17 pairs: four steps per launch), bucketed all_gather_into_tensor of the XYZZ partials on the gatherer's own stream, host fold,
+    the all-reduce / all-gather / broadcast around the timed region -- and every timed step is checked against sum_i c_i tau^i G1."""
+    env = dict(os.environ, KZG_BENCH_LOG_N="17", KZG_BENCH_FORCE_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KZG_BENCH_BACKEND", "MASTER_PORT"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-secondary",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["exchange_backend"] == "nccl"
+    assert d["config"]["bit_exact_vs_oracle"] is True and d["config"]["steps_per_launch"] == 4
     assert d["value"] > 0 and d["value_uniform"] > 0 and d["latency_ms"] > 0
 
 
