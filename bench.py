@@ -305,7 +305,7 @@ def main():
     depth_used = (DEPTH or (2 if sh.len >= (1 << 20) else 3)) if pipelined else 1
 
     # shard-sized steps (N > 1: 2^20 / N pairs per rank) share launches: `GROUP` consecutive steps are ONE batched launch of the MSM engine
-    # (ShardedMsm.auto_group: 4 below 2^18 pairs per rank, 2 below 2^19, else 1; KZG_SHARD_GROUP_AUTO=0: off); every step's commitment is still
+    # (ShardedMsm.auto_group: 4 below 2^18 pairs per rank, 2 below 2^20, else 1; KZG_SHARD_GROUP_AUTO=0: off); every step's commitment is still
     # computed, exchanged, folded and checked.  2^17 pairs per rank: 0.164 against 0.22-0.24 ms per step in steady state, 0.19-0.20 against 0.25
     # in a 20-step run
     GROUP = sh.auto_group(srs) if pipelined else 1

@@ -165,3 +165,23 @@ def test_bench_self_launch_takes_its_ranks_along_when_stopped():
     for pid in kids:
         alive = subprocess.run(["ps", "-p", str(pid), "-o", "stat="], capture_output=True, text=True).stdout.strip()
         assert alive == "" or alive.startswith("Z"), (pid, alive)
+
+
+def test_shard_steps_per_launch_by_world_size(k, monkeypatch):
+    """How many steps of a commitment stream one launch carries (ShardedMsm.auto_group; host logic, the capacity rule is
+    kzg_msm_batch_capacity): a 2^20-pair commitment over 1 / 2 / 4 / 8 ranks -> 1 / 2 / 2 / 4; every rank derives it from n // world, so
+    uneven shards agree; the switches."""
+    from rust_kzg_bn254_amd.sharding import ShardedMsm, shard_bounds
+    monkeypatch.delenv("KZG_SHARD_GROUP", raising=False)
+    monkeypatch.delenv("KZG_SHARD_GROUP_AUTO", raising=False)
+    n = 1 << 20
+    assert [ShardedMsm(None, n, 0, w).auto_group() for w in (1, 2, 4, 8)] == [1, 2, 2, 4]
+    for world in (3, 5, 6, 7):
+        groups = {ShardedMsm(None, n, r, world).auto_group() for r in range(world)}
+        assert len(groups) == 1, (world, groups)
+        assert sum(shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)) == n
+    assert ShardedMsm(None, 1 << 12, 0, 1).auto_group() == 1               # below 2^13 pairs per rank: one launch per step
+    monkeypatch.setenv("KZG_SHARD_GROUP_AUTO", "0")
+    assert ShardedMsm(None, n, 0, 8).auto_group() == 1
+    monkeypatch.setenv("KZG_SHARD_GROUP", "3")
+    assert ShardedMsm(None, n, 0, 8).auto_group() == 3
