@@ -523,18 +523,21 @@ def main():
             pr_ms = avg_ms(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(scalars), n, None, n, _lib.ptr(zq), _lib.ptr(o8),
                                                          C.byref(oi), _lib.ptr(o4)), reps=5)
             cc_ms = avg_ms(lambda: lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(scalars), n, _lib.ptr(o8), C.byref(oi)), reps=5)
-            # stream of host-buffer commitments, two in flight (kzg_msm_g1_srs_begin / _end): H2D copies overlap kernels
-            def stream_host(reps=8):
-                prev = None
+            # stream of host-buffer commitments, THREE in flight (kzg_msm_g1_srs_begin / _end): the 32 MiB H2D copy of commitment k + 2
+            # runs beside the kernels of k and k + 1 -- the PCIe-inclusive rate of the boundary (1.14-1.16 ms per 2^20 commitment from
+            # pageable and pinned caller buffers alike; 1.30 with two in flight: tools/archive/probe_pinned_stream.py)
+            def stream_host(reps=8, depth=3):
+                inflight = []
                 for i in range(reps):
-                    rc = lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, _lib.ptr(scalars), n, i & 1)
+                    if len(inflight) == depth:
+                        assert lib.kzg_msm_g1_srs_end(ctx.handle, inflight.pop(0), _lib.ptr(o8), C.byref(oi), None) == 0
+                    rc = lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, _lib.ptr(scalars), n, i % depth)
                     assert rc == 0, rc
-                    if prev is not None:
-                        assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), None) == 0
-                    prev = i & 1
-                assert lib.kzg_msm_g1_srs_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), None) == 0
-            stream_host(2)
-            t = time.perf_counter(); stream_host(8); cc_stream_ms = (time.perf_counter() - t) / 8 * 1e3
+                    inflight.append(i % depth)
+                while inflight:
+                    assert lib.kzg_msm_g1_srs_end(ctx.handle, inflight.pop(0), _lib.ptr(o8), C.byref(oi), None) == 0
+            stream_host(6)
+            t = time.perf_counter(); stream_host(24); cc_stream_ms = (time.perf_counter() - t) / 24 * 1e3
             assert np.array_equal(o8, want_a), "streamed host-buffer commitment differs"
             # config 4 front end: blob bytes (host) -> Fr -> INTT -> MSM (kzg_commit_blob), 2^20 elements = 32 MiB of padded bytes
             blob_bytes = np.frombuffer(b"".join(b"\x00" + bytes(r) for r in np.random.default_rng(7).integers(32, 127, size=(n, 31), dtype=np.uint8)), dtype=np.uint8).copy()
