@@ -1,0 +1,275 @@
+// reference_tests.cpp -- the reference's own live tests, restated against the C++ host mirror (include/kzg_bn254_mi355x.hpp) under their
+// own names: prover/tests/kzg_test.rs and verifier/tests/tests.rs.  Built with g++ and run on the GPU box by tests/test_gpu_cpp_mirror.py,
+// which also compares the values printed at the end with the Python mirror and with big-integer arithmetic.
+//
+// The reference's lazy_static SRS is mainnet-data/g1.131072.point (absent from the tree: .MISSING_LARGE_BLOBS); here the SRS is generated
+// from a known tau (argv[2], 32 big-endian bytes in hex), so verify_proof takes [tau]G2 instead of consts::G2_TAU -- the only deviation.
+// usage: reference_tests <tests/golden> <tau hex>
+#include "kzg_bn254_mi355x.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <random>
+
+using namespace rust_kzg_bn254;
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("    FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+template <class F> static bool throws(KzgError::Kind kind, const std::string& message, F&& f) {
+    try { f(); } catch (const KzgError& e) {
+        if (e.kind == kind && (message.empty() || e.message == message)) return true;
+        std::printf("    unexpected error: %s\n", e.what());
+        return false;
+    }
+    std::printf("    no error\n");
+    return false;
+}
+static std::vector<uint8_t> read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+static std::string hex(const uint64_t* w, size_t n) {
+    std::string s; char b[17];
+    for (size_t i = 0; i < n; ++i) { std::snprintf(b, sizeof b, "%016llx", (unsigned long long)w[i]); s += b; }
+    return s;
+}
+
+static std::string GOLDEN;
+static std::vector<uint8_t> GETTYSBURG_ADDRESS_BYTES;
+static std::unique_ptr<SRS> SRS_INSTANCE;           // lazy_static! SRS_INSTANCE (kzg_test.rs:9-17): 4 096 points of the known-tau setup
+static G2Affine G2_TAU;
+static std::mt19937_64 rng(20240);
+
+static std::vector<uint8_t> random_text(size_t len) {
+    std::vector<uint8_t> v(len);
+    for (auto& c : v) c = (uint8_t)(32 + rng() % 95);           // gen_range(32..=126)
+    return v;
+}
+
+// ---- prover/tests/kzg_test.rs ---------------------------------------------------------------------------------------------------------
+static void test_srs_setup_errors() {                            // :20-28
+    CHECK(throws(KzgError::Kind::GenericError, "Number of points to load exceeds SRS order.", [] { SRS::new_(GOLDEN + "/g1.point", 3000, 3001); }));
+}
+static void test_evaluate_polynomial_in_evaluation_form_random_blob_all_indexes() {      // :32-55 (blob length capped at 9 000 bytes: one GPU call per index)
+    KZG kzg = KZG::new_();
+    const Blob input = Blob::from_raw_data(random_text(35 + rng() % 8965));
+    const PolynomialEvalForm input_poly = input.to_polynomial_eval_form();
+    kzg.calculate_and_store_roots_of_unity(input.len());
+    for (size_t i = 0; i < input_poly.len_underlying_blob_field_elements(); ++i) {
+        const Fr z_fr = *kzg.get_nth_root_of_unity(i);
+        CHECK(helpers::evaluate_polynomial_in_evaluation_form(input_poly, z_fr) == input_poly.evaluations()[i]);
+    }
+}
+static void test_commit_coeff_form_and_eval_form_equivalence() { // :58-89
+    KZG kzg = KZG::new_();
+    for (size_t n : {1u, 2u, 5u, 64u, 1000u, 4096u}) {
+        std::vector<Fr> c(n);
+        for (auto& f : c) { uint8_t b[32]; for (auto& x : b) x = (uint8_t)rng(); f = Fr::from_be_bytes_mod_order(b); }
+        const PolynomialCoeffForm coeff = PolynomialCoeffForm::new_(c);
+        const PolynomialEvalForm eval = coeff.to_eval_form();
+        const G1Affine a = kzg.commit_coeff_form(coeff, *SRS_INSTANCE), b = kzg.commit_eval_form(eval, *SRS_INSTANCE);
+        CHECK(a == b && !a.is_zero());
+        const PolynomialCoeffForm back = eval.to_coeff_form();
+        CHECK(back.coeffs() == coeff.coeffs() && back.len_underlying_blob_bytes() == coeff.len_underlying_blob_bytes());
+    }
+    // the same on the reference's own fixture SRS (tests/test-files/g1.point, 3 000 points, gnark-compressed)
+    const SRS fixture = SRS::new_(GOLDEN + "/g1.point", 3000, 3000);
+    CHECK(fixture.len() == 3000);
+    const Blob blob = Blob::from_raw_data(GETTYSBURG_ADDRESS_BYTES);
+    const PolynomialEvalForm eval = blob.to_polynomial_eval_form();
+    CHECK(kzg.commit_eval_form(eval, fixture) == kzg.commit_coeff_form(eval.to_coeff_form(), fixture));
+    CHECK(kzg.commit_blob(blob, fixture) == kzg.commit_eval_form(eval, fixture));
+    // too long for the SRS: the two error variants of kzg.rs:89-94 and :112-116
+    std::vector<Fr> big(4097, Fr::one());
+    CHECK(throws(KzgError::Kind::SrsCapacityExceeded, "polynomial degree 8192 exceeds SRS capacity 3000", [&] { kzg.commit_eval_form(PolynomialEvalForm::new_(big), fixture); }));
+    CHECK(throws(KzgError::Kind::SerializationError, "polynomial length is not correct", [&] { kzg.commit_coeff_form(PolynomialCoeffForm::new_(big), fixture); }));
+}
+static void test_calculate_and_store_roots_of_unity() {          // :92-129
+    KZG kzg = KZG::new_();
+    CHECK(kzg.get_roots_of_unities().empty());
+    for (uint64_t blob_length : {(uint64_t)32, (uint64_t)50000, (uint64_t)MAINNET_SRS_G1_SIZE}) {
+        kzg.calculate_and_store_roots_of_unity(blob_length);
+        const std::vector<Fr> roots = kzg.get_roots_of_unities();
+        size_t n = 1; while (n < (blob_length + 31) / 32) n <<= 1;
+        CHECK(roots.size() == n && roots[0] == Fr::one());
+        if (n > 1) {                                             // w^(n/2) = -1 and w^n = 1: a PRIMITIVE n-th root, consecutive powers
+            Fr p = roots[1];
+            for (size_t k = 1; k < n / 2; k <<= 1) p = p * p;
+            CHECK(p != Fr::one() && p * p == Fr::one());
+            CHECK(roots[1] * roots[n - 1] == Fr::one() && roots[2 % n] == roots[1] * roots[1]);
+        }
+    }
+    CHECK(throws(KzgError::Kind::GenericError, "Length of data after padding is 0", [&] { kzg.calculate_and_store_roots_of_unity(0); }));                                    // helpers_test.rs:33-58
+    CHECK(throws(KzgError::Kind::GenericError, "the length of data after padding is not valid with respect to the SRS", [&] { kzg.calculate_and_store_roots_of_unity(((uint64_t)1 << 33) + 1); }));
+}
+static void test_g1_ifft_non_power_of_two_error() {              // :132-161
+    KZG kzg = KZG::new_();
+    for (size_t len : {3u, 5u, 6u, 7u, 100u})
+        CHECK(throws(KzgError::Kind::FFTError, "length provided is not a power of 2", [&] { kzg.g1_ifft(len, *SRS_INSTANCE); }));
+    // and the defining property for a power of two: commit_eval_form(f) == MSM(g1_ifft(n), f) (prover/src/lib.rs:43-47)
+    const std::vector<G1Affine> lagrange = kzg.g1_ifft(64, *SRS_INSTANCE);
+    const SRS lagrange_srs = SRS::from_points(lagrange, 64);
+    const PolynomialEvalForm eval = Blob::from_raw_data(GETTYSBURG_ADDRESS_BYTES).to_polynomial_eval_form();
+    CHECK(eval.len() == 64);
+    CHECK(kzg.commit_coeff_form(PolynomialCoeffForm::new_(eval.evaluations()), lagrange_srs) == kzg.commit_eval_form(eval, *SRS_INSTANCE));
+}
+static void test_compute_blob_proof_invalid_commitment() {       // :164-200
+    KZG kzg = KZG::new_();
+    const std::string text = "test data for invalid commitment";
+    const Blob blob = Blob::from_raw_data(std::vector<uint8_t>(text.begin(), text.end()));
+    kzg.calculate_and_store_roots_of_unity(blob.len());
+    G1Affine invalid_commitment;                                 // (1, 1): 1 != 1 + 3
+    const uint64_t fq_one[4] = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full};
+    for (int i = 0; i < 4; ++i) invalid_commitment.xy[i] = invalid_commitment.xy[4 + i] = fq_one[i];
+    CHECK(throws(KzgError::Kind::NotOnCurveError, "G1 point not on curve", [&] { kzg.compute_blob_proof(blob, invalid_commitment, *SRS_INSTANCE); }));
+}
+
+// ---- verifier/tests/tests.rs ------------------------------------------------------------------------------------------------------------
+static void test_compute_kzg_proof() {                           // :29-77
+    KZG kzg = KZG::new_();
+    const Blob input = Blob::from_raw_data(GETTYSBURG_ADDRESS_BYTES);
+    const PolynomialEvalForm input_poly = input.to_polynomial_eval_form();
+    kzg.calculate_and_store_roots_of_unity(input.len());
+    const G1Affine commitment = kzg.commit_eval_form(input_poly, *SRS_INSTANCE);
+    for (size_t index = 0; index + 1 < input_poly.len(); ++index) {
+        size_t rand_index;
+        do rand_index = rng() % input_poly.len_underlying_blob_field_elements(); while (rand_index == index);
+        const G1Affine proof = kzg.compute_proof_with_known_z_fr_index(input_poly, index, *SRS_INSTANCE);
+        const Fr value_fr = *input_poly.get_evalualtion(index), z_fr = *kzg.get_nth_root_of_unity(index);
+        CHECK(verify::verify_proof(commitment, proof, value_fr, z_fr, &G2_TAU) == true);
+        CHECK(verify::verify_proof(commitment, proof, value_fr, *kzg.get_nth_root_of_unity(rand_index), &G2_TAU) == false);
+    }
+    CHECK(throws(KzgError::Kind::GenericError, "Root of unity not found", [&] { kzg.compute_proof_with_known_z_fr_index(input_poly, input_poly.len(), *SRS_INSTANCE); }));     // kzg.rs:199-201
+    KZG other = KZG::new_();
+    other.calculate_and_store_roots_of_unity(32);
+    CHECK(throws(KzgError::Kind::GenericError, "inconsistent length between blob and root of unities", [&] { other.compute_proof(input_poly, Fr::one(), *SRS_INSTANCE); }));      // kzg.rs:222-226
+}
+static void test_compute_kzg_proof_random_100_blobs() {          // :80-132 (20 blobs here)
+    KZG kzg = KZG::new_();
+    for (int t = 0; t < 20; ++t) {
+        const Blob input = Blob::from_raw_data(random_text(50 + rng() % 20000));
+        const PolynomialEvalForm input_poly = input.to_polynomial_eval_form();
+        kzg.calculate_and_store_roots_of_unity(input.len());
+        const size_t index = rng() % input_poly.len_underlying_blob_field_elements();
+        const G1Affine commitment = kzg.commit_eval_form(input_poly, *SRS_INSTANCE);
+        const G1Affine proof = kzg.compute_proof_with_known_z_fr_index(input_poly, index, *SRS_INSTANCE);
+        const Fr value_fr = *input_poly.get_evalualtion(index), z_fr = *kzg.get_nth_root_of_unity(index);
+        CHECK(verify::verify_proof(commitment, proof, value_fr, z_fr, &G2_TAU));
+        uint8_t b[32]; for (auto& x : b) x = (uint8_t)rng();
+        const Fr off = Fr::from_be_bytes_mod_order(b);           // a point off the domain: y from the barycentric formula (kzg.rs:142-176)
+        const G1Affine proof_off = kzg.compute_proof(input_poly, off, *SRS_INSTANCE);
+        const Fr y_off = helpers::evaluate_polynomial_in_evaluation_form(input_poly, off);
+        CHECK(verify::verify_proof(commitment, proof_off, y_off, off, &G2_TAU));
+        CHECK(!verify::verify_proof(commitment, proof_off, value_fr, off, &G2_TAU) || y_off == value_fr);
+    }
+}
+static void test_kzg_zero_blob() {                               // :240-269
+    KZG kzg = KZG::new_();
+    const std::vector<uint8_t> input(62, 0);
+    kzg.calculate_and_store_roots_of_unity(input.size());
+    const Blob input_blob = Blob::from_raw_data(input);
+    CHECK(input_blob.data() == std::vector<uint8_t>(64, 0));
+    const PolynomialEvalForm input_poly = input_blob.to_polynomial_eval_form();
+    const G1Affine commitment = kzg.commit_eval_form(input_poly, *SRS_INSTANCE);
+    const G1Affine proof = kzg.compute_blob_proof(input_blob, commitment, *SRS_INSTANCE);
+    CHECK(commitment.is_zero() && proof.is_zero());
+    CHECK(batch::verify_blob_kzg_proof_batch({input_blob}, {commitment}, {proof}, &G2_TAU) == true);
+    CHECK(verify::verify_blob_kzg_proof(input_blob, commitment, proof, &G2_TAU) == true);
+}
+static void test_multiple_proof_random_100_blobs() {             // :135-192 (24 blobs here): the batch verifies; any swapped or foreign element breaks it
+    KZG kzg = KZG::new_();
+    std::vector<Blob> blobs; std::vector<G1Affine> commitments, proofs;
+    for (int t = 0; t < 24; ++t) {
+        const Blob input = Blob::from_raw_data(random_text(50 + rng() % 20000));
+        kzg.calculate_and_store_roots_of_unity(input.len());
+        const G1Affine commitment = kzg.commit_blob(input, *SRS_INSTANCE);
+        CHECK(commitment == kzg.commit_eval_form(input.to_polynomial_eval_form(), *SRS_INSTANCE));
+        const G1Affine proof = kzg.compute_blob_proof(input, commitment, *SRS_INSTANCE);
+        CHECK(verify::verify_blob_kzg_proof(input, commitment, proof, &G2_TAU));
+        blobs.push_back(input); commitments.push_back(commitment); proofs.push_back(proof);
+    }
+    CHECK(batch::verify_blob_kzg_proof_batch(blobs, commitments, proofs, &G2_TAU) == true);
+    std::vector<G1Affine> bad = proofs; std::swap(bad[3], bad[4]);
+    CHECK(batch::verify_blob_kzg_proof_batch(blobs, commitments, bad, &G2_TAU) == false);
+    bad = commitments; bad[7] = commitments[8];
+    CHECK(batch::verify_blob_kzg_proof_batch(blobs, bad, proofs, &G2_TAU) == false);
+    CHECK(batch::verify_blob_kzg_proof_batch(blobs, commitments, proofs) == false);       // consts::G2_TAU belongs to another setup
+    std::vector<G1Affine> fewer(proofs.begin(), proofs.end() - 1);
+    CHECK(throws(KzgError::Kind::GenericError, "length's of the input are not the same", [&] { batch::verify_blob_kzg_proof_batch(blobs, commitments, fewer, &G2_TAU); }));   // batch.rs:21-27
+    CHECK(batch::verify_blob_kzg_proof_batch({}, {}, {}, &G2_TAU) == true);
+}
+static void test_kzg_batch_proof_invalid_curve_points() {        // :314-380
+    KZG kzg = KZG::new_();
+    const Blob input = Blob::from_raw_data(GETTYSBURG_ADDRESS_BYTES);
+    kzg.calculate_and_store_roots_of_unity(input.len());
+    const G1Affine commitment = kzg.commit_blob(input, *SRS_INSTANCE), proof = kzg.compute_blob_proof(input, commitment, *SRS_INSTANCE);
+    G1Affine off = commitment; off.xy[0] ^= 1;
+    CHECK(throws(KzgError::Kind::NotOnCurveError, "G1 point not on curve", [&] { batch::verify_blob_kzg_proof_batch({input}, {off}, {proof}, &G2_TAU); }));
+    CHECK(throws(KzgError::Kind::NotOnCurveError, "G1 point not on curve", [&] { batch::verify_blob_kzg_proof_batch({input}, {commitment}, {off}, &G2_TAU); }));
+    CHECK(throws(KzgError::Kind::NotOnCurveError, "G1 point not on curve", [&] { verify::verify_proof(off, proof, Fr::one(), Fr::one(), &G2_TAU); }));
+}
+// ---- primitives/tests/blob_test.rs (the container rules the prover relies on) ----------------------------------------------------------
+static void test_blob_padding_and_validation() {
+    const Blob b = Blob::from_raw_data(GETTYSBURG_ADDRESS_BYTES);
+    CHECK(b.len() % 32 == 0 && b.len() == (GETTYSBURG_ADDRESS_BYTES.size() + 30) / 31 * 32);
+    std::vector<uint8_t> raw = b.to_raw_data();
+    CHECK(raw.size() >= GETTYSBURG_ADDRESS_BYTES.size() && std::equal(GETTYSBURG_ADDRESS_BYTES.begin(), GETTYSBURG_ADDRESS_BYTES.end(), raw.begin()));
+    CHECK(Blob::new_(b.data()) == b);
+    CHECK(throws(KzgError::Kind::InvalidInputLength, "", [] { Blob::new_(std::vector<uint8_t>(33, 0)); }));
+    CHECK(throws(KzgError::Kind::InvalidFieldElement, "Field element at position 1 is not canonical or invalid", [] { std::vector<uint8_t> v(64, 0); for (int i = 32; i < 64; ++i) v[i] = 0xff; Blob::new_(v); }));
+    const PolynomialEvalForm p = b.to_polynomial_eval_form();
+    CHECK(p.len() == 64 && p.len_underlying_blob_bytes() == b.len() && p.len_underlying_blob_field_elements() == b.len() / 32);
+    CHECK(!p.get_evalualtion(64) && p.get_evalualtion(63) && *p.get_evalualtion(63) == Fr::zero());
+    uint8_t first[32]; std::memcpy(first, b.data().data(), 32);
+    CHECK(p.evaluations()[0] == Fr::from_be_bytes_mod_order(first));
+    const std::array<uint8_t, 32> round_trip = p.evaluations()[0].to_be_bytes();
+    CHECK(std::memcmp(round_trip.data(), first, 32) == 0);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) { std::fprintf(stderr, "usage: %s <tests/golden> <tau: 64 hex digits>\n", argv[0]); return 2; }
+    GOLDEN = argv[1];
+    uint8_t tau_be[32];
+    for (int i = 0; i < 32; ++i) { unsigned v = 0; std::sscanf(argv[2] + 2 * i, "%2x", &v); tau_be[i] = (uint8_t)v; }
+    const Fr tau = Fr::from_be_bytes_mod_order(tau_be);
+    GETTYSBURG_ADDRESS_BYTES = read_file(GOLDEN + "/gettysburg.txt");
+    try {
+        SRS_INSTANCE.reset(new SRS(SRS::generate(tau, 4096)));
+        G2_TAU = G2Affine::mul_generator(tau);
+        const std::pair<const char*, std::function<void()>> tests[] = {
+            {"test_srs_setup_errors", test_srs_setup_errors},
+            {"test_evaluate_polynomial_in_evaluation_form_random_blob_all_indexes", test_evaluate_polynomial_in_evaluation_form_random_blob_all_indexes},
+            {"test_commit_coeff_form_and_eval_form_equivalence", test_commit_coeff_form_and_eval_form_equivalence},
+            {"test_calculate_and_store_roots_of_unity", test_calculate_and_store_roots_of_unity},
+            {"test_g1_ifft_non_power_of_two_error", test_g1_ifft_non_power_of_two_error},
+            {"test_compute_blob_proof_invalid_commitment", test_compute_blob_proof_invalid_commitment},
+            {"test_compute_kzg_proof", test_compute_kzg_proof},
+            {"test_compute_kzg_proof_random_100_blobs", test_compute_kzg_proof_random_100_blobs},
+            {"test_kzg_zero_blob", test_kzg_zero_blob},
+            {"test_multiple_proof_random_100_blobs", test_multiple_proof_random_100_blobs},
+            {"test_kzg_batch_proof_invalid_curve_points", test_kzg_batch_proof_invalid_curve_points},
+            {"test_blob_padding_and_validation", test_blob_padding_and_validation},
+        };
+        for (const auto& t : tests) {
+            const int before = failures;
+            t.second();
+            std::printf("%s %s\n", failures == before ? "ok    " : "FAILED", t.first);
+            std::fflush(stdout);
+        }
+        // values for the cross-check in tests/test_gpu_cpp_mirror.py
+        KZG kzg = KZG::new_();
+        const Blob g = Blob::from_raw_data(GETTYSBURG_ADDRESS_BYTES);
+        kzg.calculate_and_store_roots_of_unity(g.len());
+        const PolynomialEvalForm p = g.to_polynomial_eval_form();
+        const G1Affine c = kzg.commit_blob(g, *SRS_INSTANCE), pi7 = kzg.compute_proof_with_known_z_fr_index(p, 7, *SRS_INSTANCE), pib = kzg.compute_blob_proof(g, c, *SRS_INSTANCE);
+        std::printf("value commitment %s\nvalue proof_index_7 %s\nvalue blob_proof %s\nvalue challenge %s\n", hex(c.xy.data(), 8).c_str(), hex(pi7.xy.data(), 8).c_str(),
+                    hex(pib.xy.data(), 8).c_str(), hex(helpers::compute_challenge(g, c).limbs.data(), 4).c_str());
+    } catch (const KzgError& e) {
+        std::printf("uncaught KzgError: %s\n", e.what());
+        return 3;
+    }
+    std::printf("%d failure(s)\n", failures);
+    return failures ? 1 : 0;
+}

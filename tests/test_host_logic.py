@@ -185,3 +185,17 @@ def test_shard_steps_per_launch_by_world_size(k, monkeypatch):
     assert ShardedMsm(None, n, 0, 8).auto_group() == 1
     monkeypatch.setenv("KZG_SHARD_GROUP", "3")
     assert ShardedMsm(None, n, 0, 8).auto_group() == 3
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_a_gpu(k, tmp_path):
+    """include/kzg_bn254_mi355x.hpp (the C++ mirror of the reference's Rust API) compiles warning-free against the C header, and a program
+    built on it has no CPU path to fall back to: without a HIP device its first call throws KzgError (device error)."""
+    import subprocess
+    exe = str(tmp_path / "reference_tests")
+    libdir = os.path.join(ROOT, "rust-kzg-bn254_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "reference_tests.cpp"), "-L" + libdir, "-lkzg_bn254_mi355x", "-Wl,-rpath," + libdir, "-o", exe])
+    if k._lib.load().kzg_device_count() > 0:
+        pytest.skip("a GPU is present: tests/test_gpu_cpp_mirror.py runs the program")
+    res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden"), "%064x" % 255], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 3 and "no HIP device available (this library has no CPU fallback)" in res.stdout, (res.returncode, res.stdout, res.stderr)
