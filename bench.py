@@ -409,6 +409,45 @@ def main():
     lib.kzg_ctx_get_msm_profile(ctx.handle, phase, C.byref(launches), C.byref(pairs))
     lib.kzg_ctx_set_profiling(ctx.handle, 0)
     phase_piped = [phase[i] / max(1, launches.value) for i in range(8)]
+
+    # ---- N > 1 only, outside `value`: the OTHER way to spend N GPUs on a stream of commitments -- whole commitments per rank, no exchange
+    # ("replicas": SURVEY 8e's throughput mode).  north_star prescribes the sharded form above (one commitment split N ways: lower latency
+    # per commitment, 82-97 % of linear); replicas run every GPU at the one-GPU rate.  Reported so that a user can choose; KZG_BENCH_REPLICAS=0
+    # skips it.  Local failures are reported, never raised: every rank still joins the collectives below.
+    replicas = None
+    if world > 1 and os.environ.get("KZG_BENCH_REPLICAS", "1") != "0":
+        rep_ok, rep_err, rep_res, rep_count = True, None, None, 2 * side_steps
+        srs_full = None
+        try:
+            srs_full = k.SRS.generate(tau, n, ctx=ctx)
+            d_full = [torch.from_numpy(np.ascontiguousarray(w).view(np.int64)).cuda() for w in wire_sets[:2]]
+            shr = ShardedMsm(ctx, n, 0, 1, gather_device=None, force_exchange=False)
+            full_ptrs = [d.data_ptr() for d in d_full]
+
+            def run_full(count):
+                last = None
+                for last in shr.commit_stream(srs_full, [full_ptrs[i % 2] for i in range(count)], depth=2, group=1):
+                    pass
+                return last
+            run_full(24)
+        except Exception as e:                                       # noqa: BLE001
+            rep_ok, rep_err = False, "%s: %s" % (type(e).__name__, e)
+        barrier()
+        t0 = time.perf_counter()
+        try:
+            if rep_ok:
+                rep_res = run_full(rep_count)
+        except Exception as e:                                       # noqa: BLE001
+            rep_ok, rep_err = False, "%s: %s" % (type(e).__name__, e)
+        barrier()
+        rep_el = time.perf_counter() - t0
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t_el = torch.tensor([rep_el], dtype=torch.float64, device=dev); dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        t_ok = torch.tensor([1 if rep_ok else 0], dtype=torch.int64, device=dev); dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        replicas = {"ok_on_every_rank": bool(t_ok.item()), "error_on_rank_0": rep_err, "commitments_per_rank": rep_count,
+                    "elapsed_s_max_over_ranks": float(t_el.item()), "result": rep_res, "buffer": (rep_count - 1) % 2}
+        if srs_full is not None:
+            srs_full.close()
     if gc_off:
         gc.enable()
 
@@ -422,6 +461,18 @@ def main():
                      and all(np.array_equal(r, wants[i % N_BUFFERS]) for i, r in enumerate(timed_results)))
         if not exact:
             exit_code = 3
+        replicas_out = None
+        if replicas is not None:
+            rep_exact = replicas["result"] is not None and bool(np.array_equal(replicas["result"], wants[replicas["buffer"]]))
+            if replicas["ok_on_every_rank"] and not rep_exact:
+                exit_code = 3
+            rate = world * replicas["commitments_per_rank"] / replicas["elapsed_s_max_over_ranks"] if replicas["ok_on_every_rank"] else None
+            replicas_out = {"is": "NOT `value`: every rank commits whole 2^%d-pair polynomials over its own copy of the SRS (no exchange); "
+                                  "the sharded form above is the one north_star prescribes" % LOG_N,
+                            "commitments_per_s": rate, "pairs_per_s": rate * n if rate else None,
+                            "ms_per_commitment_per_gpu": (replicas["elapsed_s_max_over_ranks"] / replicas["commitments_per_rank"] * 1e3) if rate else None,
+                            "commitments_per_rank": replicas["commitments_per_rank"], "bit_exact_vs_oracle": rep_exact if replicas["ok_on_every_rank"] else None,
+                            "error_on_rank_0": replicas["error_on_rank_0"]}
         ms_per_step = elapsed / args.steps * 1e3
         pairs_per_s = n * args.steps / elapsed
         acc_ms = phase_alone[4]                                   # k_msm_accumulate, average launch duration, running alone
@@ -467,6 +518,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIR * units_per_launch,
                          "note": "the binding resource is integer-VALU issue (254-bit modular multiply), see `valu`; traffic (PMC) exceeds the "
                                  "algorithmic bytes by design: one 64-byte precomputed-table point is gathered per (scalar, digit)"},
+            "replicas_mode": replicas_out,
             "phases_ms_per_launch": dict(zip(phase_names, phase_alone)),
             "phases_ms_per_launch_pipelined": dict(zip(phase_names, phase_piped)),
         }

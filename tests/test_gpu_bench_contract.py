@@ -99,6 +99,8 @@ def test_bench_two_ranks_gloo_is_bit_exact():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bit_exact_vs_oracle"] is True
     assert d["config"]["steps_per_launch"] == 4          # 2^17 pairs per rank: four steps of the stream per batched launch (10 = 4 + 4 + 2)
     assert d["value"] > 0 and d["value_uniform"] > 0 and d["latency_ms"] > 0
+    rep = d["replicas_mode"]                             # N > 1: whole commitments per rank beside the sharded headline (never `value`)
+    assert rep["bit_exact_vs_oracle"] is True and rep["commitments_per_s"] > 0 and rep["error_on_rank_0"] is None
 
 
 def test_bench_one_rank_through_rccl_takes_the_multi_gpu_path():
