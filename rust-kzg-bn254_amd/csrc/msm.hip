@@ -55,6 +55,7 @@ struct Plan {
     bool bitsum;         // tiny MSM over the per-bit tables as a plain sum: one result point (k_bitsum_level1 / 2)
     bool fused;          // sparse table-mode MSM: the first reduction level adds the sorted entries itself; its group g holds the buckets gp * G1 + g (set by msm_enqueue)
     bool quad;           // reduction levels on lane quads (curve_quad.h): no other MSM in flight when this one was planned
+    bool alone = false;  // planned with no other MSM of this context in flight
     bool dual1;          // first reduction level on two groups per workgroup (k_msm_bucket_bits1p_dual): fewer instructions, longer alone -> with another MSM in flight
     bool sort2;          // two-level sort (table mode, index fits 24 bits)
     bool sort_small;     // global-atomic sort (few entries)
@@ -100,12 +101,18 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) other_in_flight |= ctx->slot_pending[sl] != nullptr;
         p.quad = p.tables && (quad_env > 0 || (quad_env < 0 && !other_in_flight));
         if (ctx->reduction_lanes) p.quad = p.tables && ctx->reduction_lanes == 4;
+        p.alone = !other_in_flight;
     }
     int c;
     if (p.polys) {
         c = batch_bucket_bits(n / p.polys);                // 7: 64 buckets per polynomial (k_batch_finish); 13 / 15 / 16: whole units of 4 096 buckets (second level + host epilogue per polynomial)
     } else if (p.tables) {
         c = bases.c;
+        // NAF mode, 2^18 .. 2^19 - 1 pairs, nothing else in flight (the reference's bench_kzg_commit_8mb shape): 2^14 buckets instead of 2^15 --
+        // alone, the reductions cost their latency, not their instructions: 0.551 -> 0.525 ms at 2^18 (with other MSMs in flight 16 stays
+        // ahead, engine.h srs_naf_c; tools/archive/sweep_naf_c_alone.py).  An explicit KZG_NAF_C wins.
+        static const bool naf_c_forced = getenv("KZG_NAF_C") != nullptr;
+        if (p.naf && c == 16 && p.alone && !naf_c_forced && n < ((size_t)1 << 19)) c = 15;
     } else {
         c = ctx->msm_c_override;
         if (c == 0) { const char* env = getenv("KZG_MSM_C"); if (env) c = atoi(env); }

@@ -216,3 +216,37 @@ def test_eval_form_commitment_and_proofs_at_2_22_and_2_24(k, log_n):
             print("  2^%d evaluations: commit_eval_form %.1f ms, compute_proof %s %.1f ms (host buffers)" % (log_n, t_commit * 1e3, which, dt * 1e3))
     finally:
         srs.close()
+
+
+def test_naf_bucket_bits_follow_the_in_flight_state(k):
+    """An MSM of 2^18 .. 2^19 - 1 pairs over the per-bit tables runs with 2^14 buckets when nothing else is in flight on its context and
+    with 2^15 when another MSM is (msm.hip make_plan; the reference's bench_kzg_commit_8mb shape is the lone case).  Both plans, at the
+    edges of the range and inside it, against sum_i c_i tau^i G1 by big integers."""
+    ctx = k.default_context(); lib = k._lib.load()
+    N = 1 << 19
+    srs = k.SRS.generate(TAU, N)
+    rng = np.random.default_rng(1819)
+    try:
+        other = _to_wire([int.from_bytes(rng.bytes(40), "little") % R_ for _ in range(1 << 14)])
+        acc, tp = 0, 1
+        for v in pyref.frs_from_mont(other):
+            acc = (acc + v * tp) % R_; tp = tp * TAU % R_
+        want_other = pyref.ec_mul(acc, (1, 2))
+        for n in ((1 << 18) - 1, 1 << 18, (3 << 17) + 5, N - 1, N):
+            vals = [int.from_bytes(rng.bytes(40), "little") % R_ for _ in range(n)]
+            wire = _to_wire(vals)
+            acc, tp = 0, 1
+            for v in vals:
+                acc = (acc + v * tp) % R_; tp = tp * TAU % R_
+            want = pyref.ec_mul(acc, (1, 2))
+            out = np.zeros(8, np.uint64); o2 = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+            assert lib.kzg_msm_g1_srs(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n, k._lib.ptr(out), C.byref(inf)) == 0           # alone
+            assert pyref.point_from_wire(out) == want, (n, "alone")
+            assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(other), len(other), 1) == 0                        # another MSM in flight
+            assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, k._lib.ptr(wire), n, 0) == 0
+            assert lib.kzg_msm_g1_srs_end(ctx.handle, 0, k._lib.ptr(out), C.byref(inf), None) == 0
+            assert lib.kzg_msm_g1_srs_end(ctx.handle, 1, k._lib.ptr(o2), C.byref(inf), None) == 0
+            assert pyref.point_from_wire(out) == want, (n, "with another MSM in flight")
+            assert pyref.point_from_wire(o2) == want_other
+    finally:
+        srs.close()
