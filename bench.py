@@ -245,6 +245,11 @@ def main():
     backend = os.environ.get("KZG_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = 0
+    # stdout carries ONE line, the JSON: native libraries write to file descriptor 1 themselves (RCCL prints a five-line version banner
+    # there when its communicator comes up), so descriptor 1 points at stderr from here on and the line goes out through the saved one.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     # KZG_BENCH_FORCE_EXCHANGE=1: a ONE-rank run takes the N > 1 path end to end -- process group, the per-step all-gather of the partials
     # (RCCL with one rank), fold, every collective below.  What a one-GPU box can rehearse of the driver's multi-GPU run over real RCCL;
@@ -792,7 +797,8 @@ def main():
                                        "single_thread": {"value": (1 << 18) / ntt_1_s, "unit": "elements/s", "cores": 1,
                                                          "sample": "one forward 2^18 NTT, 1 thread, %.3f s wall" % ntt_1_s},
                                        "gpu_bit_exact_vs_oracle": ntt_exact}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         code = torch.tensor([exit_code], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.broadcast(code, src=0)

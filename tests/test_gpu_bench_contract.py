@@ -16,7 +16,7 @@ def test_bench_emits_the_contract_line():
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and [ln for ln in res.stdout.splitlines() if ln.strip()] == lines        # ONE line on stdout, nothing else
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -117,6 +117,7 @@ def test_bench_one_rank_through_rccl_takes_the_multi_gpu_path():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    assert [ln for ln in res.stdout.splitlines() if ln.strip()] == lines, res.stdout[:600]        # nothing but the line on stdout: RCCL's version banner goes to stderr
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["exchange_backend"] == "nccl"
     assert d["config"]["bit_exact_vs_oracle"] is True and d["config"]["steps_per_launch"] == 4
     assert d["value"] > 0 and d["value_uniform"] > 0 and d["latency_ms"] > 0
