@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (profiling runs)")
     ap.add_argument("--multi", action="store_true", help="ONE process driving --gpus devices through kzg_multi_* (no torch.distributed, no "
                     "collective): the other partitioning of SURVEY.md 8e; the driver's contract (one rank per GPU over RCCL) is the default mode")
-    args = ap.parse_args()
+    args, _unknown = ap.parse_known_args()          # (a launcher may append arguments of its own, e.g. --local-rank: ignored)
     if args.multi:
         return main_multi(args)
 
