@@ -137,6 +137,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto st : ctx->stream_x) if (st) (void)hipStreamSynchronize(st);
     msm_drop_slots(ctx);
+    ctx->last_sorted = nullptr; ctx->last_sorted_stream = nullptr;
     ctx->msm.release();
     for (auto& w : ctx->msm_x) w.release();
     for (auto& st : ctx->stream_x) if (st) { (void)hipStreamDestroy(st); st = nullptr; }

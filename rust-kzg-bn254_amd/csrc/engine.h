@@ -41,6 +41,7 @@ struct MsmWorkspace {
     hipEvent_t ev[N_PHASES] = {};
     bool ev_ready = false;
     hipEvent_t ev_done = nullptr;   // recorded behind the result copy of the MSM in flight on this workspace
+    hipEvent_t ev_sorted = nullptr; // recorded behind the sort of that MSM (in front of its accumulate kernel): the next MSM of the context starts behind it
     double phase_ms[N_PHASES] = {};
     uint64_t profiled_launches = 0;
     uint64_t profiled_pairs = 0;
@@ -93,6 +94,8 @@ struct kzg_ctx {
     kzg::DeviceBuffer rccl_buf;          // this rank's partial + the gathered partials of kzg_rccl_allgather_fold (multi.hip)
     kzg::PolySet poly[KZG_NUM_SLOTS];   // polynomial / proof pipeline scratch, one set per slot ([0] also serves the synchronous calls)
     kzg::MsmWorkspace& slot_msm(int slot) { return slot ? msm_x[slot - 1] : msm; }
+    hipEvent_t last_sorted = nullptr;          // ev_sorted of the most recently enqueued MSM launch of this context ...
+    hipStream_t last_sorted_stream = nullptr;  // ... and the stream it went to (msm.hip msm_enqueue)
     kzg::NttWorkspace& slot_ntt(int slot) { return slot ? ntt_x[slot - 1] : ntt; }
 };
 

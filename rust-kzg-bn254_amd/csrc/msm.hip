@@ -34,6 +34,7 @@ void MsmWorkspace::release() {
     if (pinned_out) { (void)hipHostFree(pinned_out); pinned_out = nullptr; }
     if (ev_ready) { for (auto& e : ev) (void)hipEventDestroy(e); ev_ready = false; }
     if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
+    if (ev_sorted) { (void)hipEventDestroy(ev_sorted); ev_sorted = nullptr; }
 }
 
 static int ilog2_floor(size_t n) { int k = 0; while ((n >> (k + 1)) != 0) ++k; return k; }
@@ -421,6 +422,18 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     }
 #define KZG_MARK(i) do { tick(i); if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[i], st)); } while (0)
 
+    // Staggered start.  Two MSMs enqueued back to back on two streams (the fill of a pipeline) run their phases in lock-step: both sort
+    // (memory-bound) and then both accumulate (VALU-bound), instead of one sorting beside the other's accumulate as in steady state,
+    // where MSM k + 2 is only enqueued once MSM k is done.  So this launch starts behind the SORT of the previous launch of the context
+    // when that went to another stream -- a no-op in steady state (that sort finished long ago), the natural stagger at the fill:
+    // 20-step regions (profiles/r04_ab_msm_stagger.txt): 2^17-pair steps, four per launch, 0.188 -> 0.183 ms per step; 2^18 / 2^19, two per launch,
+    // -0.7 %; long regions unchanged.  Only GROUPED launches wait (the sharded streams): a single 2^20-pair MSM planned alone lost 0.7 %
+    // (1.115 -> 1.122: its successor's sort starts 0.2 ms later and the first MSM runs on three wave slots either way).
+    // KZG_MSM_STAGGER=0: off, =2: every table-mode launch.
+    static const int stagger_env = []() { const char* e = getenv("KZG_MSM_STAGGER"); return e ? atoi(e) : 1; }();
+    const bool stagger = p.tables && (stagger_env >= 2 || (stagger_env == 1 && p.polys >= 2));
+    if (stagger && ctx->last_sorted && ctx->last_sorted_stream != st) KZG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_sorted, 0));
+
     uint32_t* d_offs = ws.offs.as<uint32_t>();
     auto scan_counts = [&]() {
         if (p.G <= SCAN1_MAX) {
@@ -540,6 +553,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_MARK(3);
     }
     KZG_MARK(4);
+    if (stagger_env >= 1 && p.tables) {                     // (recorded by every table-mode launch: the NEXT launch decides whether it waits)
+        if (!ws.ev_sorted) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_sorted, hipEventDisableTiming));
+        KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_sorted, st));
+        ctx->last_sorted = ws.ev_sorted;
+        ctx->last_sorted_stream = st;
+    }
     static const bool debug_sort = []() { const char* e = getenv("KZG_DEBUG_SORT"); return e && atoi(e) != 0; }();
     if (debug_sort && p.tables && batch == 1 && !p.polys) {
         int32_t rc = debug_check_sort(ctx, ws, st, p, d_scalars);
