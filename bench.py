@@ -157,6 +157,64 @@ def main_multi(args):
         raise SystemExit("bench.py --multi: a commitment differs from the expected point")
 
 
+class ClockSampler:
+    """Engine clock (and socket power) of THIS rank's GPU under the bench's load, read from sysfs every ~8 ms by a side thread:
+    /sys/class/drm/cardN/device/pp_dpm_sclk marks the current level with '*'.  Box-to-box differences of the headline (1.08 .. 1.14 ms per step
+    on the same code) should show here; nothing is set, only read.  Every failure (no sysfs, no match) leaves the report None."""
+
+    def __init__(self, device_index):
+        self.sclk_path = self.power_path = None
+        self.samples, self.power = [], []
+        self._stop = None
+        try:
+            import glob
+            props = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+            for dev in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(dev)) == want and os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+                    self.sclk_path = os.path.join(dev, "pp_dpm_sclk")
+                    hw = glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_input"))
+                    self.power_path = hw[0] if hw else None
+        except Exception:                                           # noqa: BLE001
+            self.sclk_path = None
+
+    def _read(self):
+        try:
+            for ln in open(self.sclk_path):
+                if "*" in ln:
+                    self.samples.append(float(ln.split(":")[1].lower().split("mhz")[0]))
+            if self.power_path:
+                self.power.append(float(open(self.power_path).read()) / 1e6)
+        except Exception:                                           # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        if self.sclk_path:
+            import threading
+            self._stop = threading.Event()
+
+            def loop():
+                while not self._stop.wait(0.008):
+                    self._read()
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._stop is not None:
+            self._stop.set()
+            self._thread.join()
+
+    def report(self):
+        if not self.samples:
+            return None
+        r = {"sclk_mhz_mean": sum(self.samples) / len(self.samples), "sclk_mhz_min": min(self.samples), "sclk_mhz_max": max(self.samples),
+             "samples": len(self.samples), "source": "sysfs pp_dpm_sclk of this GPU, every ~8 ms during the untimed spin-up steps (the same pipelined load as the timed region)"}
+        if self.power:
+            r["socket_power_w_mean"] = sum(self.power) / len(self.power)
+        return r
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher (no WORLD_SIZE in the environment): this process has only parsed its arguments --
     no HIP call, no device query beyond counting -- so it may start the N ranks itself: N fresh children of this interpreter with
@@ -374,7 +432,9 @@ def main():
         gc.disable()
     barrier()
     spinup_steps = int(os.environ.get("KZG_BENCH_SPINUP_STEPS", str(min(48 * world, 384))))
-    run_steps(spinup_steps, rot_ptrs, depth_used)
+    clocks = ClockSampler(local_rank)                                  # engine clock under this very load, sampled in the UNTIMED spin-up only:
+    with clocks:                                                        # inside a timed region the sysfs reads cost 4-10 % (1.15 -> 1.27 ms per step at 20 steps)
+        run_steps(spinup_steps, rot_ptrs, depth_used)
     run_steps(args.warmup, rot_ptrs, depth_used)                        # the W untimed warm-up steps
     timed_results = []
     elapsed, result = timed(args.steps, rot_ptrs, depth_used, keep=timed_results)    # THE timed region: exactly --steps steps, step k on buffer k mod N_BUFFERS
@@ -523,6 +583,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIR * units_per_launch,
                          "note": "the binding resource is integer-VALU issue (254-bit modular multiply), see `valu`; traffic (PMC) exceeds the "
                                  "algorithmic bytes by design: one 64-byte precomputed-table point is gathered per (scalar, digit)"},
+            "gpu_clock_under_load": clocks.report(),
             "replicas_mode": replicas_out,
             "phases_ms_per_launch": dict(zip(phase_names, phase_alone)),
             "phases_ms_per_launch_pipelined": dict(zip(phase_names, phase_piped)),

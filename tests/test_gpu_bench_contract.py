@@ -37,6 +37,8 @@ def test_bench_emits_the_contract_line():
     assert r["traffic"] is None and len(r["traffic_source"]) > 10     # PMC passes exist for the 2^20 workload only: null + the reason
     assert d["cpu_baseline_ntt"]["value"] > 0 and d["cpu_baseline_ntt"]["gpu_bit_exact_vs_oracle"] is True
     assert "phases_ms_per_launch" in d and "phases_ms_per_launch_pipelined" in d
+    clk = d["gpu_clock_under_load"]                      # sysfs engine clock sampled in the untimed spin-up (None where sysfs does not show this GPU)
+    assert clk is None or (200 < clk["sclk_mhz_min"] <= clk["sclk_mhz_mean"] <= clk["sclk_mhz_max"] < 4000 and clk["samples"] >= 1)
 
 
 def test_bench_n_gpus_without_launcher_starts_its_own_ranks():
