@@ -8,7 +8,8 @@
 // Algorithm (decimation in time, Stockham autosort, P = ceil(log n / 10) passes: 10 + 10 at n = 2^20):
 //   pass with radix R = 2^K brings the sub-transform length from n_cur/R to n_cur (stride s = N / n_cur):
 //     y[u + j * N/R] = sum_j'  w_{n_cur}^(p j') x[q + s (R p + j')] * w_R^(j j'),   u = q + s p
-//   A workgroup (512 threads, one per CU: 129 KB of LDS) owns tiles of C = 2048 / R consecutive units u.  Per tile: the R x C
+//   A workgroup (512 threads, one per CU, tiles of 2 048 elements: 2^19, 2^20, >= 2^25 -- or 256 threads, two per CU, tiles of 1 024:
+//   the other sizes, round 4) owns tiles of C = TILE / R consecutive units u.  Per tile: the R x C
 //   elements come from global memory as canonical 256-bit words (runs of C x 32 B), go through the K radix-2 butterfly stages in
 //   LDS (9 limb planes, padded rows; radix-4 steps in registers, their multiplies in independent PAIRS: fe_mul2), and leave as
 //   256-bit words again.  The inter-pass twiddle w_{n_cur'}^(p' j') of the NEXT pass is applied at the STORE of this pass (the
@@ -28,12 +29,25 @@
 
 namespace kzg {
 
-constexpr int NTT_TILE_LOG = 11;
-constexpr int NTT_TILE = 1 << NTT_TILE_LOG;       // elements per workgroup tile
 constexpr int NTT_KMAX = 10;
-constexpr int NTT_PL = NTT_TILE + (1 << NTT_KMAX); // plane length with one pad element per row
-constexpr int NTT_THREADS = 512;
-constexpr int NTT_EPT = NTT_TILE / NTT_THREADS;    // elements per thread in the load / store phases
+constexpr int NTT_EPT = 4;                         // elements per thread in the load / store phases = one radix-4 butterfly per thread and step
+// Two tile sizes (round 4).  2 048 elements / 512 threads, one workgroup per CU: transforms of >= 2^19 elements (>= 256 tiles per pass).
+// 1 024 elements / 256 threads, two workgroups per CU: smaller transforms -- twice the workgroups (2^18: 256 instead of 128 on 256
+// CUs; one tile of a <= 1 024-point transform in half the threads) and two independent barrier domains per CU:
+// 2^12 / 2^16 / 2^18 0.052 / 0.062 / 0.073 -> 0.040 / 0.046 / 0.057 ms per call; at 2^20 the big tile stays ahead (0.140 against 0.147).
+template <int TILE_LOG> struct NttTile {
+    static constexpr int LOG = TILE_LOG;
+    static constexpr int TILE = 1 << TILE_LOG;     // elements per workgroup tile
+    static constexpr int THREADS = TILE / NTT_EPT;
+    // plane length: rows x (C + 1) words in the row-major layout (C >= 16, so at most TILE / 16 rows), C x (R + 32 / C) in the
+    // column-major one (ntt_lds_pos) -> TILE + max(TILE / 16, 32) words
+    static constexpr int PL = TILE + (TILE / 16 > 32 ? TILE / 16 : 32);
+};
+constexpr int NTT_TILE_LOG_BIG = 11, NTT_TILE_LOG_SMALL = 10;
+// measured per call, small / big tile (tools/archive/time_ntt_variants.py, KZG_NTT_TILE_LOG=10 / 11): 2^10 0.034 / 0.043, 2^14 0.045 / 0.058,
+// 2^17 0.055 / 0.067, 2^18 0.059 / 0.071, 2^19 0.086 / 0.082, 2^20 0.155 / 0.136, 2^21 0.280 / 0.297, 2^22 0.537 / 0.562, 2^23 1.195 /
+// 1.246, 2^24 2.46 / 2.52, 2^25 5.31 / 5.34, 2^26 12.1 / 11.1 ms
+inline bool ntt_small_tile_pays(int log_n) { return log_n <= 18 || (log_n >= 21 && log_n <= 24); }
 constexpr int NTT_LO_BITS = 10;
 constexpr int NTT_TW = 1 << (NTT_KMAX - 1);        // per-tile twiddles w_R^t, t < R/2
 
@@ -106,8 +120,8 @@ struct NttPassArgs {
 };
 
 // global word index of element (uu, j) of tile `tile` on the INPUT side of the pass
-__device__ __forceinline__ size_t ntt_in_index(const NttPassArgs& a, uint32_t tile, uint32_t t, uint32_t& uu, uint32_t& j, bool& valid) {
-    const int log_c = NTT_TILE_LOG - a.K;
+__device__ __forceinline__ size_t ntt_in_index(const NttPassArgs& a, int tile_log, uint32_t tile, uint32_t t, uint32_t& uu, uint32_t& j, bool& valid) {
+    const int log_c = tile_log - a.K;
     const uint32_t C = 1u << log_c, R = 1u << a.K, s = 1u << a.log_s;
     if (s >= C) { uu = t & (C - 1); j = t >> log_c; }
     else { const uint32_t q = t & (s - 1); j = (t >> a.log_s) & (R - 1); uu = ((t >> (a.log_s + a.K)) << a.log_s) | q; }
@@ -117,7 +131,8 @@ __device__ __forceinline__ size_t ntt_in_index(const NttPassArgs& a, uint32_t ti
     return (size_t)q + ((size_t)(R * p + j) << a.log_s);
 }
 
-__global__ void __launch_bounds__(NTT_THREADS)
+template <int TILE_LOG>
+__global__ void __launch_bounds__(NttTile<TILE_LOG>::THREADS)
 k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, NttPassArgs a,
            const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
            const uint4* __restrict__ next_tw /* or nullptr: w_N^(E(idx)) of the next pass for every output index, canonical words of the internal form */
@@ -125,6 +140,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
            , unsigned long long* __restrict__ stamps /* diagnostic build (tools/ntt_stamps.py): 8 phase sums per workgroup, 100 MHz ticks */
 #endif
            ) {
+    constexpr int NTT_TILE_LOG = TILE_LOG, NTT_TILE = NttTile<TILE_LOG>::TILE, NTT_PL = NttTile<TILE_LOG>::PL, NTT_THREADS = NttTile<TILE_LOG>::THREADS;
     __shared__ int32_t lds[NL * NTT_PL];
     __shared__ int32_t twl[NL * NTT_TW];
     const int K = a.K, log_n = a.log_n;
@@ -136,11 +152,11 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
     const bool last = a.next_K == 0;
 
     // per-workgroup local twiddles w_R^t = w_N^(t * N/R), t < R/2 (the same for every tile of the pass)
-    if (tid < (R >> 1)) {
+    for (uint32_t t = tid; t < (R >> 1); t += NTT_THREADS) {
         Fr w;
-        twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, tid << (log_n - K));
+        twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, t << (log_n - K));
 #pragma unroll
-        for (int j = 0; j < NL; ++j) twl[j * NTT_TW + tid] = w.l[j];
+        for (int j = 0; j < NL; ++j) twl[j * NTT_TW + t] = w.l[j];
     }
     if (R == 1 && tid == 0) {
         Fr w; fe_set_one(w);
@@ -155,7 +171,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
 #pragma unroll
         for (int k = 0; k < NTT_EPT; ++k) {
             uint32_t uu, j; bool valid;
-            const size_t idx = ntt_in_index(a, tile, tid + k * NTT_THREADS, uu, j, valid);
+            const size_t idx = ntt_in_index(a, NTT_TILE_LOG, tile, tid + k * NTT_THREADS, uu, j, valid);
             if (valid) { pre[k][0] = in_words[2 * idx]; pre[k][1] = in_words[2 * idx + 1]; }
             else { pre[k][0] = make_uint4(0, 0, 0, 0); pre[k][1] = make_uint4(0, 0, 0, 0); }
         }
@@ -173,7 +189,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
 #pragma unroll
         for (int k = 0; k < NTT_EPT; ++k) {
             uint32_t uu, j; bool valid;
-            (void)ntt_in_index(a, tile, tid + k * NTT_THREADS, uu, j, valid);
+            (void)ntt_in_index(a, NTT_TILE_LOG, tile, tid + k * NTT_THREADS, uu, j, valid);
             const uint32_t w32[8] = {pre[k][0].x, pre[k][0].y, pre[k][0].z, pre[k][0].w, pre[k][1].x, pre[k][1].y, pre[k][1].z, pre[k][1].w};
             Fr v;
             fe_unpack(v, w32);                          // canonical, or < 3 m from the previous pass: both fine for the lazy stages
@@ -191,7 +207,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
 #pragma unroll
                 for (int k = 0; k < NTT_EPT; ++k) {
                     uint32_t uu, j; bool valid;
-                    const size_t idx = ntt_in_index(a, nt, tid + k * NTT_THREADS, uu, j, valid);
+                    const size_t idx = ntt_in_index(a, NTT_TILE_LOG, nt, tid + k * NTT_THREADS, uu, j, valid);
                     if (valid) { pre[k][0] = in_words[2 * idx]; pre[k][1] = in_words[2 * idx + 1]; }
                     else { pre[k][0] = make_uint4(0, 0, 0, 0); pre[k][1] = make_uint4(0, 0, 0, 0); }
                 }
@@ -458,6 +474,9 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
     uint4* bufs[2] = {ws->data.as<uint4>(), ws->tmp.as<uint4>()};
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    static const int tile_env = []() { const char* e = getenv("KZG_NTT_TILE_LOG"); return e ? atoi(e) : 0; }();    // 10 / 11: force one tile size (A/B)
+    const bool small_tile = tile_env == NTT_TILE_LOG_SMALL || (tile_env != NTT_TILE_LOG_BIG && ntt_small_tile_pays(log_n));
+    const int tile_log = small_tile ? NTT_TILE_LOG_SMALL : NTT_TILE_LOG_BIG;
     int log_ncur = 0;
     bool scale_folded = false;      // the inverse transform's 1 / n went into the twiddle array of the last pass boundary
     for (int pi = 0; pi < P; ++pi) {
@@ -471,12 +490,12 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
         a.next_log_s = last ? 0 : log_n - (log_ncur + Ks[pi + 1]);
         a.scale_log_n = (last && inverse && !scale_folded) ? log_n : -1;
         const uint32_t n_units = (uint32_t)(n >> a.K);
-        const uint32_t C = 1u << (NTT_TILE_LOG - a.K);
+        const uint32_t C = 1u << (tile_log - a.K);
         a.n_tiles = (n_units + C - 1) / C;
         const uint4* src = pi == 0 ? reinterpret_cast<const uint4*>(d_data) : bufs[(pi - 1) & 1];
         uint4* dst = last ? reinterpret_cast<uint4*>(d_data) : bufs[pi & 1];
-        // one workgroup per CU (129 KB of LDS); it walks its tiles with the next one's words prefetched
-        const uint32_t grid = std::min<uint32_t>(a.n_tiles, (uint32_t)cus);
+        // big tile: one workgroup per CU (97 KB of LDS); small tile: two (58 KB each); a workgroup walks its tiles with the next one's words prefetched
+        const uint32_t grid = std::min<uint32_t>(a.n_tiles, (uint32_t)cus * (small_tile ? 2u : 1u));
         const uint4* next_tw = nullptr;
         if (!last && log_n <= NTT_FULL_TW_MAX_LOG) {
             const bool fold = inverse && pi == P - 2;          // the boundary in front of the last pass carries the scaling
@@ -488,9 +507,15 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
         static unsigned long long* d_stamps = nullptr;     // [pass][workgroup][8]; read back by kzg_debug_ntt_stamps
         if (!d_stamps) KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_stamps), 4 * 1024 * 8 * 8));
         g_ntt_stamps = d_stamps;
-        hipLaunchKernelGGL(k_ntt_pass, dim3(grid), dim3(NTT_THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw, d_stamps + (size_t)pi * 1024 * 8);
+        if (small_tile)
+            hipLaunchKernelGGL(k_ntt_pass<NTT_TILE_LOG_SMALL>, dim3(grid), dim3(NttTile<NTT_TILE_LOG_SMALL>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw, d_stamps + (size_t)pi * 1024 * 8);
+        else
+            hipLaunchKernelGGL(k_ntt_pass<NTT_TILE_LOG_BIG>, dim3(grid), dim3(NttTile<NTT_TILE_LOG_BIG>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw, d_stamps + (size_t)pi * 1024 * 8);
 #else
-        hipLaunchKernelGGL(k_ntt_pass, dim3(grid), dim3(NTT_THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
+        if (small_tile)
+            hipLaunchKernelGGL(k_ntt_pass<NTT_TILE_LOG_SMALL>, dim3(grid), dim3(NttTile<NTT_TILE_LOG_SMALL>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
+        else
+            hipLaunchKernelGGL(k_ntt_pass<NTT_TILE_LOG_BIG>, dim3(grid), dim3(NttTile<NTT_TILE_LOG_BIG>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
 #endif
     }
     KZG_HIP_TRY(ctx, hipGetLastError());
