@@ -20,6 +20,7 @@ import pyref
 from pyref import R_
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TAU = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % R_
 MONT = (1 << 256) % R_
@@ -153,3 +154,33 @@ def test_randomised_soak_of_commit_and_proof():
     env = dict(os.environ, SOAK_SECONDS="10", SOAK_SEED="20261004")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_proof.py")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-400:] + r.stderr[-400:]
+
+
+NTT_TILE_CHILD = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import oracle as orc
+import rust_kzg_bn254_amd as k
+k.load(); ctx = k.default_context(); lib = k._lib.load()
+for log_n in list(range(0, 22)) + [24]:
+    n = 1 << log_n
+    rng = np.random.default_rng(4000 + log_n)
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1)
+    for inverse in (0, 1):
+        got = a.copy()
+        assert lib.kzg_fr_ntt(ctx.handle, k._lib.ptr(got), n, inverse) == 0
+        want = orc.fr_ntt_mt(a, inverse=bool(inverse)) if log_n >= 14 else orc.fr_ntt(a, inverse=bool(inverse))
+        assert np.array_equal(got, want), (log_n, inverse)
+print("tile %%s ok" %% os.environ["KZG_NTT_TILE_LOG"])
+'''
+
+
+@pytest.mark.parametrize("tile_log", [10, 11])
+def test_both_ntt_tile_sizes_at_every_transform_size(tile_log):
+    """The pass kernel exists for tiles of 1 024 and of 2 048 elements and the library picks one by transform size (ntt.hip
+    ntt_small_tile_pays); here each is FORCED for every log n 0 .. 21 and 24 (KZG_NTT_TILE_LOG, read when the library loads: a child process
+    per tile size) and compared with the oracle in both directions -- sizes the default never runs on that tile included."""
+    env = dict(os.environ, KZG_NTT_TILE_LOG=str(tile_log))
+    res = subprocess.run([sys.executable, "-c", NTT_TILE_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0 and ("tile %d ok" % tile_log) in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
