@@ -1,6 +1,6 @@
 """10 compute_proof calls (2^20 evaluations from host buffers, off-domain z) and 10 eval-form commitments, for rocprofv3 --kernel-trace."""
 import ctypes as C, hashlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch, bench
 import rust_kzg_bn254_amd as k
