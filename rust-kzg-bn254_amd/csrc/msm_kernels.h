@@ -861,6 +861,9 @@ k_msm_accumulate(const uint4* __restrict__ points, const uint32_t* __restrict__ 
             cont_in_regs = true;                       // kept in registers for the segmented scan below
         }
     };
+#ifdef KZG_ACC_STAMPS
+    stamp_loop = __builtin_amdgcn_s_memrealtime();         // end of the prologue (bucket search, first offsets)
+#endif
     if (active) {
         // two-deep software pipeline: index e+2 and point e+1 are in flight while entry e is added, so neither the index
         // load (dependent address) nor the 64-byte gather from the 1 GiB table is waited for inside an iteration.  The

@@ -1,20 +1,20 @@
 """Diagnostic: per-wave start / end time and placement of k_msm_accumulate (library variant built with -DKZG_ACC_STAMPS)."""
 import ctypes as C, hashlib, os, sys, collections
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("KZG_LIB_PATH", os.path.join(ROOT, "gpurun_variants", "libkzg_stamps.so"))
 import numpy as np, torch, bench
 import rust_kzg_bn254_amd as k
 from rust_kzg_bn254_amd import _lib
-n = 1 << 20
+n = 1 << int(os.environ.get("LOG_N", "20"))
 lib = _lib.load(); ctx = k.Context(0)
 tau = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big") % bench.FR
-srs = k.SRS.generate(tau, n, ctx=ctx)
+srs = k.SRS.generate(tau, 1 << 20, ctx=ctx)
 d = torch.from_numpy(bench.blob_like_scalars(n, 12345).view(np.int64)).cuda(); torch.cuda.synchronize()
 out = np.zeros(8, np.uint64); inf = C.c_uint8(0)
 for it in range(6):
     lib.kzg_msm_g1_srs_device(ctx.handle, srs.handle, 0, C.c_void_p(d.data_ptr()), n, _lib.ptr(out), C.byref(inf))
-nw = 3072
+nw = int(os.environ.get("NW", "3072"))
 st = np.zeros((nw, 8), np.uint64)
 dbg = C.CDLL(os.environ["KZG_LIB_PATH"]).kzg_debug_acc_stamps
 dbg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
