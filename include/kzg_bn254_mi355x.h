@@ -260,6 +260,56 @@ int32_t kzg_commit_eval_form_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, siz
 int32_t kzg_compute_proof_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t shard_lo,
                                   const uint64_t* evals_mont, size_t n, const uint64_t* roots_mont, size_t n_roots,
                                   const uint64_t z_mont[4], uint64_t out_xyzz_mont[16], uint64_t* out_y_mont);
+/* ---- BASELINE config 4 sharded by EVALUATION index over the Lagrange basis (csrc/lagrange.hip) --------------------------
+ * The reference commits an evaluation-form polynomial as MSM(g1_ifft(srs), evals) (prover/src/kzg.rs:96-100) and a proof as the same MSM
+ * over the evaluations of the quotient q_i = (f_i - y) / (w^i - z) (kzg.rs:151-177; the entry of a domain point z = w^m: kzg.rs:237-260).
+ * Both are sums over the evaluation index, so a rank that holds the Lagrange points L_i and the evaluations f_i of a contiguous index
+ * range [lo, lo + len) needs nothing else: it uploads, inverts and divides its OWN slice (4 MiB at n = 2^20 over 8 ranks) -- no replicated
+ * upload, no IFFT, no whole-polynomial quotient (the kzg_*_partial forms above do all three on every rank).  Two small exchanges per proof:
+ *     phase 1   S_g = sum_{i in slice} f_i w^i / (z - w^i)   ->  all-gather of G x 64 B  ->  y = (z^n - 1) / n sum_g S_g   (helpers.rs:507-532;
+ *               z = w^m: y = f_m, sent by the slice that owns m, helpers.rs:497-504)
+ *     phase 2   q_i on the slice, MSM over the slice          ->  all-gather of G x 256 B ->  proof = fold of the partial points (+ q_m L_m)
+ * Results are the SAME field elements and the same affine point as kzg_compute_proof / kzg_commit_eval_form on one GPU.
+ *
+ * kzg_srs_slice            a copy of srs[lo, lo + len) as an SRS handle of its own (its own window / per-bit tables)
+ * kzg_srs_lagrange_shard   KZG::g1_ifft(n) of the first n points of `srs` (kzg.rs:263-285), of which the points [lo, lo + len) are kept as a
+ *                          handle of their own: this rank's shard of the Lagrange basis (one-time set-up; errors as kzg_g1_ifft).  A host that
+ *                          already holds the Lagrange points uploads its slice with kzg_srs_upload instead. */
+int32_t kzg_srs_slice(kzg_ctx* ctx, const kzg_srs* srs, size_t lo, size_t len, kzg_srs** out);
+int32_t kzg_srs_lagrange_shard(kzg_ctx* ctx, const kzg_srs* srs, size_t n, size_t lo, size_t len, kzg_srs** out);
+/* KZG::commit_eval_form (kzg.rs:84-104) of this rank's slice: sum_{i in slice} f_i L_i, unconverted (16 words, folded with
+ * kzg_g1_fold_partials).  len > kzg_srs_len(lagrange_shard) -> KZG_ERR_SRS_CAPACITY_EXCEEDED. */
+int32_t kzg_commit_eval_form_lagrange_partial(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const uint64_t* evals_slice_mont, size_t len,
+                                              uint64_t out_xyzz_mont[16]);
+int32_t kzg_commit_eval_form_lagrange_partial_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const void* d_evals_slice_mont, size_t len,
+                                                     uint64_t out_xyzz_mont[16]);
+/* KZG::compute_proof_impl (kzg.rs:128-178) on a slice, in four steps on `slot` (the asynchronous slots of kzg_msm_g1_srs_begin; several
+ * proofs may be in flight on different slots):
+ *   _begin       enqueue: upload of the slice (or, _device, the caller's resident buffer read in place: keep it untouched until _end),
+ *                the inverses 1 / (w^i - z) of the slice (one inversion per 1 024 elements, side by side) and S_g.  shard_lo = index of the
+ *                slice's first evaluation; shard_lo + len <= n, len <= kzg_srs_len(lagrange_shard), n a power of two <= 2^28.
+ *   _partial_y   waits for phase 1: out_ypart = 8 words, S_g | f_m (f_m only from the slice that owns m when z = w^m, else zero)
+ *   kzg_lagrange_fold_y        (host only) y from the G gathered 8-word parts
+ *   _continue    enqueue: y goes up, q_i on the slice, the slice's MSM over the Lagrange shard
+ *   _end         waits: out_part = 32 words: [0,16) XYZZ partial | [16,20) T_g = sum_{i != m} q_i w^i (z = w^m only) | [20,28) L_m, [28] = 1
+ *                (the owner of m only) | zeros
+ *   kzg_lagrange_fold_proof    (host only) the proof point from the G gathered 32-word parts (z = w^m: + q_m L_m, q_m = -(1/z) sum_g T_g)
+ *   _abort       gives up whatever the slot has in flight (a peer failed between two phases)
+ * An empty slice (len = 0) is valid in every step and contributes zeros / the identity.  A step called out of order, or on a slot that is
+ * busy otherwise -> KZG_ERR_INVALID_ARG. */
+#define KZG_LAGRANGE_YPART_WORDS 8
+#define KZG_LAGRANGE_PART_WORDS 32
+int32_t kzg_compute_proof_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const uint64_t* evals_slice_mont,
+                                         size_t len, size_t n, const uint64_t z_mont[4], int32_t slot);
+int32_t kzg_compute_proof_lagrange_begin_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont,
+                                                size_t len, size_t n, const uint64_t z_mont[4], int32_t slot);
+int32_t kzg_compute_proof_lagrange_partial_y(kzg_ctx* ctx, int32_t slot, uint64_t out_ypart_mont[8]);
+int32_t kzg_compute_proof_lagrange_continue(kzg_ctx* ctx, int32_t slot, const uint64_t y_mont[4]);
+int32_t kzg_compute_proof_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t out_part[32]);
+int32_t kzg_compute_proof_lagrange_abort(kzg_ctx* ctx, int32_t slot);
+int32_t kzg_lagrange_fold_y(const uint64_t* yparts_mont, size_t count, size_t n, const uint64_t z_mont[4], uint64_t out_y_mont[4]);
+int32_t kzg_lagrange_fold_proof(const uint64_t* parts, size_t count, size_t n, const uint64_t z_mont[4], uint64_t out_xy_mont[8],
+                                uint8_t* out_is_infinity);
 /* ---- several GPUs behind one handle (no torch, no RCCL) ------------------------------------------------------
  * One context, one resident SRS shard and one host thread per entry of device_ids (an id may appear more than once: several
  * contexts on one GPU).  Device g holds the SRS powers [g N / G, (g+1) N / G) and commits that slice of every polynomial; the G

@@ -125,6 +125,18 @@ PROTOTYPES = {
     "kzg_evaluate_blobs_in_evaluation_form_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, sz, u64p]),
     "kzg_rccl_allgather_fold": (i32, [vp, vp, i32, u64p, u64p, u8p]),
     "kzg_commit_coeff_form_rccl": (i32, [vp, vp, vp, sz, vp, i32, u64p, u8p]),
+    "kzg_srs_slice": (i32, [vp, vp, sz, sz, C.POINTER(vp)]),
+    "kzg_srs_lagrange_shard": (i32, [vp, vp, sz, sz, sz, C.POINTER(vp)]),
+    "kzg_commit_eval_form_lagrange_partial": (i32, [vp, vp, u64p, sz, u64p]),
+    "kzg_commit_eval_form_lagrange_partial_device": (i32, [vp, vp, vp, sz, u64p]),
+    "kzg_compute_proof_lagrange_begin": (i32, [vp, vp, sz, u64p, sz, sz, u64p, i32]),
+    "kzg_compute_proof_lagrange_begin_device": (i32, [vp, vp, sz, vp, sz, sz, u64p, i32]),
+    "kzg_compute_proof_lagrange_partial_y": (i32, [vp, i32, u64p]),
+    "kzg_compute_proof_lagrange_continue": (i32, [vp, i32, u64p]),
+    "kzg_compute_proof_lagrange_end": (i32, [vp, i32, u64p]),
+    "kzg_compute_proof_lagrange_abort": (i32, [vp, i32]),
+    "kzg_lagrange_fold_y": (i32, [u64p, sz, sz, u64p, u64p]),
+    "kzg_lagrange_fold_proof": (i32, [u64p, sz, sz, u64p, u64p, u8p]),
     "kzg_verify_blob_kzg_proof": (i32, [vp, u8p, sz, u64p, u64p, u64p, C.POINTER(i32)]),
     "kzg_verify_blob_kzg_proof_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, u64p, sz, u64p, C.POINTER(i32)]),
 }

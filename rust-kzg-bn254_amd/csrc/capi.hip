@@ -58,6 +58,14 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
 int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot);
 int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
+// Lagrange-sharded proofs (lagrange.hip)
+int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* evals, bool on_device, size_t len, size_t n, const uint64_t z[4], int slot);
+int32_t lag_partial_y(kzg_ctx* ctx, int slot, uint64_t out[8]);
+int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]);
+int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32]);
+void lag_abort(kzg_ctx* ctx, int slot);
+int32_t lag_fold_y(const uint64_t* parts, size_t count, size_t n, const uint64_t z[4], uint64_t out_y[4]);
+int32_t lag_fold_proof(const uint64_t* parts, size_t count, size_t n, const uint64_t z[4], uint64_t out_xy[8], uint8_t* out_inf);
 int32_t vb_evaluate_setup(kzg_ctx* ctx, size_t packed_len, size_t nb);
 int32_t vb_evaluate_enqueue(kzg_ctx* ctx, const uint8_t* packed, const void* meta_host, size_t nb, size_t b0, size_t b1, const uint64_t* zs,
                             uint8_t* small_pinned);
@@ -332,22 +340,36 @@ int32_t kzg_srs_has_bit_tables(kzg_srs* srs, int32_t build) {
     return srs_bits(srs) ? 1 : 0;
 }
 
-// Lagrange basis of the first n points as an SRS of its own (device resident, with its window tables)
-static int32_t build_lagrange(kzg_ctx* ctx, const kzg_srs* srs, size_t n, kzg_srs** out) {
+// Lagrange basis of the first n points as an SRS of its own (device resident, with its window tables); len < n: only the points
+// [lo, lo + len) of it are kept (a rank's shard of the basis, kzg_srs_lagrange_shard)
+static int32_t build_lagrange(kzg_ctx* ctx, const kzg_srs* srs, size_t n, kzg_srs** out, size_t lo = 0, size_t len = (size_t)-1) {
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;             // kzg.rs:265-269
     if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;                               // kzg.rs:275-278
     if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
+    if (len == (size_t)-1) len = n;
     kzg_srs* s = new (std::nothrow) kzg_srs();
     if (!s) return KZG_ERR_INVALID_ARG;
     s->ctx = ctx;
-    s->n = n;
+    s->n = len;
     s->lagrange_of = n;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n * 64);
+    uint4* full = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&full), n * 64);
     if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(lagrange srs)"); }
-    int32_t rc = g1_ifft_device(ctx, srs, n, s->d_points, false);
+    int32_t rc = g1_ifft_device(ctx, srs, n, full, false);
     if (rc == KZG_OK) { hipError_t e2 = hipStreamSynchronize(ctx->stream); if (e2 != hipSuccess) rc = set_error(ctx, e2, "g1_ifft"); }
-    if (rc == KZG_OK) rc = srs_precompute(ctx, s);
-    if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
+    if (rc == KZG_OK && len != n) {                                                 // keep the slice only
+        uint4* part = nullptr;
+        if (len) {
+            e = hipMalloc(reinterpret_cast<void**>(&part), len * 64);
+            if (e == hipSuccess) e = hipMemcpy(part, full + 4 * lo, len * 64, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) { if (part) (void)hipFree(part); part = nullptr; rc = set_error(ctx, e, "lagrange shard"); }
+        }
+        (void)hipFree(full);
+        full = part;
+    }
+    s->d_points = full;
+    if (rc == KZG_OK && len) rc = srs_precompute(ctx, s);
+    if (rc != KZG_OK) { if (s->d_points) (void)hipFree(s->d_points); delete s; return rc; }
     *out = s;
     return KZG_OK;
 }
@@ -358,6 +380,37 @@ int32_t kzg_srs_lagrange(kzg_ctx* ctx, const kzg_srs* srs, size_t n, kzg_srs** o
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return build_lagrange(ctx, srs, n, out);
+}
+
+int32_t kzg_srs_lagrange_shard(kzg_ctx* ctx, const kzg_srs* srs, size_t n, size_t lo, size_t len, kzg_srs** out) {
+    if (!ctx || !srs || srs->ctx != ctx || !out) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (lo > n || len > n - lo) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return build_lagrange(ctx, srs, n, out, lo, len);
+}
+
+int32_t kzg_srs_slice(kzg_ctx* ctx, const kzg_srs* srs, size_t lo, size_t len, kzg_srs** out) {
+    if (!ctx || !srs || srs->ctx->device != ctx->device || !out) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (lo > srs->n || len > srs->n - lo) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    kzg_srs* s = new (std::nothrow) kzg_srs();
+    if (!s) return KZG_ERR_INVALID_ARG;
+    s->ctx = ctx;
+    s->n = len;
+    s->lagrange_of = srs->lagrange_of;
+    if (len) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), len * 64);
+        if (e == hipSuccess) e = hipMemcpy(s->d_points, srs->d_points + 4 * lo, len * 64, hipMemcpyDeviceToDevice);   // table 0 of `srs` = its points
+        if (e != hipSuccess) { if (s->d_points) (void)hipFree(s->d_points); delete s; return set_error(ctx, e, "kzg_srs_slice"); }
+        int32_t rc = srs_precompute(ctx, s);
+        if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
+    }
+    *out = s;
+    return KZG_OK;
 }
 
 int32_t kzg_srs_cache_lagrange(kzg_ctx* ctx, kzg_srs* srs, size_t n) {
@@ -794,6 +847,77 @@ int32_t kzg_compute_proof_partial(kzg_ctx* ctx, const kzg_srs* srs_shard, size_t
     return proof_run(ctx, srs_shard, evals_mont, n, z_mont, nullptr, nullptr, out_y_mont, true, shard_lo, out_xyzz_mont);
 }
 
+// ---- config 4 sharded by evaluation index over the Lagrange basis (lagrange.hip) --------------------------------------------------
+int32_t kzg_commit_eval_form_lagrange_partial(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const uint64_t* evals_slice_mont, size_t len,
+                                              uint64_t out_xyzz_mont[16]) {
+    if (!ctx || !lagrange_shard || !out_xyzz_mont) return KZG_ERR_INVALID_ARG;
+    if (len > lagrange_shard->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;              // kzg.rs:89-94
+    return msm_srs_common(ctx, lagrange_shard, 0, evals_slice_mont, false, len, nullptr, nullptr, out_xyzz_mont);
+}
+int32_t kzg_commit_eval_form_lagrange_partial_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const void* d_evals_slice_mont, size_t len,
+                                                     uint64_t out_xyzz_mont[16]) {
+    if (!ctx || !lagrange_shard || !out_xyzz_mont) return KZG_ERR_INVALID_ARG;
+    if (len > lagrange_shard->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
+    return msm_srs_common(ctx, lagrange_shard, 0, d_evals_slice_mont, true, len, nullptr, nullptr, out_xyzz_mont);
+}
+static int32_t lagrange_begin_common(kzg_ctx* ctx, const kzg_srs* shard, size_t lo, const void* evals, bool on_device, size_t len, size_t n,
+                                     const uint64_t z[4], int32_t slot) {
+    if (!ctx || !shard || shard->ctx->device != ctx->device || !z || (len && !evals)) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;           // helpers.rs:485-487
+    if (n > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    if (lo > n || len > n - lo) return KZG_ERR_INVALID_ARG;
+    if (len > shard->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;                        // kzg.rs:89-94 (commit_eval_form of the quotient)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lag_begin(ctx, shard, lo, evals, on_device, len, n, z, slot);
+}
+int32_t kzg_compute_proof_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const uint64_t* evals_slice_mont,
+                                         size_t len, size_t n, const uint64_t z_mont[4], int32_t slot) {
+    return lagrange_begin_common(ctx, lagrange_shard, shard_lo, evals_slice_mont, false, len, n, z_mont, slot);
+}
+int32_t kzg_compute_proof_lagrange_begin_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont,
+                                                size_t len, size_t n, const uint64_t z_mont[4], int32_t slot) {
+    return lagrange_begin_common(ctx, lagrange_shard, shard_lo, d_evals_slice_mont, true, len, n, z_mont, slot);
+}
+int32_t kzg_compute_proof_lagrange_partial_y(kzg_ctx* ctx, int32_t slot, uint64_t out_ypart_mont[8]) {
+    if (!ctx || !out_ypart_mont) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lag_partial_y(ctx, slot, out_ypart_mont);
+}
+int32_t kzg_compute_proof_lagrange_continue(kzg_ctx* ctx, int32_t slot, const uint64_t y_mont[4]) {
+    if (!ctx || !y_mont) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lag_continue(ctx, slot, y_mont);
+}
+int32_t kzg_compute_proof_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t out_part[32]) {
+    if (!ctx || !out_part) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lag_end(ctx, slot, out_part);
+}
+int32_t kzg_compute_proof_lagrange_abort(kzg_ctx* ctx, int32_t slot) {
+    if (!ctx) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    lag_abort(ctx, slot);
+    return KZG_OK;
+}
+int32_t kzg_lagrange_fold_y(const uint64_t* yparts_mont, size_t count, size_t n, const uint64_t z_mont[4], uint64_t out_y_mont[4]) {
+    if (!z_mont || !out_y_mont || (count && !yparts_mont)) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;
+    if (n > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    return lag_fold_y(yparts_mont, count, n, z_mont, out_y_mont);
+}
+int32_t kzg_lagrange_fold_proof(const uint64_t* parts, size_t count, size_t n, const uint64_t z_mont[4], uint64_t out_xy_mont[8],
+                                uint8_t* out_is_infinity) {
+    if (!z_mont || !out_xy_mont || (count && !parts)) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;
+    if (n > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    return lag_fold_proof(parts, count, n, z_mont, out_xy_mont, out_is_infinity);
+}
+
 static size_t next_pow2_sz(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
 
 int32_t kzg_blob_to_fr(kzg_ctx* ctx, const uint8_t* blob_bytes, size_t len, uint64_t* out_mont, size_t cap, size_t* n_out) {
@@ -825,6 +949,8 @@ int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_by
     void* d = nullptr;
     int32_t rc = blob_to_fr_run(ctx, blob_bytes, len, n, &d);                        // Blob::to_polynomial_eval_form
     if (rc != KZG_OK) return rc;
+    if (const kzg_srs* cached = srs_cached_lagrange(srs, n))                         // commit_eval_form's literal form (kzg.rs:98-100): MSM over the cached Lagrange basis
+        return msm_run(ctx, srs_bases(cached, 0, n, ctx->msm_c_override == 0), d, n, out_xy_mont, out_is_infinity, nullptr);
     rc = ntt_run(ctx, d, n, true);                                                   // commit_eval_form: IFFT ...
     if (rc != KZG_OK) return rc;
     return msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), d, n, out_xy_mont, out_is_infinity, nullptr);   // ... + MSM
@@ -853,6 +979,8 @@ static int32_t commit_begin_common(kzg_ctx* ctx, const kzg_srs* srs, const uint6
         KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.scalars.p, evals_mont, n * 32, hipMemcpyHostToDevice, st));
         d = ws.scalars.p;
     }
+    if (const kzg_srs* cached = srs_cached_lagrange(srs, n))                         // no IFFT: MSM over the cached Lagrange basis
+        return msm_begin(ctx, slot, srs_bases(cached, 0, n, ctx->msm_c_override == 0), d, n);
     NttTables tb;                                                                    // make sure the tables exist before the slot stream reads them
     int log_n = 0; while (((size_t)1 << log_n) < n) ++log_n;
     if (n > 1) { rc = ntt_get_tables(ctx, log_n, true, &tb); if (rc != KZG_OK) return rc; }
@@ -1029,12 +1157,16 @@ static int32_t blob_proof_common(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t
     if (rc != KZG_OK) return rc;
     if (!commitment_in) {
         // commit_blob on a copy of the evaluations (the IFFT is in place); runs beside the hash
-        KZG_HIP_TRY(ctx, ctx->msm.scalars.reserve(n * 32 + 32));
-        KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm.scalars.p, d_evals, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-        rc = ntt_run(ctx, ctx->msm.scalars.p, n, true);
-        if (rc != KZG_OK) return rc;
         uint64_t cxy[8]; uint8_t cinf = 0;
-        rc = msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), ctx->msm.scalars.p, n, cxy, &cinf, nullptr);
+        if (const kzg_srs* cached = srs_cached_lagrange(srs, n)) {                   // the evaluations themselves are the scalars: no copy, no IFFT
+            rc = msm_run(ctx, srs_bases(cached, 0, n, ctx->msm_c_override == 0), d_evals, n, cxy, &cinf, nullptr);
+        } else {
+            KZG_HIP_TRY(ctx, ctx->msm.scalars.reserve(n * 32 + 32));
+            KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm.scalars.p, d_evals, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            rc = ntt_run(ctx, ctx->msm.scalars.p, n, true);
+            if (rc != KZG_OK) return rc;
+            rc = msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), ctx->msm.scalars.p, n, cxy, &cinf, nullptr);
+        }
         if (rc != KZG_OK) return rc;
         commitment = kzg_host::g1_from_wire(cxy);
         if (out_commitment_xy) memcpy(out_commitment_xy, cxy, 64);

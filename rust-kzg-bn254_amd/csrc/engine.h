@@ -64,7 +64,19 @@ struct NttWorkspace {
 
 }  // namespace kzg
 
-namespace kzg { struct MsmPending; }
+namespace kzg {
+struct MsmPending;
+// a proof over a slice of the evaluations and the matching slice of a Lagrange basis, in flight on one slot (lagrange.hip)
+struct LagProof {
+    int phase = 0;                 // 0 idle; 1 inverses + partial barycentric sum enqueued; 2 partial collected, waiting for y; 3 quotient (+ MSM) enqueued
+    const kzg_srs* shard = nullptr;
+    const void* d_evals = nullptr; // the caller's resident evaluations (read in place), or nullptr: the slot's copy
+    size_t base = 0, len = 0, n = 0;   // the slice holds the evaluations [base, base + len) of the n-point domain
+    bool on_domain = false;        // z = w^m
+    uint32_t m = 0;
+    bool msm_started = false;      // len > 0: an MSM is pending on the slot
+};
+}
 #ifndef KZG_NUM_SLOTS
 #define KZG_NUM_SLOTS 4      // slots of the asynchronous calls (include/kzg_bn254_mi355x.h: KZG_NUM_SLOTS)
 #endif
@@ -93,6 +105,7 @@ struct kzg_ctx {
     size_t vb_pinned_bytes = 0;
     kzg::DeviceBuffer rccl_buf;          // this rank's partial + the gathered partials of kzg_rccl_allgather_fold (multi.hip)
     kzg::PolySet poly[KZG_NUM_SLOTS];   // polynomial / proof pipeline scratch, one set per slot ([0] also serves the synchronous calls)
+    kzg::LagProof lag[KZG_NUM_SLOTS];   // Lagrange-sharded proofs in flight (kzg_compute_proof_lagrange_*)
     kzg::MsmWorkspace& slot_msm(int slot) { return slot ? msm_x[slot - 1] : msm; }
     hipEvent_t last_sorted = nullptr;          // ev_sorted of the most recently enqueued MSM launch of this context ...
     hipStream_t last_sorted_stream = nullptr;  // ... and the stream it went to (msm.hip msm_enqueue)

@@ -13,8 +13,7 @@
 // and level.  (Round 1 / first half of round 2: one Fermat inversion per lane, 381 dependent multiplies = 213 us on the
 // critical path of every proof, whatever n.)  Results are identical field elements.
 // Also: helpers::calculate_roots_of_unity (helpers.rs:553-589) as a kernel.
-#include "engine.h"
-#include "field29.h"
+#include "poly_common.h"
 #include "fe_invert.h"
 
 #include <algorithm>
@@ -24,57 +23,6 @@
 
 namespace kzg {
 
-constexpr int POLY_THREADS = 256;
-constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
-
-__device__ __forceinline__ void pl_load(Fr& v, const int32_t* __restrict__ planes, size_t stride, size_t i) {
-#pragma unroll
-    for (int j = 0; j < NL; ++j) v.l[j] = planes[(size_t)j * stride + i];
-}
-__device__ __forceinline__ void pl_store(int32_t* __restrict__ planes, size_t stride, size_t i, const Fr& v) {
-#pragma unroll
-    for (int j = 0; j < NL; ++j) planes[(size_t)j * stride + i] = v.l[j];
-}
-__device__ __forceinline__ void domain_elem(Fr& w, const NttTables& tb, uint32_t E) {   // w^E, result in (-m, 2m)
-    pl_load(w, tb.lo, tb.lo_len, E & (tb.lo_len - 1));
-    uint32_t eh = E >> tb.lo_bits;
-    if (eh != 0) {
-        Fr h;
-        pl_load(h, tb.hi, tb.hi_len, eh);
-        fe_mul(w, w, h);
-    }
-}
-__device__ __forceinline__ void wire_load(Fr& v, const uint4* __restrict__ src, size_t i) {   // wire -> internal, (-m, 2m)
-    uint4 a = src[2 * i], b = src[2 * i + 1];
-    uint32_t w32[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    fe_from_wire(v, w32);
-}
-__device__ __forceinline__ void wire_store(uint4* __restrict__ dst, size_t i, const Fr& v) {  // internal (|v| < 169 m) -> wire
-    uint32_t w32[8];
-    fe_to_wire(w32, v);
-    dst[2 * i] = make_uint4(w32[0], w32[1], w32[2], w32[3]);
-    dst[2 * i + 1] = make_uint4(w32[4], w32[5], w32[6], w32[7]);
-}
-// block-wide sum of one Fr per thread (values in (-m, 2m)); result (reduced) valid in thread 0
-__device__ __forceinline__ void block_sum(Fr& v, int32_t* lds /* NL * POLY_THREADS */) {
-    const int t = threadIdx.x;
-    int level = 0;
-    for (int d = POLY_THREADS / 2; d >= 1; d >>= 1, ++level) {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) lds[j * POLY_THREADS + t] = v.l[j];
-        __syncthreads();
-        if (t < d) {
-            Fr u;
-#pragma unroll
-            for (int j = 0; j < NL; ++j) u.l[j] = lds[j * POLY_THREADS + t + d];
-            fe_add(v, v, u);
-            fe_norm(v);
-            if (level == 3) fe_reduce(v);        // 16 terms so far: |v| < 32 m -> back to (-m, 2m)
-        }
-        __syncthreads();
-    }
-    if (t == 0) fe_reduce(v);
-}
 
 struct ProofScalars {        // device-resident small state of one proof computation
     uint32_t on_domain_index; // NO_INDEX if z is not a domain element
@@ -759,140 +707,20 @@ int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_
     return KZG_OK;
 }
 
-// ---- host Fr arithmetic on wire words (Montgomery, R = 2^256) for the one inversion of a proof -------------------------
-namespace {
-typedef unsigned __int128 hu128;
-const uint64_t H_FR[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-const uint64_t H_FR_NINV = 0xc2e1f593efffffffULL;          // -r^-1 mod 2^64
-const uint64_t H_FR_R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};   // 2^512 mod r
-bool h_geq_r(const uint64_t t[4]) {
-    for (int i = 3; i >= 0; --i) if (t[i] != H_FR[i]) return t[i] > H_FR[i];
-    return true;
-}
-void h_sub_r(uint64_t t[4]) {
-    uint64_t br = 0;
-    for (int i = 0; i < 4; ++i) { hu128 d = (hu128)t[i] - H_FR[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
-}
-void h_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
-    uint64_t t[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 4; ++i) {
-        hu128 c = 0;
-        for (int j = 0; j < 4; ++j) { c += (hu128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-        hu128 top = (hu128)t[4] + (uint64_t)c;
-        const uint64_t m = t[0] * H_FR_NINV;
-        c = ((hu128)m * H_FR[0] + t[0]) >> 64;
-        for (int j = 1; j < 4; ++j) { c += (hu128)m * H_FR[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-        top += (uint64_t)c;
-        t[3] = (uint64_t)top; t[4] = (uint64_t)(top >> 64);
-    }
-    if (t[4] || h_geq_r(t)) h_sub_r(t);
-    memcpy(out, t, 32);
-}
-// out = a - b mod r (both < r)
-void h_fr_sub(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
-    uint64_t t[4], br = 0;
-    for (int i = 0; i < 4; ++i) { hu128 d = (hu128)a[i] - b[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
-    if (br) { hu128 c = 0; for (int i = 0; i < 4; ++i) { c += (hu128)t[i] + H_FR[i]; t[i] = (uint64_t)c; c >>= 64; } }
-    memcpy(out, t, 32);
-}
-// a^(r-2), wire in / wire out
-void h_fr_inv(const uint64_t a[4], uint64_t out[4]) {
-    uint64_t e[4] = {H_FR[0] - 2, H_FR[1], H_FR[2], H_FR[3]};
-    uint64_t acc[4], base[4];
-    const uint64_t one_int[4] = {1, 0, 0, 0};
-    h_fr_mul(H_FR_R2, one_int, acc);                         // 1 in wire form
-    memcpy(base, a, 32);
-    for (int i = 0; i < 254; ++i) {
-        if ((e[i >> 6] >> (i & 63)) & 1) h_fr_mul(acc, base, acc);
-        h_fr_mul(base, base, base);
-    }
-    memcpy(out, acc, 32);
-}
-// 1/(i - 1), -1/2, 1/(-i - 1) in wire form, i = 5^((r-1)/4) (= w_n^(n/4) for every n >= 4: arkworks' roots are powers of 5^((r-1)/2^28))
-const uint64_t* h_on_domain_constants() {
-    static const struct Init {
-        uint64_t c[12];
-        Init() {
-            const uint64_t one_int[4] = {1, 0, 0, 0}, five_int[4] = {5, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
-            uint64_t one_w[4], five_w[4], two_w[4], qi[4], acc[4], base[4], t[4];
-            h_fr_mul(H_FR_R2, one_int, one_w);
-            h_fr_mul(H_FR_R2, five_int, five_w);
-            uint64_t e[4] = {H_FR[0] - 1, H_FR[1], H_FR[2], H_FR[3]};            // (r - 1) / 4
-            for (int i = 0; i < 4; ++i) e[i] = (e[i] >> 2) | (i < 3 ? e[i + 1] << 62 : 0);
-            memcpy(acc, one_w, 32); memcpy(base, five_w, 32);
-            for (int i = 0; i < 254; ++i) {
-                if ((e[i >> 6] >> (i & 63)) & 1) h_fr_mul(acc, base, acc);
-                h_fr_mul(base, base, base);
-            }
-            memcpy(qi, acc, 32);
-            h_fr_sub(qi, one_w, t); h_fr_inv(t, c);                             // 1 / (i - 1)
-            h_fr_sub(zero, one_w, two_w); h_fr_sub(two_w, one_w, two_w);         // -2
-            h_fr_inv(two_w, c + 4);                                             // -1/2
-            h_fr_sub(zero, qi, t); h_fr_sub(t, one_w, t); h_fr_inv(t, c + 8);   // 1 / (-i - 1)
-        }
-    } init;
-    return init.c;
-}
-// w_(2^k) and its inverse in wire form, k <= 28: arkworks' roots of unity are the powers of g = 5^((r-1)/2^28)
-struct HRoots { uint64_t w[29][4], winv[29][4]; };
-const HRoots& h_roots() {
-    static const struct Init {
-        HRoots r;
-        Init() {
-            const uint64_t one_int[4] = {1, 0, 0, 0}, five_int[4] = {5, 0, 0, 0};
-            uint64_t acc[4], base[4];
-            h_fr_mul(H_FR_R2, one_int, acc);
-            h_fr_mul(H_FR_R2, five_int, base);
-            uint64_t e[4] = {H_FR[0] - 1, H_FR[1], H_FR[2], H_FR[3]};            // (r - 1) >> 28
-            for (int i = 0; i < 4; ++i) e[i] = (e[i] >> 28) | (i < 3 ? e[i + 1] << 36 : 0);
-            for (int i = 0; i < 254; ++i) {
-                if ((e[i >> 6] >> (i & 63)) & 1) h_fr_mul(acc, base, acc);
-                h_fr_mul(base, base, base);
-            }
-            memcpy(r.w[28], acc, 32);
-            for (int k = 27; k >= 0; --k) h_fr_mul(r.w[k + 1], r.w[k + 1], r.w[k]);
-            h_fr_inv(r.w[28], r.winv[28]);
-            for (int k = 27; k >= 0; --k) h_fr_mul(r.winv[k + 1], r.winv[k + 1], r.winv[k]);
-        }
-    } init;
-    return init.r;
-}
-// m with w_n^m = z for a z of the n-point domain (n = 2^log_n, z^n = 1): one bit per step, lowest first (Pohlig-Hellman in a group of
-// order 2^k: ~k^2 / 2 host multiplications, 3 us at k = 11).  Returns false if z turns out not to be a power of w_n.
-bool h_domain_index(const uint64_t z[4], int log_n, uint32_t* m_out) {
-    const HRoots& R = h_roots();
-    uint64_t one_w[4];
-    const uint64_t one_int[4] = {1, 0, 0, 0};
-    h_fr_mul(H_FR_R2, one_int, one_w);
-    uint64_t h[4];
-    memcpy(h, z, 32);
-    uint32_t m = 0;
-    for (int b = 0; b < log_n; ++b) {
-        uint64_t t[4];
-        memcpy(t, h, 32);
-        for (int q = 0; q < log_n - 1 - b; ++q) h_fr_mul(t, t, t);      // h^(2^(k-1-b)) = (-1)^(bit b of m)
-        if (memcmp(t, one_w, 32) != 0) {
-            m |= 1u << b;
-            h_fr_mul(h, R.winv[log_n - b], h);                         // h *= w_n^-(2^b) = w_(n / 2^b)^-1
-        }
-    }
-    if (memcmp(h, one_w, 32) != 0) return false;
-    *m_out = m;
-    return true;
-}
-}  // namespace
 
 // Enqueue the O(n) part of a proof on `st` with the buffers of `ps_set`, without waiting: upload, denominators + batch
 // inversion, y, quotient (+ on-domain entry), IFFT of the quotient.  y is copied back into ps_set.pinned + 2048 (valid once the
 // stream has been synchronised); the quotient's coefficients are left in ps_set.c.
+// skip_intt: the caller commits the quotient's EVALUATIONS over a Lagrange basis (prover/src/kzg.rs:96-100 applied to the quotient, exactly
+// what the reference's compute_proof_impl does: kzg.rs:176-177), so they stay in set.c as they are.
 static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWorkspace* nttws, const uint64_t* evals, size_t n,
-                             const uint64_t z[4], bool want_proof) {
+                             const uint64_t z[4], bool want_proof, bool skip_intt = false) {
     RoctxRange range(want_proof ? "kzg:proof:inverses + y + quotient + intt" : "kzg:evaluate:inverses + y");
     int log_n = ilog2_exact(n);
     NttTables tb;
     int32_t rc = ntt_get_tables(ctx, log_n, false, &tb);
     if (rc != KZG_OK) return rc;
-    if (want_proof && n > 1) { NttTables tbi; rc = ntt_get_tables(ctx, log_n, true, &tbi); if (rc != KZG_OK) return rc; }
+    if (want_proof && n > 1 && !skip_intt) { NttTables tbi; rc = ntt_get_tables(ctx, log_n, true, &tbi); if (rc != KZG_OK) return rc; }
     // lanes of the last level: 4 elements each (one coset), at least one block
     const int per_lane = 4;           // = the coset size of the last inversion level (k_poly_inverses)
     uint32_t blocks = (uint32_t)((n + (size_t)POLY_THREADS * per_lane - 1) / ((size_t)POLY_THREADS * per_lane));
@@ -986,7 +814,7 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
             hipLaunchKernelGGL(k_poly_quotient_on_domain_known, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, partial, blocks,
                                m_known, ps_out, set.c.as<uint4>());
         KZG_HIP_TRY(ctx, hipGetLastError());
-        return ntt_run(ctx, set.c.p, n, true, st, nttws);
+        return skip_intt ? KZG_OK : ntt_run(ctx, set.c.p, n, true, st, nttws);
     }
     // one upload for the scalar image (pin[0, 1024) -> small[0, 1024)) and the chain's scalars right behind it (pin + 1024 -> small + 1024)
     static_assert(sizeof(ProofScalars) <= 1024, "the ProofScalars image and the zt table are uploaded as one block");
@@ -1034,7 +862,13 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
                            set.c.as<uint4>());
     KZG_HIP_TRY(ctx, hipGetLastError());
     // commit_eval_form(quotient): coefficients = IFFT(q), then MSM over the monomial SRS (kzg.rs:176-177)
-    return ntt_run(ctx, set.c.p, n, true, st, nttws);
+    return skip_intt ? KZG_OK : ntt_run(ctx, set.c.p, n, true, st, nttws);
+}
+// The cached Lagrange basis of exactly n points, if the SRS carries one (KZG_PROOF_LAGRANGE=0: never -- the IFFT + monomial-basis form, A/B)
+static const kzg_srs* proof_lagrange_basis(const kzg_srs* srs, size_t n) {
+    static const bool off = []() { const char* e = getenv("KZG_PROOF_LAGRANGE"); return e && atoi(e) == 0; }();
+    if (off || n < 2 || srs->lagrange_of != 0) return nullptr;
+    return srs_cached_lagrange(srs, n);
 }
 static void proof_read_y(const PolySet& set, uint64_t* out_y) {
     const ProofScalars* host = reinterpret_cast<const ProofScalars*>(static_cast<const uint8_t*>(set.pinned) + 3072);
@@ -1049,8 +883,15 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
     }
     PolySet& set = ctx->poly[0];
     hipStream_t st = ctx->stream;
-    int32_t rc = proof_enqueue(ctx, set, st, &ctx->ntt, evals, n, z, want_proof);
+    // a Lagrange basis of n points cached with the SRS (kzg_srs_cache_lagrange): the quotient is committed in evaluation form, no IFFT
+    const kzg_srs* lag = (want_proof && srs && coeff_lo == 0) ? proof_lagrange_basis(srs, n) : nullptr;
+    int32_t rc = proof_enqueue(ctx, set, st, &ctx->ntt, evals, n, z, want_proof, lag != nullptr);
     if (rc != KZG_OK) { (void)hipStreamSynchronize(st); return rc; }
+    if (lag) {
+        rc = msm_run(ctx, srs_bases(lag, 0, n, ctx->msm_c_override == 0), set.c.p, n, out_xy, out_inf, out_xyzz);
+        if (rc == KZG_OK && out_y) proof_read_y(set, out_y);
+        return rc;
+    }
     // the whole SRS commits the whole quotient; a shard holding powers [coeff_lo, coeff_lo + srs->n) commits its slice of it
     if (!want_proof || coeff_lo >= n) {
         KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1074,9 +915,10 @@ int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, siz
     int32_t rc = msm_slot_stream(ctx, slot, &st);
     if (rc != KZG_OK) return rc;
     PolySet& set = ctx->poly[slot];
-    rc = proof_enqueue(ctx, set, st, &ctx->slot_ntt(slot), evals, n, z, true);
+    const kzg_srs* lag = proof_lagrange_basis(srs, n);
+    rc = proof_enqueue(ctx, set, st, &ctx->slot_ntt(slot), evals, n, z, true, lag != nullptr);
     if (rc != KZG_OK) { (void)hipStreamSynchronize(st); return rc; }
-    return msm_begin(ctx, slot, srs_bases(srs, 0, n, ctx->msm_c_override == 0), set.c.p, n);
+    return msm_begin(ctx, slot, srs_bases(lag ? lag : srs, 0, n, ctx->msm_c_override == 0), set.c.p, n);
 }
 int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y) {
     int32_t rc = msm_end(ctx, slot, out_xy, out_inf, nullptr);

@@ -482,6 +482,142 @@ class ShardedKzg:
         return (proof, y) if want_y else proof
 
 
+def gather_words(words, world: int, device=None, force_collective: bool = False):
+    """all-gather of one fixed-size u64 vector per rank -> (world, len) uint64 (the two small exchanges of a Lagrange-sharded proof)."""
+    words = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
+    if world == 1 and not force_collective:
+        return words.reshape(1, -1).copy()
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(words.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return torch.stack(outs).cpu().numpy().view(np.uint64)
+
+
+class ShardedKzgLagrange:
+    """`KZG::commit_eval_form` / `KZG::compute_proof` sharded by EVALUATION index (BASELINE config 4 without replicated work): rank g
+    holds the Lagrange points L_i = g1_ifft(srs)[i] (prover/src/kzg.rs:263-285) and receives the evaluations f_i of i in [lo, hi) only.
+        commit:  sum_{i in slice} f_i L_i                    -> one all-gather of the 128-byte partials            (kzg.rs:96-100)
+        proof:   S_g = sum f_i w^i / (z - w^i) on the slice   -> all-gather of 64 B -> y                           (helpers.rs:507-532)
+                 q_i = (f_i - y) / (w^i - z) on the slice, MSM over the slice -> all-gather of 256 B -> fold      (kzg.rs:151-177, :237-260)
+    No rank uploads, transforms or divides the whole polynomial (ShardedKzg above does all three on every rank).
+    A rank whose local step fails still joins both exchanges with a POISON payload; every rank then raises ShardError."""
+
+    YPART, PART = 8, 32
+
+    def __init__(self, ctx, lagrange_shard, n: int, rank: int = 0, world: int = 1, gather_device="cuda", bounds=None, force_exchange=False):
+        self.ctx, self.srs, self.n, self.rank, self.world = ctx, lagrange_shard, n, rank, world
+        self.lo, self.hi = bounds if bounds is not None else shard_bounds(n, rank, world)
+        self.len = self.hi - self.lo
+        if len(lagrange_shard) < self.len:
+            raise ValueError("Lagrange shard shorter than this rank's slice")
+        self.gather_device = gather_device
+        self.force = bool(force_exchange)
+
+    @classmethod
+    def from_monomial(cls, ctx, srs, n: int, rank: int = 0, world: int = 1, **kw):
+        """Set-up from a monomial SRS of >= n points resident on this rank's GPU: g1_ifft(n) once, keep the rank's slice."""
+        lo, hi = kw.get("bounds") or shard_bounds(n, rank, world)
+        return cls(ctx, srs.lagrange_shard(n, lo, hi - lo), n, rank, world, **kw)
+
+    def _gather(self, words):
+        return gather_words(words, self.world, self.gather_device, self.force)
+
+    def _check(self, got, step):
+        bad = [r for r in range(got.shape[0]) if np.all(got[r] == np.uint64(0xFFFFFFFFFFFFFFFF))]
+        if bad:
+            raise ShardError(step, bad)
+
+    def _slice(self, polynomial_or_slice):
+        ev = polynomial_or_slice.evaluations() if hasattr(polynomial_or_slice, "evaluations") else polynomial_or_slice
+        ev = _lib.as_u64(ev, 4).reshape(-1, 4)
+        if len(ev) == self.n and self.len != self.n:
+            ev = ev[self.lo:self.hi]                  # a whole polynomial was passed: this rank reads its slice of it
+        if len(ev) != self.len:
+            raise ValueError("expected the %d evaluations of this rank's slice" % self.len)
+        return np.ascontiguousarray(ev)
+
+    def commit_eval_form(self, polynomial_or_slice):
+        part = np.zeros(16, dtype=np.uint64)
+        try:
+            ev = self._slice(polynomial_or_slice)
+            rc = _lib.load().kzg_commit_eval_form_lagrange_partial(self.ctx.handle, self.srs.handle, _lib.ptr(ev) if self.len else None,
+                                                                   self.len, _lib.ptr(part))
+            self.ctx.check_device(rc)
+            if rc != _lib.OK:
+                raise ValueError(_lib.status_message(rc))
+        except Exception:                                   # noqa: BLE001 -- reported to every rank through the exchange
+            if self.world == 1 and not self.force:
+                raise
+            part = POISON.copy()
+        got = self._gather(part)
+        self._check(got, 0)
+        return fold_partials(got)
+
+    def compute_proof(self, polynomial_or_slice, z_fr, want_y=False, slot=0):
+        lib = _lib.load()
+        z = np.ascontiguousarray(_lib.as_u64(z_fr, 0).reshape(4))
+        exchanging = self.world > 1 or self.force
+        failed = None
+        ypart = np.zeros(self.YPART, dtype=np.uint64)
+        try:
+            ev = self._slice(polynomial_or_slice)
+            rc = lib.kzg_compute_proof_lagrange_begin(self.ctx.handle, self.srs.handle, self.lo, _lib.ptr(ev) if self.len else None, self.len,
+                                                      self.n, _lib.ptr(z), slot)
+            self.ctx.check_device(rc)
+            if rc != _lib.OK:
+                raise ValueError(_lib.status_message(rc))
+            rc = lib.kzg_compute_proof_lagrange_partial_y(self.ctx.handle, slot, _lib.ptr(ypart))
+            self.ctx.check_device(rc)
+            if rc != _lib.OK:
+                raise ValueError(_lib.status_message(rc))
+        except Exception as e:                              # noqa: BLE001
+            if not exchanging:
+                raise
+            failed = e
+            ypart = np.full(self.YPART, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        got = self._gather(ypart)
+        bad = [r for r in range(got.shape[0]) if np.all(got[r] == np.uint64(0xFFFFFFFFFFFFFFFF))]
+        y = np.zeros(4, dtype=np.uint64)
+        part = np.zeros(self.PART, dtype=np.uint64)
+        if bad:                                             # every rank still issues the second exchange, then raises
+            if failed is None:
+                lib.kzg_compute_proof_lagrange_abort(self.ctx.handle, slot)
+            part[:] = 0xFFFFFFFFFFFFFFFF
+        else:
+            try:
+                rc = lib.kzg_lagrange_fold_y(_lib.ptr(np.ascontiguousarray(got)), got.shape[0], self.n, _lib.ptr(z), _lib.ptr(y))
+                if rc != _lib.OK:
+                    raise ValueError(_lib.status_message(rc))
+                rc = lib.kzg_compute_proof_lagrange_continue(self.ctx.handle, slot, _lib.ptr(y))
+                self.ctx.check_device(rc)
+                if rc != _lib.OK:
+                    raise ValueError(_lib.status_message(rc))
+                rc = lib.kzg_compute_proof_lagrange_end(self.ctx.handle, slot, _lib.ptr(part))
+                self.ctx.check_device(rc)
+                if rc != _lib.OK:
+                    raise ValueError(_lib.status_message(rc))
+            except Exception as e:                          # noqa: BLE001
+                if not exchanging:
+                    raise
+                failed = e
+                lib.kzg_compute_proof_lagrange_abort(self.ctx.handle, slot)
+                part[:] = 0xFFFFFFFFFFFFFFFF
+        got2 = self._gather(part)
+        bad2 = sorted(set(bad) | {r for r in range(got2.shape[0]) if np.all(got2[r] == np.uint64(0xFFFFFFFFFFFFFFFF))})
+        if bad2:
+            raise ShardError(0, bad2, failed)
+        out = np.zeros(8, dtype=np.uint64)
+        inf = C.c_uint8(0)
+        rc = lib.kzg_lagrange_fold_proof(_lib.ptr(np.ascontiguousarray(got2)), got2.shape[0], self.n, _lib.ptr(z), _lib.ptr(out), C.byref(inf))
+        if rc != _lib.OK:
+            raise ValueError(_lib.status_message(rc))
+        return (out, y) if want_y else out
+
+
 class MultiKzg:
     """Several GPUs behind one handle in ONE process (`kzg_multi_*`): device g holds the SRS powers [g N / G, (g+1) N / G) and one
     host thread of the library drives it; partial sums are folded on the host.  No torch, no collective: what a Rust host binds

@@ -102,6 +102,29 @@ class SRS:
         out.ctx, out.order, out.handle, out._n = self.ctx, n, h, n
         return out
 
+    def lagrange_shard(self, n: int, lo: int, length: int) -> "SRS":
+        """The points [lo, lo + length) of the Lagrange basis of the first n points as an SRS of their own (`kzg_srs_lagrange_shard`): one
+        rank's shard of the basis for the evaluation-index sharding of BASELINE config 4 (sharding.ShardedKzgLagrange)."""
+        h = C.c_void_p()
+        rc = _lib.load().kzg_srs_lagrange_shard(self.ctx.handle, self.handle, n, lo, length, C.byref(h))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
+        out = SRS.__new__(SRS)
+        out.ctx, out.order, out.handle, out._n = self.ctx, length, h, length
+        return out
+
+    def slice(self, lo: int, length: int) -> "SRS":
+        """A copy of the points [lo, lo + length) as an SRS of their own, with its own tables (`kzg_srs_slice`)."""
+        h = C.c_void_p()
+        rc = _lib.load().kzg_srs_slice(self.ctx.handle, self.handle, lo, length, C.byref(h))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
+        out = SRS.__new__(SRS)
+        out.ctx, out.order, out.handle, out._n = self.ctx, length, h, length
+        return out
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.load().kzg_srs_free(self.handle)
