@@ -1,6 +1,7 @@
 /* One process per GPU from plain C: the rank's shard of a known-tau SRS, its slice of the coefficients resident in HBM, and
  * kzg_commit_coeff_form_rccl -- partial MSM + ONE RCCL all-gather of the 128-byte partial sums + fold -- with a communicator this
- * program creates itself (the calling sequence a Rust host makes with its own RCCL binding).  Run as ONE rank it checks the result
+ * program creates itself (the calling sequence a Rust host makes with its own RCCL binding); then BASELINE config 4 the same way:
+ * kzg_commit_eval_form_rccl / kzg_compute_proof_rccl on the rank's slice of the evaluations and of the Lagrange basis.  Run as ONE rank it checks the result
  * against the plain single-GPU commitment; with RANK / WORLD_SIZE set (and the unique id passed through KZG_RCCL_ID_FILE, written by
  * rank 0) every rank prints the same point.
  *   gcc -O2 -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ examples/rccl_commit.c -o examples/rccl_commit \
@@ -48,11 +49,11 @@ int main(void) {
     }
     ncclComm_t comm;
     if (ncclCommInitRank(&comm, world, id, rank) != ncclSuccess) { printf("ncclCommInitRank failed\n"); return 1; }
-    /* this rank's shard: SRS powers [lo, hi) and the coefficient slice (all ones) resident on the device */
+    /* this rank's shard: SRS powers [lo, hi) and the coefficient slice resident on the device */
     kzg_srs* shard = NULL;
     CHECK_KZG(kzg_srs_generate(ctx, tau, lo, hi - lo, &shard));
     uint64_t* coeffs = malloc(n * 32);
-    for (size_t i = 0; i < n; ++i) memcpy(coeffs + 4 * i, one, 32);
+    for (size_t i = 0; i < n; ++i) memcpy(coeffs + 4 * i, (i % 3) ? one : tau, 32);     /* 5, 1, 1, 5, 1, 1, .. */
     void* d_slice = NULL;
     if (hipMalloc(&d_slice, (hi - lo) * 32) != hipSuccess || hipMemcpy(d_slice, coeffs + 4 * lo, (hi - lo) * 32, hipMemcpyHostToDevice) != hipSuccess) return 1;
     uint64_t xy[8]; uint8_t inf = 0;
@@ -64,6 +65,34 @@ int main(void) {
         CHECK_KZG(kzg_commit_coeff_form(ctx, shard, coeffs, n, want, &inf));
         ok = memcmp(xy, want, 64) == 0;
         printf("one-rank RCCL commitment %s the plain commitment\n", ok ? "==" : "!=");
+    }
+    /* BASELINE config 4, one call per rank each: the rank's shard of the LAGRANGE basis (g1_ifft once, its slice kept) and its slice of the
+     * EVALUATIONS -> commitment, then a proof at z (two small exchanges inside: partial barycentric sums -> y, partial points -> proof).
+     * No rank uploads, transforms or divides more than its own slice.  A failing rank still joins the collectives and the others get
+     * KZG_ERR_PEER (kzg_ctx_last_error names it); a missing rank shows up as KZG_ERR_EXCHANGE_TIMEOUT after KZG_EXCHANGE_TIMEOUT_S. */
+    {
+        kzg_srs* full = NULL; kzg_srs* lag = NULL;
+        CHECK_KZG(kzg_srs_generate(ctx, tau, 0, n, &full));                    /* (a real host loads the ceremony file: kzg_srs_load_compressed_be) */
+        CHECK_KZG(kzg_srs_lagrange_shard(ctx, full, n, lo, hi - lo, &lag));    /* one-time set-up */
+        kzg_srs_free(full);
+        uint64_t c4[8], p4[8], y4[4], z[4];
+        memcpy(z, tau, 32);                                                    /* any field element; 5 is not a domain point */
+        CHECK_KZG(kzg_commit_eval_form_rccl(ctx, lag, coeffs + 4 * lo, hi - lo, comm, world, c4, &inf));
+        CHECK_KZG(kzg_compute_proof_rccl(ctx, lag, lo, coeffs + 4 * lo, hi - lo, n, z, comm, world, p4, &inf, y4));
+        printf("rank %d of %d: config 4 over RCCL, commitment x limb 0 = %016llx, proof x limb 0 = %016llx\n", rank, world,
+               (unsigned long long)c4[0], (unsigned long long)p4[0]);
+        if (world == 1) {                   /* one rank: the same polynomial through the one-GPU calls */
+            kzg_srs* mono = NULL;
+            uint64_t wc[8], wp[8], wy[4];
+            CHECK_KZG(kzg_srs_generate(ctx, tau, 0, n, &mono));
+            CHECK_KZG(kzg_commit_eval_form(ctx, mono, coeffs, n, wc, &inf));
+            CHECK_KZG(kzg_compute_proof(ctx, mono, coeffs, n, NULL, n, z, wp, &inf, wy));
+            const int same = memcmp(c4, wc, 64) == 0 && memcmp(p4, wp, 64) == 0 && memcmp(y4, wy, 32) == 0;
+            printf("one-rank config 4 over RCCL %s the one-GPU commitment, proof and y\n", same ? "==" : "!=");
+            ok = ok && same;
+            kzg_srs_free(mono);
+        }
+        kzg_srs_free(lag);
     }
     ncclCommDestroy(comm);
     hipFree(d_slice); kzg_srs_free(shard); kzg_ctx_destroy(ctx); free(coeffs);

@@ -52,7 +52,10 @@ typedef enum {
     KZG_ERR_NOT_ON_CURVE = -16,          /* NotOnCurveError("compressed g1 point not on curve: ..") (helpers.rs:203-208) */
     KZG_ERR_G1_NOT_ON_CURVE = -17,       /* NotOnCurveError("G1 point not on curve") (helpers.rs:694-699, validate_g1_point) */
     KZG_ERR_G2_TAU_NOT_ON_CURVE = -18,   /* NotOnCurveError("Invalid trusted setup: G2_TAU not on curve") (verify.rs:29-33, batch.rs:214-216) */
-    KZG_ERR_TAU_EQUALS_Z = -19           /* GenericError("Evaluation point equals trusted setup secret") (verify.rs:56-60) */
+    KZG_ERR_TAU_EQUALS_Z = -19,          /* GenericError("Evaluation point equals trusted setup secret") (verify.rs:56-60) */
+    /* multi-rank calls only (no counterpart in the single-process reference): */
+    KZG_ERR_PEER = -20,                  /* another rank of the communicator failed in this collective call (it returns its own error) */
+    KZG_ERR_EXCHANGE_TIMEOUT = -21       /* the all-gather did not complete within KZG_EXCHANGE_TIMEOUT_S (default 60): a peer is gone */
 } kzg_status;
 
 /* The reference's error string for a status (Appendix B of SURVEY.md). */
@@ -337,23 +340,40 @@ int32_t kzg_multi_scalars_upload(kzg_multi* m, int32_t buffer_id, const uint64_t
 int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids, size_t count, uint64_t* out_xy_mont,
                                          uint8_t* out_is_infinity);
 
-/* ---- one process per GPU: the exchange of the partial sums over RCCL, behind the C-ABI (BASELINE north_star) ------------
- * The MSM shards by scalar index: rank g holds the SRS powers and coefficients [g n / G, (g+1) n / G) and computes one XYZZ partial
- * (kzg_msm_g1_srs_partial[_device]).  RCCL has no reduction operator for elliptic-curve addition, so the "all-reduce" of the G partial
- * sums is ONE all-gather of G x 128 bytes over xGMI and a fold of G points on every rank:
- *   kzg_rccl_allgather_fold      partial in -> the same folded affine point on every rank; the collective runs on the context's stream
- *   kzg_commit_coeff_form_rccl   KZG::commit_coeff_form (prover/src/kzg.rs:107-125) of this rank's resident coefficient slice over its
- *                                SRS shard + the exchange + the fold, in one call
- * Eval-form commitments and proofs shard the same way (BASELINE config 4): kzg_commit_eval_form_partial / kzg_compute_proof_partial give
- * this rank's partial, kzg_rccl_allgather_fold exchanges and folds it.
- * nccl_comm = the caller's ncclComm_t for this context's device (the host creates it: ncclGetUniqueId / ncclCommInitRank of the RCCL that
- * belongs to /opt/rocm -- librccl.so is dlopen'ed on first use, KZG_RCCL_LIB overrides the path; no link-time dependency).  Every rank of
- * the communicator must make the call (it is a collective).  Python hosts use torch.distributed instead (sharding.py: the same
- * all-gather through PyTorch's communicator, several steps per collective); one process driving all GPUs uses kzg_multi_* (no collective). */
+/* ---- one process per GPU: the exchanges over RCCL, behind the C-ABI (BASELINE north_star) -----------------------------------
+ * RCCL has no reduction operator for elliptic-curve addition, so the "all-reduce" of the G partial sums is ONE all-gather of G small rows
+ * over xGMI and a fold of G points on every rank.  Every rank of the communicator must make the same call (they are collectives).
+ *   kzg_rccl_allgather_fold        partial in -> the same folded affine point on every rank
+ *   kzg_commit_coeff_form_rccl     KZG::commit_coeff_form (prover/src/kzg.rs:107-125): this rank's resident coefficient slice over its shard of the
+ *                                  monomial SRS + the exchange + the fold
+ *   kzg_commit_eval_form_rccl      KZG::commit_eval_form (kzg.rs:84-104), BASELINE config 4's commitment: this rank's slice of the EVALUATIONS
+ *                                  over its shard of the Lagrange basis (kzg_srs_lagrange_shard) + the exchange + the fold
+ *   kzg_compute_proof_rccl         KZG::compute_proof_impl (kzg.rs:128-178, :237-260), config 4's proof, from the same slice: two exchanges
+ *                                  (G x 72 B: partial barycentric sums -> y;  G x 264 B: partial points) -- the four steps of
+ *                                  kzg_compute_proof_lagrange_* with the collectives in between; out_y (optional) = p(z)
+ *   (_device: the slice is already in device memory and is read in place)
+ * nccl_comm = the caller's ncclComm_t for this context's device.  The library uses the RCCL that is already in the process (the one that
+ * made the communicator), else loads /opt/rocm/lib/librccl.so (KZG_RCCL_LIB overrides); no link-time dependency.  `world` must equal
+ * ncclCommCount(comm) (checked: KZG_ERR_INVALID_ARG).
+ * FAILURES.  A rank whose local work fails still issues every collective of the call with a poisoned row and then returns its own
+ * status; every other rank returns KZG_ERR_PEER (kzg_ctx_last_error names the failed ranks): no rank is left blocked.  A peer that never
+ * arrives: the wait is bounded by KZG_EXCHANGE_TIMEOUT_S seconds (default 60) -> KZG_ERR_EXCHANGE_TIMEOUT; exit, the communicator is
+ * unusable.  Python hosts use torch.distributed instead (sharding.py: the same rows through PyTorch's communicator); one process driving
+ * all GPUs uses kzg_multi_* (no collective). */
 int32_t kzg_rccl_allgather_fold(kzg_ctx* ctx, void* nccl_comm, int32_t world, const uint64_t partial_xyzz_mont[16],
                                 uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
 int32_t kzg_commit_coeff_form_rccl(kzg_ctx* ctx, const kzg_srs* srs_shard, const void* d_coeffs_shard_mont, size_t n_shard, void* nccl_comm,
                                    int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+int32_t kzg_commit_eval_form_rccl(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const uint64_t* evals_slice_mont, size_t len, void* nccl_comm,
+                                  int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+int32_t kzg_commit_eval_form_rccl_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const void* d_evals_slice_mont, size_t len, void* nccl_comm,
+                                         int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
+int32_t kzg_compute_proof_rccl(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const uint64_t* evals_slice_mont, size_t len, size_t n,
+                               const uint64_t z_mont[4], void* nccl_comm, int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity,
+                               uint64_t* out_y_mont);
+int32_t kzg_compute_proof_rccl_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont, size_t len, size_t n,
+                                      const uint64_t z_mont[4], void* nccl_comm, int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity,
+                                      uint64_t* out_y_mont);
 
 /* NOTE on the two Fiat-Shamir transcripts below (kzg_compute_challenge, kzg_compute_r_powers): their byte layout follows the reference
  * line by line, but the 32-byte compressed G1 encoding inside them (x little-endian, 0x80 = larger y, 0x40 = infinity) is ark-serialize's

@@ -36,6 +36,8 @@ NUM_SLOTS = int(os.environ.get("KZG_NUM_SLOTS", "4"))          # KZG_NUM_SLOTS o
 ERR_G1_NOT_ON_CURVE = -17
 ERR_G2_TAU_NOT_ON_CURVE = -18
 ERR_TAU_EQUALS_Z = -19
+ERR_PEER = -20
+ERR_EXCHANGE_TIMEOUT = -21
 
 u64p = C.POINTER(C.c_uint64)
 u8p = C.POINTER(C.c_uint8)
@@ -137,6 +139,10 @@ PROTOTYPES = {
     "kzg_compute_proof_lagrange_abort": (i32, [vp, i32]),
     "kzg_lagrange_fold_y": (i32, [u64p, sz, sz, u64p, u64p]),
     "kzg_lagrange_fold_proof": (i32, [u64p, sz, sz, u64p, u64p, u8p]),
+    "kzg_commit_eval_form_rccl": (i32, [vp, vp, u64p, sz, vp, i32, u64p, u8p]),
+    "kzg_commit_eval_form_rccl_device": (i32, [vp, vp, vp, sz, vp, i32, u64p, u8p]),
+    "kzg_compute_proof_rccl": (i32, [vp, vp, sz, u64p, sz, sz, u64p, vp, i32, u64p, u8p, u64p]),
+    "kzg_compute_proof_rccl_device": (i32, [vp, vp, sz, vp, sz, sz, u64p, vp, i32, u64p, u8p, u64p]),
     "kzg_verify_blob_kzg_proof": (i32, [vp, u8p, sz, u64p, u64p, u64p, C.POINTER(i32)]),
     "kzg_verify_blob_kzg_proof_batch": (i32, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), u64p, u64p, sz, u64p, C.POINTER(i32)]),
 }

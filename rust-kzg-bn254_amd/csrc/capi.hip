@@ -101,6 +101,8 @@ const char* kzg_status_message(int32_t status) {
         case KZG_ERR_G1_NOT_ON_CURVE: return "G1 point not on curve";
         case KZG_ERR_G2_TAU_NOT_ON_CURVE: return "Invalid trusted setup: G2_TAU not on curve";
         case KZG_ERR_TAU_EQUALS_Z: return "Evaluation point equals trusted setup secret";
+        case KZG_ERR_PEER: return "another rank of the communicator failed in this collective call";
+        case KZG_ERR_EXCHANGE_TIMEOUT: return "the exchange between the ranks timed out";
         default: return "unknown status";
     }
 }
@@ -153,6 +155,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     for (auto& w : ctx->ntt_x) w.release();
     for (auto& ps : ctx->poly) ps.release();
     ctx->rccl_buf.release();
+    if (ctx->rccl_pinned) { (void)hipHostFree(ctx->rccl_pinned); ctx->rccl_pinned = nullptr; ctx->rccl_pinned_bytes = 0; }
     if (ctx->vb_pinned) { (void)hipHostFree(ctx->vb_pinned); ctx->vb_pinned = nullptr; ctx->vb_pinned_bytes = 0; }
     for (auto& t : ctx->ondomain_inv) if (t) { (void)hipFree(t); t = nullptr; }
     (void)hipStreamDestroy(ctx->stream);

@@ -104,6 +104,8 @@ struct kzg_ctx {
     void* vb_pinned = nullptr;           // pinned staging of the packed blobs of one batch verification (capi.hip), grown on demand
     size_t vb_pinned_bytes = 0;
     kzg::DeviceBuffer rccl_buf;          // this rank's partial + the gathered partials of kzg_rccl_allgather_fold (multi.hip)
+    void* rccl_pinned = nullptr;         // pinned host staging of the same rows (row out | world rows in)
+    size_t rccl_pinned_bytes = 0;
     kzg::PolySet poly[KZG_NUM_SLOTS];   // polynomial / proof pipeline scratch, one set per slot ([0] also serves the synchronous calls)
     kzg::LagProof lag[KZG_NUM_SLOTS];   // Lagrange-sharded proofs in flight (kzg_compute_proof_lagrange_*)
     kzg::MsmWorkspace& slot_msm(int slot) { return slot ? msm_x[slot - 1] : msm; }

@@ -7,6 +7,8 @@
 #include "engine.h"
 #include "host_curve.h"
 
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
 #include <cstdlib>
@@ -225,18 +227,32 @@ int32_t kzg_multi_commit_resident_stream(kzg_multi* m, const int32_t* buffer_ids
     return KZG_OK;
 }
 
-// ---- the exchange of the partial sums over RCCL, behind the C-ABI (one process per GPU; north_star's "single RCCL all-reduce") ----------
-// RCCL has no reduction operator for elliptic-curve addition, so the all-reduce of G partial sums is an all-gather of G x 128 bytes and a
-// fold of G points on every rank.  The communicator belongs to the HOST (a Rust host creates it with its own RCCL binding:
-// ncclGetUniqueId on rank 0, the id handed to the other ranks by whatever channel it has, ncclCommInitRank on this context's device);
-// the library only issues the collective on its own stream.  librccl is dlopen'ed on first use -- /opt/rocm/lib/librccl.so, the build
-// that belongs to the HIP runtime this library links (KZG_RCCL_LIB overrides; a process that also holds PyTorch's bundled copy keeps
-// the two apart) -- so there is no link-time dependency and single-GPU users never load it.
+// ---- the exchanges over RCCL, behind the C-ABI (one process per GPU; north_star's "single RCCL all-reduce") ------------------------------
+// RCCL has no reduction operator for elliptic-curve addition, so the all-reduce of G partial sums is an all-gather of G fixed-size rows
+// and a fold on every rank.  The communicator belongs to the HOST (a Rust host creates it with its own RCCL binding: ncclGetUniqueId on
+// rank 0, the id handed to the other ranks by whatever channel it has, ncclCommInitRank on this context's device); the library only
+// issues the collective on its own stream.
+// Which RCCL: the copy that is ALREADY in the process (the one the host created the communicator with) -- dlsym(RTLD_DEFAULT), then
+// dlopen(.., RTLD_NOLOAD) of the usual names -- and only then a fresh load of /opt/rocm/lib/librccl.so (KZG_RCCL_LIB overrides every
+// step).  No link-time dependency; single-GPU users never load it.  (a private RTLD_LOCAL copy need not be the instance
+// the caller's ncclComm_t belongs to.)
+//
+// A row = 8 status bytes + payload.  FAILURE PROTOCOL: a rank whose local work failed still issues every collective of the call, with
+// the status word POISON; it then returns its own error, every other rank returns KZG_ERR_PEER (last_error names the ranks) -- nobody
+// is left blocked in ncclAllGather (round 4 returned before the collective).  A peer that never arrives: the wait on the stream is
+// bounded by KZG_EXCHANGE_TIMEOUT_S (default 60 s) -> KZG_ERR_EXCHANGE_TIMEOUT; the communicator (and this context's stream) cannot
+// be used afterwards, exit.
+// The rows start in HOST memory: the partial sum of an MSM is produced by the host epilogue (bit-Horner over 208 points),
+// and y / T of a proof are folded on the host; a row is <= 264 bytes, one pinned staging buffer each way.
 }  // extern "C"
 namespace {
 typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*nccl_errstr_fn)(int);
-struct Rccl { void* lib = nullptr; nccl_allgather_fn all_gather = nullptr; nccl_errstr_fn err = nullptr; bool tried = false; };
+typedef int (*nccl_count_fn)(void*, int*);
+struct Rccl {
+    void* lib = nullptr; nccl_allgather_fn all_gather = nullptr; nccl_errstr_fn err = nullptr; nccl_count_fn count = nullptr, user_rank = nullptr;
+    const char* how = "not loaded"; bool tried = false, have = false;
+};
 Rccl& rccl() {
     static Rccl r;
     static std::mutex mu;
@@ -244,18 +260,103 @@ Rccl& rccl() {
     if (!r.tried) {
         r.tried = true;
         const char* env = getenv("KZG_RCCL_LIB");
-        const char* names[] = {env, "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
-        for (const char* n : names) {
-            if (!n || !*n) continue;
-            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+        if (env && *env) { r.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL); r.have = r.lib != nullptr; r.how = "KZG_RCCL_LIB"; }
+        if (!r.have && dlsym(RTLD_DEFAULT, "ncclAllGather")) { r.lib = RTLD_DEFAULT; r.have = true; r.how = "the RCCL already in the process (global scope)"; }
+        if (!r.have) {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+            for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (r.lib) { r.have = true; r.how = "the RCCL already loaded by the host (RTLD_NOLOAD)"; break; } }
         }
-        if (r.lib) {
+        if (!r.have) {
+            const char* names[] = {"/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
+            for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) { r.have = true; r.how = "a fresh load of librccl.so"; break; } }
+        }
+        if (r.have) {
             r.all_gather = reinterpret_cast<nccl_allgather_fn>(dlsym(r.lib, "ncclAllGather"));
             r.err = reinterpret_cast<nccl_errstr_fn>(dlsym(r.lib, "ncclGetErrorString"));
+            r.count = reinterpret_cast<nccl_count_fn>(dlsym(r.lib, "ncclCommCount"));
+            r.user_rank = reinterpret_cast<nccl_count_fn>(dlsym(r.lib, "ncclCommUserRank"));
         }
     }
     return r;
+}
+
+constexpr uint64_t ROW_OK = 0, ROW_POISON = 0xFFFFFFFFFFFFFFFFULL;
+constexpr size_t ROW_PAYLOAD_MAX = 256;
+
+double exchange_timeout_s() {
+    const char* e = getenv("KZG_EXCHANGE_TIMEOUT_S");
+    const double v = e ? atof(e) : 60.0;
+    return v > 0 ? v : 60.0;
+}
+
+// One all-gather of `bytes` <= 256 payload bytes per rank (+ the status word).  local_rc != KZG_OK: this rank sends POISON.
+// gathered = world x bytes (payload only).  Returns KZG_OK, the rank's own local_rc (it was the one that failed), KZG_ERR_PEER,
+// KZG_ERR_EXCHANGE_TIMEOUT, or an argument / device error.  Caller holds no lock; takes ctx->mu.
+int32_t rccl_exchange(kzg_ctx* ctx, void* comm, int32_t world, const void* payload, size_t bytes, int32_t local_rc, std::vector<uint64_t>& gathered) {
+    if (!ctx || !comm || world < 1 || world > 4096 || bytes > ROW_PAYLOAD_MAX || (bytes & 7)) return KZG_ERR_INVALID_ARG;
+    Rccl& r = rccl();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!r.all_gather) { ctx->last_error = "librccl.so could not be loaded (KZG_RCCL_LIB, the process's own copy, /opt/rocm/lib/librccl.so)"; return KZG_ERR_DEVICE; }
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (r.count) {                                                   // the staging buffer is sized by `world`: it must be the communicator's size
+        int cnt = -1;
+        if (r.count(comm, &cnt) != 0 || cnt != world) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "world = %d but the communicator has %d rank(s)", (int)world, cnt);
+            ctx->last_error = buf;
+            return KZG_ERR_INVALID_ARG;
+        }
+    }
+    static const bool poison_self = []() { const char* e = getenv("KZG_RCCL_TEST_POISON"); return e && atoi(e) != 0; }();   // test hook: a healthy rank that reports failure
+    const size_t row = 8 + bytes, need = row * ((size_t)world + 1);
+    kzg::DeviceBuffer& d = ctx->rccl_buf;
+    KZG_HIP_TRY(ctx, d.reserve(need + 256));
+    if (ctx->rccl_pinned_bytes < need) {
+        if (ctx->rccl_pinned) { (void)hipHostFree(ctx->rccl_pinned); ctx->rccl_pinned = nullptr; ctx->rccl_pinned_bytes = 0; }
+        KZG_HIP_TRY(ctx, hipHostMalloc(&ctx->rccl_pinned, need + 4096, hipHostMallocDefault));
+        ctx->rccl_pinned_bytes = need + 4096;
+    }
+    char* pin = static_cast<char*>(ctx->rccl_pinned);
+    const uint64_t status = (local_rc != KZG_OK || poison_self) ? ROW_POISON : ROW_OK;
+    memcpy(pin, &status, 8);
+    if (bytes) { if (local_rc == KZG_OK && payload) memcpy(pin + 8, payload, bytes); else memset(pin + 8, 0, bytes); }
+    char* dev = d.as<char>();
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(dev, pin, row, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = r.all_gather(dev, dev + row, row, /* ncclUint8 */ 1, comm, ctx->stream);
+    if (rc != 0) {
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->last_error = std::string("ncclAllGather: ") + (r.err ? r.err(rc) : "error");
+        return KZG_ERR_DEVICE;
+    }
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + row, dev + row, row * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+    // bounded wait: a peer that never issues its collective must not block this rank for ever
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        const double limit = exchange_timeout_s();
+        unsigned spins = 0;
+        for (;;) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return kzg::set_error(ctx, q, "the exchange on the context's stream");
+            (void)hipGetLastError();
+            if (++spins > 4000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                ctx->last_error = "the all-gather did not complete within KZG_EXCHANGE_TIMEOUT_S: a peer rank is gone or hung; the communicator is unusable";
+                return KZG_ERR_EXCHANGE_TIMEOUT;
+            }
+        }
+    }
+    gathered.assign((size_t)world * (bytes / 8), 0);
+    std::string bad;
+    for (int32_t g = 0; g < world; ++g) {
+        uint64_t st_g;
+        memcpy(&st_g, pin + row * ((size_t)g + 1), 8);
+        if (st_g != ROW_OK) { if (!bad.empty()) bad += ", "; bad += std::to_string(g); }
+        if (bytes) memcpy(gathered.data() + (size_t)g * (bytes / 8), pin + row * ((size_t)g + 1) + 8, bytes);
+    }
+    if (local_rc != KZG_OK) return local_rc;                          // this rank's own failure (the others see KZG_ERR_PEER)
+    if (!bad.empty()) { ctx->last_error = "rank(s) " + bad + " of the communicator failed in this call"; return KZG_ERR_PEER; }
+    return KZG_OK;
 }
 }  // namespace
 extern "C" {
@@ -263,38 +364,91 @@ extern "C" {
 int32_t kzg_rccl_allgather_fold(kzg_ctx* ctx, void* nccl_comm, int32_t world, const uint64_t partial_xyzz_mont[16],
                                 uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
     if (!ctx || !nccl_comm || world < 1 || world > 4096 || !partial_xyzz_mont || !out_xy_mont) return KZG_ERR_INVALID_ARG;
-    Rccl& r = rccl();
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!r.all_gather) { ctx->last_error = "librccl.so could not be loaded (KZG_RCCL_LIB, /opt/rocm/lib/librccl.so)"; return KZG_ERR_DEVICE; }
-    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // device staging: this rank's 128 bytes | world x 128 gathered bytes (grown on demand, kept with the context)
-    const size_t need = 128 + 128 * (size_t)world;
-    static thread_local std::vector<uint64_t> gathered;
-    gathered.resize(16 * (size_t)world);
-    kzg::DeviceBuffer& d = ctx->rccl_buf;
-    KZG_HIP_TRY(ctx, d.reserve(need + 256));
-    char* dev = d.as<char>();
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(dev, partial_xyzz_mont, 128, hipMemcpyHostToDevice, ctx->stream));
-    const int rc = r.all_gather(dev, dev + 128, 128, /* ncclUint8 */ 1, nccl_comm, ctx->stream);
-    if (rc != 0) {
-        (void)hipStreamSynchronize(ctx->stream);
-        ctx->last_error = std::string("ncclAllGather: ") + (r.err ? r.err(rc) : "error");
-        return KZG_ERR_DEVICE;
-    }
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(gathered.data(), dev + 128, 128 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
-    KZG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> gathered;
+    const int32_t rc = rccl_exchange(ctx, nccl_comm, world, partial_xyzz_mont, 128, KZG_OK, gathered);
+    if (rc != KZG_OK) return rc;
     return kzg_g1_fold_partials(gathered.data(), (size_t)world, out_xy_mont, out_is_infinity);
 }
 
 int32_t kzg_commit_coeff_form_rccl(kzg_ctx* ctx, const kzg_srs* srs_shard, const void* d_coeffs_shard_mont, size_t n_shard, void* nccl_comm,
                                    int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
-    if (!ctx || !srs_shard || !nccl_comm || !out_xy_mont || (n_shard && !d_coeffs_shard_mont)) return KZG_ERR_INVALID_ARG;
+    if (!ctx || !srs_shard || !nccl_comm || !out_xy_mont || world < 1 || world > 4096) return KZG_ERR_INVALID_ARG;
     uint64_t part[16] = {0};                                         // an empty shard contributes the identity (ZZ = 0)
-    if (n_shard) {
-        const int32_t rc = kzg_msm_g1_srs_partial_device(ctx, srs_shard, 0, d_coeffs_shard_mont, n_shard, part);
-        if (rc != KZG_OK) return rc;                                 // (the caller's ranks must then agree to stop: the collective has not been issued)
+    int32_t local = KZG_OK;
+    if (n_shard) local = d_coeffs_shard_mont ? kzg_msm_g1_srs_partial_device(ctx, srs_shard, 0, d_coeffs_shard_mont, n_shard, part) : KZG_ERR_INVALID_ARG;
+    std::vector<uint64_t> gathered;
+    const int32_t rc = rccl_exchange(ctx, nccl_comm, world, part, 128, local, gathered);    // a failed rank still joins the collective
+    if (rc != KZG_OK) return rc;
+    return kzg_g1_fold_partials(gathered.data(), (size_t)world, out_xy_mont, out_is_infinity);
+}
+
+// KZG::commit_eval_form (prover/src/kzg.rs:84-104) of this rank's slice of the evaluations over its shard of the Lagrange basis + the
+// exchange + the fold, in one call (BASELINE config 4's commitment)
+static int32_t commit_eval_form_rccl_common(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const void* evals, bool on_device, size_t len, void* nccl_comm,
+                                            int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    if (!ctx || !lagrange_shard || !nccl_comm || !out_xy_mont || world < 1 || world > 4096) return KZG_ERR_INVALID_ARG;
+    uint64_t part[16] = {0};
+    int32_t local = KZG_OK;
+    if (len && !evals) local = KZG_ERR_INVALID_ARG;
+    else if (len) local = on_device ? kzg_commit_eval_form_lagrange_partial_device(ctx, lagrange_shard, evals, len, part)
+                                    : kzg_commit_eval_form_lagrange_partial(ctx, lagrange_shard, static_cast<const uint64_t*>(evals), len, part);
+    std::vector<uint64_t> gathered;
+    const int32_t rc = rccl_exchange(ctx, nccl_comm, world, part, 128, local, gathered);
+    if (rc != KZG_OK) return rc;
+    return kzg_g1_fold_partials(gathered.data(), (size_t)world, out_xy_mont, out_is_infinity);
+}
+int32_t kzg_commit_eval_form_rccl(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const uint64_t* evals_slice_mont, size_t len, void* nccl_comm,
+                                  int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    return commit_eval_form_rccl_common(ctx, lagrange_shard, evals_slice_mont, false, len, nccl_comm, world, out_xy_mont, out_is_infinity);
+}
+int32_t kzg_commit_eval_form_rccl_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, const void* d_evals_slice_mont, size_t len, void* nccl_comm,
+                                         int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity) {
+    return commit_eval_form_rccl_common(ctx, lagrange_shard, d_evals_slice_mont, true, len, nccl_comm, world, out_xy_mont, out_is_infinity);
+}
+
+// KZG::compute_proof_impl (kzg.rs:128-178, :237-260) of this rank's slice, both exchanges inside: S_g -> y, then the partial points
+static int32_t compute_proof_rccl_common(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* evals, bool on_device, size_t len,
+                                         size_t n, const uint64_t z_mont[4], void* nccl_comm, int32_t world, uint64_t out_xy_mont[8],
+                                         uint8_t* out_is_infinity, uint64_t* out_y_mont) {
+    if (!ctx || !lagrange_shard || !nccl_comm || !out_xy_mont || !z_mont || world < 1 || world > 4096) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;           // the same on every rank: nobody issues a collective
+    if (n > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
+    const int32_t slot = 0;
+    uint64_t ypart[KZG_LAGRANGE_YPART_WORDS] = {0}, part[KZG_LAGRANGE_PART_WORDS] = {0}, y[4] = {0, 0, 0, 0};
+    int32_t local = on_device ? kzg_compute_proof_lagrange_begin_device(ctx, lagrange_shard, shard_lo, evals, len, n, z_mont, slot)
+                              : kzg_compute_proof_lagrange_begin(ctx, lagrange_shard, shard_lo, static_cast<const uint64_t*>(evals), len, n, z_mont, slot);
+    bool in_flight = local == KZG_OK;
+    if (local == KZG_OK) { local = kzg_compute_proof_lagrange_partial_y(ctx, slot, ypart); if (local != KZG_OK) in_flight = false; }
+    std::vector<uint64_t> got;
+    int32_t rc = rccl_exchange(ctx, nccl_comm, world, ypart, sizeof ypart, local, got);
+    if (rc == KZG_ERR_EXCHANGE_TIMEOUT || rc == KZG_ERR_DEVICE || rc == KZG_ERR_INVALID_ARG) { if (in_flight) (void)kzg_compute_proof_lagrange_abort(ctx, slot); return rc; }
+    int32_t first = rc;                                               // KZG_OK, this rank's own error, or KZG_ERR_PEER: the second collective is issued all the same
+    if (first == KZG_OK) {
+        local = kzg_lagrange_fold_y(got.data(), (size_t)world, n, z_mont, y);
+        if (local == KZG_OK) local = kzg_compute_proof_lagrange_continue(ctx, slot, y);
+        if (local == KZG_OK) local = kzg_compute_proof_lagrange_end(ctx, slot, part);
+        if (local != KZG_OK) (void)kzg_compute_proof_lagrange_abort(ctx, slot);
+    } else {
+        if (in_flight) (void)kzg_compute_proof_lagrange_abort(ctx, slot);
+        local = first;
     }
-    return kzg_rccl_allgather_fold(ctx, nccl_comm, world, part, out_xy_mont, out_is_infinity);
+    rc = rccl_exchange(ctx, nccl_comm, world, part, sizeof part, local == KZG_ERR_PEER ? KZG_OK : local, got);
+    if (first != KZG_OK) return first;
+    if (rc != KZG_OK) return rc;
+    if (out_y_mont) memcpy(out_y_mont, y, 32);
+    return kzg_lagrange_fold_proof(got.data(), (size_t)world, n, z_mont, out_xy_mont, out_is_infinity);
+}
+int32_t kzg_compute_proof_rccl(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const uint64_t* evals_slice_mont, size_t len, size_t n,
+                               const uint64_t z_mont[4], void* nccl_comm, int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity,
+                               uint64_t* out_y_mont) {
+    return compute_proof_rccl_common(ctx, lagrange_shard, shard_lo, evals_slice_mont, false, len, n, z_mont, nccl_comm, world, out_xy_mont,
+                                     out_is_infinity, out_y_mont);
+}
+int32_t kzg_compute_proof_rccl_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont, size_t len, size_t n,
+                                      const uint64_t z_mont[4], void* nccl_comm, int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity,
+                                      uint64_t* out_y_mont) {
+    return compute_proof_rccl_common(ctx, lagrange_shard, shard_lo, d_evals_slice_mont, true, len, n, z_mont, nccl_comm, world, out_xy_mont,
+                                     out_is_infinity, out_y_mont);
 }
 
 }  // extern "C"

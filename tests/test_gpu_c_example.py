@@ -46,3 +46,4 @@ def test_rccl_c_example_one_rank(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr[-1500:])
     assert "one-rank RCCL commitment == the plain commitment" in res.stdout
+    assert "one-rank config 4 over RCCL == the one-GPU commitment, proof and y" in res.stdout      # kzg_commit_eval_form_rccl / kzg_compute_proof_rccl

@@ -44,6 +44,9 @@ comm = C.c_void_p()
 rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
 assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0, "ncclCommInitRank"
 
+'''
+
+HEALTHY = r'''
 want = np.zeros(8, np.uint64); inf = C.c_uint8(0)
 assert lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(wire), n, _lib.ptr(want), C.byref(inf)) == 0
 acc, tp = 0, 1
@@ -87,14 +90,85 @@ assert np.array_equal(gc, want_c) and np.array_equal(gp, want_p) and np.array_eq
 # argument errors
 assert lib.kzg_rccl_allgather_fold(ctx.handle, None, 1, _lib.ptr(part), _lib.ptr(got), C.byref(inf)) == -1
 assert lib.kzg_rccl_allgather_fold(ctx.handle, comm, 0, _lib.ptr(part), _lib.ptr(got), C.byref(inf)) == -1
+# `world` must be the communicator's size (ADVICE r4: the staging buffer is sized by it)
+assert lib.kzg_rccl_allgather_fold(ctx.handle, comm, 2, _lib.ptr(part), _lib.ptr(got), C.byref(inf)) == -1
+assert b"communicator has 1 rank" in lib.kzg_ctx_last_error(ctx.handle)
+
+# ---- round 5: config 4 in ONE call per rank over the Lagrange shard (kzg_commit_eval_form_rccl / kzg_compute_proof_rccl) ----------------
+m = 1 << 12
+ev4 = np.ascontiguousarray(ev[:m])
+lag = srs.lagrange_shard(m, 0, m)                    # one rank: its shard is the whole basis
+want_c4 = np.zeros(8, np.uint64); want_p4 = np.zeros(8, np.uint64); want_y4 = np.zeros(4, np.uint64)
+assert lib.kzg_commit_eval_form(ctx.handle, srs.handle, _lib.ptr(ev4), m, _lib.ptr(want_c4), C.byref(inf)) == 0
+g4 = np.zeros(8, np.uint64)
+rc = lib.kzg_commit_eval_form_rccl(ctx.handle, lag.handle, _lib.ptr(ev4), m, comm, 1, _lib.ptr(g4), C.byref(inf))
+assert rc == 0 and np.array_equal(g4, want_c4), (rc, lib.kzg_ctx_last_error(ctx.handle))
+roots = np.zeros((m, 4), np.uint64); nr = C.c_size_t(0)
+assert lib.kzg_calculate_roots_of_unity(ctx.handle, m * 32, _lib.ptr(roots), m, C.byref(nr)) == 0
+for zz in (z, np.ascontiguousarray(roots[1234])):    # off the domain, and the domain point w^1234 (kzg.rs:237-260)
+    assert lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(ev4), m, None, m, _lib.ptr(zz), _lib.ptr(want_p4), C.byref(inf), _lib.ptr(want_y4)) == 0
+    gp4 = np.zeros(8, np.uint64); gy4 = np.zeros(4, np.uint64)
+    rc = lib.kzg_compute_proof_rccl(ctx.handle, lag.handle, 0, _lib.ptr(ev4), m, m, _lib.ptr(zz), comm, 1, _lib.ptr(gp4), C.byref(inf), _lib.ptr(gy4))
+    assert rc == 0, (rc, lib.kzg_ctx_last_error(ctx.handle))
+    assert np.array_equal(gp4, want_p4) and np.array_equal(gy4, want_y4)
+    # the resident form reads the caller's device buffer in place
+    assert hip.hipMemcpy(d, ev4.ctypes.data_as(C.c_void_p), C.c_size_t(m * 32), 1) == 0
+    gp5 = np.zeros(8, np.uint64)
+    assert lib.kzg_compute_proof_rccl_device(ctx.handle, lag.handle, 0, d, m, m, _lib.ptr(zz), comm, 1, _lib.ptr(gp5), C.byref(inf), None) == 0
+    assert np.array_equal(gp5, want_p4)
+    g5 = np.zeros(8, np.uint64)
+    assert lib.kzg_commit_eval_form_rccl_device(ctx.handle, lag.handle, d, m, comm, 1, _lib.ptr(g5), C.byref(inf)) == 0 and np.array_equal(g5, want_c4)
+# a LOCAL failure (this rank's slice is longer than its shard) still goes through the collectives and comes back as the rank's own status
+big = np.zeros((m + 1, 4), np.uint64)
+assert lib.kzg_commit_eval_form_rccl(ctx.handle, lag.handle, _lib.ptr(big), m + 1, comm, 1, _lib.ptr(g4), C.byref(inf)) == _lib.ERR_SRS_CAPACITY_EXCEEDED
+assert lib.kzg_compute_proof_rccl(ctx.handle, lag.handle, 0, _lib.ptr(big), m + 1, 2 * m, _lib.ptr(z), comm, 1, _lib.ptr(g4), C.byref(inf), None) == _lib.ERR_SRS_CAPACITY_EXCEEDED
+assert lib.kzg_commit_coeff_form_rccl(ctx.handle, srs.handle, d, n + 1, comm, 1, _lib.ptr(got2), C.byref(inf)) == _lib.ERR_MSM_LENGTH_MISMATCH
+# ... and the context is usable afterwards (no slot left in flight)
+assert lib.kzg_compute_proof_rccl(ctx.handle, lag.handle, 0, _lib.ptr(ev4), m, m, _lib.ptr(z), comm, 1, _lib.ptr(gp4), C.byref(inf), None) == 0
+lag.close()
 rccl.ncclCommDestroy.argtypes = [C.c_void_p]
 rccl.ncclCommDestroy(comm)
 print("rccl c-abi ok")
 '''
 
 
-def test_rccl_exchange_behind_the_c_abi_one_rank():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+POISONED = r'''
+# KZG_RCCL_TEST_POISON=1 (test hook of csrc/multi.hip): this healthy rank marks every row it sends as failed -> every rank of a call returns
+# KZG_ERR_PEER after the SAME collectives a successful call issues, and nothing stays in flight
+inf = C.c_uint8(0)
+part = np.zeros(16, np.uint64)
+assert lib.kzg_msm_g1_srs_partial(ctx.handle, srs.handle, 0, _lib.ptr(wire), n, _lib.ptr(part)) == 0
+got = np.zeros(8, np.uint64)
+assert lib.kzg_rccl_allgather_fold(ctx.handle, comm, 1, _lib.ptr(part), _lib.ptr(got), C.byref(inf)) == _lib.ERR_PEER
+assert b"rank(s) 0" in lib.kzg_ctx_last_error(ctx.handle)
+m = 1 << 12
+ev4 = np.ascontiguousarray(wire[:m]); z = pyref.fr_to_mont(0x1234567)
+lag = srs.lagrange_shard(m, 0, m)
+assert lib.kzg_commit_eval_form_rccl(ctx.handle, lag.handle, _lib.ptr(ev4), m, comm, 1, _lib.ptr(got), C.byref(inf)) == _lib.ERR_PEER
+assert lib.kzg_compute_proof_rccl(ctx.handle, lag.handle, 0, _lib.ptr(ev4), m, m, _lib.ptr(z), comm, 1, _lib.ptr(got), C.byref(inf), None) == _lib.ERR_PEER
+roots = np.zeros((m, 4), np.uint64); nr = C.c_size_t(0)
+assert lib.kzg_calculate_roots_of_unity(ctx.handle, m * 32, _lib.ptr(roots), m, C.byref(nr)) == 0
+zon = np.ascontiguousarray(roots[5])
+assert lib.kzg_compute_proof_rccl(ctx.handle, lag.handle, 0, _lib.ptr(ev4), m, m, _lib.ptr(zon), comm, 1, _lib.ptr(got), C.byref(inf), None) == _lib.ERR_PEER
+p1 = np.zeros(8, np.uint64)
+assert lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(ev4), m, None, m, _lib.ptr(z), _lib.ptr(p1), C.byref(inf), None) == 0   # slot 0 is free again
+lag.close()
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+print("poison path ok")
+'''
+
+
+def run_child(body, **env_extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    res = subprocess.run([sys.executable, "-c", (CHILD + body) % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-800:], res.stderr[-2500:])
-    assert "rccl c-abi ok" in res.stdout
+    return res.stdout
+
+
+def test_rccl_exchange_behind_the_c_abi_one_rank():
+    assert "rccl c-abi ok" in run_child(HEALTHY)
+
+
+def test_rccl_failure_protocol_poisoned_rank():
+    assert "poison path ok" in run_child(POISONED, KZG_RCCL_TEST_POISON="1")
