@@ -93,6 +93,30 @@ def expected_commitment(canonical_scalars, tau):
     return pyref.point_to_wire(pyref.ec_mul(acc, (1, 2)))
 
 
+def eval_form_ground_truth(evals, log_n, points):
+    """f^(x) for every x in `points` (none on the domain) of the polynomial with the canonical evaluations `evals` on the 2^log_n-point
+    domain w^i, w = 5^((r-1)/n): barycentric formula (primitives/src/helpers.rs:507-532) in python big integers -- the independent check
+    of BASELINE config 4's commitment (x = tau) and proof (x = z)."""
+    n = 1 << log_n
+    w = pow(5, (FR - 1) >> log_n, FR)
+    roots, cur = [], 1
+    for _ in range(n):
+        roots.append(cur); cur = cur * w % FR
+    out = []
+    for x in points:
+        pre, acc = [], 1
+        for r_ in roots:
+            pre.append(acc); acc = acc * ((x - r_) % FR) % FR
+        inv = pow(acc, -1, FR)
+        s_ = 0
+        for i in range(n - 1, -1, -1):
+            iv = inv * pre[i] % FR
+            inv = inv * ((x - roots[i]) % FR) % FR
+            s_ += evals[i] * roots[i] % FR * iv
+        out.append(s_ % FR * (pow(x, n, FR) - 1) % FR * pow(n, -1, FR) % FR)
+    return out
+
+
 def blob_like_canonical(n, seed):
     """Scalars-A of SURVEY.md 8(d): raw bytes uniform in [32,126] (bench_kzg_commit.rs:18), 31 per element behind
     a zero byte (helpers.rs:823-840)  ->  canonical values < 2^248 (python ints)."""
@@ -475,6 +499,135 @@ def main():
     lib.kzg_ctx_set_profiling(ctx.handle, 0)
     phase_piped = [phase[i] / max(1, launches.value) for i in range(8)]
 
+    # ---- BASELINE config 4 ("Full blob -> commit + proof, 2^20 SRS, sharded MSM") at every world size, outside `value` -------------------------
+    # evaluations of one polynomial in HOST memory -> commitment and proof at z = Scalars-B[0], through
+    #   "lagrange" : evaluation-index shards of the Lagrange basis (csrc/lagrange.hip): a rank uploads, inverts and divides ITS slice only;
+    #                two small exchanges per proof (partial barycentric sums -> y, partial points)              [prover/src/kzg.rs:96-100, :128-178]
+    #   "replicated": round 4's kzg_*_partial -- every rank uploads, transforms (IFFT) and divides the WHOLE polynomial, then commits its slice
+    # Local failures are reported, never raised, so that every rank still joins the collectives.  KZG_BENCH_CONFIG4=0 skips it.
+    config4 = None
+    if os.environ.get("KZG_BENCH_CONFIG4", "1") != "0" and not args.no_secondary and LOG_N <= 22:
+        from rust_kzg_bn254_amd.sharding import ShardedKzg, ShardedKzgLagrange
+        c4_reps = max(2, min(8, args.steps))
+        c4 = {"ok": True, "err": None}
+        gdev = "cuda" if backend == "nccl" else None
+        ev_wire = wire_sets[1]                                           # Scalars-A set 1 as EVALUATIONS (identical on every rank)
+        z_c4 = np.ascontiguousarray(scalars_b[0])
+        lag_shard = None
+        try:
+            t_su = time.perf_counter()
+            os.environ["KZG_NO_PRECOMPUTE"] = "1"                        # the points only: g1_ifft reads them once
+            try:
+                srs_plain = k.SRS.generate(tau, n, ctx=ctx)
+            finally:
+                del os.environ["KZG_NO_PRECOMPUTE"]
+            lag_shard = srs_plain.lagrange_shard(n, sh.lo, sh.len)       # KZG::g1_ifft(n) once per rank, its slice kept (with tables)
+            srs_plain.close()
+            c4["setup_s"] = time.perf_counter() - t_su
+            sk_new = ShardedKzgLagrange(ctx, lag_shard, n, rank, world, gather_device=gdev, force_exchange=multi)
+            sk_old = ShardedKzg(ctx, srs, n, rank, world, gather_device=gdev)
+            poly_c4 = k.PolynomialEvalForm(ev_wire)
+        except Exception as e:                                           # noqa: BLE001
+            c4["ok"], c4["err"] = False, "%s: %s" % (type(e).__name__, e)
+
+        def c4_region(fn):
+            """reps calls of fn between barriers; (seconds per call, MAX over ranks; last result)"""
+            res = None
+            try:
+                if c4["ok"]:
+                    fn()                                                 # untimed: workspaces, tables
+            except Exception as e:                                       # noqa: BLE001
+                c4["ok"], c4["err"] = False, "%s: %s" % (type(e).__name__, e)
+            barrier()
+            t0_ = time.perf_counter()
+            try:
+                if c4["ok"]:
+                    for _ in range(c4_reps):
+                        res = fn()
+            except Exception as e:                                       # noqa: BLE001
+                c4["ok"], c4["err"] = False, "%s: %s" % (type(e).__name__, e)
+            barrier()
+            el_ = time.perf_counter() - t0_
+            if multi:
+                t_ = torch.tensor([el_], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                el_ = float(t_.item())
+            return el_ / c4_reps, res
+
+        c4["new_commit_s"], c4["new_commit"] = c4_region(lambda: sk_new.commit_eval_form(ev_wire))
+        c4["new_proof_s"], c4["new_proof"] = c4_region(lambda: sk_new.compute_proof(ev_wire, z_c4, want_y=True))
+        c4["old_commit_s"], c4["old_commit"] = c4_region(lambda: sk_old.commit_eval_form(poly_c4))
+        c4["old_proof_s"], c4["old_proof"] = c4_region(lambda: sk_old.compute_proof(poly_c4, z_c4, want_y=True))
+        if multi:
+            okt = torch.tensor([1 if c4["ok"] else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            c4["ok_everywhere"] = bool(okt.item())
+        else:
+            c4["ok_everywhere"] = c4["ok"]
+        if lag_shard is not None:
+            lag_shard.close()
+        config4 = c4
+
+    # ---- N = 1 only: what every rank of an N-rank run computes per step, on THIS box (VERDICT r4 item 2b) ---------------------------------
+    # A 2^20-pair commitment over N ranks is 2^20 / N pairs per rank.  Rank-sized steps (2^19 / 2^18 / 2^17 pairs over an SRS shard of that
+    # length, grouped launches as ShardedMsm.auto_group picks them for that shard size) run here through the WHOLE N > 1 path: nccl process
+    # group (one rank -- RCCL refuses two ranks on one device), bucketed all_gather_into_tensor on the gatherer's stream, fold.  From the
+    # step times, the strong-scaling efficiency an N-GPU run of this bench can reach: t(2^20) / (N t(2^20 / N)).  20-step regions (the driver's
+    # default K) and 96-step regions (steady state).  KZG_BENCH_REHEARSAL=0 skips it.
+    shard_rehearsal = None
+    if world == 1 and LOG_N >= 14 and not args.no_secondary and os.environ.get("KZG_BENCH_REHEARSAL", "1") != "0":
+        shard_rehearsal = {"is": "per-rank step of a 2^%d-pair commitment split N ways, measured on ONE GPU through the N > 1 code path (grouped launches, "
+                                 "one-rank RCCL all-gather, fold); efficiency = t(2^%d pairs) / (N x t(2^%d / N pairs)); not a multi-GPU measurement" % (LOG_N, LOG_N, LOG_N),
+                           "exchange": None, "sizes": {}}
+        try:
+            if not multi:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                if "MASTER_PORT" not in os.environ:
+                    import socket
+                    with socket.socket() as so:
+                        so.bind(("127.0.0.1", 0))
+                        os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            shard_rehearsal["exchange"] = "nccl (RCCL), 1 rank"
+
+            def region(shm, srs_r, ptrs, count, depth, group):
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                last = None
+                for last in shm.commit_stream(srs_r, [ptrs[i % len(ptrs)] for i in range(count)], depth=depth, group=group):
+                    pass
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / count * 1e3, last
+
+            # the 2^20 step itself through the same exchange path (N = 1 reference of the ratios), same box, same minute
+            sh_ref = ShardedMsm(ctx, n, 0, 1, gather_device="cuda", force_exchange=True)
+            region(sh_ref, srs, rot_ptrs, 24, depth_used, 1)
+            ref20, _ = region(sh_ref, srs, rot_ptrs, 20, depth_used, 1)
+            ref96, res_ref = region(sh_ref, srs, rot_ptrs, 96, depth_used, 1)
+            shard_rehearsal["step_2_%d_ms" % LOG_N] = {"20_steps": ref20, "96_steps": ref96}
+            ok_all = bool(np.array_equal(res_ref, expected_commitment(canon_sets[95 % N_BUFFERS], tau)))
+            for lg, ranks in ((LOG_N - 1, 2), (LOG_N - 2, 4), (LOG_N - 3, 8)):
+                per = 1 << lg
+                srs_r = k.SRS.generate(tau, per, ctx=ctx)                  # the shard of rank 0: powers [0, per)
+                shm = ShardedMsm(ctx, per, 0, 1, gather_device="cuda", force_exchange=True)
+                ptrs = [d.data_ptr() for d in d_sets]                       # the first `per` scalars of every resident buffer
+                grp = shm.auto_group(srs_r)
+                dep = shm.group_depth(3, grp)
+                region(shm, srs_r, ptrs, 48, dep, grp)
+                t20, _ = region(shm, srs_r, ptrs, 20, dep, grp)
+                t96, last = region(shm, srs_r, ptrs, 96, dep, grp)
+                want_r = expected_commitment(canon_sets[95 % N_BUFFERS][:per], tau)
+                exact_r = bool(np.array_equal(last, want_r))
+                ok_all = ok_all and exact_r
+                shard_rehearsal["sizes"]["2^%d" % lg] = {"ranks": ranks, "ms_per_step_20": t20, "ms_per_step_96": t96, "steps_per_launch": grp, "pipeline_depth": dep,
+                                                        "efficiency_20": ref20 / (ranks * t20), "efficiency_96": ref96 / (ranks * t96), "bit_exact_vs_oracle": exact_r}
+                srs_r.close()
+            shard_rehearsal["bit_exact_vs_oracle"] = ok_all
+            if not multi:
+                dist.destroy_process_group()
+        except Exception as e:                                              # noqa: BLE001 -- never takes the headline down
+            shard_rehearsal["error"] = "%s: %s" % (type(e).__name__, e)
+
     # ---- N > 1 only, outside `value`: the OTHER way to spend N GPUs on a stream of commitments -- whole commitments per rank, no exchange
     # ("replicas": SURVEY 8e's throughput mode).  north_star prescribes the sharded form above (one commitment split N ways: lower latency
     # per commitment, 82-97 % of linear); replicas run every GPU at the one-GPU rate.  Reported so that a user can choose; KZG_BENCH_REPLICAS=0
@@ -538,6 +691,34 @@ def main():
                             "ms_per_commitment_per_gpu": (replicas["elapsed_s_max_over_ranks"] / replicas["commitments_per_rank"] * 1e3) if rate else None,
                             "commitments_per_rank": replicas["commitments_per_rank"], "bit_exact_vs_oracle": rep_exact if replicas["ok_on_every_rank"] else None,
                             "error_on_rank_0": replicas["error_on_rank_0"]}
+        config4_out = None
+        if config4 is not None:
+            config4_out = {"is": "BASELINE config 4, NOT `value`: one evaluation-form polynomial of 2^%d elements in HOST memory -> commitment and proof at "
+                                 "z = Scalars-B[0], sharded over %d rank(s); seconds are per call, MAX over ranks, %d calls between barriers" % (LOG_N, world, c4_reps),
+                           "ok_on_every_rank": config4.get("ok_everywhere"), "error_on_rank_0": config4.get("err"), "lagrange_shard_setup_s": config4.get("setup_s")}
+            if config4.get("ok_everywhere"):
+                ev_canon = canon_sets[1]
+                z_int = canon_b[0]
+                ftau, fz = eval_form_ground_truth(ev_canon, LOG_N, [tau, z_int])
+                import pyref
+                want_c4 = pyref.point_to_wire(pyref.ec_mul(ftau, (1, 2)))
+                want_p4 = pyref.point_to_wire(pyref.ec_mul((ftau - fz) * pow(tau - z_int, -1, FR) % FR, (1, 2)))
+                want_y4 = ints_to_wire([fz])[0]
+                new_ok = bool(np.array_equal(config4["new_commit"], want_c4) and np.array_equal(config4["new_proof"][0], want_p4) and np.array_equal(config4["new_proof"][1], want_y4))
+                old_ok = bool(np.array_equal(config4["old_commit"], want_c4) and np.array_equal(config4["old_proof"][0], want_p4) and np.array_equal(config4["old_proof"][1], want_y4))
+                if not (new_ok and old_ok):
+                    exit_code = 3
+                per_rank_mib = 32.0 * n / world / 2 ** 20
+                config4_out.update({
+                    "lagrange_shards": {"commit_ms": config4["new_commit_s"] * 1e3, "proof_ms": config4["new_proof_s"] * 1e3,
+                                        "commit_plus_proof_per_s": 1.0 / (config4["new_commit_s"] + config4["new_proof_s"]),
+                                        "per_rank": "uploads %.1f MiB, inverts and divides 2^%d / %d elements, MSM over its slice; exchanges: 128 B (commitment), 64 B + 256 B (proof) per rank" % (per_rank_mib, LOG_N, world),
+                                        "bit_exact_vs_big_integers": new_ok},
+                    "replicated_r4": {"commit_ms": config4["old_commit_s"] * 1e3, "proof_ms": config4["old_proof_s"] * 1e3,
+                                      "commit_plus_proof_per_s": 1.0 / (config4["old_commit_s"] + config4["old_proof_s"]),
+                                      "per_rank": "uploads %.0f MiB, IFFT and quotient of all 2^%d elements on every rank, MSM over its slice; exchange: 128 B per rank" % (32.0 * n / 2 ** 20, LOG_N),
+                                      "bit_exact_vs_big_integers": old_ok},
+                    "bit_exact_check": "commitment == f^(tau) G1, y == f^(z), proof == ((f^(tau) - y) / (tau - z)) G1 with f^ by big-integer barycentric evaluation (bench.py eval_form_ground_truth)"})
         ms_per_step = elapsed / args.steps * 1e3
         pairs_per_s = n * args.steps / elapsed
         acc_ms = phase_alone[4]                                   # k_msm_accumulate, average launch duration, running alone
@@ -585,6 +766,8 @@ def main():
                                  "algorithmic bytes by design: one 64-byte precomputed-table point is gathered per (scalar, digit)"},
             "gpu_clock_under_load": clocks.report(),
             "replicas_mode": replicas_out,
+            "config4": config4_out,
+            "shard_rehearsal": shard_rehearsal,
             "phases_ms_per_launch": dict(zip(phase_names, phase_alone)),
             "phases_ms_per_launch_pipelined": dict(zip(phase_names, phase_piped)),
         }
@@ -673,18 +856,23 @@ def main():
             stream_blob(2)
             t = time.perf_counter(); stream_blob(8); cb_stream_ms = (time.perf_counter() - t) / 8 * 1e3
             assert np.array_equal(o8, want_blob), "streamed blob commitment differs"
-            def stream_proof(reps=6):
-                prev = None
+            def stream_proof(reps=6, depth=3):
+                # THREE proofs in flight, as the commitment stream above: the 32 MiB upload of proof k + 2 runs beside the kernels of k and k + 1
+                inflight = []
                 for i in range(reps):
-                    assert lib.kzg_compute_proof_begin(ctx.handle, srs.handle, _lib.ptr(scalars), n, None, n, _lib.ptr(zq), i & 1) == 0
-                    if prev is not None:
-                        assert lib.kzg_compute_proof_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), _lib.ptr(o4)) == 0
-                    prev = i & 1
-                assert lib.kzg_compute_proof_end(ctx.handle, prev, _lib.ptr(o8), C.byref(oi), _lib.ptr(o4)) == 0
+                    if len(inflight) == depth:
+                        assert lib.kzg_compute_proof_end(ctx.handle, inflight.pop(0), _lib.ptr(o8), C.byref(oi), _lib.ptr(o4)) == 0
+                    assert lib.kzg_compute_proof_begin(ctx.handle, srs.handle, _lib.ptr(scalars), n, None, n, _lib.ptr(zq), i % depth) == 0
+                    inflight.append(i % depth)
+                while inflight:
+                    assert lib.kzg_compute_proof_end(ctx.handle, inflight.pop(0), _lib.ptr(o8), C.byref(oi), _lib.ptr(o4)) == 0
             assert lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(scalars), n, None, n, _lib.ptr(zq), _lib.ptr(o8), C.byref(oi), _lib.ptr(o4)) == 0
             want_proof = o8.copy()
-            stream_proof(2)
-            t = time.perf_counter(); stream_proof(6); pr_stream_ms = (time.perf_counter() - t) / 6 * 1e3
+            stream_proof(4)
+            t = time.perf_counter(); stream_proof(12); pr_stream_ifft_ms = (time.perf_counter() - t) / 12 * 1e3
+            assert np.array_equal(o8, want_proof), "streamed proof differs"
+            stream_proof(4, depth=2)
+            t = time.perf_counter(); stream_proof(12, depth=2); pr_stream_ifft_d2_ms = (time.perf_counter() - t) / 12 * 1e3
             assert np.array_equal(o8, want_proof), "streamed proof differs"
             # KZG::compute_blob_proof end to end (kzg.rs:288-309): bytes in, Fiat-Shamir challenge (SHA-256 over 32 MiB on a host
             # thread) and proof out; and commit + proof of the same blob in one call (the hash runs beside the GPU commitment)
@@ -697,6 +885,20 @@ def main():
                                                                  C.byref(oci), _lib.ptr(ob2), C.byref(oi), _lib.ptr(oz), _lib.ptr(oy)), reps=4, warm=1)
             assert np.array_equal(oc2, oc) and np.array_equal(ob2, ob), "commit + proof in one call differs from the two calls"
             ch_ms = avg_ms(lambda: lib.kzg_compute_challenge(blob_bytes.ctypes.data_as(u8p), blob_bytes.size, _lib.ptr(oc), _lib.ptr(oz)), reps=3, warm=1)
+            # The same calls with the Lagrange basis of 2^LOG_N points cached on the device (kzg_srs_cache_lagrange: KZG::g1_ifft once instead of inside
+            # every commit_eval_form, prover/src/kzg.rs:96-98): eval-form commitments and proofs are ONE MSM over it -- no IFFT (kzg.rs:98-100, :176-177)
+            t = time.perf_counter()
+            assert lib.kzg_srs_cache_lagrange(ctx.handle, srs.handle, n) == 0
+            lag_cache_s = time.perf_counter() - t
+            ce_lag_ms = avg_ms(lambda: lib.kzg_commit_eval_form(ctx.handle, srs.handle, _lib.ptr(scalars), n, _lib.ptr(o8), C.byref(oi)), reps=5)
+            pr_lag_ms = avg_ms(lambda: lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(scalars), n, None, n, _lib.ptr(zq), _lib.ptr(o8), C.byref(oi), _lib.ptr(o4)), reps=5)
+            assert np.array_equal(o8, want_proof), "proof over the cached Lagrange basis differs from the IFFT path"
+            stream_proof(4)
+            t = time.perf_counter(); stream_proof(12); pr_stream_ms = (time.perf_counter() - t) / 12 * 1e3
+            assert np.array_equal(o8, want_proof), "streamed proof over the cached Lagrange basis differs"
+            cb_lag_ms = avg_ms(lambda: lib.kzg_commit_blob(ctx.handle, srs.handle, blob_bytes.ctypes.data_as(u8p), blob_bytes.size, _lib.ptr(o8), C.byref(oi)), reps=5)
+            assert np.array_equal(o8, want_blob), "blob commitment over the cached Lagrange basis differs"
+            assert lib.kzg_srs_drop_lagrange(ctx.handle, srs.handle) == 0
             # config 5 shape: verify_kzg_proof_batch core at n = 4096 (three 4096-point MSMs batched on the GPU + host pairing check)
             nb = 4096
             g1w = np.zeros((nb, 8), dtype=np.uint64)
@@ -820,7 +1022,13 @@ def main():
                 "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,
                 "fr_ntt_algorithmic_GBps": 64.0 * n / (ntt_ms * 1e-3) / 1e9, "fr_ntt_frac_of_hbm_peak": 64.0 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "host_buffers_commit_coeff_ms": cc_ms, "host_buffers_commit_eval_ms": ce_ms, "host_buffers_compute_proof_ms": pr_ms, "host_buffers_compute_proof_streamed_ms": pr_stream_ms,
+                "host_buffers_commit_coeff_ms": cc_ms, "host_buffers_commit_eval_ms": ce_ms, "host_buffers_compute_proof_ms": pr_ms,
+                "host_buffers_compute_proof_streamed_ms": pr_stream_ms,
+                "host_buffers_compute_proof_streamed_is": "three proofs in flight over the Lagrange basis cached with the SRS (kzg_srs_cache_lagrange, %.2f s once): no IFFT; "
+                                                          "the IFFT + monomial-basis path beside it" % lag_cache_s,
+                "host_buffers_compute_proof_streamed_ifft_path_ms": pr_stream_ifft_ms, "host_buffers_compute_proof_streamed_ifft_path_two_in_flight_ms": pr_stream_ifft_d2_ms,
+                "cached_lagrange_basis": {"cache_once_s": lag_cache_s, "host_buffers_commit_eval_ms": ce_lag_ms, "host_buffers_compute_proof_ms": pr_lag_ms,
+                                          "commit_blob_from_host_bytes_ms": cb_lag_ms, "memory_GiB": (255 + 15 + 17) * n * 64 / 2.0 ** 30},
                 "note": "NTT on device-resident data (64 B per element algorithmic); host_buffers_* include the 32 MiB H2D copy of the scalars (PCIe)"}
         if world == 1 and not args.no_cpu_baseline:
             import oracle as orc                                   # checker + reported CPU baseline only
@@ -834,7 +1042,7 @@ def main():
                 exit_code = 3
             out["cpu_baseline"] = {"value": n / cpu_s, "unit": "pairs/s", "cores": min(cores, 17), "kind": "port",
                                    "sample": "the same 2^%d-pair MSM once: oracle/ C restatement of arkworks' signed-window "
-                                             "Pippenger (c=15, one thread per window, 17 windows), %.2f s wall" % (LOG_N, cpu_s)}
+                                             "Pippenger (c=15, one thread per window, 17 windows: 17 of the box's %d hardware threads), %.2f s wall" % (LOG_N, cores, cpu_s)}
             m1 = 1 << 16                                           # single-thread sample (SURVEY.md 8d asks for both)
             t1 = time.perf_counter()
             orc.msm_pippenger(g1[:m1], scalars[:m1], threads=1)

@@ -327,6 +327,12 @@ int32_t kzg_multi_device_count(const kzg_multi* m);
 size_t kzg_multi_srs_len(const kzg_multi* m);
 int32_t kzg_multi_srs_upload(kzg_multi* m, const uint64_t* g1_xy_mont, size_t n_points);
 int32_t kzg_multi_srs_generate(kzg_multi* m, const uint64_t tau_mont[4], size_t n_points);        /* known-tau SRS (tests, bench) */
+/* One-time set-up for BASELINE config 4 WITHOUT replicated work: the Lagrange basis of the first n powers (KZG::g1_ifft, kzg.rs:263-285),
+ * sharded by evaluation index (device g keeps L_i, i in [g n / G, (g+1) n / G), with its own tables).  From then on
+ * kzg_multi_commit_eval_form / kzg_multi_compute_proof of exactly n evaluations make every device read, invert and divide ITS slice of the
+ * caller's buffer only (csrc/lagrange.hip): no whole-polynomial upload, IFFT or quotient per device.  Same results.  Replaced by the next
+ * kzg_multi_srs_upload / _generate. */
+int32_t kzg_multi_cache_lagrange(kzg_multi* m, size_t n);
 int32_t kzg_multi_commit_coeff_form(kzg_multi* m, const uint64_t* coeffs_mont, size_t n, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
 int32_t kzg_multi_commit_eval_form(kzg_multi* m, const uint64_t* evals_mont, size_t n, uint64_t out_xy_mont[8], uint8_t* out_is_infinity);
 int32_t kzg_multi_compute_proof(kzg_multi* m, const uint64_t* evals_mont, size_t n, size_t n_roots, const uint64_t z_mont[4],

@@ -104,6 +104,7 @@ PROTOTYPES = {
     "kzg_multi_srs_len": (sz, [vp]),
     "kzg_multi_srs_upload": (i32, [vp, u64p, sz]),
     "kzg_multi_srs_generate": (i32, [vp, u64p, sz]),
+    "kzg_multi_cache_lagrange": (i32, [vp, sz]),
     "kzg_multi_commit_coeff_form": (i32, [vp, u64p, sz, u64p, u8p]),
     "kzg_multi_commit_eval_form": (i32, [vp, u64p, sz, u64p, u8p]),
     "kzg_multi_compute_proof": (i32, [vp, u64p, sz, sz, u64p, u64p, u8p, u64p]),

@@ -238,7 +238,7 @@ static int32_t upload_points(kzg_ctx* ctx, const uint64_t* xy, size_t n, uint4* 
     return KZG_OK;
 }
 
-int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out) {
+static int32_t srs_upload_impl(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out, bool tables) {
     if (!ctx || !out || (!g1_xy_mont && n_points)) return KZG_ERR_INVALID_ARG;
     *out = nullptr;
     if (n_points > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
@@ -252,11 +252,14 @@ int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n_points * 64);
         if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
         int32_t rc = upload_points(ctx, g1_xy_mont, n_points, s->d_points, ctx->msm.bases_wire);
-        if (rc == KZG_OK) rc = srs_precompute(ctx, s);
+        if (rc == KZG_OK && tables) rc = srs_precompute(ctx, s);
         if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
     }
     *out = s;
     return KZG_OK;
+}
+int32_t kzg_srs_upload(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out) {
+    return srs_upload_impl(ctx, g1_xy_mont, n_points, out, true);
 }
 
 int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_power, size_t n_points, kzg_srs** out) {
@@ -1569,3 +1572,7 @@ int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blob
 }
 
 }  // extern "C"
+
+namespace kzg {
+int32_t srs_upload_plain(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out) { return srs_upload_impl(ctx, g1_xy_mont, n_points, out, false); }
+}  // namespace kzg

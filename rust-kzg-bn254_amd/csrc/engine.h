@@ -243,6 +243,8 @@ int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy
 int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out, bool wire);
 
 int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);
+// the points only, no window / per-bit tables (set-up paths that need the points once: kzg_multi_cache_lagrange)
+int32_t srs_upload_plain(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);
 
 // process-wide caches keyed by device (NTT twiddles, g1_ifft scalar sets): released when the LAST context of a device is destroyed
 void ntt_release_device_caches(int dev);

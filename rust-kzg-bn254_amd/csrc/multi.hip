@@ -28,6 +28,10 @@ struct kzg_multi {
     // resident scalars: buffer b of device g holds the coefficients [lo[g], min(lo[g+1], n_b)) of polynomial b
     std::vector<std::vector<void*>> dbuf;         // [g][b]
     size_t buf_n[KZG_MULTI_BUFFERS] = {};
+    // evaluation-index shards of the Lagrange basis of lag_n points (kzg_multi_cache_lagrange): device g holds L_i, i in [elo[g], elo[g+1])
+    std::vector<kzg_srs*> lag_shard;
+    std::vector<size_t> elo;
+    size_t lag_n = 0;
 };
 
 namespace {
@@ -53,6 +57,10 @@ void set_bounds(kzg_multi* m, size_t n) {
 void drop_shards(kzg_multi* m) {
     for (auto& s : m->shard) { if (s) kzg_srs_free(s); s = nullptr; }
 }
+void drop_lagrange(kzg_multi* m) {
+    for (auto& l : m->lag_shard) { if (l) kzg_srs_free(l); l = nullptr; }
+    m->lag_n = 0;
+}
 void drop_buffers(kzg_multi* m) {
     for (size_t g = 0; g < m->dbuf.size(); ++g) {
         (void)hipSetDevice(m->ctx[g]->device);
@@ -77,6 +85,7 @@ int32_t kzg_multi_create(const int32_t* device_ids, int32_t n_devices, kzg_multi
         m->ctx.push_back(c);
     }
     m->shard.assign((size_t)n_devices, nullptr);
+    m->lag_shard.assign((size_t)n_devices, nullptr);
     m->dbuf.assign((size_t)n_devices, std::vector<void*>(KZG_MULTI_BUFFERS, nullptr));
     *out = m;
     return KZG_OK;
@@ -85,6 +94,7 @@ int32_t kzg_multi_create(const int32_t* device_ids, int32_t n_devices, kzg_multi
 void kzg_multi_destroy(kzg_multi* m) {
     if (!m) return;
     drop_buffers(m);
+    drop_lagrange(m);
     drop_shards(m);
     for (auto* c : m->ctx) kzg_ctx_destroy(c);
     delete m;
@@ -96,6 +106,7 @@ size_t kzg_multi_srs_len(const kzg_multi* m) { return m ? m->n_total : 0; }
 int32_t kzg_multi_srs_upload(kzg_multi* m, const uint64_t* g1_xy_mont, size_t n_points) {
     if (!m || (n_points && !g1_xy_mont)) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(m->mu);
+    drop_lagrange(m);
     drop_shards(m);
     set_bounds(m, n_points);
     return for_each_device(m, [&](size_t g) {
@@ -106,6 +117,7 @@ int32_t kzg_multi_srs_upload(kzg_multi* m, const uint64_t* g1_xy_mont, size_t n_
 int32_t kzg_multi_srs_generate(kzg_multi* m, const uint64_t tau_mont[4], size_t n_points) {
     if (!m || !tau_mont) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(m->mu);
+    drop_lagrange(m);
     drop_shards(m);
     set_bounds(m, n_points);
     return for_each_device(m, [&](size_t g) {
@@ -139,6 +151,15 @@ int32_t kzg_multi_commit_eval_form(kzg_multi* m, const uint64_t* evals_mont, siz
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
     const size_t G = m->ctx.size();
     std::vector<uint64_t> parts(16 * G, 0);
+    if (m->lag_n == n) {                                                             // sharded by evaluation index: every device reads ITS slice only, no IFFT
+        int32_t rcl = for_each_device(m, [&](size_t g) -> int32_t {
+            const size_t lo = m->elo[g], len = m->elo[g + 1] - lo;
+            if (len == 0) return KZG_OK;
+            return kzg_commit_eval_form_lagrange_partial(m->ctx[g], m->lag_shard[g], evals_mont + 4 * lo, len, parts.data() + 16 * g);
+        });
+        if (rcl != KZG_OK) return rcl;
+        return fold(parts, G, out_xy_mont, out_is_infinity);
+    }
     int32_t rc = for_each_device(m, [&](size_t g) -> int32_t {
         if (m->lo[g] >= n || m->lo[g + 1] == m->lo[g]) return KZG_OK;
         return kzg_commit_eval_form_partial(m->ctx[g], m->shard[g], m->lo[g], evals_mont, n, parts.data() + 16 * g);
@@ -155,6 +176,31 @@ int32_t kzg_multi_compute_proof(kzg_multi* m, const uint64_t* evals_mont, size_t
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;
     if (n > m->n_total) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
     const size_t G = m->ctx.size();
+    if (m->lag_n == n) {                                                             // the four steps of kzg_compute_proof_lagrange_* with a host join in the middle
+        std::vector<uint64_t> yparts(KZG_LAGRANGE_YPART_WORDS * G, 0), pparts(KZG_LAGRANGE_PART_WORDS * G, 0);
+        std::vector<int32_t> started(G, 0);
+        int32_t rcl = for_each_device(m, [&](size_t g) -> int32_t {
+            const size_t lo = m->elo[g], len = m->elo[g + 1] - lo;
+            int32_t r = kzg_compute_proof_lagrange_begin(m->ctx[g], m->lag_shard[g], lo, len ? evals_mont + 4 * lo : nullptr, len, n, z_mont, 0);
+            if (r != KZG_OK) return r;
+            started[g] = 1;
+            r = kzg_compute_proof_lagrange_partial_y(m->ctx[g], 0, yparts.data() + KZG_LAGRANGE_YPART_WORDS * g);
+            if (r != KZG_OK) started[g] = 0;
+            return r;
+        });
+        uint64_t y[4] = {0, 0, 0, 0};
+        if (rcl == KZG_OK) rcl = kzg_lagrange_fold_y(yparts.data(), G, n, z_mont, y);
+        if (rcl != KZG_OK) { for (size_t g = 0; g < G; ++g) if (started[g]) (void)kzg_compute_proof_lagrange_abort(m->ctx[g], 0); return rcl; }
+        rcl = for_each_device(m, [&](size_t g) -> int32_t {
+            int32_t r = kzg_compute_proof_lagrange_continue(m->ctx[g], 0, y);
+            if (r == KZG_OK) r = kzg_compute_proof_lagrange_end(m->ctx[g], 0, pparts.data() + KZG_LAGRANGE_PART_WORDS * g);
+            if (r != KZG_OK) (void)kzg_compute_proof_lagrange_abort(m->ctx[g], 0);
+            return r;
+        });
+        if (rcl != KZG_OK) return rcl;
+        if (out_y_mont) memcpy(out_y_mont, y, 32);
+        return kzg_lagrange_fold_proof(pparts.data(), G, n, z_mont, out_xy_mont, out_is_infinity);
+    }
     std::vector<uint64_t> parts(16 * G, 0), ys(4 * G, 0);
     int32_t rc = for_each_device(m, [&](size_t g) -> int32_t {
         if (g != 0 && (m->lo[g] >= n || m->lo[g + 1] == m->lo[g])) return KZG_OK;   // device 0 always runs: it reports y
@@ -164,6 +210,42 @@ int32_t kzg_multi_compute_proof(kzg_multi* m, const uint64_t* evals_mont, size_t
     if (rc != KZG_OK) return rc;
     if (out_y_mont) memcpy(out_y_mont, ys.data(), 32);
     return fold(parts, G, out_xy_mont, out_is_infinity);
+}
+
+// Lagrange basis of the first n powers, sharded by EVALUATION index (device g keeps L_i for i in [g n / G, (g+1) n / G) with its own tables).
+// One-time set-up: the powers are collected from the devices' shards, device 0 runs KZG::g1_ifft(n) (kzg.rs:263-285) over a plain copy,
+// every device uploads its slice of the result.  From then on kzg_multi_commit_eval_form / kzg_multi_compute_proof of exactly n
+// evaluations read only the device's own slice of the caller's buffer: no replicated upload, no IFFT, no whole-polynomial quotient.
+int32_t kzg_multi_cache_lagrange(kzg_multi* m, size_t n) {
+    if (!m) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;              // kzg.rs:265-269
+    if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (n > m->n_total) return KZG_ERR_SRS_CAPACITY_EXCEEDED;
+    if (m->lag_n == n) return KZG_OK;
+    drop_lagrange(m);
+    const size_t G = m->ctx.size();
+    std::vector<uint64_t> pts(n * 8);
+    int32_t rc = for_each_device(m, [&](size_t g) -> int32_t {
+        const size_t lo = m->lo[g], hi = std::min(m->lo[g + 1], n);
+        if (lo >= hi) return KZG_OK;
+        return kzg_srs_download(m->ctx[g], m->shard[g], 0, hi - lo, pts.data() + 8 * lo);
+    });
+    if (rc != KZG_OK) return rc;
+    kzg_srs* plain = nullptr;
+    rc = kzg::srs_upload_plain(m->ctx[0], pts.data(), n, &plain);                    // no tables: g1_ifft of this size works on the points
+    if (rc != KZG_OK) return rc;
+    rc = kzg_g1_ifft(m->ctx[0], plain, n, pts.data());
+    kzg_srs_free(plain);
+    if (rc != KZG_OK) return rc;
+    m->elo.assign(G + 1, 0);
+    for (size_t g = 0; g <= G; ++g) m->elo[g] = g * n / G;
+    rc = for_each_device(m, [&](size_t g) -> int32_t {
+        return kzg_srs_upload(m->ctx[g], pts.data() + 8 * m->elo[g], m->elo[g + 1] - m->elo[g], &m->lag_shard[g]);
+    });
+    if (rc != KZG_OK) { drop_lagrange(m); return rc; }
+    m->lag_n = n;
+    return KZG_OK;
 }
 
 // ---- resident scalars and streams of commitments (what bench.py --multi times: inputs in HBM, several MSMs in flight per device) ----

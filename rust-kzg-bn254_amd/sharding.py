@@ -646,6 +646,11 @@ class MultiKzg:
     def __len__(self):
         return _lib.load().kzg_multi_srs_len(self.handle)
 
+    def cache_lagrange(self, n: int):
+        """Shard the Lagrange basis of the first n powers by evaluation index over the devices (`kzg_multi_cache_lagrange`): from then on
+        `commit_eval_form` / `compute_proof` of exactly n evaluations touch each device's own slice only."""
+        self._check(_lib.load().kzg_multi_cache_lagrange(self.handle, n))
+
     def commit_coeff_form(self, coeffs):
         c = _lib.as_u64(coeffs, 4).reshape(-1, 4)
         out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0)

@@ -37,6 +37,21 @@ def test_bench_emits_the_contract_line():
     assert r["traffic"] is None and len(r["traffic_source"]) > 10     # PMC passes exist for the 2^20 workload only: null + the reason
     assert d["cpu_baseline_ntt"]["value"] > 0 and d["cpu_baseline_ntt"]["gpu_bit_exact_vs_oracle"] is True
     assert "phases_ms_per_launch" in d and "phases_ms_per_launch_pipelined" in d
+    # round 5: BASELINE config 4 in the line (both sharding schemes, checked against big integers), the one-GPU rehearsal of the N-rank
+    # steps through a real one-rank RCCL exchange with the implied strong-scaling efficiency, proofs over the cached Lagrange basis
+    c4 = d["config4"]
+    assert c4["ok_on_every_rank"] is True and c4["error_on_rank_0"] is None
+    for scheme in ("lagrange_shards", "replicated_r4"):
+        assert c4[scheme]["bit_exact_vs_big_integers"] is True and c4[scheme]["commit_ms"] > 0 and c4[scheme]["proof_ms"] > 0
+    sr = d["shard_rehearsal"]
+    assert "error" not in sr and sr["bit_exact_vs_oracle"] is True and sr["exchange"].startswith("nccl")
+    assert sorted(sr["sizes"]) == ["2^11", "2^12", "2^13"]
+    for ranks, key in ((2, "2^13"), (4, "2^12"), (8, "2^11")):
+        e = sr["sizes"][key]
+        assert e["ranks"] == ranks and e["ms_per_step_20"] > 0 and e["ms_per_step_96"] > 0 and 0 < e["efficiency_96"] and e["bit_exact_vs_oracle"] is True
+    sec = d["secondary"]
+    assert sec["host_buffers_compute_proof_streamed_ms"] > 0 and sec["host_buffers_compute_proof_streamed_ifft_path_ms"] > 0
+    assert sec["cached_lagrange_basis"]["host_buffers_compute_proof_ms"] > 0
     clk = d["gpu_clock_under_load"]                      # sysfs engine clock sampled in the untimed spin-up (None where sysfs does not show this GPU)
     assert clk is None or (200 < clk["sclk_mhz_min"] <= clk["sclk_mhz_mean"] <= clk["sclk_mhz_max"] < 4000 and clk["samples"] >= 1)
 
@@ -103,6 +118,25 @@ def test_bench_two_ranks_gloo_is_bit_exact():
     assert d["value"] > 0 and d["value_uniform"] > 0 and d["latency_ms"] > 0
     rep = d["replicas_mode"]                             # N > 1: whole commitments per rank beside the sharded headline (never `value`)
     assert rep["bit_exact_vs_oracle"] is True and rep["commitments_per_s"] > 0 and rep["error_on_rank_0"] is None
+
+
+def test_bench_two_ranks_gloo_carries_config4():
+    """at N > 1 the line times BASELINE config 4 (evaluations in host memory -> commitment and proof) through the
+    evaluation-index shards of the Lagrange basis AND through round 4's replicated path, every result checked against big integers."""
+    env = dict(os.environ, KZG_BENCH_LOG_N="15", KZG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", KZG_BENCH_REPLICAS="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["bit_exact_vs_oracle"] is True
+    c4 = d["config4"]
+    assert c4["ok_on_every_rank"] is True, c4
+    for scheme in ("lagrange_shards", "replicated_r4"):
+        assert c4[scheme]["bit_exact_vs_big_integers"] is True and c4[scheme]["commit_ms"] > 0 and c4[scheme]["proof_ms"] > 0
+    assert "16384 / 2" not in c4["lagrange_shards"]["per_rank"] and "/ 2 elements" in c4["lagrange_shards"]["per_rank"]
+    assert d["shard_rehearsal"] is None                   # the rehearsal belongs to the N = 1 line
 
 
 def test_bench_one_rank_through_rccl_takes_the_multi_gpu_path():

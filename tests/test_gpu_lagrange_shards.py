@@ -265,3 +265,28 @@ def test_config4_2_20_eight_uneven_lagrange_shards(k):
     for s in shards:
         s.close()
     srs.close()
+
+
+def test_multi_handle_over_lagrange_shards(k, test_srs_wire):
+    """kzg_multi_* (one process, several device contexts -- three on this one GPU) after kzg_multi_cache_lagrange(n): eval-form commitments
+    and proofs of exactly n evaluations go through the evaluation-index shards (every context reads its own slice of the caller's buffer),
+    other lengths keep the replicated path; all against the oracle."""
+    from rust_kzg_bn254_amd.sharding import MultiKzg
+    mk = MultiKzg([0, 0, 0])
+    mk.srs_upload(test_srs_wire[:2048])
+    rnd = random.Random(31)
+    mk.cache_lagrange(512)
+    for n in (512, 256):                                   # 512: Lagrange shards; 256: the replicated path (no basis cached for it)
+        wire = pyref.frs_to_mont([rnd.randrange(R_) for _ in range(n)])
+        rc, roots = orc.calculate_roots_of_unity(n * 32)
+        rc, want_c = orc.commit_eval_form(test_srs_wire, wire, literal=False)
+        assert np.array_equal(mk.commit_eval_form(wire), want_c)
+        for z in (pyref.fr_to_mont(rnd.randrange(R_)), np.ascontiguousarray(roots[0]), np.ascontiguousarray(roots[n // 3 + 1]), np.ascontiguousarray(roots[n - 1])):
+            rc, want_p, want_y = orc.compute_proof(test_srs_wire, wire, roots, z, literal=False)
+            proof, y = mk.compute_proof(wire, z)
+            assert np.array_equal(proof, want_p) and np.array_equal(y, want_y), n
+    with pytest.raises(ValueError):
+        mk.cache_lagrange(100)                             # "length provided is not a power of 2"
+    with pytest.raises(ValueError):
+        mk.cache_lagrange(4096)                            # more points than the SRS holds
+    mk.close()
