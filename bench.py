@@ -35,7 +35,7 @@ LOG_N = int(os.environ.get("KZG_BENCH_LOG_N", "20"))
 DEPTH = int(os.environ["KZG_BENCH_DEPTH"]) if os.environ.get("KZG_BENCH_DEPTH") else None    # MSMs in flight (default: sharding.py)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 BYTES_PER_PAIR = 96            # 64 B packed affine point + 32 B scalar, each read once
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
 MADS_PER_MIXED_ADD = 1467      # v_mad_i64_i32 per xyzz_madd (8 x 162 + 2 x 126 - 81 for the fused Y3)
 # The instruction stream of one mixed addition on the fast path of k_msm_accumulate's loop, by class: v_mad_i64_i32, v_mul_lo_u32, 64-bit
 # shifts, v_and_b32, every other instruction (32-bit VALU / SALU / loads), s_nop.  REGENERATED from the compiler's listing by
@@ -56,6 +56,15 @@ def pmc_traffic_bytes(log_n):
         return None, "no PMC summary committed for this round (%s)" % type(e).__name__
     if d.get("log_n") != log_n:
         return None, "the committed PMC passes were collected at 2^%s pairs, this run is 2^%d" % (d.get("log_n"), log_n)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_summarize import kernel_sources_sha256
+        now = kernel_sources_sha256(ROOT)
+    except Exception as e:                                          # noqa: BLE001
+        return None, "cannot digest the kernel sources (%s)" % type(e).__name__
+    if d.get("kernel_sources_sha256") != now:
+        return None, ("STALE: %s was collected on other kernel sources (sha256 %s..., the tree has %s...): re-run tools/collect_profiles.sh"
+                      % (os.path.basename(PMC_JSON), str(d.get("kernel_sources_sha256"))[:12], now[:12]))
     a = d["kernels"]["k_msm_accumulate"]
     return (a["FETCH_SIZE_KB"] + a["WRITE_SIZE_KB"]) * 1024.0, "profiles/" + os.path.basename(PMC_JSON)
 
@@ -239,6 +248,28 @@ class ClockSampler:
         return r
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT touching HIP: the KFD topology nodes with SIMDs (CPU nodes have none), narrowed by
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None when the topology cannot be read (the ranks then
+    fail fast on a missing device themselves)."""
+    import glob
+    try:
+        gpus = 0
+        for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for ln in open(props):
+                if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                    gpus += 1
+        if gpus == 0 and not glob.glob("/sys/class/kfd/kfd/topology/nodes/*"):
+            return None
+    except Exception:                                           # noqa: BLE001
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            gpus = min(gpus, len([x for x in v.split(",") if x.strip() != ""]))
+    return gpus
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher (no WORLD_SIZE in the environment): this process has only parsed its arguments --
     no HIP call, no device query beyond counting -- so it may start the N ranks itself: N fresh children of this interpreter with
@@ -250,16 +281,16 @@ def self_launch(args):
     n = args.gpus
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    have = torch.cuda.device_count()                      # counting does not initialise the runtime
-    if have < n and env.get("KZG_BENCH_BACKEND", "nccl") == "nccl":
+    have = visible_gpu_count()                            # from the KFD topology: the launcher itself never initialises a HIP runtime
+    if have is not None and have < n and env.get("KZG_BENCH_BACKEND", "nccl") == "nccl":
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible.  One rank per GPU over RCCL needs %d devices; to rehearse the N-rank "
                          "path on fewer (every rank on GPU 0, exchange over gloo) set KZG_BENCH_BACKEND=gloo" % (n, have, n))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    if os.environ.get("KZG_BENCH_TEST_CHILD_CMD"):        # test hook (tests/test_host_logic.py): stand-in ranks, to test the launcher without a GPU
-        cmd = os.environ["KZG_BENCH_TEST_CHILD_CMD"].split()
+    if args.test_child_cmd:                               # test hook (tests/test_host_logic.py passes the flag): stand-in ranks, to test the launcher without a GPU
+        cmd = args.test_child_cmd.split()
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
@@ -308,6 +339,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (profiling runs)")
+    ap.add_argument("--test-child-cmd", default=None, help=argparse.SUPPRESS)      # tests only: the command the self-launcher starts per rank
     ap.add_argument("--multi", action="store_true", help="ONE process driving --gpus devices through kzg_multi_* (no torch.distributed, no "
                     "collective): the other partitioning of SURVEY.md 8e; the driver's contract (one rank per GPU over RCCL) is the default mode")
     args, _unknown = ap.parse_known_args()          # (a launcher may append arguments of its own, e.g. --local-rank: ignored)

@@ -135,8 +135,11 @@ int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out) {
         const char* env = getenv("KZG_ACC_SLOTS");
         if (env && atoi(env) > 0) { ctx->acc_wave_slots = (uint32_t)atoi(env); ctx->acc_slots_forced = true; }
     }
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete ctx; return KZG_ERR_DEVICE; }
-    { std::lock_guard<std::mutex> lk(g_ctx_count_mu); ++g_ctx_count[device_id]; }
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_count_mu);          // (taken before the handle exists: no call on it can reach a cache that kzg_ctx_destroy is freeing)
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete ctx; return KZG_ERR_DEVICE; }
+        ++g_ctx_count[device_id];
+    }
     *out = ctx;
     return KZG_OK;
 }
@@ -161,9 +164,11 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
     const int dev = ctx->device;
     delete ctx;
-    bool last = false;
-    { std::lock_guard<std::mutex> lk(g_ctx_count_mu); last = --g_ctx_count[dev] <= 0; if (last) g_ctx_count.erase(dev); }
-    if (last) { kzg::ntt_release_device_caches(dev); kzg::g1fft_release_device_caches(dev); }
+    // the caches are released UNDER the count mutex: a context created on this device meanwhile waits in kzg_ctx_create until they are gone
+    // and then builds its own, instead of picking up pointers that are about to be freed
+    std::lock_guard<std::mutex> lk(g_ctx_count_mu);
+    const bool last = --g_ctx_count[dev] <= 0;
+    if (last) { g_ctx_count.erase(dev); kzg::ntt_release_device_caches(dev); kzg::g1fft_release_device_caches(dev); }
 }
 
 const char* kzg_ctx_last_error(const kzg_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }

@@ -78,7 +78,7 @@ static int generic_window(size_t n, uint32_t batch) {
 // buckets, one group of the first reduction level each; from 2^13 coefficients whole units of 4 096 buckets, reduced like a single MSM.
 static int batch_bucket_bits(size_t poly_len) {
     static const int forced = []() { const char* e = getenv("KZG_BATCH_C"); return e ? atoi(e) : 0; }();
-    if (forced == 7 || (forced >= 12 && forced <= 16)) return forced;
+    if (forced == 7 || (forced >= 13 && forced <= 16)) return forced;    // (c = 12 would be 0 units of 4 096 buckets per polynomial: ADVICE r4)
     if (poly_len < ((size_t)1 << 13)) return 7;
     if (poly_len < ((size_t)1 << 15)) return 13;
     if (poly_len < ((size_t)1 << 18)) return 15;

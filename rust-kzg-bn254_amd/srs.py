@@ -46,6 +46,8 @@ class SRS:
         rc = load(self.ctx.handle, buf.ctypes.data_as(_lib.u8p), points_to_load, C.byref(h), C.byref(bad))
         if rc == _lib.ERR_DESERIALIZE:
             raise DeserializationError("Deserialization failed" if is_native else "point at infinity not coded properly for g1")   # traits.rs:17 / helpers.rs:191-195
+        if rc == _lib.ERR_NOT_ON_CURVE and is_native:
+            raise DeserializationError("Deserialization failed")          # G1Affine::deserialize_compressed reports every bad encoding alike (traits.rs:34-36)
         if rc == _lib.ERR_NOT_ON_CURVE:
             chunk = list(data[32 * bad.value:32 * bad.value + 32])
             raise NotOnCurveError(f"compressed g1 point not on curve: {chunk}")

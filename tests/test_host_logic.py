@@ -141,15 +141,16 @@ def test_srs_order_guard(k):
 
 def test_bench_self_launch_takes_its_ranks_along_when_stopped():
     """`bench.py --gpus N` without a launcher is the parent of its ranks: when it is told to stop (the driver's time-out sends SIGTERM) no rank
-    may stay behind.  CPU-only: the ranks are replaced by sleepers through KZG_BENCH_TEST_CHILD_CMD."""
+    may stay behind.  CPU-only: the ranks are replaced by sleepers through the
+    --test-child-cmd flag (an explicit argument only tests pass; round 4 read it from the environment: ADVICE r4)."""
     import signal
     import subprocess
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KZG_BENCH_BACKEND="gloo", KZG_BENCH_TEST_CHILD_CMD="sleep 300")
+    env = dict(os.environ, KZG_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
-    p = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+    p = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--test-child-cmd", "sleep 300"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     deadline = time.time() + 60
     kids = []

@@ -2,15 +2,22 @@
 tools/count_isa.py recompiles csrc/msm.hip to gfx950 assembly and counts the fast path of the accumulate loop."""
 import json
 import os
+import shutil
 import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_instruction_mix_matches_the_compiler_listing():
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc on this machine (the listing is regenerated with the ROCm compiler)")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "count_isa.py"), "--check"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-800:]
     got = json.loads(res.stdout.strip().splitlines()[-1])
     assert got["mads_per_mixed_add"] == 1467 == 8 * 162 + 2 * 126 - 81          # 8M + 2S with one fused reduction
+    if "warning:" in res.stderr:                                                  # scheduling-detail classes moved (another ROCm release): visible, not fatal
+        print(res.stderr.strip())
     assert got["vgprs"] <= 168 and got["mfma_in_kernel"] == 0 and got["scratch_ops_in_hot_block"] == 0

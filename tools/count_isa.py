@@ -140,15 +140,23 @@ def bench_constants():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--strict", action="store_true", help="with --check: any drifting class fails, not only the multiply-adds")
     ap.add_argument("--asm")
     args = ap.parse_args()
     got = count(args.asm)
     print(json.dumps(got))
     if args.check:
         mix, mads = bench_constants()
-        if tuple(got["mix"]) != mix or got["mads_per_mixed_add"] != mads:
-            print("bench.py drifted: VALU_MIX_COUNTS = %s, MADS_PER_MIXED_ADD = %d; the compiler's listing says %s" % (mix, mads, got["mix"]), file=sys.stderr)
+        # structural: the multiply-adds of one mixed addition (8M + 2S with one fused reduction) -- a different count is a different formula.
+        # The other classes (shifts, masks, moves, nops) are scheduling detail that a ROCm point release may move by a few: reported, not fatal
+        # (ADVICE r4), unless --strict.
+        if got["mads_per_mixed_add"] != mads or got["mix"][0] != mix[0]:
+            print("bench.py drifted: MADS_PER_MIXED_ADD = %d, the compiler's listing says %d" % (mads, got["mads_per_mixed_add"]), file=sys.stderr)
             sys.exit(1)
+        if tuple(got["mix"]) != mix:
+            print("warning: bench.py VALU_MIX_COUNTS = %s, the compiler's listing says %s (regenerate with tools/count_isa.py)" % (mix, tuple(got["mix"])), file=sys.stderr)
+            if args.strict:
+                sys.exit(1)
 
 
 if __name__ == "__main__":

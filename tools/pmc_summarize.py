@@ -9,8 +9,23 @@ the counter reads 1.2x that minimum, i.e. it is NOT halved for this pattern, so 
 Usage: python tools/pmc_summarize.py <fetch_csv> <write_csv> <out_json> [log_n]"""
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources k_msm_accumulate is compiled from: the summary is stamped with their digest, and bench.py reports `roofline.traffic` as
+# stale (null + the reason) when the tree no longer matches -- the one figure of the line the run does not produce itself (VERDICT r4 item 7)
+KERNEL_SOURCES = ("msm_kernels.h", "msm.hip", "curve.h", "field29.h", "fe_asm.h")
+
+
+def kernel_sources_sha256(root=ROOT):
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(root, "rust-kzg-bn254_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
 
 
 def load(path):
@@ -26,6 +41,8 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         out["kernels"][k] = {"FETCH_SIZE_KB": fetch.get(k), "WRITE_SIZE_KB": write.get(k)}
     out["log_n"] = int(sys.argv[4]) if len(sys.argv) > 4 else 20          # workload the passes were collected on (bench.py checks it)
+    out["kernel_sources"] = list(KERNEL_SOURCES)
+    out["kernel_sources_sha256"] = kernel_sources_sha256()                 # of the tree the passes ran on (the snapshot gpurun sent)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     acc = out["kernels"].get("k_msm_accumulate")
     if acc:
