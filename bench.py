@@ -249,20 +249,29 @@ class ClockSampler:
 
 
 def visible_gpu_count():
-    """GPUs this process may use, WITHOUT touching HIP: the KFD topology nodes with SIMDs (CPU nodes have none), narrowed by
-    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None when the topology cannot be read (the ranks then
-    fail fast on a missing device themselves)."""
+    """GPUs this process may use, WITHOUT touching HIP (the launcher must stay free of a GPU runtime): the render nodes it can open
+    (/dev/dri/renderD*: a container that is given one GPU has exactly one) and the KFD topology nodes with SIMDs it can read (the other
+    GPUs of the host are not readable from inside such a container), narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when set.  None when neither source exists (the ranks then fail fast on a missing device themselves)."""
     import glob
-    try:
+    counts = []
+    nodes = glob.glob("/dev/dri/renderD*")
+    if nodes or os.path.isdir("/dev/dri"):
+        counts.append(sum(1 for p_ in nodes if os.access(p_, os.R_OK | os.W_OK)))
+    kfd_nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if kfd_nodes:
         gpus = 0
-        for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-            for ln in open(props):
-                if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
-                    gpus += 1
-        if gpus == 0 and not glob.glob("/sys/class/kfd/kfd/topology/nodes/*"):
-            return None
-    except Exception:                                           # noqa: BLE001
+        for props in kfd_nodes:
+            try:
+                for ln in open(props):
+                    if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                        gpus += 1
+            except OSError:                                     # a GPU of the host this container was not given
+                pass
+        counts.append(gpus)
+    if not counts:
         return None
+    gpus = min(counts)
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:

@@ -585,8 +585,9 @@ class ShardedKzgLagrange:
         part = np.zeros(self.PART, dtype=np.uint64)
         if bad:                                             # every rank still issues the second exchange, then raises
             if failed is None:
-                lib.kzg_compute_proof_lagrange_abort(self.ctx.handle, slot)
-            part[:] = 0xFFFFFFFFFFFFFFFF
+                lib.kzg_compute_proof_lagrange_abort(self.ctx.handle, slot)      # a healthy rank: gives up its slot, sends a harmless row
+            else:
+                part[:] = 0xFFFFFFFFFFFFFFFF
         else:
             try:
                 rc = lib.kzg_lagrange_fold_y(_lib.ptr(np.ascontiguousarray(got)), got.shape[0], self.n, _lib.ptr(z), _lib.ptr(y))

@@ -112,7 +112,7 @@ def test_srs_load_ark_le_matches_the_reference_points(k, tmp_path, test_srs_poin
 
 
 def test_srs_load_ark_le_rejects_malformed_points(k, tmp_path, test_srs_points):
-    from rust_kzg_bn254_amd.errors import DeserializationError, NotOnCurveError
+    from rust_kzg_bn254_amd.errors import DeserializationError
     good = [ark_compress(p) for p in test_srs_points[:8]]
 
     def load(rows):
@@ -129,7 +129,7 @@ def test_srs_load_ark_le_rejects_malformed_points(k, tmp_path, test_srs_points):
     x = 1
     while pow((x ** 3 + 3) % pyref.P, (pyref.P - 1) // 2, pyref.P) == 1:                  # an x with no point on the curve
         x += 1
-    with pytest.raises(NotOnCurveError):
+    with pytest.raises(DeserializationError, match="Deserialization failed"):          # deserialize_compressed reports every bad encoding alike: traits.rs:34-36
         load([x.to_bytes(32, "little")] + good[:2])
     flipped = bytearray(good[2]); flipped[31] ^= 0x80                                     # the other root: a valid point, -P
     s = load([bytes(flipped)])
