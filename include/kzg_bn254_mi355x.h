@@ -55,7 +55,8 @@ typedef enum {
     KZG_ERR_TAU_EQUALS_Z = -19,          /* GenericError("Evaluation point equals trusted setup secret") (verify.rs:56-60) */
     /* multi-rank calls only (no counterpart in the single-process reference): */
     KZG_ERR_PEER = -20,                  /* another rank of the communicator failed in this collective call (it returns its own error) */
-    KZG_ERR_EXCHANGE_TIMEOUT = -21       /* the all-gather did not complete within KZG_EXCHANGE_TIMEOUT_S (default 60): a peer is gone */
+    KZG_ERR_EXCHANGE_TIMEOUT = -21,      /* the all-gather did not complete within KZG_EXCHANGE_TIMEOUT_S (default 60): a peer is gone */
+    KZG_ERR_IO = -22                     /* kzg_srs_save_packed / kzg_srs_load_packed: the file could not be opened, read or written */
 } kzg_status;
 
 /* The reference's error string for a status (Appendix B of SURVEY.md). */
@@ -103,6 +104,14 @@ int32_t kzg_srs_load_compressed_be(kzg_ctx* ctx, const uint8_t* bytes, size_t n_
  * first_power > 0); and read-back of a resident SRS in wire format. */
 int32_t kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau_mont[4], uint64_t first_power, size_t n_points, kzg_srs** out);
 int32_t kzg_srs_download(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, size_t n, uint64_t* out_xy_mont);
+/* A loaded SRS written once in the library's own packed form and read back WITHOUT decoding (the reference decodes the ceremony
+ * file at every SRS::new, prover/src/srs.rs:35-188 -- one field exponentiation per point; its README quotes "a few minutes" for the mainnet file):
+ * "KZGSRS1\0" | u64 n | u64 0 | SHA-256 of the payload | n x 64 B points exactly as kzg_srs_upload takes them.  Loading verifies the digest
+ * (KZG_ERR_DESERIALIZE: wrong magic, truncated, trailing bytes, digest mismatch) and, on the device, that every point is on the curve or the
+ * identity (KZG_ERR_NOT_ON_CURVE), then builds the tables like kzg_srs_upload.  points_to_load = 0: all of them; more than the file holds ->
+ * KZG_ERR_SRS_LENGTH; a file that cannot be opened / written -> KZG_ERR_IO. */
+int32_t kzg_srs_save_packed(kzg_ctx* ctx, const kzg_srs* srs, const char* path);
+int32_t kzg_srs_load_packed(kzg_ctx* ctx, const char* path, size_t points_to_load, kzg_srs** out);
 void    kzg_srs_free(kzg_srs* srs);
 size_t  kzg_srs_len(const kzg_srs* srs);
 /* The same loader for the "native" format of SRS::parallel_read_g1_points_native(.., is_native = true) (prover/src/srs.rs:205-251 ->

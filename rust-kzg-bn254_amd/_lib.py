@@ -38,6 +38,7 @@ ERR_G2_TAU_NOT_ON_CURVE = -18
 ERR_TAU_EQUALS_Z = -19
 ERR_PEER = -20
 ERR_EXCHANGE_TIMEOUT = -21
+ERR_IO = -22
 
 u64p = C.POINTER(C.c_uint64)
 u8p = C.POINTER(C.c_uint8)
@@ -64,6 +65,8 @@ PROTOTYPES = {
     "kzg_ctx_get_msm_profile_entries": (i32, [vp, C.POINTER(C.c_uint64)]),
     "kzg_ctx_measure_valu_rates": (i32, [vp, i32, C.POINTER(C.c_double)]),
     "kzg_srs_download": (i32, [vp, vp, sz, sz, u64p]),
+    "kzg_srs_save_packed": (i32, [vp, vp, C.c_char_p]),
+    "kzg_srs_load_packed": (i32, [vp, C.c_char_p, sz, C.POINTER(vp)]),
     "kzg_srs_free": (None, [vp]),
     "kzg_srs_len": (sz, [vp]),
     "kzg_msm_g1": (i32, [vp, u64p, sz, u64p, sz, u64p, u8p]),

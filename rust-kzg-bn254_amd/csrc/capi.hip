@@ -3,6 +3,7 @@
 #include "host_curve.h"
 #include "host_pairing.h"
 #include "host_sha256.h"
+#include "host_lagrange.h"
 
 #include <algorithm>
 #include <atomic>
@@ -64,8 +65,7 @@ int32_t lag_partial_y(kzg_ctx* ctx, int slot, uint64_t out[8]);
 int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]);
 int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32]);
 void lag_abort(kzg_ctx* ctx, int slot);
-int32_t lag_fold_y(const uint64_t* parts, size_t count, size_t n, const uint64_t z[4], uint64_t out_y[4]);
-int32_t lag_fold_proof(const uint64_t* parts, size_t count, size_t n, const uint64_t z[4], uint64_t out_xy[8], uint8_t* out_inf);
+// (lag_fold_y / lag_fold_proof: host_lagrange.h)
 int32_t vb_evaluate_setup(kzg_ctx* ctx, size_t packed_len, size_t nb);
 int32_t vb_evaluate_enqueue(kzg_ctx* ctx, const uint8_t* packed, const void* meta_host, size_t nb, size_t b0, size_t b1, const uint64_t* zs,
                             uint8_t* small_pinned);
@@ -103,6 +103,7 @@ const char* kzg_status_message(int32_t status) {
         case KZG_ERR_TAU_EQUALS_Z: return "Evaluation point equals trusted setup secret";
         case KZG_ERR_PEER: return "another rank of the communicator failed in this collective call";
         case KZG_ERR_EXCHANGE_TIMEOUT: return "the exchange between the ranks timed out";
+        case KZG_ERR_IO: return "file could not be read or written";
         default: return "unknown status";
     }
 }
@@ -316,6 +317,87 @@ static int32_t srs_load_compressed(kzg_ctx* ctx, const uint8_t* bytes, size_t n_
         }
         if (rc == KZG_OK) rc = srs_precompute(ctx, s);
         if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
+    }
+    *out = s;
+    return KZG_OK;
+}
+
+// ---- packed SRS file: the decoded points as they cross the C-ABI (64 B each), so that a restart skips the decoding of the ceremony file ----
+// layout: "KZGSRS1\0" | u64 n | u64 0 | SHA-256 of the payload (32 B) | payload = n x 64 B (x || y Montgomery words, identity = zeros), little-endian
+namespace {
+const char PACKED_MAGIC[8] = {'K', 'Z', 'G', 'S', 'R', 'S', '1', 0};
+constexpr size_t PACKED_HEADER = 8 + 8 + 8 + 32;
+void sha256_of(const uint8_t* data, size_t len, uint8_t out[32]) {
+    kzg_host::Sha256 sh;
+    kzg_host::sha256_init(sh);
+    kzg_host::sha256_update(sh, data, len);
+    kzg_host::sha256_final(sh, out);
+}
+}  // namespace
+
+int32_t kzg_srs_save_packed(kzg_ctx* ctx, const kzg_srs* srs, const char* path) {
+    if (!ctx || !srs || srs->ctx != ctx || !path) return KZG_ERR_INVALID_ARG;
+    std::vector<uint64_t> pts(srs->n * 8 + 1);
+    if (srs->n) { const int32_t rc = kzg_srs_download(ctx, srs, 0, srs->n, pts.data()); if (rc != KZG_OK) return rc; }
+    uint8_t head[PACKED_HEADER] = {0};
+    memcpy(head, PACKED_MAGIC, 8);
+    const uint64_t n64 = (uint64_t)srs->n;
+    memcpy(head + 8, &n64, 8);
+    sha256_of(reinterpret_cast<const uint8_t*>(pts.data()), srs->n * 64, head + 24);
+    FILE* f = fopen(path, "wb");
+    if (!f) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = std::string("cannot create ") + path; return KZG_ERR_IO; }
+    const bool ok = fwrite(head, 1, sizeof head, f) == sizeof head && (srs->n == 0 || fwrite(pts.data(), 64, srs->n, f) == srs->n);
+    const bool closed = fclose(f) == 0;
+    if (!ok || !closed) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = std::string("short write to ") + path; return KZG_ERR_IO; }
+    return KZG_OK;
+}
+
+int32_t kzg_srs_load_packed(kzg_ctx* ctx, const char* path, size_t points_to_load, kzg_srs** out) {
+    if (!ctx || !path || !out) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = std::string("cannot open ") + path; return KZG_ERR_IO; }
+    uint8_t head[PACKED_HEADER];
+    uint64_t n64 = 0;
+    std::vector<uint64_t> pts;
+    int32_t rc = KZG_OK;
+    if (fread(head, 1, sizeof head, f) != sizeof head || memcmp(head, PACKED_MAGIC, 8) != 0) rc = KZG_ERR_DESERIALIZE;
+    if (rc == KZG_OK) {
+        memcpy(&n64, head + 8, 8);
+        if (n64 > ((uint64_t)1 << 28)) rc = KZG_ERR_TOO_LARGE;
+    }
+    if (rc == KZG_OK) {
+        pts.resize((size_t)n64 * 8 + 1);
+        uint8_t extra;
+        if ((n64 && fread(pts.data(), 64, (size_t)n64, f) != (size_t)n64) || fread(&extra, 1, 1, f) != 0) rc = KZG_ERR_DESERIALIZE;   // truncated, or bytes behind the payload
+    }
+    fclose(f);
+    if (rc == KZG_OK) {
+        uint8_t dig[32];
+        sha256_of(reinterpret_cast<const uint8_t*>(pts.data()), (size_t)n64 * 64, dig);
+        if (memcmp(dig, head + 24, 32) != 0) rc = KZG_ERR_DESERIALIZE;
+    }
+    if (rc != KZG_OK) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->last_error = std::string(path) + ": not a packed SRS file of this library, or damaged"; return rc; }
+    const size_t n = points_to_load ? points_to_load : (size_t)n64;
+    if (n > (size_t)n64) return KZG_ERR_SRS_LENGTH;               // more points asked for than the file holds
+    // the points are validated on the device while they are converted (y^2 = x^3 + 3 or the identity): a file from elsewhere cannot smuggle in garbage
+    kzg_srs* s = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        s = new (std::nothrow) kzg_srs();
+        if (!s) return KZG_ERR_INVALID_ARG;
+        s->ctx = ctx;
+        s->n = n;
+        if (n) {
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_points), n * 64);
+            if (e != hipSuccess) { delete s; return set_error(ctx, e, "hipMalloc(srs)"); }
+            uint32_t off_curve = 0;
+            rc = upload_points(ctx, pts.data(), n, s->d_points, ctx->msm.bases_wire, &off_curve);
+            if (rc == KZG_OK && off_curve) rc = KZG_ERR_NOT_ON_CURVE;
+            if (rc == KZG_OK) rc = srs_precompute(ctx, s);
+            if (rc != KZG_OK) { (void)hipFree(s->d_points); delete s; return rc; }
+        }
     }
     *out = s;
     return KZG_OK;

@@ -17,8 +17,7 @@
 // inversion of latency whatever its length.
 #include "poly_common.h"
 #include "fe_invert.h"
-#include "host_curve.h"
-#include "host_pairing.h"
+#include "host_lagrange.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -180,21 +179,6 @@ k_lag_quotient(const uint4* __restrict__ evals, uint32_t len, uint32_t base, Ntt
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------
 namespace {
-int ilog2_sz(size_t n) { int k = 0; while (((size_t)1 << k) < n) ++k; return k; }
-void h_one(uint64_t out[4]) { const uint64_t one_int[4] = {1, 0, 0, 0}; h_fr_mul(H_FR_R2, one_int, out); }
-void h_fr_add(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
-    uint64_t t[4]; hu128 c = 0;
-    for (int i = 0; i < 4; ++i) { c += (hu128)a[i] + b[i]; t[i] = (uint64_t)c; c >>= 64; }
-    if (c || h_geq_r(t)) h_sub_r(t);
-    memcpy(out, t, 32);
-}
-// z^n (n = 2^log_n) in wire form
-void h_pow2k(const uint64_t z[4], int log_n, uint64_t out[4]) {
-    memcpy(out, z, 32);
-    for (int a = 0; a < log_n; ++a) h_fr_mul(out, out, out);
-}
-bool h_is_one(const uint64_t a[4]) { uint64_t o[4]; h_one(o); return memcmp(a, o, 32) == 0; }
-
 // pinned layout of a slot's PolySet for this path: [0,32) z | [32,64) y | [64,96) S readback | [96,128) f_m readback | [128,160) T readback
 // device `small`:  [0,32) z | [32,64) y | [64,68) on-domain slice index | [128,160) S | [160,192) T | [4096, ..) per-workgroup partials
 constexpr size_t LAG_SMALL_PARTIALS = 4096;
@@ -334,51 +318,6 @@ void lag_abort(kzg_ctx* ctx, int slot) {
     (void)msm_slot_stream(ctx, slot, &st);
     if (lp.msm_started && ctx->slot_pending[slot]) { uint64_t sink[16]; (void)msm_end(ctx, slot, nullptr, nullptr, sink); }
     else if (st) (void)hipStreamSynchronize(st);
-}
-
-// y from the gathered partials (count x 8 words: S_g | f_m): helpers.rs:497-504 (z on the domain: y = f_m) / :507-532
-int32_t lag_fold_y(const uint64_t* parts, size_t count, size_t n, const uint64_t z[4], uint64_t out_y[4]) {
-    const int log_n = ilog2_sz(n);
-    uint64_t zn[4], s[4] = {0, 0, 0, 0}, fm[4] = {0, 0, 0, 0};
-    h_pow2k(z, log_n, zn);
-    for (size_t g = 0; g < count; ++g) { h_fr_add(s, parts + 8 * g, s); h_fr_add(fm, parts + 8 * g + 4, fm); }
-    if (h_is_one(zn)) { memcpy(out_y, fm, 32); return KZG_OK; }
-    uint64_t one[4], num[4], n_int[4] = {(uint64_t)n, 0, 0, 0}, n_w[4], n_inv[4];
-    h_one(one);
-    h_fr_sub(zn, one, num);                                   // z^n - 1
-    h_fr_mul(H_FR_R2, n_int, n_w);
-    h_fr_inv(n_w, n_inv);
-    h_fr_mul(s, num, s);
-    h_fr_mul(s, n_inv, out_y);
-    return KZG_OK;
-}
-
-// proof from the gathered parts (count x 32 words, lag_end's layout): fold of the partial points, plus q_m L_m when z = w^m with
-// q_m = -(1/z) sum_g T_g (kzg.rs:237-260)
-int32_t lag_fold_proof(const uint64_t* parts, size_t count, size_t n, const uint64_t z[4], uint64_t out_xy[8], uint8_t* out_inf) {
-    using namespace kzg_host;
-    Xyzz acc = xyzz_inf();
-    for (size_t g = 0; g < count; ++g) { Xyzz p; memcpy(&p, parts + 32 * g, 128); acc = xyzz_add(acc, p); }
-    uint64_t zn[4];
-    h_pow2k(z, ilog2_sz(n), zn);
-    if (h_is_one(zn)) {
-        uint64_t t[4] = {0, 0, 0, 0}, zinv[4], qm[4], zero[4] = {0, 0, 0, 0}, qm_int[4];
-        const uint64_t* lm = nullptr;
-        for (size_t g = 0; g < count; ++g) { h_fr_add(t, parts + 32 * g + 16, t); if (parts[32 * g + 28] == 1 && !lm) lm = parts + 32 * g + 20; }
-        if (!lm) return KZG_ERR_ROOT_NOT_FOUND;               // no slice owned w^m: the slices do not cover the domain
-        h_fr_inv(z, zinv);
-        h_fr_mul(t, zinv, qm);
-        h_fr_sub(zero, qm, qm);
-        fr_wire_to_canonical(qm, qm_int);
-        G1 term = g1_mul(g1_from_wire(lm), qm_int);
-        if (!term.inf) {
-            uint64_t txy[8];
-            g1_to_wire(term, txy);
-            acc = xyzz_add(acc, xyzz_from_affine_wire(txy));
-        }
-    }
-    xyzz_to_affine(acc, out_xy, out_inf);
-    return KZG_OK;
 }
 
 }  // namespace kzg

@@ -3,6 +3,7 @@
 `SRS.new(path, order, points_to_load)` reads the gnark-format file and decompresses all points in one GPU kernel
 (`kzg_srs_load_compressed_be`); `SRS(points)` takes already-decoded wire-format points."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -54,6 +55,35 @@ class SRS:
         self.ctx.check_device(rc)
         self.handle = h
         self._n = points_to_load
+        return self
+
+    def save_packed(self, path: str):
+        """Write the decoded points in the library's packed form (`kzg_srs_save_packed`): `SRS.load_packed` reads them back without decoding
+        the ceremony file again (digest-checked, curve-checked on the GPU)."""
+        rc = _lib.load().kzg_srs_save_packed(self.ctx.handle, self.handle, os.fsencode(path))
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(f"{_lib.status_message(rc)}: {path}")
+
+    @classmethod
+    def load_packed(cls, path: str, points_to_load: int = 0, order=None, ctx=None):
+        """`kzg_srs_load_packed`: the first `points_to_load` points (0: all) of a file written by `save_packed`."""
+        self = cls.__new__(cls)
+        self.ctx = ctx or _lib.default_context()
+        h = C.c_void_p()
+        rc = _lib.load().kzg_srs_load_packed(self.ctx.handle, os.fsencode(path), points_to_load, C.byref(h))
+        if rc == _lib.ERR_DESERIALIZE:
+            raise DeserializationError(f"{path}: not a packed SRS file, or damaged")
+        if rc == _lib.ERR_NOT_ON_CURVE:
+            raise NotOnCurveError(f"{path}: a point of the packed SRS is not on the curve")
+        if rc == _lib.ERR_SRS_LENGTH:
+            raise GenericError("Number of points to load exceeds SRS order.")               # srs.rs:36-40
+        self.ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(f"{_lib.status_message(rc)}: {path}")
+        self.handle = h
+        self._n = int(_lib.load().kzg_srs_len(h))
+        self.order = int(order if order is not None else self._n)
         return self
 
     @classmethod

@@ -2,7 +2,7 @@
 //   * the product's device math headers in their host form (field29.h / curve.h through hostcheck.cpp, with KZG_BOUND_CHECK):
 //     signed-limb arithmetic must never overflow an int32 / int64 (UB) on the lazy-reduction paths the kernels run,
 //   * the product's host code that needs no GPU: host_sha256.h (both the portable and, when the CPU has it, the SHA-NI path),
-//     host_curve.h's fold of partial sums,
+//     host_curve.h's fold of partial sums, host_lagrange.h's folds of the sharded proofs (y from partial barycentric sums, q_m L_m),
 //   * the oracle (plain C, linked in): Pippenger with threads, NTT, g1_ifft, decompression, transcripts.
 // The reference's CI runs its suite on two targets (.github/workflows/rust.yml:35-49); this is this repo's counterpart for memory
 // and UB errors.  Built and run by tests/test_sanitizers_host.py; prints "sanitize ok" at the end.
@@ -15,6 +15,7 @@
 #include "hostcheck.cpp"          // hc_* entry points over field29.h / curve.h
 #include "host_sha256.h"
 #include "host_curve.h"
+#include "host_lagrange.h"   // the host folds of the Lagrange-sharded proofs (round 5)
 
 extern "C" {
 void orc_init(void);
@@ -116,6 +117,54 @@ int main() {
         uint64_t xy[8]; uint8_t inf = 0;
         kzg_host::xyzz_to_affine(acc, xy, &inf);
         CHECK(inf == 0);
+    }
+    // 5. host folds of the Lagrange-sharded proofs (host_lagrange.h) against the oracle's field / group arithmetic: three ranks' rows
+    {
+        uint64_t FR_M[4], FR_ONE_M[4], FR_R2[4], fr_inv;
+        orc_constants(1, FR_M, &fr_inv, FR_ONE_M, FR_R2);
+        const size_t nn = 8;                                       // domain size of the toy case
+        // z off the domain: y = (z^n - 1) / n * sum_g S_g
+        uint64_t z[4], S[3][4], rows[3 * 8] = {0}, y[4];
+        orc_f_mul(1, z, sc.data(), FR_ONE_M);                       // some canonical Montgomery residue
+        for (int g2 = 0; g2 < 3; ++g2) { orc_f_mul(1, S[g2], sc.data() + 4 * (g2 + 1), FR_ONE_M); memcpy(rows + 8 * g2, S[g2], 32); }
+        CHECK(kzg::lag_fold_y(rows, 3, nn, z, y) == 0);
+        uint64_t sum[4], zn[4], t[4], n_m[4], n_inv[4], want[4];
+        const uint64_t n_plain[4] = {nn, 0, 0, 0};
+        kzg::h_fr_add(S[0], S[1], sum); kzg::h_fr_add(sum, S[2], sum);
+        memcpy(zn, z, 32);
+        for (int q = 0; q < 3; ++q) orc_f_mul(1, zn, zn, zn);        // z^8
+        kzg::h_fr_sub(zn, FR_ONE_M, t);
+        orc_f_mul(1, n_m, n_plain, FR_R2);
+        kzg::h_fr_inv(n_m, n_inv);
+        orc_f_mul(1, want, sum, t); orc_f_mul(1, want, want, n_inv);
+        CHECK(memcmp(y, want, 32) == 0);
+        // z on the domain (z = 1 = w^0): y is the owner's f_m; the proof fold adds q_m L_m with q_m = -(1/z) sum_g T_g
+        uint64_t rows2[3 * 8] = {0};
+        memcpy(rows2 + 8 * 1 + 4, S[1], 32);                        // rank 1 owns m
+        CHECK(kzg::lag_fold_y(rows2, 3, nn, FR_ONE_M, y) == 0 && memcmp(y, S[1], 32) == 0);
+        uint64_t one_m[4];
+        orc_f_mul(0, one_m, one_plain, FQ_R2);
+        uint64_t parts[3 * 32] = {0};
+        for (int g2 = 0; g2 < 3; ++g2) {
+            memcpy(parts + 32 * g2, pts.data() + 8 * g2, 64);        // partial point = an affine point with ZZ = ZZZ = 1
+            memcpy(parts + 32 * g2 + 8, one_m, 32); memcpy(parts + 32 * g2 + 12, one_m, 32);
+            memcpy(parts + 32 * g2 + 16, S[g2], 32);                 // T_g
+        }
+        memcpy(parts + 32 * 1 + 20, pts.data() + 8 * 5, 64);         // L_m from the owner
+        parts[32 * 1 + 28] = 1;
+        uint64_t got[8]; uint8_t ginf = 0;
+        CHECK(kzg::lag_fold_proof(parts, 3, nn, FR_ONE_M, got, &ginf) == 0 && ginf == 0);
+        // expectation through the oracle: P0 + P1 + P2 + [-(T0 + T1 + T2)] P5   (1/z = 1)
+        uint64_t zero[4] = {0, 0, 0, 0}, negsum[4], term[8], bases2[4 * 8], ones[4 * 4], expect[8];
+        kzg::h_fr_sub(zero, sum, negsum);
+        for (int g2 = 0; g2 < 3; ++g2) { memcpy(bases2 + 8 * g2, pts.data() + 8 * g2, 64); memcpy(ones + 4 * g2, FR_ONE_M, 32); }
+        memcpy(bases2 + 24, pts.data() + 8 * 5, 64); memcpy(ones + 12, negsum, 32);
+        CHECK(orc_msm_naive(bases2, ones, 4, expect) == 0);
+        (void)term;
+        CHECK(memcmp(got, expect, 64) == 0);
+        // no rank owns the domain point: reported, not folded
+        parts[32 * 1 + 28] = 0;
+        CHECK(kzg::lag_fold_proof(parts, 3, nn, FR_ONE_M, got, &ginf) == kzg::LAG_ERR_ROOT_NOT_FOUND);
     }
     printf("sanitize ok\n");
     return 0;
