@@ -597,6 +597,14 @@ def main():
 
         c4["new_commit_s"], c4["new_commit"] = c4_region(lambda: sk_new.commit_eval_form(ev_wire))
         c4["new_proof_s"], c4["new_proof"] = c4_region(lambda: sk_new.compute_proof(ev_wire, z_c4, want_y=True))
+        # the same through the STREAM (sharding.commit_and_prove_stream: commitment and proof of a blob from one upload, two blobs in flight)
+        def c4_stream():
+            last = None
+            for last in sk_new.commit_and_prove_stream([(ev_wire, z_c4)] * c4_reps, depth=2):
+                pass
+            return last
+        c4["stream_s"], c4["stream_last"] = c4_region(c4_stream)
+        c4["stream_s"] /= c4_reps                                        # c4_region divides by its repetitions; each repetition streams c4_reps blobs
         c4["old_commit_s"], c4["old_commit"] = c4_region(lambda: sk_old.commit_eval_form(poly_c4))
         c4["old_proof_s"], c4["old_proof"] = c4_region(lambda: sk_old.compute_proof(poly_c4, z_c4, want_y=True))
         if multi:
@@ -664,6 +672,36 @@ def main():
                                                         "efficiency_20": ref20 / (ranks * t20), "efficiency_96": ref96 / (ranks * t96), "bit_exact_vs_oracle": exact_r}
                 srs_r.close()
             shard_rehearsal["bit_exact_vs_oracle"] = ok_all
+            # the same for BASELINE config 4: the per-rank stream of (commitment, proof) over a 2^LOG_N / N-element slice of the evaluations and of
+            # the Lagrange basis, resident slices, two blobs in flight, both exchanges through the one-rank nccl group.  One rank's rows do not
+            # fold to the true y / proof (the other ranks' parts are missing): the WORK is what each rank of an N-rank run does, the values are
+            # checked where all parts exist (bench `config4`, tests/test_gpu_lagrange_shards.py, tests/test_sharding_gloo.py).
+            from rust_kzg_bn254_amd.sharding import ShardedKzgLagrange as _SKL
+            os.environ["KZG_NO_PRECOMPUTE"] = "1"
+            try:
+                plain_r = k.SRS.generate(tau, n, ctx=ctx)
+            finally:
+                del os.environ["KZG_NO_PRECOMPUTE"]
+            c4r = {}
+            z_r = np.ascontiguousarray(scalars_b[0])
+            for lg, ranks in ((LOG_N, 1), (LOG_N - 1, 2), (LOG_N - 2, 4), (LOG_N - 3, 8)):
+                per = 1 << lg
+                lag_r = plain_r.lagrange_shard(n, 0, per)
+                skl = _SKL(ctx, lag_r, n, 0, 1, gather_device="cuda", bounds=(0, per), force_exchange=True)
+                items = [(d_sets[i % N_BUFFERS].data_ptr(), z_r) for i in range(24)]
+                list(skl.commit_and_prove_stream(items[:6], resident=True))
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                cnt = sum(1 for _ in skl.commit_and_prove_stream(items, resident=True))
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                c4r["2^%d" % lg] = {"ranks": ranks, "ms_per_blob": (time.perf_counter() - t0_) / cnt * 1e3, "blobs": cnt}
+                lag_r.close()
+            plain_r.close()
+            base = c4r["2^%d" % LOG_N]["ms_per_blob"]
+            for v in c4r.values():
+                v["efficiency"] = base / (v["ranks"] * v["ms_per_blob"])
+            shard_rehearsal["config4_stream"] = {"is": "commitment + proof per blob, resident evaluation slices, two blobs in flight, exchanges of 64 B and 384 B per blob "
+                                                       "through the one-rank nccl group; efficiency = t(1 rank) / (N x t(slice of 1 / N))", "sizes": c4r}
             if not multi:
                 dist.destroy_process_group()
         except Exception as e:                                              # noqa: BLE001 -- never takes the headline down
@@ -746,6 +784,10 @@ def main():
                 want_p4 = pyref.point_to_wire(pyref.ec_mul((ftau - fz) * pow(tau - z_int, -1, FR) % FR, (1, 2)))
                 want_y4 = ints_to_wire([fz])[0]
                 new_ok = bool(np.array_equal(config4["new_commit"], want_c4) and np.array_equal(config4["new_proof"][0], want_p4) and np.array_equal(config4["new_proof"][1], want_y4))
+                st_last = config4["stream_last"]
+                stream_ok = bool(st_last is not None and np.array_equal(st_last[0], want_c4) and np.array_equal(st_last[1], want_p4) and np.array_equal(st_last[2], want_y4))
+                if not stream_ok:
+                    exit_code = 3
                 old_ok = bool(np.array_equal(config4["old_commit"], want_c4) and np.array_equal(config4["old_proof"][0], want_p4) and np.array_equal(config4["old_proof"][1], want_y4))
                 if not (new_ok and old_ok):
                     exit_code = 3
@@ -755,6 +797,10 @@ def main():
                                         "commit_plus_proof_per_s": 1.0 / (config4["new_commit_s"] + config4["new_proof_s"]),
                                         "per_rank": "uploads %.1f MiB, inverts and divides 2^%d / %d elements, MSM over its slice; exchanges: 128 B (commitment), 64 B + 256 B (proof) per rank" % (per_rank_mib, LOG_N, world),
                                         "bit_exact_vs_big_integers": new_ok},
+                    "lagrange_shards_streamed": {"commit_plus_proof_ms": config4["stream_s"] * 1e3, "commit_plus_proof_per_s": 1.0 / config4["stream_s"],
+                                                 "is": "commit_and_prove_stream: one upload per blob for both results, two blobs in flight per rank (all four slots), "
+                                                       "%d blobs per timed stream, %d streams between barriers" % (c4_reps, c4_reps),
+                                                 "bit_exact_vs_big_integers": stream_ok},
                     "replicated_r4": {"commit_ms": config4["old_commit_s"] * 1e3, "proof_ms": config4["old_proof_s"] * 1e3,
                                       "commit_plus_proof_per_s": 1.0 / (config4["old_commit_s"] + config4["old_proof_s"]),
                                       "per_rank": "uploads %.0f MiB, IFFT and quotient of all 2^%d elements on every rank, MSM over its slice; exchange: 128 B per rank" % (32.0 * n / 2 ** 20, LOG_N),

@@ -315,6 +315,15 @@ int32_t kzg_compute_proof_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrange_s
                                          size_t len, size_t n, const uint64_t z_mont[4], int32_t slot);
 int32_t kzg_compute_proof_lagrange_begin_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont,
                                                 size_t len, size_t n, const uint64_t z_mont[4], int32_t slot);
+/* Commitment AND proof of one slice, for streams of blobs (BASELINE config 4 per rank, several blobs in flight): as _begin on `proof_slot`, and the
+ * slice's commitment sum_i f_i L_i is enqueued on `commit_slot` from the SAME uploaded copy (one H2D for both; _device: both read the caller's buffer).
+ * Collect the commitment's partial with kzg_msm_g1_srs_end(ctx, commit_slot, NULL, NULL, out_xyzz) (len = 0: nothing was enqueued there, the partial
+ * is the identity); proof_slot must not be begun again before that.  The lagrange_shard handle and (_device) the evaluations must stay valid and
+ * untouched until _end / _abort of the proof and the end of the commitment. */
+int32_t kzg_commit_and_prove_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const uint64_t* evals_slice_mont, size_t len,
+                                            size_t n, const uint64_t z_mont[4], int32_t commit_slot, int32_t proof_slot);
+int32_t kzg_commit_and_prove_lagrange_begin_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont, size_t len,
+                                                   size_t n, const uint64_t z_mont[4], int32_t commit_slot, int32_t proof_slot);
 int32_t kzg_compute_proof_lagrange_partial_y(kzg_ctx* ctx, int32_t slot, uint64_t out_ypart_mont[8]);
 int32_t kzg_compute_proof_lagrange_continue(kzg_ctx* ctx, int32_t slot, const uint64_t y_mont[4]);
 int32_t kzg_compute_proof_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t out_part[32]);

@@ -60,7 +60,7 @@ int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, siz
 int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
 // Lagrange-sharded proofs (lagrange.hip)
-int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* evals, bool on_device, size_t len, size_t n, const uint64_t z[4], int slot);
+int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* evals, bool on_device, size_t len, size_t n, const uint64_t z[4], int slot, int commit_slot);
 int32_t lag_partial_y(kzg_ctx* ctx, int slot, uint64_t out[8]);
 int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]);
 int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32]);
@@ -162,6 +162,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     if (ctx->rccl_pinned) { (void)hipHostFree(ctx->rccl_pinned); ctx->rccl_pinned = nullptr; ctx->rccl_pinned_bytes = 0; }
     if (ctx->vb_pinned) { (void)hipHostFree(ctx->vb_pinned); ctx->vb_pinned = nullptr; ctx->vb_pinned_bytes = 0; }
     for (auto& t : ctx->ondomain_inv) if (t) { (void)hipFree(t); t = nullptr; }
+    for (auto& ev : ctx->lag_uploaded) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     (void)hipStreamDestroy(ctx->stream);
     const int dev = ctx->device;
     delete ctx;
@@ -954,7 +955,7 @@ int32_t kzg_commit_eval_form_lagrange_partial_device(kzg_ctx* ctx, const kzg_srs
     return msm_srs_common(ctx, lagrange_shard, 0, d_evals_slice_mont, true, len, nullptr, nullptr, out_xyzz_mont);
 }
 static int32_t lagrange_begin_common(kzg_ctx* ctx, const kzg_srs* shard, size_t lo, const void* evals, bool on_device, size_t len, size_t n,
-                                     const uint64_t z[4], int32_t slot) {
+                                     const uint64_t z[4], int32_t slot, int32_t commit_slot = -1) {
     if (!ctx || !shard || shard->ctx->device != ctx->device || !z || (len && !evals)) return KZG_ERR_INVALID_ARG;
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_INVALID_INPUT_LENGTH;           // helpers.rs:485-487
     if (n > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;
@@ -962,7 +963,7 @@ static int32_t lagrange_begin_common(kzg_ctx* ctx, const kzg_srs* shard, size_t 
     if (len > shard->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;                        // kzg.rs:89-94 (commit_eval_form of the quotient)
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return lag_begin(ctx, shard, lo, evals, on_device, len, n, z, slot);
+    return lag_begin(ctx, shard, lo, evals, on_device, len, n, z, slot, commit_slot);
 }
 int32_t kzg_compute_proof_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const uint64_t* evals_slice_mont,
                                          size_t len, size_t n, const uint64_t z_mont[4], int32_t slot) {
@@ -971,6 +972,16 @@ int32_t kzg_compute_proof_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrange_s
 int32_t kzg_compute_proof_lagrange_begin_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont,
                                                 size_t len, size_t n, const uint64_t z_mont[4], int32_t slot) {
     return lagrange_begin_common(ctx, lagrange_shard, shard_lo, d_evals_slice_mont, true, len, n, z_mont, slot);
+}
+int32_t kzg_commit_and_prove_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const uint64_t* evals_slice_mont, size_t len,
+                                            size_t n, const uint64_t z_mont[4], int32_t commit_slot, int32_t proof_slot) {
+    if (commit_slot < 0) return KZG_ERR_INVALID_ARG;
+    return lagrange_begin_common(ctx, lagrange_shard, shard_lo, evals_slice_mont, false, len, n, z_mont, proof_slot, commit_slot);
+}
+int32_t kzg_commit_and_prove_lagrange_begin_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont, size_t len,
+                                                   size_t n, const uint64_t z_mont[4], int32_t commit_slot, int32_t proof_slot) {
+    if (commit_slot < 0) return KZG_ERR_INVALID_ARG;
+    return lagrange_begin_common(ctx, lagrange_shard, shard_lo, d_evals_slice_mont, true, len, n, z_mont, proof_slot, commit_slot);
 }
 int32_t kzg_compute_proof_lagrange_partial_y(kzg_ctx* ctx, int32_t slot, uint64_t out_ypart_mont[8]) {
     if (!ctx || !out_ypart_mont) return KZG_ERR_INVALID_ARG;

@@ -108,6 +108,7 @@ struct kzg_ctx {
     size_t rccl_pinned_bytes = 0;
     kzg::PolySet poly[KZG_NUM_SLOTS];   // polynomial / proof pipeline scratch, one set per slot ([0] also serves the synchronous calls)
     kzg::LagProof lag[KZG_NUM_SLOTS];   // Lagrange-sharded proofs in flight (kzg_compute_proof_lagrange_*)
+    hipEvent_t lag_uploaded[KZG_NUM_SLOTS] = {};   // behind the slice's upload on the proof slot's stream: the commitment on another slot starts after it
     kzg::MsmWorkspace& slot_msm(int slot) { return slot ? msm_x[slot - 1] : msm; }
     hipEvent_t last_sorted = nullptr;          // ev_sorted of the most recently enqueued MSM launch of this context ...
     hipStream_t last_sorted_stream = nullptr;  // ... and the stream it went to (msm.hip msm_enqueue)

@@ -184,11 +184,15 @@ namespace {
 constexpr size_t LAG_SMALL_PARTIALS = 4096;
 }  // namespace
 
+// commit_slot >= 0: the slice's COMMITMENT (MSM of the evaluations themselves over the same shard, kzg.rs:96-100) is enqueued on that slot as
+// well, reading the copy this call uploads (one H2D for both) -- collect it with msm_end(commit_slot); the proof slot must not be begun
+// again before that
 int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* evals, bool on_device, size_t len, size_t n,
-                  const uint64_t z[4], int slot) {
-    if (slot < 0 || slot >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
+                  const uint64_t z[4], int slot, int commit_slot) {
+    if (slot < 0 || slot >= KZG_NUM_SLOTS || commit_slot >= KZG_NUM_SLOTS || commit_slot == slot) return KZG_ERR_INVALID_ARG;
     LagProof& lp = ctx->lag[slot];
     if (lp.phase != 0 || ctx->slot_pending[slot]) { ctx->last_error = "the slot is in flight"; return KZG_ERR_INVALID_ARG; }
+    if (commit_slot >= 0 && (ctx->lag[commit_slot].phase != 0 || ctx->slot_pending[commit_slot])) { ctx->last_error = "the commitment's slot is in flight"; return KZG_ERR_INVALID_ARG; }
     hipStream_t st = nullptr;
     int32_t rc = msm_slot_stream(ctx, slot, &st);
     if (rc != KZG_OK) return rc;
@@ -206,7 +210,7 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     if (lp.on_domain && !h_domain_index(z, log_n, &lp.m)) { ctx->last_error = "z^n = 1 but z is no power of the domain generator"; return KZG_ERR_ROOT_NOT_FOUND; }
     memcpy(pin, z, 32);
     memset(pin + 64, 0, 96);
-    if (len == 0) { lp.phase = 1; return KZG_OK; }             // an empty slice contributes zero sums and the identity
+    if (len == 0) { lp.phase = 1; return KZG_OK; }             // an empty slice contributes zero sums and the identity (no commitment MSM is enqueued either)
     NttTables tb;
     rc = ntt_get_tables(ctx, log_n, false, &tb);
     if (rc != KZG_OK) { lp = LagProof(); return rc; }
@@ -224,6 +228,18 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     LAG_TRY(hipMemcpyAsync(small + 64, pin + 160, 4, hipMemcpyHostToDevice, st));
     if (!on_device) LAG_TRY(hipMemcpyAsync(set.a.p, evals, len * 32, hipMemcpyHostToDevice, st));
     const uint4* d_ev = on_device ? static_cast<const uint4*>(evals) : set.a.as<uint4>();     // resident evaluations are read in place
+    if (commit_slot >= 0) {                                     // the commitment of the same slice on its own slot, behind the upload
+        hipStream_t st_c = nullptr;
+        rc = msm_slot_stream(ctx, commit_slot, &st_c);
+        if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(st); return rc; }
+        if (!on_device && st_c != st) {
+            if (!ctx->lag_uploaded[slot]) LAG_TRY(hipEventCreateWithFlags(&ctx->lag_uploaded[slot], hipEventDisableTiming));
+            LAG_TRY(hipEventRecord(ctx->lag_uploaded[slot], st));
+            LAG_TRY(hipStreamWaitEvent(st_c, ctx->lag_uploaded[slot], 0));
+        }
+        rc = msm_begin(ctx, commit_slot, srs_bases(shard, 0, len, ctx->msm_c_override == 0), d_ev, len);
+        if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(st); return rc; }
+    }
     hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, d_ev, (uint32_t)len, (uint32_t)base, tb,
                        reinterpret_cast<const uint4*>(small), set.b.as<int32_t>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS),
                        reinterpret_cast<uint32_t*>(small + 64));

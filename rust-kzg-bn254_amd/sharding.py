@@ -619,6 +619,136 @@ class ShardedKzgLagrange:
         return (out, y) if want_y else out
 
 
+    # ---- streams of blobs: commitment AND proof of each, several blobs in flight per rank ---------------------------------------------
+    def commit_and_prove_stream(self, items, depth=2, resident=False):
+        """BASELINE config 4 as a stream: `items` yields (evaluations, z_fr) -- this rank's slice of the evaluations (host array, or with
+        `resident=True` a device pointer to it) and the evaluation point; yields (commitment, proof, y) per blob, in order, the same on
+        every rank.  Per blob the rank enqueues ONE upload, the inverses + partial barycentric sum and the commitment's MSM
+        (`kzg_commit_and_prove_lagrange_begin`: two slots), exchanges 64 B -> y, enqueues quotient + MSM, and one step later collects both
+        partial points and exchanges them (128 + 256 B in one all-gather).  `depth` blobs in flight (2: all four slots): the MSMs of blob
+        t - 1 run while blob t's phase 1 and both exchanges happen, so the ~0.1 ms inversion latency and the exchange latencies are hidden
+        (one call at a time they are half of a 2^17-element proof, profiles/r05_config4_shards.md).
+        A local failure: the rank sends POISON in the collectives that remain in its iteration and every rank raises ShardError."""
+        lib = _lib.load()
+        depth = max(1, min(int(depth), _lib.NUM_SLOTS // 2))
+        exchanging = self.world > 1 or self.force
+        g_y = g_r = None
+        if exchanging:
+            g_y = PartialGatherer(self.world, self.gather_device)
+            g_r = PartialGatherer(self.world, self.gather_device)
+        ONES = np.uint64(0xFFFFFFFFFFFFFFFF)
+        state = {"failed": None, "bad": []}
+
+        def xchg(g, rows):
+            """rows: (k, 16) u64 -> (world, k, 16); POISON instead when this rank has failed; records poisoned ranks"""
+            rows = np.ascontiguousarray(rows, dtype=np.uint64).reshape(-1, 16)
+            if state["failed"] is not None:
+                rows = np.full_like(rows, ONES)
+            if not exchanging:
+                got = rows.reshape(1, -1, 16)
+            else:
+                g.start(rows)
+                got = g.finish()
+            bad = [r for r in range(got.shape[0]) if np.all(got[r] == ONES)]
+            if bad:
+                state["bad"] = sorted(set(state["bad"]) | set(bad))
+            return got
+
+        def guard(fn, *a):
+            """run one local step unless this rank (or a peer) has already failed"""
+            if state["failed"] is not None or state["bad"]:
+                return None
+            try:
+                rc = fn(*a)
+                self.ctx.check_device(rc)
+                if rc != _lib.OK:
+                    raise ValueError(_lib.status_message(rc))
+                return rc
+            except Exception as e:                          # noqa: BLE001 -- reported to every rank through the next collective
+                if not exchanging:
+                    raise
+                state["failed"] = e
+                return None
+
+        inflight = collections.deque()                      # (commit slot, proof slot, z, y)
+
+        def release(cs, ps):
+            """give two slots back whatever state they are in (best effort: a slot with nothing pending answers INVALID_ARG)"""
+            sink = np.zeros(16, dtype=np.uint64)
+            lib.kzg_msm_g1_srs_end(self.ctx.handle, cs, None, None, _lib.ptr(sink))
+            lib.kzg_compute_proof_lagrange_abort(self.ctx.handle, ps)
+
+        def finish_oldest():
+            cs, ps, z, y = inflight.popleft()
+            cpart = np.zeros(16, dtype=np.uint64)
+            ppart = np.zeros(self.PART, dtype=np.uint64)
+            if self.len:
+                guard(lib.kzg_msm_g1_srs_end, self.ctx.handle, cs, None, None, _lib.ptr(cpart))
+            guard(lib.kzg_compute_proof_lagrange_end, self.ctx.handle, ps, _lib.ptr(ppart))
+            if state["failed"] is not None:
+                release(cs, ps)                                              # the guarded calls were skipped (or one of them failed)
+            got = xchg(g_r, np.concatenate([cpart, ppart]))                 # (world, 3, 16): commitment partial | the proof's 32 words
+            if state["bad"]:
+                return None
+            got = np.ascontiguousarray(got.reshape(got.shape[0], 48))
+            commitment = fold_partials(got[:, :16])
+            proof = np.zeros(8, dtype=np.uint64)
+            inf = C.c_uint8(0)
+            parts = np.ascontiguousarray(got[:, 16:])
+            rc = lib.kzg_lagrange_fold_proof(_lib.ptr(parts), parts.shape[0], self.n, _lib.ptr(z), _lib.ptr(proof), C.byref(inf))
+            if rc != _lib.OK:
+                raise ValueError(_lib.status_message(rc))
+            return commitment, proof, y
+
+        def drain_and_raise():
+            for cs, ps, _z, _y in inflight:                                  # give the slots back; no more collectives are issued
+                release(cs, ps)
+            inflight.clear()
+            raise ShardError(0, state["bad"], state["failed"])
+
+        t = 0
+        try:
+            for ev, z_fr in items:
+                z = np.ascontiguousarray(_lib.as_u64(z_fr, 0).reshape(4))
+                cs, ps = (2 * t) % (2 * depth), (2 * t + 1) % (2 * depth)
+                if len(inflight) == depth:
+                    out = finish_oldest()
+                    if state["bad"]:
+                        drain_and_raise()
+                    yield out
+                if resident:
+                    guard(lib.kzg_commit_and_prove_lagrange_begin_device, self.ctx.handle, self.srs.handle, self.lo, C.c_void_p(int(ev)) if self.len else None,
+                          self.len, self.n, _lib.ptr(z), cs, ps)
+                else:
+                    sl = self._slice(ev)
+                    guard(lib.kzg_commit_and_prove_lagrange_begin, self.ctx.handle, self.srs.handle, self.lo, _lib.ptr(sl) if self.len else None, self.len,
+                          self.n, _lib.ptr(z), cs, ps)
+                ypart = np.zeros(16, dtype=np.uint64)                           # 8 words used: S_g | f_m
+                guard(lib.kzg_compute_proof_lagrange_partial_y, self.ctx.handle, ps, _lib.ptr(ypart))
+                got = xchg(g_y, ypart)
+                y = np.zeros(4, dtype=np.uint64)
+                inflight.append((cs, ps, z, y))
+                if state["bad"]:                                                 # every rank sees the same rows: all stop here, in step
+                    drain_and_raise()
+                yp = np.ascontiguousarray(got.reshape(got.shape[0], 16)[:, :8])
+                rc = lib.kzg_lagrange_fold_y(_lib.ptr(yp), yp.shape[0], self.n, _lib.ptr(z), _lib.ptr(y))
+                if rc != _lib.OK:
+                    raise ValueError(_lib.status_message(rc))
+                # a failure from here on is local knowledge until the NEXT collective of the common schedule (the result exchange of the oldest
+                # blob, or the next blob's y exchange): this rank walks on through that schedule without touching the GPU and sends POISON there
+                guard(lib.kzg_compute_proof_lagrange_continue, self.ctx.handle, ps, _lib.ptr(y))
+                t += 1
+            while inflight:
+                out = finish_oldest()
+                if state["bad"]:
+                    drain_and_raise()
+                yield out
+        finally:
+            for cs, ps, _z, _y in inflight:                                  # a consumer that stopped early: nothing may stay in flight
+                release(cs, ps)
+            inflight.clear()
+
+
 class MultiKzg:
     """Several GPUs behind one handle in ONE process (`kzg_multi_*`): device g holds the SRS powers [g N / G, (g+1) N / G) and one
     host thread of the library drives it; partial sums are folded on the host.  No torch, no collective: what a Rust host binds

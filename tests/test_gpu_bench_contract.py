@@ -43,8 +43,11 @@ def test_bench_emits_the_contract_line():
     assert c4["ok_on_every_rank"] is True and c4["error_on_rank_0"] is None
     for scheme in ("lagrange_shards", "replicated_r4"):
         assert c4[scheme]["bit_exact_vs_big_integers"] is True and c4[scheme]["commit_ms"] > 0 and c4[scheme]["proof_ms"] > 0
+    assert c4["lagrange_shards_streamed"]["bit_exact_vs_big_integers"] is True and c4["lagrange_shards_streamed"]["commit_plus_proof_ms"] > 0
     sr = d["shard_rehearsal"]
     assert "error" not in sr and sr["bit_exact_vs_oracle"] is True and sr["exchange"].startswith("nccl")
+    c4s = sr["config4_stream"]["sizes"]                  # the per-rank config-4 stream at the slice sizes of 1 / 2 / 4 / 8 ranks
+    assert sorted(c4s) == ["2^11", "2^12", "2^13", "2^14"] and all(v["ms_per_blob"] > 0 and v["blobs"] == 24 for v in c4s.values())
     assert sorted(sr["sizes"]) == ["2^11", "2^12", "2^13"]
     for ranks, key in ((2, "2^13"), (4, "2^12"), (8, "2^11")):
         e = sr["sizes"][key]
@@ -135,6 +138,7 @@ def test_bench_two_ranks_gloo_carries_config4():
     assert c4["ok_on_every_rank"] is True, c4
     for scheme in ("lagrange_shards", "replicated_r4"):
         assert c4[scheme]["bit_exact_vs_big_integers"] is True and c4[scheme]["commit_ms"] > 0 and c4[scheme]["proof_ms"] > 0
+    assert c4["lagrange_shards_streamed"]["bit_exact_vs_big_integers"] is True          # two blobs in flight per rank, exchanges over gloo
     assert "16384 / 2" not in c4["lagrange_shards"]["per_rank"] and "/ 2 elements" in c4["lagrange_shards"]["per_rank"]
     assert d["shard_rehearsal"] is None                   # the rehearsal belongs to the N = 1 line
 

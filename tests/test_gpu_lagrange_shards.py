@@ -290,3 +290,38 @@ def test_multi_handle_over_lagrange_shards(k, test_srs_wire):
     with pytest.raises(ValueError):
         mk.cache_lagrange(4096)                            # more points than the SRS holds
     mk.close()
+
+
+def test_commit_and_prove_stream_one_rank(k, ref_srs, test_srs_wire):
+    """sharding.ShardedKzgLagrange.commit_and_prove_stream (two blobs in flight over the four slots; commitment and proof of a blob from ONE
+    upload: kzg_commit_and_prove_lagrange_begin) from host slices and from resident device buffers, on and off the domain, against the oracle;
+    a consumer that stops early leaves no slot in flight."""
+    import torch
+    from rust_kzg_bn254_amd.sharding import ShardedKzgLagrange
+    n = 1024
+    rnd = random.Random(91)
+    rc, roots = orc.calculate_roots_of_unity(n * 32)
+    sk = ShardedKzgLagrange.from_monomial(k.default_context(), ref_srs, n, gather_device=None)
+    blobs, wants = [], []
+    for j in range(7):
+        wire = pyref.frs_to_mont([rnd.randrange(R_) for _ in range(n)])
+        z = np.ascontiguousarray(roots[rnd.randrange(n)]) if j % 3 == 1 else pyref.fr_to_mont(rnd.randrange(R_))
+        rc, want_c = orc.commit_eval_form(test_srs_wire, wire, literal=False)
+        rc, want_p, want_y = orc.compute_proof(test_srs_wire, wire, roots, z, literal=False)
+        blobs.append((wire, z)); wants.append((want_c, want_p, want_y))
+    for depth in (2, 1):
+        got = list(sk.commit_and_prove_stream(blobs, depth=depth))
+        assert len(got) == 7
+        for (c, p, y), (wc, wp, wy) in zip(got, wants):
+            assert np.array_equal(c, wc) and np.array_equal(p, wp) and np.array_equal(y, wy)
+    dev = [torch.from_numpy(w.view(np.int64)).cuda() for w, _ in blobs]
+    torch.cuda.synchronize()
+    got = list(sk.commit_and_prove_stream([(d.data_ptr(), z) for d, (_, z) in zip(dev, blobs)], resident=True))
+    assert all(np.array_equal(c, wc) and np.array_equal(p, wp) and np.array_equal(y, wy) for (c, p, y), (wc, wp, wy) in zip(got, wants))
+    gen = sk.commit_and_prove_stream(blobs)
+    first = next(gen); next(gen)
+    gen.close()                                                         # two blobs still in flight
+    assert np.array_equal(first[0], wants[0][0])
+    proof, y = sk.compute_proof(blobs[3][0], blobs[3][1], want_y=True)   # every slot is free again: slot 0 serves the one-call form
+    assert np.array_equal(proof, wants[3][1]) and np.array_equal(y, wants[3][2])
+    sk.srs.close()

@@ -231,6 +231,7 @@ def _lag_worker(rank, world, port, q):
     roots = [pow(w, i, R_) for i in range(n)]
     real = _lib.load()
     state = {}
+    commits = {}
 
     def words(ptr, count):
         return np.ctypeslib.as_array(ptr, shape=(count,))
@@ -263,6 +264,18 @@ def _lag_worker(rank, world, port, q):
             state[slot] = {"lo": lo, "ev": ev, "z": pyref.fr_from_mont(words(z_ptr, 4).copy())}
             return 0
 
+        def kzg_commit_and_prove_lagrange_begin(self, ctx, shard, lo, ev_ptr, length, n_, z_ptr, cslot, pslot):
+            rc = self.kzg_compute_proof_lagrange_begin(ctx, shard, lo, ev_ptr, length, n_, z_ptr, pslot)
+            if rc == 0 and length:
+                commits[cslot] = xyzz(pyref.msm(lag[lo:lo + length], state[pslot]["ev"]))
+            return rc
+
+        def kzg_msm_g1_srs_end(self, ctx, slot, out_xy, out_inf, out_xyzz):
+            if slot not in commits:
+                return _lib.ERR_INVALID_ARG
+            words(out_xyzz, 16)[:] = commits.pop(slot)
+            return 0
+
         def kzg_compute_proof_lagrange_partial_y(self, ctx, slot, out_ptr):
             st = state[slot]
             z, lo, ev = st["z"], st["lo"], st["ev"]
@@ -277,7 +290,13 @@ def _lag_worker(rank, world, port, q):
                 out[:4] = pyref.fr_to_mont(s_)
             return 0
 
+        fail_continue_on = None          # (rank, number of the continue call that fails)
+        continues = 0
+
         def kzg_compute_proof_lagrange_continue(self, ctx, slot, y_ptr):
+            FakeLib.continues += 1
+            if self.fail_continue_on == (rank, FakeLib.continues):
+                return _lib.ERR_DEVICE
             state[slot]["y"] = pyref.fr_from_mont(words(y_ptr, 4).copy())
             return 0
 
@@ -352,6 +371,39 @@ def _lag_worker(rank, world, port, q):
     idx, x, y = rows[7]
     proof = sk.compute_proof(wire, pyref.fr_to_mont(roots[int(idx)]))
     check("proof after a failed call", pyref.point_from_wire(proof) == (int(x), int(y)))
+    # ---- the stream: commitment + proof per blob, two blobs in flight, the same results in order on both ranks ----
+    zs = [pyref.fr_to_mont(roots[int(r_[0])]) for r_ in rows[:5]] + [pyref.fr_to_mont(5)]
+    outs = list(sk.commit_and_prove_stream([(wire, z_) for z_ in zs], depth=2))
+    check("stream length", len(outs) == len(zs))
+    for j, (c_, p_, y_) in enumerate(outs[:5]):
+        check("stream commitment %d" % j, np.array_equal(c_, want_c))
+        check("stream golden proof %d" % j, pyref.point_from_wire(p_) == (int(rows[j][1]), int(rows[j][2])))
+    check("stream drained", not state and not commits)
+    check("stream depth 1", all(np.array_equal(a_[1], b_[1]) for a_, b_ in zip(outs, sk.commit_and_prove_stream([(wire, z_) for z_ in zs], depth=1))))
+    # a rank that fails BEFORE the y exchange of blob 2 (its begin), and one that fails AFTER it (its continue): in both cases both ranks
+    # raise ShardError naming rank 1 after the same collectives, blobs 0 .. are yielded only when every rank had them, and nothing stays in flight
+    for mode in ("begin", "continue"):
+        FakeLib.continues = 0
+        outs, err = [], None
+
+        def items():
+            for j, z_ in enumerate(zs):
+                if mode == "begin" and j == 2:
+                    FakeLib.fail_begin_on = 1
+                yield wire, z_
+        if mode == "continue":
+            FakeLib.fail_continue_on = (1, 3)
+        try:
+            for o_ in sk.commit_and_prove_stream(items(), depth=2):
+                outs.append(o_)
+        except sharding.ShardError as e:
+            err = e
+        FakeLib.fail_begin_on = None
+        FakeLib.fail_continue_on = None
+        check("stream failure (%s) raised on every rank" % mode, err is not None and err.ranks == [1])
+        check("stream failure (%s): what was yielded is right" % mode, len(outs) <= 2 and all(np.array_equal(o_[0], want_c) for o_ in outs))
+        check("stream failure (%s): nothing in flight" % mode, not state and not commits)
+        check("stream after a failure (%s)" % mode, len(list(sk.commit_and_prove_stream([(wire, zs[0])] * 3))) == 3 and not state and not commits)
     q.put((rank, failed))
     dist.destroy_process_group()
 
