@@ -571,6 +571,12 @@ def main():
         except Exception as e:                                           # noqa: BLE001
             c4["ok"], c4["err"] = False, "%s: %s" % (type(e).__name__, e)
 
+        if multi:                                                        # a rank whose SET-UP failed would skip the calls below, whose collectives its peers then wait in:
+            okt = torch.tensor([1 if c4["ok"] else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)                    # every rank runs config 4, or none does
+            if not bool(okt.item()) and c4["ok"]:
+                c4["ok"], c4["err"] = False, "set-up failed on another rank"
+
         def c4_region(fn):
             """reps calls of fn between barriers; (seconds per call, MAX over ranks; last result)"""
             res = None
@@ -600,7 +606,7 @@ def main():
         # the same through the STREAM (sharding.commit_and_prove_stream: commitment and proof of a blob from one upload, two blobs in flight)
         def c4_stream():
             last = None
-            for last in sk_new.commit_and_prove_stream([(ev_wire, z_c4)] * c4_reps, depth=2):
+            for last in sk_new.commit_and_prove_stream([(ev_wire, z_c4)] * c4_reps):
                 pass
             return last
         c4["stream_s"], c4["stream_last"] = c4_region(c4_stream)
@@ -798,7 +804,7 @@ def main():
                                         "per_rank": "uploads %.1f MiB, inverts and divides 2^%d / %d elements, MSM over its slice; exchanges: 128 B (commitment), 64 B + 256 B (proof) per rank" % (per_rank_mib, LOG_N, world),
                                         "bit_exact_vs_big_integers": new_ok},
                     "lagrange_shards_streamed": {"commit_plus_proof_ms": config4["stream_s"] * 1e3, "commit_plus_proof_per_s": 1.0 / config4["stream_s"],
-                                                 "is": "commit_and_prove_stream: one upload per blob for both results, two blobs in flight per rank (all four slots), "
+                                                 "is": "commit_and_prove_stream: one upload per blob for both results, two or three blobs in flight per rank (grouped launches where the slice allows), "
                                                        "%d blobs per timed stream, %d streams between barriers" % (c4_reps, c4_reps),
                                                  "bit_exact_vs_big_integers": stream_ok},
                     "replicated_r4": {"commit_ms": config4["old_commit_s"] * 1e3, "proof_ms": config4["old_proof_s"] * 1e3,

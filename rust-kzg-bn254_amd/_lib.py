@@ -139,6 +139,7 @@ PROTOTYPES = {
     "kzg_compute_proof_lagrange_begin_device": (i32, [vp, vp, sz, vp, sz, sz, u64p, i32]),
     "kzg_commit_and_prove_lagrange_begin": (i32, [vp, vp, sz, u64p, sz, sz, u64p, i32, i32]),
     "kzg_commit_and_prove_lagrange_begin_device": (i32, [vp, vp, sz, vp, sz, sz, u64p, i32, i32]),
+    "kzg_commit_and_prove_lagrange_end": (i32, [vp, i32, u64p, u64p]),
     "kzg_compute_proof_lagrange_partial_y": (i32, [vp, i32, u64p]),
     "kzg_compute_proof_lagrange_continue": (i32, [vp, i32, u64p]),
     "kzg_compute_proof_lagrange_end": (i32, [vp, i32, u64p]),

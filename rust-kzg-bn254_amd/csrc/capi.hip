@@ -63,7 +63,7 @@ int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
 int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* evals, bool on_device, size_t len, size_t n, const uint64_t z[4], int slot, int commit_slot);
 int32_t lag_partial_y(kzg_ctx* ctx, int slot, uint64_t out[8]);
 int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]);
-int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32]);
+int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32], uint64_t* out_commit);
 void lag_abort(kzg_ctx* ctx, int slot);
 // (lag_fold_y / lag_fold_proof: host_lagrange.h)
 int32_t vb_evaluate_setup(kzg_ctx* ctx, size_t packed_len, size_t nb);
@@ -163,6 +163,8 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     if (ctx->vb_pinned) { (void)hipHostFree(ctx->vb_pinned); ctx->vb_pinned = nullptr; ctx->vb_pinned_bytes = 0; }
     for (auto& t : ctx->ondomain_inv) if (t) { (void)hipFree(t); t = nullptr; }
     for (auto& ev : ctx->lag_uploaded) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    for (auto& ev : ctx->lag_phase1) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    if (ctx->lag_stream) { (void)hipStreamSynchronize(ctx->lag_stream); (void)hipStreamDestroy(ctx->lag_stream); ctx->lag_stream = nullptr; }
     (void)hipStreamDestroy(ctx->stream);
     const int dev = ctx->device;
     delete ctx;
@@ -999,7 +1001,13 @@ int32_t kzg_compute_proof_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t out_
     if (!ctx || !out_part) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return lag_end(ctx, slot, out_part);
+    return lag_end(ctx, slot, out_part, nullptr);
+}
+int32_t kzg_commit_and_prove_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t out_commit_xyzz_mont[16], uint64_t out_part[32]) {
+    if (!ctx || !out_part || !out_commit_xyzz_mont) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lag_end(ctx, slot, out_part, out_commit_xyzz_mont);
 }
 int32_t kzg_compute_proof_lagrange_abort(kzg_ctx* ctx, int32_t slot) {
     if (!ctx) return KZG_ERR_INVALID_ARG;

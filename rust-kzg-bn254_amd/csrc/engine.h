@@ -75,6 +75,7 @@ struct LagProof {
     bool on_domain = false;        // z = w^m
     uint32_t m = 0;
     bool msm_started = false;      // len > 0: an MSM is pending on the slot
+    bool grouped = false;          // commitment and proof leave as ONE batched launch (two scalar sets) on this slot
 };
 }
 #ifndef KZG_NUM_SLOTS
@@ -108,6 +109,8 @@ struct kzg_ctx {
     size_t rccl_pinned_bytes = 0;
     kzg::PolySet poly[KZG_NUM_SLOTS];   // polynomial / proof pipeline scratch, one set per slot ([0] also serves the synchronous calls)
     kzg::LagProof lag[KZG_NUM_SLOTS];   // Lagrange-sharded proofs in flight (kzg_compute_proof_lagrange_*)
+    hipStream_t lag_stream = nullptr;       // high-priority stream of phase 1 (upload, inverses, partial sum) of every Lagrange-sharded proof of this context
+    hipEvent_t lag_phase1[KZG_NUM_SLOTS] = {};     // behind phase 1 of the proof on that slot
     hipEvent_t lag_uploaded[KZG_NUM_SLOTS] = {};   // behind the slice's upload on the proof slot's stream: the commitment on another slot starts after it
     kzg::MsmWorkspace& slot_msm(int slot) { return slot ? msm_x[slot - 1] : msm; }
     hipEvent_t last_sorted = nullptr;          // ev_sorted of the most recently enqueued MSM launch of this context ...

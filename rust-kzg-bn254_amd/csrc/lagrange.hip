@@ -184,15 +184,39 @@ namespace {
 constexpr size_t LAG_SMALL_PARTIALS = 4096;
 }  // namespace
 
+// Phase 1 of every Lagrange-sharded proof of a context (upload, inverses, partial sum: ~0.1 ms of latency-bound work on few waves) runs on ONE
+// high-priority stream of its own.  On the slot's stream it shared a hardware queue with other slots' MSM kernels (HIP maps its streams onto a
+// handful of queues) and sat behind them: in a stream of 2^17-element proofs the host waited 0.45 ms per blob for a 0.1 ms phase
+// (tools/trace_config4_stream.py).  KZG_LAG_PRIO=0: the slot's stream (A/B).
+static int32_t lag_phase1_stream(kzg_ctx* ctx, hipStream_t slot_stream, hipStream_t* out) {
+    static const bool off = []() { const char* e = getenv("KZG_LAG_PRIO"); return e && atoi(e) == 0; }();
+    if (off) { *out = slot_stream; return KZG_OK; }
+    if (!ctx->lag_stream) {
+        int least = 0, greatest = 0;
+        KZG_HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        KZG_HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->lag_stream, hipStreamNonBlocking, greatest));
+    }
+    *out = ctx->lag_stream;
+    return KZG_OK;
+}
+
 // commit_slot >= 0: the slice's COMMITMENT (MSM of the evaluations themselves over the same shard, kzg.rs:96-100) is enqueued on that slot as
 // well, reading the copy this call uploads (one H2D for both) -- collect it with msm_end(commit_slot); the proof slot must not be begun
 // again before that
 int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* evals, bool on_device, size_t len, size_t n,
                   const uint64_t z[4], int slot, int commit_slot) {
-    if (slot < 0 || slot >= KZG_NUM_SLOTS || commit_slot >= KZG_NUM_SLOTS || commit_slot == slot) return KZG_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= KZG_NUM_SLOTS || commit_slot >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
     LagProof& lp = ctx->lag[slot];
     if (lp.phase != 0 || ctx->slot_pending[slot]) { ctx->last_error = "the slot is in flight"; return KZG_ERR_INVALID_ARG; }
-    if (commit_slot >= 0 && (ctx->lag[commit_slot].phase != 0 || ctx->slot_pending[commit_slot])) { ctx->last_error = "the commitment's slot is in flight"; return KZG_ERR_INVALID_ARG; }
+    // commit_slot == slot: GROUPED -- the commitment's MSM is not launched here but together with the proof's, as ONE batched launch over the shard's
+    // per-bit tables (two scalar sets, one kernel sequence: msm_begin_batch) once the quotient exists.  Shard-sized MSMs are bound by dependent
+    // latency; two of them per launch cost 0.33 ms where two launches cost 0.46 (2^17 pairs each).  Needs the tables and room for two sets.
+    const bool grouped = commit_slot == slot;
+    if (grouped && len && (!srs_bits(shard) || msm_batch_capacity(len) < 2)) {
+        ctx->last_error = "grouped commitment + proof needs the shard's per-bit tables and room for two scalar sets in one launch (kzg_msm_batch_capacity)";
+        return KZG_ERR_INVALID_ARG;
+    }
+    if (commit_slot >= 0 && !grouped && (ctx->lag[commit_slot].phase != 0 || ctx->slot_pending[commit_slot])) { ctx->last_error = "the commitment's slot is in flight"; return KZG_ERR_INVALID_ARG; }
     hipStream_t st = nullptr;
     int32_t rc = msm_slot_stream(ctx, slot, &st);
     if (rc != KZG_OK) return rc;
@@ -206,6 +230,7 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     lp = LagProof();
     lp.shard = shard; lp.base = base; lp.len = len; lp.n = n;
     lp.d_evals = on_device ? evals : nullptr;
+    lp.grouped = grouped;
     lp.on_domain = h_is_one(zn);
     if (lp.on_domain && !h_domain_index(z, log_n, &lp.m)) { ctx->last_error = "z^n = 1 but z is no power of the domain generator"; return KZG_ERR_ROOT_NOT_FOUND; }
     memcpy(pin, z, 32);
@@ -215,7 +240,8 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     rc = ntt_get_tables(ctx, log_n, false, &tb);
     if (rc != KZG_OK) { lp = LagProof(); return rc; }
     const uint32_t blocks = (uint32_t)((len + LAG_BLOCK - 1) / LAG_BLOCK);
-    auto fail = [&](hipError_t e, const char* where) { lp = LagProof(); (void)hipStreamSynchronize(st); return set_error(ctx, e, where); };
+    hipStream_t s1 = nullptr;                                    // phase 1's stream (high priority; KZG_LAG_PRIO=0: = st)
+    auto fail = [&](hipError_t e, const char* where) { lp = LagProof(); (void)hipStreamSynchronize(st); if (s1) (void)hipStreamSynchronize(s1); return set_error(ctx, e, where); };
 #define LAG_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(_e, #expr); } while (0)
     LAG_TRY(set.a.reserve(len * 32 + 32));
     LAG_TRY(set.b.reserve(len * NL * 4 + 64));
@@ -223,32 +249,36 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     LAG_TRY(set.small.reserve(LAG_SMALL_PARTIALS + (size_t)blocks * NL * 4 + 64));
     uint8_t* small = set.small.as<uint8_t>();
     const uint32_t no_index = NO_INDEX;
+    rc = lag_phase1_stream(ctx, st, &s1);
+    if (rc != KZG_OK) { lp = LagProof(); return rc; }
+    if (!ctx->lag_phase1[slot]) LAG_TRY(hipEventCreateWithFlags(&ctx->lag_phase1[slot], hipEventDisableTiming));
     memcpy(pin + 160, &no_index, 4);
-    LAG_TRY(hipMemcpyAsync(small, pin, 32, hipMemcpyHostToDevice, st));
-    LAG_TRY(hipMemcpyAsync(small + 64, pin + 160, 4, hipMemcpyHostToDevice, st));
-    if (!on_device) LAG_TRY(hipMemcpyAsync(set.a.p, evals, len * 32, hipMemcpyHostToDevice, st));
+    LAG_TRY(hipMemcpyAsync(small, pin, 32, hipMemcpyHostToDevice, s1));
+    LAG_TRY(hipMemcpyAsync(small + 64, pin + 160, 4, hipMemcpyHostToDevice, s1));
+    if (!on_device) LAG_TRY(hipMemcpyAsync(set.a.p, evals, len * 32, hipMemcpyHostToDevice, s1));
     const uint4* d_ev = on_device ? static_cast<const uint4*>(evals) : set.a.as<uint4>();     // resident evaluations are read in place
-    if (commit_slot >= 0) {                                     // the commitment of the same slice on its own slot, behind the upload
+    if (commit_slot >= 0 && !grouped) {                         // the commitment of the same slice on its own slot, behind the upload
         hipStream_t st_c = nullptr;
         rc = msm_slot_stream(ctx, commit_slot, &st_c);
-        if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(st); return rc; }
-        if (!on_device && st_c != st) {
+        if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(s1); return rc; }
+        if (!on_device && st_c != s1) {
             if (!ctx->lag_uploaded[slot]) LAG_TRY(hipEventCreateWithFlags(&ctx->lag_uploaded[slot], hipEventDisableTiming));
-            LAG_TRY(hipEventRecord(ctx->lag_uploaded[slot], st));
+            LAG_TRY(hipEventRecord(ctx->lag_uploaded[slot], s1));
             LAG_TRY(hipStreamWaitEvent(st_c, ctx->lag_uploaded[slot], 0));
         }
         rc = msm_begin(ctx, commit_slot, srs_bases(shard, 0, len, ctx->msm_c_override == 0), d_ev, len);
-        if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(st); return rc; }
+        if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(s1); return rc; }
     }
-    hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, d_ev, (uint32_t)len, (uint32_t)base, tb,
+    hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, s1, d_ev, (uint32_t)len, (uint32_t)base, tb,
                        reinterpret_cast<const uint4*>(small), set.b.as<int32_t>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS),
                        reinterpret_cast<uint32_t*>(small + 64));
-    hipLaunchKernelGGL(k_lag_sum, dim3(1), dim3(POLY_THREADS), 0, st, reinterpret_cast<const int32_t*>(small + LAG_SMALL_PARTIALS), blocks,
+    hipLaunchKernelGGL(k_lag_sum, dim3(1), dim3(POLY_THREADS), 0, s1, reinterpret_cast<const int32_t*>(small + LAG_SMALL_PARTIALS), blocks,
                        reinterpret_cast<uint4*>(small + 128));
     LAG_TRY(hipGetLastError());
-    LAG_TRY(hipMemcpyAsync(pin + 64, small + 128, 32, hipMemcpyDeviceToHost, st));
+    LAG_TRY(hipMemcpyAsync(pin + 64, small + 128, 32, hipMemcpyDeviceToHost, s1));
     if (lp.on_domain && lp.m >= base && lp.m - base < len)     // this slice owns f_m = y (helpers.rs:497-504)
-        LAG_TRY(hipMemcpyAsync(pin + 96, reinterpret_cast<const uint8_t*>(d_ev) + (size_t)(lp.m - base) * 32, 32, hipMemcpyDeviceToHost, st));
+        LAG_TRY(hipMemcpyAsync(pin + 96, reinterpret_cast<const uint8_t*>(d_ev) + (size_t)(lp.m - base) * 32, 32, hipMemcpyDeviceToHost, s1));
+    LAG_TRY(hipEventRecord(ctx->lag_phase1[slot], s1));            // phase 2 (the slot's stream) and lag_partial_y wait for THIS proof's phase 1 only
     lp.phase = 1;
     return KZG_OK;
 }
@@ -256,9 +286,7 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
 int32_t lag_partial_y(kzg_ctx* ctx, int slot, uint64_t out[8]) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->lag[slot].phase != 1) return KZG_ERR_INVALID_ARG;
     LagProof& lp = ctx->lag[slot];
-    hipStream_t st = nullptr;
-    (void)msm_slot_stream(ctx, slot, &st);
-    hipError_t e = hipStreamSynchronize(st);
+    hipError_t e = lp.len ? hipEventSynchronize(ctx->lag_phase1[slot]) : hipSuccess;
     if (e != hipSuccess) { lp = LagProof(); return set_error(ctx, e, "lagrange proof: partial sum"); }
     const uint8_t* pin = static_cast<const uint8_t*>(ctx->poly[slot].pinned);
     memcpy(out, pin + 64, 64);                                // S_g | f_m (zero unless this slice owns m)
@@ -281,6 +309,7 @@ int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]) {
     if (rc != KZG_OK) { lp = LagProof(); return rc; }
     auto fail = [&](hipError_t e, const char* where) { lp = LagProof(); (void)hipStreamSynchronize(st); return set_error(ctx, e, where); };
     memcpy(pin + 32, y, 32);
+    LAG_TRY(hipStreamWaitEvent(st, ctx->lag_phase1[slot], 0));     // the inverses (already complete: lag_partial_y waited for the event)
     LAG_TRY(hipMemcpyAsync(small + 32, pin + 32, 32, hipMemcpyHostToDevice, st));
     const bool owner = lp.on_domain && lp.m >= lp.base && lp.m - lp.base < lp.len;
     const uint32_t m_slice = owner ? (uint32_t)(lp.m - lp.base) : NO_INDEX;
@@ -297,7 +326,14 @@ int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]) {
     }
     LAG_TRY(hipGetLastError());
 #undef LAG_TRY
-    rc = msm_begin(ctx, slot, srs_bases(lp.shard, 0, lp.len, ctx->msm_c_override == 0), set.c.p, lp.len);
+    if (lp.grouped) {                                           // commitment (the evaluations) and proof (the quotient) as ONE launch, in that order
+        MsmBases b;
+        b.points = srs_bits(lp.shard); b.table_stride = (uint32_t)lp.shard->n; b.c = 7; b.W = 255; b.naf = true;
+        const void* sets[2] = {d_ev, set.c.p};
+        rc = msm_begin_batch(ctx, slot, b, sets, lp.len, 2);
+    } else {
+        rc = msm_begin(ctx, slot, srs_bases(lp.shard, 0, lp.len, ctx->msm_c_override == 0), set.c.p, lp.len);
+    }
     if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(st); return rc; }
     lp.msm_started = true;
     lp.phase = 3;
@@ -306,13 +342,23 @@ int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]) {
 
 // out_part (32 words): [0,16) XYZZ partial | [16,20) T = sum_{i in slice, i != m} q_i w^i (z on the domain, else 0) | [20,28) L_m (wire; the
 // owner of m only, else 0) | [28] 1 if this slice owns m | [29,32) 0
-int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32]) {
+// out_commit (grouped launches only, else ignored): the commitment's XYZZ partial, 16 words
+int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32], uint64_t* out_commit) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->lag[slot].phase != 3) return KZG_ERR_INVALID_ARG;
     LagProof lp = ctx->lag[slot];
+    if (lp.grouped && !out_commit) return KZG_ERR_INVALID_ARG;           // (left in flight: collect it with kzg_commit_and_prove_lagrange_end)
     ctx->lag[slot] = LagProof();
     memset(out_part, 0, 256);
+    if (out_commit) memset(out_commit, 0, 128);
     if (lp.len == 0) return KZG_OK;
-    int32_t rc = msm_end(ctx, slot, nullptr, nullptr, out_part);         // waits for the slot's stream: T is in the pinned buffer as well
+    int32_t rc;
+    if (lp.grouped) {
+        uint64_t both[32];
+        rc = msm_end_batch(ctx, slot, 2, nullptr, nullptr, both);
+        if (rc == KZG_OK) { memcpy(out_commit, both, 128); memcpy(out_part, both + 16, 128); }
+    } else {
+        rc = msm_end(ctx, slot, nullptr, nullptr, out_part);             // waits for the slot's stream: T is in the pinned buffer as well
+    }
     if (rc != KZG_OK) return rc;
     if (!lp.on_domain) return KZG_OK;
     const uint8_t* pin = static_cast<const uint8_t*>(ctx->poly[slot].pinned);
@@ -332,7 +378,12 @@ void lag_abort(kzg_ctx* ctx, int slot) {
     ctx->lag[slot] = LagProof();
     hipStream_t st = nullptr;
     (void)msm_slot_stream(ctx, slot, &st);
-    if (lp.msm_started && ctx->slot_pending[slot]) { uint64_t sink[16]; (void)msm_end(ctx, slot, nullptr, nullptr, sink); }
+    if (lp.phase >= 1 && lp.len && ctx->lag_phase1[slot]) (void)hipEventSynchronize(ctx->lag_phase1[slot]);
+    if (lp.msm_started && ctx->slot_pending[slot]) {
+        uint64_t sink[32];
+        if (lp.grouped) (void)msm_end_batch(ctx, slot, 2, nullptr, nullptr, sink);
+        else (void)msm_end(ctx, slot, nullptr, nullptr, sink);
+    }
     else if (st) (void)hipStreamSynchronize(st);
 }
 

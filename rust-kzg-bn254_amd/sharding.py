@@ -620,18 +620,35 @@ class ShardedKzgLagrange:
 
 
     # ---- streams of blobs: commitment AND proof of each, several blobs in flight per rank ---------------------------------------------
-    def commit_and_prove_stream(self, items, depth=2, resident=False):
+    def commit_and_prove_stream(self, items, depth=None, resident=False, grouped=None):
         """BASELINE config 4 as a stream: `items` yields (evaluations, z_fr) -- this rank's slice of the evaluations (host array, or with
         `resident=True` a device pointer to it) and the evaluation point; yields (commitment, proof, y) per blob, in order, the same on
-        every rank.  Per blob the rank enqueues ONE upload, the inverses + partial barycentric sum and the commitment's MSM
-        (`kzg_commit_and_prove_lagrange_begin`: two slots), exchanges 64 B -> y, enqueues quotient + MSM, and one step later collects both
-        partial points and exchanges them (128 + 256 B in one all-gather).  `depth` blobs in flight (2: all four slots): the MSMs of blob
-        t - 1 run while blob t's phase 1 and both exchanges happen, so the ~0.1 ms inversion latency and the exchange latencies are hidden
-        (one call at a time they are half of a 2^17-element proof, profiles/r05_config4_shards.md).
+        every rank.  Per blob the rank enqueues ONE upload, the inverses + partial barycentric sum (on the context's high-priority stream) and the
+        commitment's MSM (`kzg_commit_and_prove_lagrange_begin`), exchanges 64 B -> y, enqueues quotient + MSM, and later collects both
+        partial points and exchanges them (128 + 256 B in one all-gather, collected one step after it was started).  `depth` blobs in flight
+        (default 2 with two slots per blob, 3 with grouped launches): the MSMs of earlier blobs run while blob t's phase 1 and both exchanges
+        happen, so the ~0.1 ms inversion latency and the exchange latencies are hidden (one call at a time they are half of a 2^17-element
+        proof, profiles/r05_config4_shards.md).
+        `grouped` (None: when every rank can): one slot per blob, the blob's two MSMs as ONE batched launch once the quotient exists (up to
+        four blobs in flight) -- at 2^17-element slices 0.63 -> ~0.45 ms per blob.
         A local failure: the rank sends POISON in the collectives that remain in its iteration and every rank raises ShardError."""
         lib = _lib.load()
-        depth = max(1, min(int(depth), _lib.NUM_SLOTS // 2))
         exchanging = self.world > 1 or self.force
+        # GROUPED launches (one slot per blob, commitment + proof as one batched launch: kzg_commit_and_prove_lagrange_begin with commit_slot ==
+        # proof_slot) when every rank's shard has its per-bit tables and room for two scalar sets per launch; else two slots per blob.  The mode
+        # decides how many blobs fit in flight, hence the order of the collectives: the ranks agree on it first (one tiny all-gather).
+        can_group = grouped is not False and self.len > 0 and bool(lib.kzg_srs_has_bit_tables(self.srs.handle, 1)) and int(lib.kzg_msm_batch_capacity(self.len)) >= 2
+        if self.len == 0:
+            can_group = grouped is not False
+        if exchanging:
+            votes = gather_words(np.array([1 if can_group else 0], dtype=np.uint64), self.world, self.gather_device, self.force)
+            can_group = bool(votes.min())
+        if grouped is True and not can_group:
+            raise ValueError("grouped launches need per-bit tables and room for two scalar sets on every rank's shard")
+        grouped = can_group
+        if depth is None:                                    # measured (tools/trace_config4_stream.py, 2^17-element slices): grouped 0.489 / 0.475 / 0.569 ms per blob
+            depth = 3 if grouped else 2                      # with 2 / 3 / 4 blobs in flight; two slots per blob: 0.637 with 2
+        depth = max(1, min(int(depth), _lib.NUM_SLOTS if grouped else _lib.NUM_SLOTS // 2))
         g_y = g_r = None
         if exchanging:
             g_y = PartialGatherer(self.world, self.gather_device)
@@ -675,20 +692,44 @@ class ShardedKzgLagrange:
         def release(cs, ps):
             """give two slots back whatever state they are in (best effort: a slot with nothing pending answers INVALID_ARG)"""
             sink = np.zeros(16, dtype=np.uint64)
-            lib.kzg_msm_g1_srs_end(self.ctx.handle, cs, None, None, _lib.ptr(sink))
+            if cs != ps:
+                lib.kzg_msm_g1_srs_end(self.ctx.handle, cs, None, None, _lib.ptr(sink))
             lib.kzg_compute_proof_lagrange_abort(self.ctx.handle, ps)
 
+        pending_result = []                                  # [z, y] of the blob whose result exchange is in flight (at most one)
+
         def finish_oldest():
+            """wait for the two MSMs of the oldest blob and START the exchange of its partial points (collected one step later, so that
+            its latency runs beside the next blob's phase 1)"""
             cs, ps, z, y = inflight.popleft()
             cpart = np.zeros(16, dtype=np.uint64)
             ppart = np.zeros(self.PART, dtype=np.uint64)
-            if self.len:
-                guard(lib.kzg_msm_g1_srs_end, self.ctx.handle, cs, None, None, _lib.ptr(cpart))
-            guard(lib.kzg_compute_proof_lagrange_end, self.ctx.handle, ps, _lib.ptr(ppart))
+            if grouped:
+                guard(lib.kzg_commit_and_prove_lagrange_end, self.ctx.handle, ps, _lib.ptr(cpart), _lib.ptr(ppart))
+            else:
+                if self.len:
+                    guard(lib.kzg_msm_g1_srs_end, self.ctx.handle, cs, None, None, _lib.ptr(cpart))
+                guard(lib.kzg_compute_proof_lagrange_end, self.ctx.handle, ps, _lib.ptr(ppart))
             if state["failed"] is not None:
                 release(cs, ps)                                              # the guarded calls were skipped (or one of them failed)
-            got = xchg(g_r, np.concatenate([cpart, ppart]))                 # (world, 3, 16): commitment partial | the proof's 32 words
-            if state["bad"]:
+            rows = np.concatenate([cpart, ppart]).reshape(3, 16)            # commitment partial | the proof's 32 words
+            if state["failed"] is not None:
+                rows = np.full_like(rows, ONES)
+            if exchanging:
+                g_r.start(rows)
+                pending_result[:] = [z, y, None]
+            else:
+                pending_result[:] = [z, y, rows.reshape(1, 3, 16)]
+
+        def collect_result():
+            """the folded (commitment, proof, y) of the exchange in flight; None (and state["bad"]) when a rank sent POISON"""
+            z, y, got = pending_result
+            pending_result[:] = []
+            if got is None:
+                got = g_r.finish()
+            bad = [r for r in range(got.shape[0]) if np.all(got[r] == ONES)]
+            if bad:
+                state["bad"] = sorted(set(state["bad"]) | set(bad))
                 return None
             got = np.ascontiguousarray(got.reshape(got.shape[0], 48))
             commitment = fold_partials(got[:, :16])
@@ -704,18 +745,26 @@ class ShardedKzgLagrange:
             for cs, ps, _z, _y in inflight:                                  # give the slots back; no more collectives are issued
                 release(cs, ps)
             inflight.clear()
+            if pending_result and pending_result[2] is None and g_r is not None and g_r.busy:
+                g_r.finish()                                                # started on every rank before the failure became visible
+            pending_result[:] = []
             raise ShardError(0, state["bad"], state["failed"])
 
         t = 0
         try:
             for ev, z_fr in items:
                 z = np.ascontiguousarray(_lib.as_u64(z_fr, 0).reshape(4))
-                cs, ps = (2 * t) % (2 * depth), (2 * t + 1) % (2 * depth)
-                if len(inflight) == depth:
-                    out = finish_oldest()
+                if grouped:
+                    cs = ps = t % depth
+                else:
+                    cs, ps = (2 * t) % (2 * depth), (2 * t + 1) % (2 * depth)
+                if pending_result:
+                    out = collect_result()
                     if state["bad"]:
                         drain_and_raise()
                     yield out
+                if len(inflight) == depth:
+                    finish_oldest()
                 if resident:
                     guard(lib.kzg_commit_and_prove_lagrange_begin_device, self.ctx.handle, self.srs.handle, self.lo, C.c_void_p(int(ev)) if self.len else None,
                           self.len, self.n, _lib.ptr(z), cs, ps)
@@ -738,15 +787,23 @@ class ShardedKzgLagrange:
                 # blob, or the next blob's y exchange): this rank walks on through that schedule without touching the GPU and sends POISON there
                 guard(lib.kzg_compute_proof_lagrange_continue, self.ctx.handle, ps, _lib.ptr(y))
                 t += 1
-            while inflight:
-                out = finish_oldest()
-                if state["bad"]:
-                    drain_and_raise()
-                yield out
+            while inflight or pending_result:
+                if pending_result:
+                    out = collect_result()
+                    if state["bad"]:
+                        drain_and_raise()
+                    yield out
+                if inflight:
+                    finish_oldest()
         finally:
             for cs, ps, _z, _y in inflight:                                  # a consumer that stopped early: nothing may stay in flight
                 release(cs, ps)
             inflight.clear()
+            if pending_result and pending_result[2] is None and g_r is not None and g_r.busy:
+                try:
+                    g_r.finish()                                            # every rank issued this collective: only a wait
+                except ExchangeTimeout:
+                    pass
 
 
 class MultiKzg:

@@ -309,8 +309,8 @@ def test_commit_and_prove_stream_one_rank(k, ref_srs, test_srs_wire):
         rc, want_c = orc.commit_eval_form(test_srs_wire, wire, literal=False)
         rc, want_p, want_y = orc.compute_proof(test_srs_wire, wire, roots, z, literal=False)
         blobs.append((wire, z)); wants.append((want_c, want_p, want_y))
-    for depth in (2, 1):
-        got = list(sk.commit_and_prove_stream(blobs, depth=depth))
+    for depth, grp in ((2, False), (1, False), (4, True), (3, None), (1, True)):       # two slots per blob / grouped launches (one slot per blob)
+        got = list(sk.commit_and_prove_stream(blobs, depth=depth, grouped=grp))
         assert len(got) == 7
         for (c, p, y), (wc, wp, wy) in zip(got, wants):
             assert np.array_equal(c, wc) and np.array_equal(p, wp) and np.array_equal(y, wy)
@@ -318,9 +318,20 @@ def test_commit_and_prove_stream_one_rank(k, ref_srs, test_srs_wire):
     torch.cuda.synchronize()
     got = list(sk.commit_and_prove_stream([(d.data_ptr(), z) for d, (_, z) in zip(dev, blobs)], resident=True))
     assert all(np.array_equal(c, wc) and np.array_equal(p, wp) and np.array_equal(y, wy) for (c, p, y), (wc, wp, wy) in zip(got, wants))
+    # grouped launches through the C-ABI: refused where two scalar sets do not fit one launch, and kzg_compute_proof_lagrange_end refuses a grouped slot
+    lib = k._lib.load(); ctx = k.default_context(); P = k._lib.ptr
+    w0, z0 = blobs[0]
+    assert lib.kzg_commit_and_prove_lagrange_begin(ctx.handle, sk.srs.handle, 0, P(w0), n, n, P(z0), 2, 2) == 0
+    yp = np.zeros(8, np.uint64); yy = np.zeros(4, np.uint64); part = np.zeros(32, np.uint64); cpart = np.zeros(16, np.uint64)
+    assert lib.kzg_compute_proof_lagrange_partial_y(ctx.handle, 2, P(yp)) == 0 and lib.kzg_lagrange_fold_y(P(yp), 1, n, P(z0), P(yy)) == 0
+    assert lib.kzg_compute_proof_lagrange_continue(ctx.handle, 2, P(yy)) == 0
+    assert lib.kzg_compute_proof_lagrange_end(ctx.handle, 2, P(part)) == k._lib.ERR_INVALID_ARG          # a grouped slot: both sums belong together
+    assert lib.kzg_commit_and_prove_lagrange_end(ctx.handle, 2, P(cpart), P(part)) == 0
+    from rust_kzg_bn254_amd.sharding import fold_partials
+    assert np.array_equal(fold_partials(cpart.reshape(1, 16)), wants[0][0])
     gen = sk.commit_and_prove_stream(blobs)
     first = next(gen); next(gen)
-    gen.close()                                                         # two blobs still in flight
+    gen.close()                                                         # blobs still in flight
     assert np.array_equal(first[0], wants[0][0])
     proof, y = sk.compute_proof(blobs[3][0], blobs[3][1], want_y=True)   # every slot is free again: slot 0 serves the one-call form
     assert np.array_equal(proof, wants[3][1]) and np.array_equal(y, wants[3][2])

@@ -270,6 +270,13 @@ def _lag_worker(rank, world, port, q):
                 commits[cslot] = xyzz(pyref.msm(lag[lo:lo + length], state[pslot]["ev"]))
             return rc
 
+        def kzg_srs_has_bit_tables(self, shard, build):
+            return 1
+
+        def kzg_commit_and_prove_lagrange_end(self, ctx, slot, out_commit, out_part):      # grouped launches: both partial sums of the slot
+            words(out_commit, 16)[:] = commits.pop(slot) if slot in commits else 0
+            return self.kzg_compute_proof_lagrange_end(ctx, slot, out_part)
+
         def kzg_msm_g1_srs_end(self, ctx, slot, out_xy, out_inf, out_xyzz):
             if slot not in commits:
                 return _lib.ERR_INVALID_ARG
@@ -317,6 +324,7 @@ def _lag_worker(rank, world, port, q):
 
         def kzg_compute_proof_lagrange_abort(self, ctx, slot):
             state.pop(slot, None)
+            commits.pop(slot, None)                          # (a grouped slot also holds the blob's commitment)
             return 0
 
     fake = FakeLib()
@@ -373,8 +381,13 @@ def _lag_worker(rank, world, port, q):
     check("proof after a failed call", pyref.point_from_wire(proof) == (int(x), int(y)))
     # ---- the stream: commitment + proof per blob, two blobs in flight, the same results in order on both ranks ----
     zs = [pyref.fr_to_mont(roots[int(r_[0])]) for r_ in rows[:5]] + [pyref.fr_to_mont(5)]
-    outs = list(sk.commit_and_prove_stream([(wire, z_) for z_ in zs], depth=2))
+    outs = list(sk.commit_and_prove_stream([(wire, z_) for z_ in zs], depth=2, grouped=False))
     check("stream length", len(outs) == len(zs))
+    for dpt in (4, 3):                                   # grouped launches: one slot per blob, up to four blobs in flight
+        outs_g = list(sk.commit_and_prove_stream([(wire, z_) for z_ in zs], depth=dpt))
+        check("grouped stream (depth %d) == two-slot stream" % dpt, len(outs_g) == len(outs) and all(np.array_equal(a_[0], b_[0]) and np.array_equal(a_[1], b_[1])
+                                                                                                       and np.array_equal(a_[2], b_[2]) for a_, b_ in zip(outs_g, outs)))
+        check("grouped stream drained", not state and not commits)
     for j, (c_, p_, y_) in enumerate(outs[:5]):
         check("stream commitment %d" % j, np.array_equal(c_, want_c))
         check("stream golden proof %d" % j, pyref.point_from_wire(p_) == (int(rows[j][1]), int(rows[j][2])))
@@ -382,7 +395,7 @@ def _lag_worker(rank, world, port, q):
     check("stream depth 1", all(np.array_equal(a_[1], b_[1]) for a_, b_ in zip(outs, sk.commit_and_prove_stream([(wire, z_) for z_ in zs], depth=1))))
     # a rank that fails BEFORE the y exchange of blob 2 (its begin), and one that fails AFTER it (its continue): in both cases both ranks
     # raise ShardError naming rank 1 after the same collectives, blobs 0 .. are yielded only when every rank had them, and nothing stays in flight
-    for mode in ("begin", "continue"):
+    for mode, grp in (("begin", False), ("continue", False), ("begin", None), ("continue", None)):
         FakeLib.continues = 0
         outs, err = [], None
 
@@ -394,14 +407,14 @@ def _lag_worker(rank, world, port, q):
         if mode == "continue":
             FakeLib.fail_continue_on = (1, 3)
         try:
-            for o_ in sk.commit_and_prove_stream(items(), depth=2):
+            for o_ in sk.commit_and_prove_stream(items(), depth=2 if grp is False else 4, grouped=grp):
                 outs.append(o_)
         except sharding.ShardError as e:
             err = e
         FakeLib.fail_begin_on = None
         FakeLib.fail_continue_on = None
         check("stream failure (%s) raised on every rank" % mode, err is not None and err.ranks == [1])
-        check("stream failure (%s): what was yielded is right" % mode, len(outs) <= 2 and all(np.array_equal(o_[0], want_c) for o_ in outs))
+        check("stream failure (%s): what was yielded is right" % mode, len(outs) <= 3 and all(np.array_equal(o_[0], want_c) for o_ in outs))
         check("stream failure (%s): nothing in flight" % mode, not state and not commits)
         check("stream after a failure (%s)" % mode, len(list(sk.commit_and_prove_stream([(wire, zs[0])] * 3))) == 3 and not state and not commits)
     q.put((rank, failed))
