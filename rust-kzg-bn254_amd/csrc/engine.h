@@ -54,7 +54,12 @@ struct MsmWorkspace {
 struct PolySet {
     DeviceBuffer a, b, c, small;
     void* pinned = nullptr;
-    void release() { a.release(); b.release(); c.release(); small.release(); if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; } }
+    hipEvent_t ev_chain = nullptr;   // behind the inversion chain of a proof when it runs on the auxiliary stream (poly.hip proof_enqueue)
+    void release() {
+        a.release(); b.release(); c.release(); small.release();
+        if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; }
+        if (ev_chain) { (void)hipEventDestroy(ev_chain); ev_chain = nullptr; }
+    }
 };
 
 struct NttWorkspace {
@@ -247,6 +252,8 @@ int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy
 int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out, bool wire);
 
 int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);
+// the context's high-priority auxiliary stream (lagrange.hip), or `fallback` with KZG_LAG_PRIO=0
+int32_t ctx_aux_stream(kzg_ctx* ctx, hipStream_t fallback, hipStream_t* out);
 // the points only, no window / per-bit tables (set-up paths that need the points once: kzg_multi_cache_lagrange)
 int32_t srs_upload_plain(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);
 

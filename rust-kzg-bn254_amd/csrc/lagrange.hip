@@ -184,11 +184,12 @@ namespace {
 constexpr size_t LAG_SMALL_PARTIALS = 4096;
 }  // namespace
 
-// Phase 1 of every Lagrange-sharded proof of a context (upload, inverses, partial sum: ~0.1 ms of latency-bound work on few waves) runs on ONE
-// high-priority stream of its own.  On the slot's stream it shared a hardware queue with other slots' MSM kernels (HIP maps its streams onto a
+// The context's AUXILIARY stream (high priority, created on first use; engine.h ctx_aux_stream): short latency-bound kernel sequences that other
+// work waits for.  Phase 1 of every Lagrange-sharded proof of a context (upload, inverses, partial sum: ~0.1 ms on few waves) runs here, and so
+// does the coset inversion chain of poly.hip's proofs (beside the upload of the evaluations).  On the slot's stream it shared a hardware queue with other slots' MSM kernels (HIP maps its streams onto a
 // handful of queues) and sat behind them: in a stream of 2^17-element proofs the host waited 0.45 ms per blob for a 0.1 ms phase
 // (tools/trace_config4_stream.py).  KZG_LAG_PRIO=0: the slot's stream (A/B).
-static int32_t lag_phase1_stream(kzg_ctx* ctx, hipStream_t slot_stream, hipStream_t* out) {
+int32_t ctx_aux_stream(kzg_ctx* ctx, hipStream_t slot_stream, hipStream_t* out) {
     static const bool off = []() { const char* e = getenv("KZG_LAG_PRIO"); return e && atoi(e) == 0; }();
     if (off) { *out = slot_stream; return KZG_OK; }
     if (!ctx->lag_stream) {
@@ -249,7 +250,7 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     LAG_TRY(set.small.reserve(LAG_SMALL_PARTIALS + (size_t)blocks * NL * 4 + 64));
     uint8_t* small = set.small.as<uint8_t>();
     const uint32_t no_index = NO_INDEX;
-    rc = lag_phase1_stream(ctx, st, &s1);
+    rc = ctx_aux_stream(ctx, st, &s1);
     if (rc != KZG_OK) { lp = LagProof(); return rc; }
     if (!ctx->lag_phase1[slot]) LAG_TRY(hipEventCreateWithFlags(&ctx->lag_phase1[slot], hipEventDisableTiming));
     memcpy(pin + 160, &no_index, 4);

@@ -819,8 +819,17 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     // one upload for the scalar image (pin[0, 1024) -> small[0, 1024)) and the chain's scalars right behind it (pin + 1024 -> small + 1024)
     static_assert(sizeof(ProofScalars) <= 1024, "the ProofScalars image and the zt table are uploaded as one block");
     memset(pin + sizeof(ProofScalars), 0, 1024 - sizeof(ProofScalars));
-    KZG_HIP_TRY(ctx, hipMemcpyAsync(small, pin, 1024 + (size_t)(2 * log_n + 6) * 32, hipMemcpyHostToDevice, st));
-    if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));   // nullptr: set.a already holds the n evaluations (blob proofs)
+    // The chain below needs z only, not the evaluations: for a proof from HOST evaluations it is enqueued FIRST, on the context's auxiliary stream, and
+    // runs while this thread is inside the pageable upload of the evaluations (0.6 ms at 2^20; the chain: six launches, ~0.09 ms of latency).
+    // KZG_PROOF_CHAIN_AUX=0: everything on the slot's stream, chain behind the upload (A/B).
+    static const bool chain_aux = []() { const char* e = getenv("KZG_PROOF_CHAIN_AUX"); return !(e && atoi(e) == 0); }();
+    hipStream_t sc = st;
+    if (chain_aux && evals && n > chain_small_max) {
+        int32_t rca = ctx_aux_stream(ctx, st, &sc);
+        if (rca != KZG_OK) return rca;
+    }
+    KZG_HIP_TRY(ctx, hipMemcpyAsync(small, pin, 1024 + (size_t)(2 * log_n + 6) * 32, hipMemcpyHostToDevice, sc));
+    if (evals && sc == st) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));   // nullptr: set.a already holds the n evaluations (blob proofs)
 
     // the chain of smaller domains, coarsest first: small kernel (<= 4096 points, in LDS), then x4 levels, then the last level
     const int32_t* next = nullptr;
@@ -836,15 +845,22 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         int32_t* cursor = d_lvl;
         for (int l : logs) { bufs.push_back(cursor); cursor += ((size_t)NL << l); }
         int32_t* small_out = cursor;                         // 2^log_l <= 4096 entries
-        hipLaunchKernelGGL(k_poly_inv_small, dim3(1), dim3(POLY_SMALL_THREADS), ((size_t)NL << log_l) * 4, st, d_zt, log_n, log_l, tb, small_out);
+        hipLaunchKernelGGL(k_poly_inv_small, dim3(1), dim3(POLY_SMALL_THREADS), ((size_t)NL << log_l) * 4, sc, d_zt, log_n, log_l, tb, small_out);
         const int32_t* prev = small_out;
         for (int q = (int)logs.size() - 1; q >= 0; --q) {
             const uint32_t T = 1u << (logs[q] - 2);
-            hipLaunchKernelGGL(k_poly_inv_level, dim3((T + POLY_THREADS - 1) / POLY_THREADS), dim3(POLY_THREADS), 0, st, d_zt, log_n, logs[q], tb,
+            hipLaunchKernelGGL(k_poly_inv_level, dim3((T + POLY_THREADS - 1) / POLY_THREADS), dim3(POLY_THREADS), 0, sc, d_zt, log_n, logs[q], tb,
                                prev, bufs[q]);
             prev = bufs[q];
         }
         next = prev;
+        if (sc != st) {                                      // the upload of the evaluations now (the host sits in it while the chain runs), then join
+            KZG_HIP_TRY(ctx, hipGetLastError());
+            if (!set.ev_chain) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&set.ev_chain, hipEventDisableTiming));
+            KZG_HIP_TRY(ctx, hipEventRecord(set.ev_chain, sc));
+            KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));
+            KZG_HIP_TRY(ctx, hipStreamWaitEvent(st, set.ev_chain, 0));
+        }
     }
     const int fused_y = blocks == 1 && !z_on_domain;         // one workgroup holds the whole barycentric sum: no second launch for y
     hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, tb, d_z,
