@@ -322,8 +322,8 @@ int32_t kzg_compute_proof_lagrange_begin_device(kzg_ctx* ctx, const kzg_srs* lag
  * untouched until _end / _abort of the proof and the end of the commitment. */
 /* commit_slot == proof_slot: GROUPED -- the two MSMs of the blob (the evaluations and the quotient over the same shard) leave as ONE batched launch
  * of the MSM engine from _continue (shard-sized MSMs are bound by dependent latency: two per launch cost 0.33 ms where two launches cost 0.46 at 2^17 pairs);
- * one slot per blob, so four blobs may be in flight.  Needs the shard's per-bit tables and kzg_msm_batch_capacity(len) >= 2 (slices of up to 2^19
- * elements), else KZG_ERR_INVALID_ARG.  Collect BOTH partial sums with kzg_commit_and_prove_lagrange_end (kzg_compute_proof_lagrange_end refuses a
+ * one slot per blob, so four blobs may be in flight.  Needs the shard's per-bit tables (kzg_srs_has_bit_tables(shard, 1) builds them for a shard of
+ * fewer than 2^11 points) and kzg_msm_batch_capacity(len) >= 2 (slices of up to 2^18 elements), else KZG_ERR_INVALID_ARG.  Collect BOTH partial sums with kzg_commit_and_prove_lagrange_end (kzg_compute_proof_lagrange_end refuses a
  * grouped slot). */
 int32_t kzg_commit_and_prove_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t out_commit_xyzz_mont[16], uint64_t out_part[32]);
 int32_t kzg_commit_and_prove_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const uint64_t* evals_slice_mont, size_t len,
