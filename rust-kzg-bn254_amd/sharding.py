@@ -637,7 +637,11 @@ class ShardedKzgLagrange:
         # GROUPED launches (one slot per blob, commitment + proof as one batched launch: kzg_commit_and_prove_lagrange_begin with commit_slot ==
         # proof_slot) when every rank's shard has its per-bit tables and room for two scalar sets per launch; else two slots per blob.  The mode
         # decides how many blobs fit in flight, hence the order of the collectives: the ranks agree on it first (one tiny all-gather).
-        can_group = grouped is not False and self.len > 0 and bool(lib.kzg_srs_has_bit_tables(self.srs.handle, 1)) and int(lib.kzg_msm_batch_capacity(self.len)) >= 2
+        # (by default only for slices of <= 2^18 elements: beyond, two sets per launch mean narrower windows than a lone MSM's -- measured per blob
+        # with / without grouping, one-rank RCCL exchange: 2^17 0.63 / 0.77, 2^18 0.99 / 0.93-0.99, 2^19 1.65 / 1.40, 2^20 2.96 / 2.68 ms)
+        small_enough = self.len <= (1 << 18) or grouped is True
+        can_group = (grouped is not False and small_enough and self.len > 0 and bool(lib.kzg_srs_has_bit_tables(self.srs.handle, 1))
+                     and int(lib.kzg_msm_batch_capacity(self.len)) >= 2)
         if self.len == 0:
             can_group = grouped is not False
         if exchanging:

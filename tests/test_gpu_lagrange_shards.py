@@ -336,3 +336,14 @@ def test_commit_and_prove_stream_one_rank(k, ref_srs, test_srs_wire):
     proof, y = sk.compute_proof(blobs[3][0], blobs[3][1], want_y=True)   # every slot is free again: slot 0 serves the one-call form
     assert np.array_equal(proof, wants[3][1]) and np.array_equal(y, wants[3][2])
     sk.srs.close()
+
+
+def test_randomised_soak_of_the_lagrange_shards():
+    """tools/soak_lagrange.py for ten seconds with a fixed seed: random domain sizes 2^0 .. 2^13, random shard edges (empty, one element, next to the
+    evaluation point), z on and off the domain, the four-step calls / two-slot / grouped launches / the Python stream -- bit-identical to the one-GPU calls."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOAK_SECONDS="10", SOAK_SEED="20261004")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_lagrange.py")], env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-400:] + r.stderr[-1200:]
