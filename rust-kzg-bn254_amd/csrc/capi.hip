@@ -590,6 +590,8 @@ int32_t kzg_msm_g1_batch(kzg_ctx* ctx, const uint64_t* bases_xy_mont, const uint
     return msm_g1_batch_impl(ctx, bases_xy_mont, scalars_mont, n, batch, out_xy_mont, out_is_infinity, nullptr);
 }
 
+constexpr size_t MSM_SPLIT_MAX = (size_t)1 << 21;     // halves of up to 2^20 pairs: one launch each
+
 static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
                               uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
     if (!ctx || !srs || srs->ctx->device != ctx->device || (!out_xy && !out_xyzz)) return KZG_ERR_INVALID_ARG;   // an SRS may be shared by the contexts of its GPU
@@ -600,6 +602,46 @@ static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, c
     if (n == 0) { write_identity(out_xy, out_inf, out_xyzz); return KZG_OK; }
     const void* d_scalars = scalars;
     if (!on_device) {
+        // A large MSM from a HOST buffer, one call at a time: as TWO halves on two slots.  The upload of the second half (a pageable copy: this
+        // thread sits in it) runs beside the kernels of the first half, and the first half's accumulate beside the second half's sort; the two
+        // partial sums are added on the host.  Resident, two halves cost what the whole costs (tools/probe_split_lone.py: 2^19 0.872 against
+        // 0.887 ms, 2^20 1.444 against 1.445) -- so the hidden part of the upload is the gain: 2^19 1.15 -> 1.07 ms, 2^20 2.00 -> 1.76.
+        // Below 2^19 pairs the second bucket set costs more than the hidden copy (2^18: 0.601 against 0.553 resident).  KZG_SPLIT_UPLOAD=0: off.
+        static const bool split_on = []() { const char* e = getenv("KZG_SPLIT_UPLOAD"); return !(e && atoi(e) == 0); }();
+        // share of the FIRST half (the smaller it is, the sooner the GPU starts and the more of the upload is hidden; too small and the second MSM runs alone):
+        // measured from host buffers, 0.375 / 0.44 / 0.5 / 0.56: 2^19 1.116 / 1.070 / 1.084 / 1.111 ms (unsplit 1.148), 2^20 1.756 / 1.786 / 1.901 / 1.863 (unsplit 2.000)
+        static const double frac_env = []() { const char* e = getenv("KZG_SPLIT_FRAC"); const double v = e ? atof(e) : 0.0; return v > 0.05 && v < 0.95 ? v : 0.0; }();
+        const double split_frac = frac_env > 0.0 ? frac_env : (n >= ((size_t)1 << 20) ? 0.375 : 0.44);
+        const bool idle = !ctx->slot_pending[0] && !ctx->slot_pending[1] && ctx->lag[0].phase == 0 && ctx->lag[1].phase == 0;
+        if (split_on && idle && n >= ((size_t)1 << 19) && n <= MSM_SPLIT_MAX && ctx->msm_c_override == 0 && srs_bits(srs)) {
+            const size_t half = ((size_t)((double)n * split_frac) + 255) / 256 * 256;
+            const uint64_t* sc = static_cast<const uint64_t*>(scalars);
+            const size_t lo[2] = {0, half}, len[2] = {half, n - half};
+            int32_t rc = KZG_OK;
+            int begun = 0;
+            for (int h = 0; h < 2 && rc == KZG_OK; ++h) {
+                hipStream_t st = nullptr;
+                rc = msm_slot_stream(ctx, h, &st);
+                if (rc != KZG_OK) break;
+                MsmWorkspace& ws = ctx->slot_msm(h);
+                hipError_t e = ws.scalars.reserve(len[h] * 32 + 32);
+                if (e == hipSuccess) e = hipMemcpyAsync(ws.scalars.p, sc + 4 * lo[h], len[h] * 32, hipMemcpyHostToDevice, st);
+                if (e != hipSuccess) { rc = set_error(ctx, e, "split upload"); break; }
+                rc = msm_begin(ctx, h, srs_bases(srs, offset + lo[h], len[h], true), ws.scalars.p, len[h]);
+                if (rc == KZG_OK) ++begun;
+            }
+            kzg_host::Xyzz parts[2] = {kzg_host::xyzz_inf(), kzg_host::xyzz_inf()};
+            for (int h = 0; h < begun; ++h) {                          // (also after a failure of the second half: nothing may stay in flight)
+                uint64_t w[16];
+                const int32_t r2 = msm_end(ctx, h, nullptr, nullptr, w);
+                if (r2 == KZG_OK) memcpy(&parts[h], w, 128); else if (rc == KZG_OK) rc = r2;
+            }
+            if (rc != KZG_OK) return rc;
+            const kzg_host::Xyzz total = kzg_host::xyzz_add(parts[0], parts[1]);
+            if (out_xyzz) memcpy(out_xyzz, &total, 128);
+            if (out_xy) kzg_host::xyzz_to_affine(total, out_xy, out_inf);
+            return KZG_OK;
+        }
         int32_t rc = stage_scalars(ctx, static_cast<const uint64_t*>(scalars), n, &d_scalars);
         if (rc != KZG_OK) return rc;
     }
