@@ -877,12 +877,12 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;             // kzg.rs:89-94
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO; // kzg.rs:265-269 (g1_ifft)
     if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
+    if (const kzg_srs* cached = srs_cached_lagrange(srs, n))            // the reference's literal form: MSM over the Lagrange basis (kzg.rs:98-100);
+        return msm_srs_common(ctx, cached, 0, evals_mont, false, n, out_xy_mont, out_is_infinity, nullptr);   // large ones in two parts, the second upload hidden
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (const kzg_srs* cached = srs_cached_lagrange(srs, n))            // the reference's literal form: MSM over the Lagrange basis (kzg.rs:98-100)
-        return msm_run(ctx, srs_bases(cached, 0, n, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
     int32_t rc = ntt_run(ctx, ctx->poly[0].a.p, n, true);               // coefficients = IFFT(evaluations)
     if (rc != KZG_OK) return rc;
     return msm_run(ctx, srs_bases(srs, 0, n, ctx->msm_c_override == 0), ctx->poly[0].a.p, n, out_xy_mont, out_is_infinity, nullptr);
@@ -1100,10 +1100,43 @@ int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_by
     if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;                            // kzg.rs:89-94
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const kzg_srs* cached = srs_cached_lagrange(srs, n);
+    {
+        // over the cached Lagrange basis a large blob goes in TWO parts on two slots, as msm_srs_common does for scalars: bytes -> Fr and the MSM of the
+        // first part run while this thread sits in the upload of the second (no IFFT ties the parts together)
+        static const bool split_on = []() { const char* e = getenv("KZG_SPLIT_UPLOAD"); return !(e && atoi(e) == 0); }();
+        const bool idle = !ctx->slot_pending[0] && !ctx->slot_pending[1] && ctx->lag[0].phase == 0 && ctx->lag[1].phase == 0;
+        if (cached && split_on && idle && n >= ((size_t)1 << 19) && n <= MSM_SPLIT_MAX && ctx->msm_c_override == 0 && srs_bits(cached)) {
+            const size_t half = ((size_t)((double)n * (n >= ((size_t)1 << 20) ? 0.375 : 0.44)) + 255) / 256 * 256;
+            const size_t e_lo[2] = {0, half}, e_n[2] = {half, n - half};
+            int32_t rc = KZG_OK;
+            int begun = 0;
+            for (int h = 0; h < 2 && rc == KZG_OK; ++h) {
+                hipStream_t st = nullptr;
+                rc = msm_slot_stream(ctx, h, &st);
+                if (rc != KZG_OK) break;
+                MsmWorkspace& ws = ctx->slot_msm(h);
+                const size_t b_lo = std::min(len, e_lo[h] * 32), b_hi = std::min(len, (e_lo[h] + e_n[h]) * 32);
+                void* d_part = nullptr;
+                rc = blob_to_fr_run(ctx, blob_bytes + b_lo, b_hi - b_lo, e_n[h], &d_part, st, &ws.blob, &ws.scalars);
+                if (rc == KZG_OK) rc = msm_begin(ctx, h, srs_bases(cached, e_lo[h], e_n[h], true), d_part, e_n[h]);
+                if (rc == KZG_OK) ++begun;
+            }
+            kzg_host::Xyzz parts[2] = {kzg_host::xyzz_inf(), kzg_host::xyzz_inf()};
+            for (int h = 0; h < begun; ++h) {
+                uint64_t w[16];
+                const int32_t r2 = msm_end(ctx, h, nullptr, nullptr, w);
+                if (r2 == KZG_OK) memcpy(&parts[h], w, 128); else if (rc == KZG_OK) rc = r2;
+            }
+            if (rc != KZG_OK) return rc;
+            kzg_host::xyzz_to_affine(kzg_host::xyzz_add(parts[0], parts[1]), out_xy_mont, out_is_infinity);
+            return KZG_OK;
+        }
+    }
     void* d = nullptr;
     int32_t rc = blob_to_fr_run(ctx, blob_bytes, len, n, &d);                        // Blob::to_polynomial_eval_form
     if (rc != KZG_OK) return rc;
-    if (const kzg_srs* cached = srs_cached_lagrange(srs, n))                         // commit_eval_form's literal form (kzg.rs:98-100): MSM over the cached Lagrange basis
+    if (cached)                                                                      // commit_eval_form's literal form (kzg.rs:98-100): MSM over the cached Lagrange basis
         return msm_run(ctx, srs_bases(cached, 0, n, ctx->msm_c_override == 0), d, n, out_xy_mont, out_is_infinity, nullptr);
     rc = ntt_run(ctx, d, n, true);                                                   // commit_eval_form: IFFT ...
     if (rc != KZG_OK) return rc;

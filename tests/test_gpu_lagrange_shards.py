@@ -347,3 +347,38 @@ def test_randomised_soak_of_the_lagrange_shards():
     env = dict(os.environ, SOAK_SECONDS="10", SOAK_SEED="20261004")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_lagrange.py")], env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-400:] + r.stderr[-1200:]
+
+
+def test_large_host_buffer_commitments_in_two_parts(k):
+    """One call at a time from HOST buffers, 2^19 elements: kzg_commit_coeff_form, and over a cached Lagrange basis kzg_commit_eval_form /
+    kzg_commit_blob, go in TWO parts on two slots (the second part's upload hidden behind the first part's kernels; capi.hip msm_srs_common).
+    Coefficient form against sum_i c_i tau^i G1 by big integers; the eval / blob forms against the SAME calls on an SRS handle without the
+    cached basis (IFFT + monomial MSM in one part: an independent path); a ragged blob whose tail falls into the second part."""
+    n = 1 << 19
+    srs_plain = k.SRS.generate(TAU, n)
+    srs_lag = k.SRS.generate(TAU, n)
+    srs_lag.cache_lagrange(n)
+    rnd = random.Random(519)
+    vals = [rnd.randrange(R_) for _ in range(n)]
+    wire = pyref.frs_to_mont(vals)
+    kz = k.KZG.new()
+    acc, tp = 0, 1
+    for v in vals:
+        acc = (acc + v * tp) % R_
+        tp = tp * TAU % R_
+    c = kz.commit_coeff_form(k.PolynomialCoeffForm(wire), srs_plain)
+    assert pyref.point_from_wire(c) == pyref.ec_mul(acc, (1, 2))
+    e_lag = kz.commit_eval_form(k.PolynomialEvalForm(wire), srs_lag)
+    e_plain = kz.commit_eval_form(k.PolynomialEvalForm(wire), srs_plain)
+    assert np.array_equal(e_lag, e_plain)
+    for n_bytes in (32 * n, 32 * ((1 << 18) + 12345) - 9, 32 * ((1 << 18) + 1)):
+        raw = bytes(rnd.getrandbits(8) for _ in range(1024)) * (n_bytes // 1024 + 1)
+        blob = k.Blob.from_padded_unchecked(raw[:n_bytes])
+        assert np.array_equal(kz.commit_blob(blob, srs_lag), kz.commit_blob(blob, srs_plain)), n_bytes
+    # slot 0 / 1 busy: the same call falls back to one part and still agrees
+    lib = k._lib.load(); ctx = k.default_context(); P = k._lib.ptr
+    assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs_plain.handle, 0, P(wire), 4096, 1) == 0
+    out = np.zeros(8, np.uint64); inf = C.c_uint8(0)
+    assert lib.kzg_commit_coeff_form(ctx.handle, srs_plain.handle, P(wire), n, P(out), C.byref(inf)) == 0 and np.array_equal(out, c)
+    assert lib.kzg_msm_g1_srs_end(ctx.handle, 1, P(out), C.byref(inf), None) == 0
+    srs_plain.close(); srs_lag.close()

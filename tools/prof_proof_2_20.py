@@ -53,7 +53,7 @@ def stream(begin, end, count):
     assert end(prev) == 0
 
 
-if what == "proof_lag":
+if what in ("proof_lag", "commit_eval_lag", "commit_blob_lag"):
     t = time.perf_counter()
     assert lib.kzg_srs_cache_lagrange(ctx.handle, srs.handle, n) == 0
     print("kzg_srs_cache_lagrange(2^%d) %.1f ms" % (log_n, (time.perf_counter() - t) * 1e3), flush=True)
@@ -61,6 +61,8 @@ fns = {
     "proof_off": lambda: proof(z_off),
     "proof_lag": lambda: proof(z_off),
     "proof_on": lambda: proof(z_on),
+    "commit_eval_lag": lambda: lib.kzg_commit_eval_form(ctx.handle, srs.handle, _lib.ptr(sc), n, _lib.ptr(o8), C.byref(oi)),
+    "commit_blob_lag": lambda: lib.kzg_commit_blob(ctx.handle, srs.handle, blob.ctypes.data_as(u8p), blob.size, _lib.ptr(o8), C.byref(oi)),
     "commit_eval": lambda: lib.kzg_commit_eval_form(ctx.handle, srs.handle, _lib.ptr(sc), n, _lib.ptr(o8), C.byref(oi)),
     "commit_blob": lambda: lib.kzg_commit_blob(ctx.handle, srs.handle, blob.ctypes.data_as(u8p), blob.size, _lib.ptr(o8), C.byref(oi)),
     "proof_stream": lambda: stream(lambda s: lib.kzg_compute_proof_begin(ctx.handle, srs.handle, _lib.ptr(sc), n, None, n, _lib.ptr(z_off), s),
