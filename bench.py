@@ -1110,7 +1110,7 @@ def main():
                 "compute_challenge_host_sha256_ms": ch_ms,
                 "batch_verify_4096_core_ms": bv_ms, "batch_verify_4096_three_msms_ms": m3_ms,
                 "batch_verify_4096_end_to_end_ms": e2e_ms, "batch_verify_4096_end_to_end_stats": e2e_stats, "batch_verify_4096_end_to_end_blob_MiB": e2e_bytes / 2.0 ** 20,
-                "batch_verify_4096_end_to_end_host_threads": min(32, os.cpu_count() or 1),
+                "batch_verify_4096_end_to_end_host_threads": min(int(os.environ.get("KZG_HOST_THREADS_MAX", "48")), os.cpu_count() or 1),
                 "reference_bench_shapes": small, "reference_bench_shapes_stats": small_stats, "beyond_the_tables": beyond,
                 "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,

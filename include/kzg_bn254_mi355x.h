@@ -482,7 +482,7 @@ int32_t kzg_compute_r_powers(const uint64_t* commitments_xy_mont, const uint64_t
 /* helpers::compute_challenges_and_evaluate_polynomial (primitives/src/helpers.rs:613-662) for n blobs in ONE call:
  * out_zs[i] = compute_challenge(blob_i, commitment_i) (helpers.rs:411-472), out_ys[i] = p_i(z_i) (helpers.rs:475-535).
  * blobs[i] / blob_lens[i] = the padded bytes of blob i (Blob::data()).  The n transcripts are hashed on a pool of host threads
- * (KZG_HOST_THREADS, default: all cores up to 32); the n barycentric evaluations run as one batched GPU launch for blobs of up to
+ * (KZG_HOST_THREADS, default: all cores up to 48 = KZG_HOST_THREADS_MAX); the n barycentric evaluations run as one batched GPU launch for blobs of up to
  * 4096 field elements (one workgroup per blob, one inversion per blob) and through the single-polynomial path beyond.  Errors, for
  * the first failing blob in order: KZG_ERR_TOO_LARGE (polynomial.rs:42-46), KZG_ERR_G1_NOT_ON_CURVE (helpers.rs:413),
  * KZG_ERR_ZERO_LENGTH (empty blob: helpers.rs:554-558). */

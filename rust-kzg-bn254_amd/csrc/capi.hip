@@ -1426,11 +1426,18 @@ void digest_to_fr_wire(const uint8_t dig[32], uint64_t out[4]) {            // h
     while (kzg_host::fr_geq_r(w)) kzg_host::fr_sub_r(w);
     kzg_host::fr_mul(w, FR_R2_WORDS, out);
 }
+// Upper bound of the pool, whatever the core count (KZG_HOST_THREADS_MAX).  Measured on the 256-thread host of an MI355X box, 4 096-row batch verification
+// end to end (tools/trace_batch_verify.py): 32 threads 6.3-6.5 ms, 48 5.4-5.5, 64 5.3-5.6, 96 5.8-5.9, 128 6.0-6.5 (the transcripts scale, the upload and the
+// serial parts do not, and past 64 the pool's wake-ups cost more than they gain) -> 48.
+unsigned host_threads_cap() {
+    static const unsigned cap = []() { const char* e = getenv("KZG_HOST_THREADS_MAX"); const int v = e ? atoi(e) : 48; return (unsigned)(v >= 1 && v <= 256 ? v : 48); }();
+    return cap;
+}
 unsigned host_threads(size_t jobs) {
     unsigned t = std::thread::hardware_concurrency();
     if (t == 0) t = 4;
     { const char* env = getenv("KZG_HOST_THREADS"); if (env && atoi(env) > 0) t = (unsigned)atoi(env); }
-    if (t > 32) t = 32;
+    if (t > host_threads_cap()) t = host_threads_cap();
     if ((size_t)t > jobs) t = (unsigned)jobs;
     return t ? t : 1;
 }
