@@ -788,6 +788,9 @@ int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t pr
     return KZG_OK;
 }
 
+}  // extern "C"
+namespace { void parallel_for(size_t n, const std::function<void(size_t)>& job); }   // the host pool (defined with the batch verifier's front end below)
+extern "C" {
 static int32_t verify_batch_core(kzg_ctx* ctx, const uint64_t* commitments_xy_mont, const uint64_t* zs_mont, const uint64_t* ys_mont,
                                  const uint64_t* proofs_xy_mont, const uint64_t* r_powers_mont, size_t n,
                                  const uint64_t* g2_tau_mont, int32_t* out_ok) {
@@ -801,11 +804,22 @@ static int32_t verify_batch_core(kzg_ctx* ctx, const uint64_t* commitments_xy_mo
     // sum_i r^i C_i - [sum_i r^i y_i] G: the same group element with one fixed-base product instead of n.
     std::vector<uint64_t> bases(3 * n * 8), scalars(3 * n * 4);
     uint64_t s[4] = {0, 0, 0, 0};
-    for (size_t i = 0; i < n; ++i) {
-        uint64_t t[4];
-        fr_mul(r_powers_mont + 4 * i, zs_mont + 4 * i, scalars.data() + (n + i) * 4);      // r^i z_i
-        fr_mul(r_powers_mont + 4 * i, ys_mont + 4 * i, t);
-        fr_add(s, t, s);
+    {
+        // 2 n field products (0.15 ms at n = 4096 on one core): chunks on the host pool, one partial sum per chunk
+        const size_t chunks = n >= 1024 ? 32 : 1, per = (n + chunks - 1) / chunks;
+        std::vector<uint64_t> partial(4 * chunks, 0);
+        auto body = [&](size_t c) {
+            uint64_t acc[4] = {0, 0, 0, 0};
+            for (size_t i = c * per; i < std::min(n, (c + 1) * per); ++i) {
+                uint64_t t[4];
+                fr_mul(r_powers_mont + 4 * i, zs_mont + 4 * i, scalars.data() + (n + i) * 4);      // r^i z_i
+                fr_mul(r_powers_mont + 4 * i, ys_mont + 4 * i, t);
+                fr_add(acc, t, acc);
+            }
+            memcpy(partial.data() + 4 * c, acc, 32);
+        };
+        if (chunks > 1) parallel_for(chunks, body); else body(0);
+        for (size_t c = 0; c < chunks; ++c) fr_add(s, partial.data() + 4 * c, s);
     }
     if (n) {
         memcpy(bases.data(), proofs_xy_mont, n * 64);
