@@ -660,21 +660,6 @@ class ShardedKzgLagrange:
         ONES = np.uint64(0xFFFFFFFFFFFFFFFF)
         state = {"failed": None, "bad": []}
 
-        def xchg(g, rows):
-            """rows: (k, 16) u64 -> (world, k, 16); POISON instead when this rank has failed; records poisoned ranks"""
-            rows = np.ascontiguousarray(rows, dtype=np.uint64).reshape(-1, 16)
-            if state["failed"] is not None:
-                rows = np.full_like(rows, ONES)
-            if not exchanging:
-                got = rows.reshape(1, -1, 16)
-            else:
-                g.start(rows)
-                got = g.finish()
-            bad = [r for r in range(got.shape[0]) if np.all(got[r] == ONES)]
-            if bad:
-                state["bad"] = sorted(set(state["bad"]) | set(bad))
-            return got
-
         def guard(fn, *a):
             """run one local step unless this rank (or a peer) has already failed"""
             if state["failed"] is not None or state["bad"]:
@@ -749,10 +734,53 @@ class ShardedKzgLagrange:
             for cs, ps, _z, _y in inflight:                                  # give the slots back; no more collectives are issued
                 release(cs, ps)
             inflight.clear()
-            if pending_result and pending_result[2] is None and g_r is not None and g_r.busy:
-                g_r.finish()                                                # started on every rank before the failure became visible
-            pending_result[:] = []
+            settle()                                                        # exchanges started on every rank before the failure became visible
             raise ShardError(0, state["bad"], state["failed"])
+
+        # The y exchange of blob t is started and collected ONE ITERATION LATER (with two or more blobs in flight): its latency -- ~0.15 ms per
+        # blob on a saturated GPU -- then runs beside the next blob's begin and the collection of older results instead of stalling the host.
+        # Only with three or more blobs in flight (grouped launches): with two, the blob whose phase 2 waits a whole iteration leaves the GPU short of
+        # work (one-rank RCCL rehearsal, ms per blob without / with the lag: 2^17 0.60 / 0.53, 2^18 0.86 / 0.82, 2^19 1.57 / 1.59, 2^20 2.86 / 3.12).
+        lag_y = exchanging and depth >= 3
+        pending_y = []                                       # [ps, z, y] of the blob whose y exchange is in flight
+
+        def start_y(ps, z, y, ypart):
+            rows = np.ascontiguousarray(ypart, dtype=np.uint64).reshape(1, 16)
+            if state["failed"] is not None:
+                rows = np.full_like(rows, ONES)
+            if exchanging:
+                g_y.start(rows)
+                pending_y[:] = [ps, z, y, None]
+            else:
+                pending_y[:] = [ps, z, y, rows.reshape(1, 1, 16)]
+
+        def finish_y():
+            """fold y of the exchange in flight and enqueue that blob's phase 2; state["bad"] when a rank sent POISON"""
+            ps, z, y, got = pending_y
+            pending_y[:] = []
+            if got is None:
+                got = g_y.finish()
+            bad = [r for r in range(got.shape[0]) if np.all(got[r] == ONES)]
+            if bad:
+                state["bad"] = sorted(set(state["bad"]) | set(bad))
+                return
+            yp = np.ascontiguousarray(got.reshape(got.shape[0], 16)[:, :8])
+            rc = lib.kzg_lagrange_fold_y(_lib.ptr(yp), yp.shape[0], self.n, _lib.ptr(z), _lib.ptr(y))
+            if rc != _lib.OK:
+                raise ValueError(_lib.status_message(rc))
+            # a failure from here on is local knowledge until the NEXT collective of the common schedule: this rank walks on through that
+            # schedule without touching the GPU and sends POISON there
+            guard(lib.kzg_compute_proof_lagrange_continue, self.ctx.handle, ps, _lib.ptr(y))
+
+        def settle():
+            """wait for whatever exchange this rank has started (every rank started the same ones)"""
+            for g, pend in ((g_y, pending_y), (g_r, pending_result)):
+                if pend and pend[-1 if pend is pending_y else 2] is None and g is not None and g.busy:
+                    try:
+                        g.finish()
+                    except ExchangeTimeout:
+                        pass
+                pend[:] = []
 
         t = 0
         try:
@@ -776,21 +804,25 @@ class ShardedKzgLagrange:
                     sl = self._slice(ev)
                     guard(lib.kzg_commit_and_prove_lagrange_begin, self.ctx.handle, self.srs.handle, self.lo, _lib.ptr(sl) if self.len else None, self.len,
                           self.n, _lib.ptr(z), cs, ps)
+                if pending_y:                                                    # (lag_y) the previous blob's y: fold, enqueue its quotient + MSM
+                    finish_y()
+                    if state["bad"]:
+                        inflight.append((cs, ps, z, None))
+                        drain_and_raise()
                 ypart = np.zeros(16, dtype=np.uint64)                           # 8 words used: S_g | f_m
                 guard(lib.kzg_compute_proof_lagrange_partial_y, self.ctx.handle, ps, _lib.ptr(ypart))
-                got = xchg(g_y, ypart)
                 y = np.zeros(4, dtype=np.uint64)
                 inflight.append((cs, ps, z, y))
-                if state["bad"]:                                                 # every rank sees the same rows: all stop here, in step
-                    drain_and_raise()
-                yp = np.ascontiguousarray(got.reshape(got.shape[0], 16)[:, :8])
-                rc = lib.kzg_lagrange_fold_y(_lib.ptr(yp), yp.shape[0], self.n, _lib.ptr(z), _lib.ptr(y))
-                if rc != _lib.OK:
-                    raise ValueError(_lib.status_message(rc))
-                # a failure from here on is local knowledge until the NEXT collective of the common schedule (the result exchange of the oldest
-                # blob, or the next blob's y exchange): this rank walks on through that schedule without touching the GPU and sends POISON there
-                guard(lib.kzg_compute_proof_lagrange_continue, self.ctx.handle, ps, _lib.ptr(y))
+                start_y(ps, z, y, ypart)
+                if not lag_y:
+                    finish_y()
+                    if state["bad"]:                                             # every rank sees the same rows: all stop here, in step
+                        drain_and_raise()
                 t += 1
+            if pending_y:
+                finish_y()
+                if state["bad"]:
+                    drain_and_raise()
             while inflight or pending_result:
                 if pending_result:
                     out = collect_result()
@@ -803,11 +835,7 @@ class ShardedKzgLagrange:
             for cs, ps, _z, _y in inflight:                                  # a consumer that stopped early: nothing may stay in flight
                 release(cs, ps)
             inflight.clear()
-            if pending_result and pending_result[2] is None and g_r is not None and g_r.busy:
-                try:
-                    g_r.finish()                                            # every rank issued this collective: only a wait
-                except ExchangeTimeout:
-                    pass
+            settle()
 
 
 class MultiKzg:
