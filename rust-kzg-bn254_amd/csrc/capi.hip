@@ -613,7 +613,8 @@ static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, c
         static const double frac_env = []() { const char* e = getenv("KZG_SPLIT_FRAC"); const double v = e ? atof(e) : 0.0; return v > 0.05 && v < 0.95 ? v : 0.0; }();
         const double split_frac = frac_env > 0.0 ? frac_env : (n >= ((size_t)1 << 20) ? 0.375 : 0.44);
         const bool idle = !ctx->slot_pending[0] && !ctx->slot_pending[1] && ctx->lag[0].phase == 0 && ctx->lag[1].phase == 0;
-        if (split_on && idle && n >= ((size_t)1 << 19) && n <= MSM_SPLIT_MAX && ctx->msm_c_override == 0 && srs_bits(srs)) {
+        static const size_t split_min = []() { const char* e = getenv("KZG_SPLIT_MIN_LOG"); const int v = e ? atoi(e) : 19; return (size_t)1 << (v >= 14 && v <= 21 ? v : 19); }();
+        if (split_on && idle && n >= split_min && n <= MSM_SPLIT_MAX && ctx->msm_c_override == 0 && srs_bits(srs)) {
             const size_t half = ((size_t)((double)n * split_frac) + 255) / 256 * 256;
             const uint64_t* sc = static_cast<const uint64_t*>(scalars);
             const size_t lo[2] = {0, half}, len[2] = {half, n - half};
