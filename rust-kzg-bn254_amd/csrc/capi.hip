@@ -1676,12 +1676,15 @@ void r_powers_host(const uint64_t* commitments, const uint64_t* zs, const uint64
     for (int b = 0; b < 8; ++b) data[32 + b] = (uint8_t)((uint64_t)n >> (8 * (7 - b)));
     for (size_t i = 0; i < n; ++i) for (int b = 0; b < 8; ++b) data[40 + 8 * i + b] = (uint8_t)(lens_elems[i] >> (8 * (7 - b)));
     uint8_t* rows = data.data() + 40 + 8 * n;
-    parallel_for(n, [&](size_t i) {
-        uint8_t* p = rows + 128 * i;
-        g1_serialize_compressed_ark(g1_from_wire(commitments + 8 * i), p);
-        fr_wire_to_be_bytes(zs + 4 * i, p + 32);
-        fr_wire_to_be_bytes(ys + 4 * i, p + 64);
-        g1_serialize_compressed_ark(g1_from_wire(proofs + 8 * i), p + 96);
+    const size_t per = 64, jobs = (n + per - 1) / per;
+    parallel_for(jobs, [&](size_t j) {
+        for (size_t i = j * per; i < std::min(n, (j + 1) * per); ++i) {
+            uint8_t* p = rows + 128 * i;
+            g1_serialize_compressed_ark(g1_from_wire(commitments + 8 * i), p);
+            fr_wire_to_be_bytes(zs + 4 * i, p + 32);
+            fr_wire_to_be_bytes(ys + 4 * i, p + 64);
+            g1_serialize_compressed_ark(g1_from_wire(proofs + 8 * i), p + 96);
+        }
     });
     Sha256 sh;
     sha256_init(sh);
@@ -1748,9 +1751,12 @@ int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blob
     // batch.rs:29-37: every commitment, then every proof, on the curve (cofactor 1: no subgroup check to make) -- before anything else
     {
         std::atomic<int> bad{0};
-        parallel_for(2 * n, [&](size_t k) {
-            const uint64_t* p = k < n ? commitments_xy_mont + 8 * k : proofs_xy_mont + 8 * (k - n);
-            if (!g1_on_curve(g1_from_wire(p))) bad.store(1, std::memory_order_relaxed);
+        const size_t per = 128, jobs = (2 * n + per - 1) / per;           // (one pool job per point was 8 192 contended counter increments: 0.3 ms for 0.05 ms of work)
+        parallel_for(jobs, [&](size_t j) {
+            for (size_t k = j * per; k < std::min(2 * n, (j + 1) * per); ++k) {
+                const uint64_t* p = k < n ? commitments_xy_mont + 8 * k : proofs_xy_mont + 8 * (k - n);
+                if (!g1_on_curve(g1_from_wire(p))) bad.store(1, std::memory_order_relaxed);
+            }
         });
         if (bad.load()) return KZG_ERR_G1_NOT_ON_CURVE;
     }
