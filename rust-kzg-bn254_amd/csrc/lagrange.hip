@@ -242,7 +242,14 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     if (rc != KZG_OK) { lp = LagProof(); return rc; }
     const uint32_t blocks = (uint32_t)((len + LAG_BLOCK - 1) / LAG_BLOCK);
     hipStream_t s1 = nullptr;                                    // phase 1's stream (high priority; KZG_LAG_PRIO=0: = st)
-    auto fail = [&](hipError_t e, const char* where) { lp = LagProof(); (void)hipStreamSynchronize(st); if (s1) (void)hipStreamSynchronize(s1); return set_error(ctx, e, where); };
+    bool commit_started = false;                                 // a failure after the commitment's MSM was enqueued collects it, so that no slot stays pending without an owner
+    auto fail = [&](hipError_t e, const char* where) {
+        lp = LagProof();
+        (void)hipStreamSynchronize(st);
+        if (s1) (void)hipStreamSynchronize(s1);
+        if (commit_started) { uint64_t sink[16]; (void)msm_end(ctx, commit_slot, nullptr, nullptr, sink); }
+        return set_error(ctx, e, where);
+    };
 #define LAG_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(_e, #expr); } while (0)
     LAG_TRY(set.a.reserve(len * 32 + 32));
     LAG_TRY(set.b.reserve(len * NL * 4 + 64));
@@ -269,6 +276,7 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
         }
         rc = msm_begin(ctx, commit_slot, srs_bases(shard, 0, len, ctx->msm_c_override == 0), d_ev, len);
         if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(s1); return rc; }
+        commit_started = true;
     }
     hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, s1, d_ev, (uint32_t)len, (uint32_t)base, tb,
                        reinterpret_cast<const uint4*>(small), set.b.as<int32_t>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS),

@@ -801,9 +801,15 @@ class ShardedKzgLagrange:
                     guard(lib.kzg_commit_and_prove_lagrange_begin_device, self.ctx.handle, self.srs.handle, self.lo, C.c_void_p(int(ev)) if self.len else None,
                           self.len, self.n, _lib.ptr(z), cs, ps)
                 else:
-                    sl = self._slice(ev)
-                    guard(lib.kzg_commit_and_prove_lagrange_begin, self.ctx.handle, self.srs.handle, self.lo, _lib.ptr(sl) if self.len else None, self.len,
-                          self.n, _lib.ptr(z), cs, ps)
+                    sl = None
+                    try:
+                        sl = self._slice(ev)
+                    except Exception as e:                                       # noqa: BLE001 -- a wrong-sized slice on ONE rank: its peers learn it from the next collective
+                        if not exchanging:
+                            raise
+                        state["failed"] = state["failed"] or e
+                    guard(lib.kzg_commit_and_prove_lagrange_begin, self.ctx.handle, self.srs.handle, self.lo, _lib.ptr(sl) if self.len and sl is not None else None,
+                          self.len, self.n, _lib.ptr(z), cs, ps)
                 if pending_y:                                                    # (lag_y) the previous blob's y: fold, enqueue its quotient + MSM
                     finish_y()
                     if state["bad"]:

@@ -417,6 +417,13 @@ def _lag_worker(rank, world, port, q):
         check("stream failure (%s): what was yielded is right" % mode, len(outs) <= 3 and all(np.array_equal(o_[0], want_c) for o_ in outs))
         check("stream failure (%s): nothing in flight" % mode, not state and not commits)
         check("stream after a failure (%s)" % mode, len(list(sk.commit_and_prove_stream([(wire, zs[0])] * 3))) == 3 and not state and not commits)
+    # a wrong-sized slice handed to ONE rank (a host-side error before any C-ABI call): the same lockstep failure, not a hang
+    err = None
+    try:
+        list(sk.commit_and_prove_stream([(wire, zs[0]), (wire[:-1] if rank == 1 else wire, zs[1]), (wire, zs[2])], depth=2, grouped=False))
+    except sharding.ShardError as e:
+        err = e
+    check("wrong-sized slice on rank 1: ShardError on every rank", err is not None and err.ranks == [1] and not state and not commits)
     q.put((rank, failed))
     dist.destroy_process_group()
 
