@@ -335,6 +335,12 @@ int32_t kzg_compute_proof_lagrange_continue(kzg_ctx* ctx, int32_t slot, const ui
 int32_t kzg_compute_proof_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t out_part[32]);
 int32_t kzg_compute_proof_lagrange_abort(kzg_ctx* ctx, int32_t slot);
 int32_t kzg_lagrange_fold_y(const uint64_t* yparts_mont, size_t count, size_t n, const uint64_t z_mont[4], uint64_t out_y_mont[4]);
+/* KZG::compute_quotient_eval_on_domain (prover/src/kzg.rs:237-260): sum over the n roots w^i != z of (f_i - value) w^i / ((z - w^i) z), i.e. the
+ * quotient's evaluation AT the domain point z = w^m when value = f_m; like the reference, z need not be a domain point (then no term is skipped).
+ * n evaluations in host memory, n a power of two (else KZG_ERR_NOT_POWER_OF_TWO; n > 2^28 -> KZG_ERR_DOMAIN); z = 0 -> KZG_ERR_INVALID_ARG (the
+ * reference divides by z).  Computed on the GPU by the kernels of the Lagrange-sharded proof (csrc/lagrange.hip) on slot 0, which must be idle. */
+int32_t kzg_compute_quotient_eval_on_domain(kzg_ctx* ctx, const uint64_t z_mont[4], const uint64_t* evals_mont, size_t n, const uint64_t value_mont[4],
+                                            uint64_t out_quotient_mont[4]);
 int32_t kzg_lagrange_fold_proof(const uint64_t* parts, size_t count, size_t n, const uint64_t z_mont[4], uint64_t out_xy_mont[8],
                                 uint8_t* out_is_infinity);
 /* ---- several GPUs behind one handle (no torch, no RCCL) ------------------------------------------------------
@@ -448,6 +454,12 @@ int32_t kzg_calculate_roots_of_unity(kzg_ctx* ctx, uint64_t length_of_data_after
 int32_t kzg_g2_generator(uint64_t out_g2_mont[16]);                  /* G2Affine::generator() */
 int32_t kzg_g2_tau_mainnet(uint64_t out_g2_mont[16]);                /* consts::G2_TAU */
 int32_t kzg_g2_mul_generator(const uint64_t scalar_mont[4], uint64_t out_g2_mont[16]);   /* [s]G2 (tests / custom setups) */
+/* helpers::is_on_curve_g2 (helpers.rs:263-285): y^2 = x^3 + 3 / (9 + u) on the twist; the identity counts as on the curve.  Host-only. */
+int32_t kzg_g2_is_on_curve(const uint64_t g2_mont[16], int32_t* out_on_curve);
+/* helpers::example_validate_g2_point (helpers.rs:740-766), checks in the reference's order: *out_reason = 0 valid | 1 NotOnCurveError("G2 point not on
+ * curve") | 2 NotOnCurveError("G2 point is point at infinity") | 3 NotOnCurveError("G2 point not in correct subgroup") ([r]P != O) |
+ * 4 G2GeneratorNotAcceptedError("G2 point cannot be the generator point").  Host-only. */
+int32_t kzg_validate_g2_point(const uint64_t g2_mont[16], int32_t* out_reason);
 /* helpers::pairings_verify(a1, a2, b1, b2) (helpers.rs:392-398): *out_ok = (e(a1,a2) == e(b1,b2)).  Host-only. */
 int32_t kzg_pairings_verify(const uint64_t a1_xy_mont[8], const uint64_t a2_g2_mont[16],
                             const uint64_t b1_xy_mont[8], const uint64_t b2_g2_mont[16], int32_t* out_ok);

@@ -123,6 +123,9 @@ PROTOTYPES = {
     "kzg_g2_generator": (i32, [u64p]),
     "kzg_g2_tau_mainnet": (i32, [u64p]),
     "kzg_g2_mul_generator": (i32, [u64p, u64p]),
+    "kzg_g2_is_on_curve": (i32, [u64p, C.POINTER(i32)]),
+    "kzg_validate_g2_point": (i32, [u64p, C.POINTER(i32)]),
+    "kzg_compute_quotient_eval_on_domain": (i32, [vp, u64p, u64p, C.c_size_t, u64p, u64p]),
     "kzg_pairings_verify": (i32, [u64p, u64p, u64p, u64p, C.POINTER(i32)]),
     "kzg_verify_proof": (i32, [u64p, u64p, u64p, u64p, u64p, C.POINTER(i32)]),
     "kzg_verify_kzg_proof_batch": (i32, [vp, u64p, u64p, u64p, u64p, u64p, sz, u64p, C.POINTER(i32)]),

@@ -9,11 +9,7 @@ from .polynomial import PolynomialCoeffForm, PolynomialEvalForm
 class Blob:
     def __init__(self, blob_data: bytes):
         """Blob::new (blob.rs:30-35): validates canonical elements (helpers.rs:783-810)."""
-        if len(blob_data) % BYTES_PER_FIELD_ELEMENT != 0:
-            raise InvalidInputLength()
-        for i in range(0, len(blob_data), 32):
-            if int.from_bytes(blob_data[i:i + 32], "big") >= FR_MODULUS:
-                raise InvalidFieldElement(f"Field element at position {i // 32} is not canonical or invalid")
+        helpers.validate_blob_data_as_canonical_field_elements(blob_data)
         self.blob_data = bytes(blob_data)
 
     @classmethod

@@ -65,6 +65,7 @@ int32_t lag_partial_y(kzg_ctx* ctx, int slot, uint64_t out[8]);
 int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]);
 int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32], uint64_t* out_commit);
 void lag_abort(kzg_ctx* ctx, int slot);
+int32_t lag_quotient_eval_on_domain(kzg_ctx* ctx, const uint64_t z[4], const uint64_t* evals, size_t n, const uint64_t value[4], uint64_t out[4]);
 // (lag_fold_y / lag_fold_proof: host_lagrange.h)
 int32_t vb_evaluate_setup(kzg_ctx* ctx, size_t packed_len, size_t nb);
 int32_t vb_evaluate_enqueue(kzg_ctx* ctx, const uint8_t* packed, const void* meta_host, size_t nb, size_t b0, size_t b1, const uint64_t* zs,
@@ -759,6 +760,25 @@ int32_t kzg_g2_mul_generator(const uint64_t scalar_mont[4], uint64_t out_g2_mont
     return KZG_OK;
 }
 
+int32_t kzg_g2_is_on_curve(const uint64_t g2_mont[16], int32_t* out_on_curve) {
+    if (!g2_mont || !out_on_curve) return KZG_ERR_INVALID_ARG;
+    *out_on_curve = kzg_host::g2_on_curve(kzg_host::g2_from_wire(g2_mont)) ? 1 : 0;
+    return KZG_OK;
+}
+
+int32_t kzg_validate_g2_point(const uint64_t g2_mont[16], int32_t* out_reason) {
+    if (!g2_mont || !out_reason) return KZG_ERR_INVALID_ARG;
+    using namespace kzg_host;
+    const G2 p = g2_from_wire(g2_mont);
+    *out_reason = 0;
+    if (!g2_on_curve(p)) { *out_reason = 1; return KZG_OK; }                               // helpers.rs:741-745
+    if (p.inf) { *out_reason = 2; return KZG_OK; }                                          // :747-751
+    if (!g2_mul(p, FR_MODULUS_WORDS).inf) { *out_reason = 3; return KZG_OK; }                          // :753-757: [r] P = O <=> P in the order-r subgroup of the twist
+    const G2 g = g2_generator();
+    if (eq(p.x, g.x) && eq(p.y, g.y)) { *out_reason = 4; return KZG_OK; }                   // :759-763
+    return KZG_OK;
+}
+
 int32_t kzg_pairings_verify(const uint64_t a1_xy_mont[8], const uint64_t a2_g2_mont[16], const uint64_t b1_xy_mont[8],
                             const uint64_t b2_g2_mont[16], int32_t* out_ok) {
     if (!a1_xy_mont || !a2_g2_mont || !b1_xy_mont || !b2_g2_mont || !out_ok) return KZG_ERR_INVALID_ARG;
@@ -1072,6 +1092,15 @@ int32_t kzg_compute_proof_lagrange_abort(kzg_ctx* ctx, int32_t slot) {
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     lag_abort(ctx, slot);
     return KZG_OK;
+}
+int32_t kzg_compute_quotient_eval_on_domain(kzg_ctx* ctx, const uint64_t z_mont[4], const uint64_t* evals_mont, size_t n, const uint64_t value_mont[4],
+                                            uint64_t out_quotient_mont[4]) {
+    if (!ctx || !z_mont || !evals_mont || !value_mont || !out_quotient_mont) return KZG_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO;
+    if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lag_quotient_eval_on_domain(ctx, z_mont, evals_mont, n, value_mont, out_quotient_mont);
 }
 int32_t kzg_lagrange_fold_y(const uint64_t* yparts_mont, size_t count, size_t n, const uint64_t z_mont[4], uint64_t out_y_mont[4]) {
     if (!z_mont || !out_y_mont || (count && !yparts_mont)) return KZG_ERR_INVALID_ARG;

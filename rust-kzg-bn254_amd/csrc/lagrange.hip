@@ -380,6 +380,62 @@ int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32], uint64_t* out_com
     return KZG_OK;
 }
 
+// KZG::compute_quotient_eval_on_domain (prover/src/kzg.rs:237-260): sum over the n roots w^i != z of (f_i - value) w^i / ((z - w^i) z), the quotient's
+// evaluation AT the domain point z -- here as -(1/z) T with T = sum_{w^i != z} q_i w^i, q_i = (f_i - value) / (w^i - z): the two kernels of a slice
+// (base 0, len n) and the sum, on slot 0's working set; the reference does not require z to be a domain point (then no term is skipped).
+// z = 0: the reference divides by zero (a panic in ark-ff) -> KZG_ERR_INVALID_ARG.
+int32_t lag_quotient_eval_on_domain(kzg_ctx* ctx, const uint64_t z[4], const uint64_t* evals, size_t n, const uint64_t value[4], uint64_t out[4]) {
+    const int slot = 0;
+    if (ctx->lag[slot].phase != 0 || ctx->slot_pending[slot]) { ctx->last_error = "slot 0 is in flight"; return KZG_ERR_INVALID_ARG; }
+    static const uint64_t zero[4] = {0, 0, 0, 0};
+    if (memcmp(z, zero, 32) == 0) { ctx->last_error = "compute_quotient_eval_on_domain: z = 0 (the reference divides by z)"; return KZG_ERR_INVALID_ARG; }
+    hipStream_t st = nullptr;
+    int32_t rc = msm_slot_stream(ctx, slot, &st);
+    if (rc != KZG_OK) return rc;
+    const int log_n = ilog2_sz(n);
+    NttTables tb;
+    rc = ntt_get_tables(ctx, log_n, false, &tb);
+    if (rc != KZG_OK) return rc;
+    PolySet& set = ctx->poly[slot];
+    if (!set.pinned) KZG_HIP_TRY(ctx, hipHostMalloc(&set.pinned, 4096, hipHostMallocDefault));
+    uint8_t* pin = static_cast<uint8_t*>(set.pinned);
+    const uint32_t blocks = (uint32_t)((n + LAG_BLOCK - 1) / LAG_BLOCK);
+    auto fail = [&](hipError_t e, const char* where) { (void)hipStreamSynchronize(st); return set_error(ctx, e, where); };
+#define LAG_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(_e, #expr); } while (0)
+    LAG_TRY(set.a.reserve(n * 32 + 32));
+    LAG_TRY(set.b.reserve(n * NL * 4 + 64));
+    LAG_TRY(set.c.reserve(n * 32 + 32));
+    LAG_TRY(set.small.reserve(LAG_SMALL_PARTIALS + (size_t)blocks * NL * 4 + 64));
+    uint8_t* small = set.small.as<uint8_t>();
+    memcpy(pin, z, 32);
+    memcpy(pin + 32, value, 32);
+    const uint32_t no_index = NO_INDEX;
+    memcpy(pin + 160, &no_index, 4);
+    LAG_TRY(hipMemcpyAsync(small, pin, 64, hipMemcpyHostToDevice, st));
+    LAG_TRY(hipMemcpyAsync(small + 64, pin + 160, 4, hipMemcpyHostToDevice, st));
+    LAG_TRY(hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, 0u, tb, reinterpret_cast<const uint4*>(small),
+                       set.b.as<int32_t>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS), reinterpret_cast<uint32_t*>(small + 64));
+    LAG_TRY(hipMemcpyAsync(pin + 160, small + 64, 4, hipMemcpyDeviceToHost, st));
+    LAG_TRY(hipStreamSynchronize(st));                          // the index of the root equal to z, if any (found by the kernel)
+    uint32_t m_slice = NO_INDEX;
+    memcpy(&m_slice, pin + 160, 4);
+    hipLaunchKernelGGL(k_lag_quotient, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, 0u, tb, set.b.as<int32_t>(),
+                       reinterpret_cast<const uint4*>(small + 32), m_slice, 1, set.c.as<uint4>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS));
+    hipLaunchKernelGGL(k_lag_sum, dim3(1), dim3(POLY_THREADS), 0, st, reinterpret_cast<const int32_t*>(small + LAG_SMALL_PARTIALS), blocks,
+                       reinterpret_cast<uint4*>(small + 160));
+    LAG_TRY(hipGetLastError());
+    LAG_TRY(hipMemcpyAsync(pin + 128, small + 160, 32, hipMemcpyDeviceToHost, st));
+    LAG_TRY(hipStreamSynchronize(st));
+#undef LAG_TRY
+    uint64_t t[4], zi[4], prod[4];
+    memcpy(t, pin + 128, 32);
+    h_fr_inv(z, zi);
+    h_fr_mul(t, zi, prod);
+    h_fr_sub(zero, prod, out);
+    return KZG_OK;
+}
+
 // the slot gives up whatever it has in flight (error paths of the hosts above: a peer failed between two phases)
 void lag_abort(kzg_ctx* ctx, int slot) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS) return;

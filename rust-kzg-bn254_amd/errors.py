@@ -37,6 +37,17 @@ class DeserializationError(KzgError):
     variant = "DeserializationError"; prefix = "deserialization error: "
 
 
+class G2GeneratorNotAcceptedError(KzgError):
+    variant = "G2GeneratorNotAcceptedError"; prefix = "g2 generator not accepted error: "
+
+
+class InvalidDenominator(KzgError):
+    variant = "InvalidDenominator"
+
+    def __init__(self, message=""):
+        super().__init__("invalid denominator")
+
+
 class NotOnCurveError(KzgError):
     variant = "NotOnCurveError"; prefix = "not on curve error: "
 

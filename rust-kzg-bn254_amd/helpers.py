@@ -4,13 +4,15 @@ the kernel scope); everything that touches group or NTT ari
 the C-ABI to the HIP kernels."""
 import ctypes as C
 import hashlib
+import re
 
 import numpy as np
 
 from . import _lib
 from .consts import (BYTES_PER_FIELD_ELEMENT, FIAT_SHAMIR_PROTOCOL_DOMAIN, FQ_MODULUS, FR_MODULUS,
                      MAINNET_SRS_G1_SIZE, primitive_root_of_unity)
-from .errors import GenericError, InvalidInputLength, MsmError, NotOnCurveError
+from .errors import (DeserializationError, G2GeneratorNotAcceptedError, GenericError, InvalidFieldElement, InvalidInputLength, MsmError,
+                     NotOnCurveError)
 from .fr import fq_to_int, fr_from_int, fr_to_int, frs_from_ints, frs_to_ints, g1_is_identity
 
 
@@ -53,6 +55,72 @@ def to_fr_array(data: bytes, ctx=None) -> np.ndarray:
         return out[:n]
     data = data + b"\x00" * (n * 32 - len(data))
     return frs_from_ints([int.from_bytes(data[32 * i:32 * i + 32], "big") for i in range(n)])
+
+
+def blob_to_polynomial(blob: bytes, ctx=None) -> np.ndarray:
+    """helpers.rs:28-30."""
+    return to_fr_array(blob, ctx)
+
+
+def set_bytes_canonical(data: bytes) -> np.ndarray:
+    """helpers.rs:32-34: Fr::from_be_bytes_mod_order."""
+    return fr_from_int(int.from_bytes(bytes(data), "big") % FR_MODULUS)
+
+
+def is_zeroed(first_byte: int, buf) -> bool:
+    """helpers.rs:121-132."""
+    return first_byte == 0 and not any(bytes(buf))
+
+
+def str_vec_to_fr_vec(input) -> np.ndarray:
+    """helpers.rs:134-149: decimal strings ("-1" spelled out by the reference); ark-ff 0.5's Fr::from_str parses a signed decimal integer and
+    reduces it mod r; what it refuses is the reference's panic ("could not load string to Fr")."""
+    out = []
+    for element in input:
+        if not re.fullmatch(r"[+-]?[0-9]+", element):
+            raise ValueError("could not load string to Fr")
+        out.append(int(element) % FR_MODULUS)
+    return frs_from_ints(out)
+
+
+def validate_blob_data_as_canonical_field_elements(data: bytes) -> None:
+    """helpers.rs:784-810: every 32-byte big-endian chunk < r (one vectorised comparison of the four 64-bit words, no loop over the elements)."""
+    if len(data) % BYTES_PER_FIELD_ELEMENT != 0:
+        raise InvalidInputLength()
+    if not data:
+        return
+    a = np.frombuffer(data, dtype=">u8").reshape(-1, 4)
+    m = [(FR_MODULUS >> (64 * (3 - k))) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+    ge = a[:, 3] >= m[3]
+    for k in (2, 1, 0):
+        ge = (a[:, k] > m[k]) | ((a[:, k] == m[k]) & ge)
+    if ge.any():
+        raise InvalidFieldElement(f"Field element at position {int(np.argmax(ge))} is not canonical or invalid")
+
+
+def read_g1_point_from_bytes_be(g1_bytes_be: bytes, ctx=None) -> np.ndarray:
+    """helpers.rs:175-227: one gnark-compressed point -> wire-format affine point, through the kernel that decodes a whole SRS file
+    (`kzg_srs_load_compressed_be`, the square root on the GPU) and a read-back."""
+    if len(g1_bytes_be) != 32:
+        raise DeserializationError("not enough bytes for g1 point")
+    ctx = ctx or _lib.default_context()
+    lib = _lib.load()
+    h = C.c_void_p()
+    bad = C.c_uint64(0)
+    buf = np.frombuffer(bytes(g1_bytes_be), dtype=np.uint8)
+    rc = lib.kzg_srs_load_compressed_be(ctx.handle, buf.ctypes.data_as(_lib.u8p), 1, C.byref(h), C.byref(bad))
+    if rc == _lib.ERR_DESERIALIZE:
+        raise DeserializationError("point at infinity not coded properly for g1")
+    if rc == _lib.ERR_NOT_ON_CURVE:
+        raise NotOnCurveError(f"compressed g1 point not on curve: {list(bytes(g1_bytes_be))}")
+    ctx.check_device(rc)
+    out = np.zeros(8, dtype=np.uint64)
+    try:
+        rc = lib.kzg_srs_download(ctx.handle, h, 0, 1, _lib.ptr(out))
+        ctx.check_device(rc)
+    finally:
+        lib.kzg_srs_free(h)
+    return out
 
 
 def to_byte_array(data_fr, max_output_size: int) -> bytes:
@@ -181,6 +249,31 @@ def validate_g1_point(point) -> None:
     """helpers.rs:694-708: on curve + correct subgroup (G1 of BN254 has cofactor 1, so the second check is implied)."""
     if not is_on_curve_g1(point):
         raise NotOnCurveError("G1 point not on curve")
+
+
+def is_on_curve_g2(point) -> bool:
+    """helpers.rs:263-285 (the twist y^2 = x^3 + 3 / (9 + u)); `point`: G2 wire format, 16 u64."""
+    ok = _lib.i32(0)
+    rc = _lib.load().kzg_g2_is_on_curve(_lib.ptr(_lib.as_u64(point, 0).reshape(16)), C.byref(ok))
+    if rc != _lib.OK:
+        raise ValueError(_lib.status_message(rc))
+    return bool(ok.value)
+
+
+def example_validate_g2_point(point) -> None:
+    """helpers.rs:740-766: on the curve, not the identity, in the order-r subgroup, not the generator -- in that order."""
+    reason = _lib.i32(0)
+    rc = _lib.load().kzg_validate_g2_point(_lib.ptr(_lib.as_u64(point, 0).reshape(16)), C.byref(reason))
+    if rc != _lib.OK:
+        raise ValueError(_lib.status_message(rc))
+    if reason.value == 1:
+        raise NotOnCurveError("G2 point not on curve")
+    if reason.value == 2:
+        raise NotOnCurveError("G2 point is point at infinity")
+    if reason.value == 3:
+        raise NotOnCurveError("G2 point not in correct subgroup")
+    if reason.value == 4:
+        raise G2GeneratorNotAcceptedError("G2 point cannot be the generator point")
 
 
 def compute_powers(base, count: int) -> np.ndarray:

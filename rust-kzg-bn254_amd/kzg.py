@@ -308,6 +308,28 @@ class KZG:
             raise GenericError("Root of unity not found")
         return self.compute_proof(polynomial, z, srs)
 
+    # kzg.rs:237-260
+    def compute_quotient_eval_on_domain(self, z_fr, eval_fr, value_fr):
+        """sum over the stored roots w^i != z of (f_i - value) w^i / ((z - w^i) z): the quotient's evaluation at the domain point z, on the GPU
+        (`kzg_compute_quotient_eval_on_domain`).  Like the reference it reads one evaluation per stored root."""
+        n = len(self.expanded_roots_of_unity)
+        ev = _lib.as_u64(eval_fr, 4).reshape(-1, 4)
+        if len(ev) < n:
+            raise IndexError("index out of bounds: the len is %d but the index is %d" % (len(ev), len(ev)))      # eval_fr[i] in the reference's loop
+        if n == 0:
+            return np.zeros(4, dtype=np.uint64)
+        ctx = self._ctx()
+        out = np.zeros(4, dtype=np.uint64)
+        ev = np.ascontiguousarray(ev[:n])
+        rc = _lib.load().kzg_compute_quotient_eval_on_domain(ctx.handle, _lib.ptr(_lib.as_u64(z_fr, 0).reshape(4)), _lib.ptr(ev), n,
+                                                             _lib.ptr(_lib.as_u64(value_fr, 0).reshape(4)), _lib.ptr(out))
+        if rc == _lib.ERR_INVALID_ARG and not _lib.as_u64(z_fr, 0).any():
+            raise ZeroDivisionError("compute_quotient_eval_on_domain: z = 0 (the reference divides by z)")
+        ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(_lib.status_message(rc))
+        return out
+
     # kzg.rs:263-285
     def g1_ifft(self, length: int, srs):
         """Lagrange-basis SRS of size `length` (natural order), (length, 8) uint64 wire points."""

@@ -57,6 +57,48 @@ class SRS:
         self._n = points_to_load
         return self
 
+    @staticmethod
+    def parallel_read_g1_points_native(file_path, points_to_load, is_native, ctx=None):
+        """srs.rs:205-251 (and :76-126 for is_native = False): the first `points_to_load` points of the file as (n, 8) wire-format points.  The
+        reference spreads the 32-byte chunks over one worker per core; here one kernel decodes them all and the points are read back."""
+        srs = SRS.new(file_path, points_to_load, points_to_load, ctx=ctx, is_native=is_native)
+        try:
+            return srs.g1
+        finally:
+            srs.close()
+
+    @staticmethod
+    def process_chunks(receiver, ctx=None):
+        """srs.rs:51-70: `receiver` yields (chunk, position, is_native) -> [(point, position)], in the order received.  The chunks of each format go
+        through the decoding kernel together; a chunk that does not decode raises (the reference panics: "Failed to read point from bytes")."""
+        items = list(receiver)
+        out = [None] * len(items)
+        for native in (False, True):
+            idx = [k for k, it in enumerate(items) if bool(it[2]) == native]
+            if not idx:
+                continue
+            data = b"".join(bytes(items[k][0]) for k in idx)
+            if any(len(items[k][0]) != 32 for k in idx):
+                raise DeserializationError("not enough bytes for g1 point")
+            lib = _lib.load()
+            c = ctx or _lib.default_context()
+            h = C.c_void_p()
+            bad = C.c_uint64(0)
+            buf = np.frombuffer(data, dtype=np.uint8)
+            load = lib.kzg_srs_load_compressed_ark_le if native else lib.kzg_srs_load_compressed_be
+            rc = load(c.handle, buf.ctypes.data_as(_lib.u8p), len(idx), C.byref(h), C.byref(bad))
+            if rc in (_lib.ERR_DESERIALIZE, _lib.ERR_NOT_ON_CURVE):
+                raise DeserializationError("Failed to read point from bytes")
+            c.check_device(rc)
+            pts = np.zeros((len(idx), 8), dtype=np.uint64)
+            try:
+                c.check_device(lib.kzg_srs_download(c.handle, h, 0, len(idx), _lib.ptr(pts)))
+            finally:
+                lib.kzg_srs_free(h)
+            for j, k in enumerate(idx):
+                out[k] = (pts[j], items[k][1])
+        return out
+
     def save_packed(self, path: str):
         """Write the decoded points in the library's packed form (`kzg_srs_save_packed`): `SRS.load_packed` reads them back without decoding
         the ceremony file again (digest-checked, curve-checked on the GPU)."""

@@ -5,8 +5,8 @@ C-ABI / the HIP kernels for every commitment, transform, evaluation and proof). 
     primitives/tests/polynomial_test.rs (all 5)
     primitives/tests/blob_test.rs       (all 4; the 1 000 x 16 MiB rayon loop of test_convert_by_padding_empty_byte runs 4 x 1 MiB per thread)
     primitives/tests/helpers_test.rs    (the 9 calculate_roots_of_unity tests -- the roots are generated on the GPU -- and the 5 G1 curve /
-                                         validation tests; its fixture tests (to_fr_array, pad_payload, PRIMITIVE_ROOTS_OF_UNITY ...) are
-                                         in tests/test_oracle.py and tests/test_host_logic.py)
+                                         validation tests; the other 19 -- pad_payload, is_zeroed, the G2 checks, compute_challenge ... --
+                                         are in tests/test_reference_helpers.py, the fixtures also in tests/test_oracle.py)
     verifier/tests/tests.rs             (the 4 tests not already in tests/test_gpu_verifier.py: identity points, intermediate point
                                          validation, zero commitment, random inputs)
 
