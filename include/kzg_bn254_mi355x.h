@@ -411,6 +411,11 @@ int32_t kzg_compute_proof_rccl_device(kzg_ctx* ctx, const kzg_srs* lagrange_shar
                                       const uint64_t z_mont[4], void* nccl_comm, int32_t world, uint64_t out_xy_mont[8], uint8_t* out_is_infinity,
                                       uint64_t* out_y_mont);
 
+/* helpers::validate_g1_point (helpers.rs:694-708): KZG_OK, or KZG_ERR_G1_NOT_ON_CURVE (y^2 != x^3 + 3; the identity = all zeros is accepted, the
+ * cofactor of G1 is 1 so there is no subgroup check to make).  Host-only. */
+int32_t kzg_validate_g1_point(const uint64_t xy_mont[8]);
+/* helpers::hash_to_field_element (helpers.rs:382-390): SHA-256 of msg, read big-endian, mod r.  Host-only. */
+int32_t kzg_hash_to_field_element(const uint8_t* msg, size_t len, uint64_t out_mont[4]);
 /* NOTE on the two Fiat-Shamir transcripts below (kzg_compute_challenge, kzg_compute_r_powers): their byte layout follows the reference
  * line by line, but the 32-byte compressed G1 encoding inside them (x little-endian, 0x80 = larger y, 0x40 = infinity) is ark-serialize's
  * `serialize_compressed`, RESTATED here and in oracle/ alike and pinned by NO vector the reference holds -- its own tests only check that the

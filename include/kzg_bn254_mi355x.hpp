@@ -34,8 +34,8 @@ constexpr size_t MAINNET_SRS_G1_SIZE = 268435456;                     // primiti
 // ---- errors (primitives/src/errors.rs:13-24, :32-86) ---------------------------------------------------------------------------------
 class KzgError : public std::runtime_error {
 public:
-    enum class Kind { PolynomialError, MsmError, SerializationError, DeserializationError, SrsCapacityExceeded, NotOnCurveError,
-                      CommitError, FFTError, GenericError, InvalidInputLength, InvalidFieldElement, DeviceError };
+    enum class Kind { PolynomialError, MsmError, SerializationError, DeserializationError, SrsCapacityExceeded, G2GeneratorNotAcceptedError, NotOnCurveError,
+                      CommitError, FFTError, GenericError, InvalidDenominator, InvalidInputLength, InvalidFieldElement, DeviceError };
     Kind kind;
     std::string message;                                              // the variant's payload (without the Display prefix)
     size_t polynomial_len = 0, srs_len = 0;                           // SrsCapacityExceeded only
@@ -45,6 +45,11 @@ public:
     static KzgError CommitError(const std::string& m) { return KzgError(Kind::CommitError, m); }
     static KzgError SerializationError(const std::string& m) { return KzgError(Kind::SerializationError, m); }
     static KzgError NotOnCurveError(const std::string& m) { return KzgError(Kind::NotOnCurveError, m); }
+    static KzgError MsmError(const std::string& m) { return KzgError(Kind::MsmError, m); }
+    static KzgError DeserializationError(const std::string& m) { return KzgError(Kind::DeserializationError, m); }
+    static KzgError G2GeneratorNotAcceptedError(const std::string& m) { return KzgError(Kind::G2GeneratorNotAcceptedError, m); }
+    static KzgError InvalidFieldElement(const std::string& m) { return KzgError(Kind::InvalidFieldElement, m); }
+    static KzgError InvalidDenominator() { return KzgError(Kind::InvalidDenominator, "invalid denominator"); }
     static KzgError InvalidInputLength() { return KzgError(Kind::InvalidInputLength, "input length must be a multiple of 32"); }
     static KzgError SrsCapacityExceeded(size_t polynomial_len, size_t srs_len) {
         KzgError e(Kind::SrsCapacityExceeded, "polynomial degree " + std::to_string(polynomial_len) + " exceeds SRS capacity " + std::to_string(srs_len));
@@ -59,13 +64,14 @@ private:
             case Kind::MsmError: return "MSM error: ";
             case Kind::SerializationError: return "serialization error: ";
             case Kind::DeserializationError: return "deserialization error: ";
+            case Kind::G2GeneratorNotAcceptedError: return "g2 generator not accepted error: ";
             case Kind::NotOnCurveError: return "not on curve error: ";
             case Kind::CommitError: return "commit error: ";
             case Kind::FFTError: return "FFT error: ";
             case Kind::GenericError: return "generic error: ";
             case Kind::InvalidFieldElement: return "invalid field element: ";
             case Kind::DeviceError: return "device error: ";
-            default: return "";                                       // SrsCapacityExceeded, InvalidInputLength: the payload is the text
+            default: return "";                                       // SrsCapacityExceeded, InvalidInputLength, InvalidDenominator: the payload is the text
         }
     }
 };
@@ -108,6 +114,24 @@ struct Fr {
         Fr c;
         for (int i = 0; i < 4; ++i) { uint64_t w = 0; for (int j = 0; j < 8; ++j) w = (w << 8) | b[(3 - i) * 8 + j]; c.limbs[i] = w; }
         return mont_mul(c, r2());                                     // any 256-bit value: the product is reduced below 2 r, then once more
+    }
+    // Fr::from_be_bytes_mod_order of any length (helpers::set_bytes_canonical, helpers.rs:32-34): Horner over the bytes
+    static Fr from_be_bytes_mod_order(const uint8_t* b, size_t len) {
+        const Fr k256 = from_u64(256);
+        Fr acc = zero();
+        for (size_t i = 0; i < len; ++i) acc = add(mont_mul(acc, k256), from_u64(b[i]));
+        return acc;
+    }
+    static Fr add(const Fr& a, const Fr& b) {                         // both < r
+        using u128 = unsigned __int128;
+        uint64_t t[4]; u128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (u128)a.limbs[j] + b.limbs[j]; t[j] = (uint64_t)c; c >>= 64; }
+        bool ge = c != 0;
+        if (!ge) { ge = true; for (int j = 3; j >= 0; --j) if (t[j] != N[j]) { ge = t[j] > N[j]; break; } }
+        Fr out;
+        if (ge) { u128 br = 0; for (int j = 0; j < 4; ++j) { const u128 d = (u128)t[j] - N[j] - (uint64_t)br; out.limbs[j] = (uint64_t)d; br = (d >> 64) & 1; } }
+        else for (int j = 0; j < 4; ++j) out.limbs[j] = t[j];
+        return out;
     }
     std::array<uint8_t, 32> to_be_bytes() const {                     // canonical big-endian (into_bigint().to_bytes_be())
         Fr u; u.limbs = {1, 0, 0, 0};
@@ -152,6 +176,8 @@ struct G2Affine {
     std::array<uint64_t, 16> w{};
     static G2Affine generator() { G2Affine g; kzg_g2_generator(g.w.data()); return g; }
     static G2Affine mul_generator(const Fr& s) { G2Affine g; detail::check(kzg_g2_mul_generator(s.limbs.data(), g.w.data())); return g; }   // [s]G2 (custom setups, tests)
+    static G2Affine identity() { return G2Affine{}; }
+    bool operator==(const G2Affine& o) const { return w == o.w; }
 };
 static_assert(sizeof(Fr) == 32 && sizeof(G1Affine) == 64 && sizeof(G2Affine) == 128, "wire formats are passed by pointer");
 
@@ -275,6 +301,7 @@ public:
     PolynomialEvalForm to_polynomial_eval_form(const Context& ctx = Context::default_context()) const { return PolynomialEvalForm::new_(to_fr_array(ctx)); }
     PolynomialCoeffForm to_polynomial_coeff_form(const Context& ctx = Context::default_context()) const { return PolynomialCoeffForm::new_(to_fr_array(ctx)); }
     bool operator==(const Blob& o) const { return blob_data_ == o.blob_data_; }
+    std::vector<Fr> to_polynomial_eval_form_elements(const Context& ctx = Context::default_context()) const { return to_fr_array(ctx); }   // helpers::to_fr_array of the bytes (no padding to a power of two)
 private:
     std::vector<Fr> to_fr_array(const Context& ctx) const {
         const size_t n = (blob_data_.size() + 31) / 32;               // get_num_element
@@ -307,6 +334,22 @@ public:
         uint64_t bad = 0;
         detail::check(kzg_srs_load_compressed_be(ctx.handle(), bytes.data(), points_to_load, &h, &bad), ctx.handle());
         return SRS(h, order, ctx);
+    }
+    // srs.rs:205-251 (is_native = true: arkworks' compressed little-endian format; false: the gnark format of SRS::new): the decoded points
+    static std::vector<G1Affine> parallel_read_g1_points_native(const std::string& file_path, uint32_t points_to_load, bool is_native,
+                                                                const Context& ctx = Context::default_context()) {
+        std::ifstream f(file_path, std::ios::binary);
+        if (!f) throw KzgError::GenericError("Error opening the file: " + file_path);
+        std::vector<uint8_t> bytes((size_t)points_to_load * 32);
+        f.read(reinterpret_cast<char*>(bytes.data()), (std::streamsize)bytes.size());
+        if ((size_t)f.gcount() != bytes.size()) throw KzgError::GenericError("Expected " + std::to_string(points_to_load) + " points, only read " + std::to_string((size_t)f.gcount() / 32));
+        kzg_srs* h = nullptr;
+        uint64_t bad = 0;
+        const int32_t rc = is_native ? kzg_srs_load_compressed_ark_le(ctx.handle(), bytes.data(), points_to_load, &h, &bad)
+                                     : kzg_srs_load_compressed_be(ctx.handle(), bytes.data(), points_to_load, &h, &bad);
+        if (is_native && (rc == KZG_ERR_DESERIALIZE || rc == KZG_ERR_NOT_ON_CURVE)) throw KzgError::DeserializationError("Deserialization failed");   // traits.rs:34-36
+        detail::check(rc, ctx.handle());
+        return SRS(h, points_to_load, ctx).g1();
     }
     // already decoded points (the `g1: Cow<[G1Affine]>` field), uploaded once
     static SRS from_points(const std::vector<G1Affine>& g1, uint32_t order, const Context& ctx = Context::default_context()) {
@@ -393,6 +436,15 @@ public:
         if (!z) throw KzgError::GenericError("Root of unity not found");
         return compute_proof(polynomial, *z, srs);
     }
+    // kzg.rs:237-260: sum over the stored roots w^i != z of (f_i - value) w^i / ((z - w^i) z), on the GPU (kzg_compute_quotient_eval_on_domain)
+    Fr compute_quotient_eval_on_domain(const Fr& z_fr, const std::vector<Fr>& eval_fr, const Fr& value_fr, const Context& ctx = Context::default_context()) const {
+        const size_t n = expanded_roots_of_unity_.size();
+        if (eval_fr.size() < n) throw std::out_of_range("index out of bounds: eval_fr is shorter than the roots of unity");      // eval_fr[i] panics in the reference
+        Fr out;
+        if (n == 0) return out;
+        detail::check(kzg_compute_quotient_eval_on_domain(ctx.handle(), z_fr.limbs.data(), eval_fr.data()->limbs.data(), n, value_fr.limbs.data(), out.limbs.data()), ctx.handle());
+        return out;
+    }
     // kzg.rs:263-285
     std::vector<G1Affine> g1_ifft(size_t length, const SRS& srs) const {
         if (length == 0 || (length & (length - 1)) != 0) throw KzgError::FFTError("length provided is not a power of 2");
@@ -412,8 +464,136 @@ private:
     std::vector<Fr> expanded_roots_of_unity_;
 };
 
-// ---- primitives/src/helpers.rs (the two functions the reference's tests call directly) -----------------------------------------------
+// ---- primitives/src/helpers.rs ------------------------------------------------------------------------------------------------------------
+// Byte codecs are host loops (data formats); curve checks, the transcript hash and the pairing are the library's host code; conversions of whole
+// blobs, roots of unity, evaluations, linear combinations and point decoding run on the GPU through the C-ABI.
 namespace helpers {
+inline size_t get_num_element(size_t data_len, size_t symbol_size) { return (data_len + symbol_size - 1) / symbol_size; }     // helpers.rs:36-38
+inline Fr set_bytes_canonical(const std::vector<uint8_t>& data) { return Fr::from_be_bytes_mod_order(data.data(), data.size()); }   // helpers.rs:32-34
+inline std::vector<uint8_t> pad_payload(const std::vector<uint8_t>& input_data) { return Blob::from_raw_data(input_data).data(); }   // helpers.rs:823-840
+inline std::vector<uint8_t> remove_internal_padding(const std::vector<uint8_t>& padded_data) { return Blob::from(padded_data).to_raw_data(); }   // helpers.rs:856-874
+inline bool is_zeroed(uint8_t first_byte, const std::vector<uint8_t>& buf) {                                                    // helpers.rs:121-132
+    if (first_byte != 0) return false;
+    for (uint8_t b : buf) if (b != 0) return false;
+    return true;
+}
+inline std::array<uint8_t, 8> usize_to_be_bytes(size_t number) {                                                                // helpers.rs:769-780
+    std::array<uint8_t, 8> out{};
+    for (int i = 0; i < 8; ++i) out[i] = (uint8_t)((uint64_t)number >> (8 * (7 - i)));
+    return out;
+}
+// helpers.rs:40-57 (the last chunk right-padded with zeros), on the device
+inline std::vector<Fr> to_fr_array(const std::vector<uint8_t>& data, const Context& ctx = Context::default_context()) {
+    return Blob::from(data).to_polynomial_eval_form_elements(ctx);
+}
+inline std::vector<Fr> blob_to_polynomial(const std::vector<uint8_t>& blob, const Context& ctx = Context::default_context()) { return to_fr_array(blob, ctx); }   // helpers.rs:28-30
+// helpers.rs:80-119: canonical big-endian bytes of every element, cut at max_output_size
+inline std::vector<uint8_t> to_byte_array(const std::vector<Fr>& data_fr, size_t max_output_size) {
+    const size_t n = data_fr.size() * BYTES_PER_FIELD_ELEMENT < max_output_size ? data_fr.size() * BYTES_PER_FIELD_ELEMENT : max_output_size;
+    std::vector<uint8_t> out(n);
+    for (size_t i = 0; i * 32 < n; ++i) {
+        const std::array<uint8_t, 32> b = data_fr[i].to_be_bytes();
+        std::memcpy(out.data() + 32 * i, b.data(), n - 32 * i < 32 ? n - 32 * i : 32);
+    }
+    return out;
+}
+// helpers.rs:784-810
+inline void validate_blob_data_as_canonical_field_elements(const std::vector<uint8_t>& data) { (void)Blob::new_(data); }
+// helpers.rs:298-315
+inline std::vector<Fr> compute_powers(const Fr& base, size_t count) {
+    std::vector<Fr> out(count);
+    Fr cur = Fr::one();
+    for (size_t i = 0; i < count; ++i) { out[i] = cur; cur = cur * base; }
+    return out;
+}
+// helpers.rs:382-390
+inline Fr hash_to_field_element(const std::vector<uint8_t>& msg) {
+    Fr out;
+    detail::check(kzg_hash_to_field_element(msg.data(), msg.size(), out.limbs.data()));
+    return out;
+}
+// helpers.rs:538-551: consts::PRIMITIVE_ROOTS_OF_UNITY[power] = w_28^(2^(28 - power)), w_28 = 5^((r - 1) / 2^28)
+inline Fr get_primitive_root_of_unity(size_t power) {
+    if (power > 28) throw KzgError::GenericError("power must be <= 28");
+    Fr w; w.limbs = {0x636e735580d13d9cull, 0xa22bf3742445ffd6ull, 0x56452ac01eb203d8ull, 0x1860ef942963f9e7ull};
+    for (size_t k = power; k < 28; ++k) w = w * w;
+    return w;
+}
+// helpers.rs:553-589, generated on the device
+inline std::vector<Fr> calculate_roots_of_unity(uint64_t length_of_data_after_padding, const Context& ctx = Context::default_context()) {
+    size_t n_out = 0;
+    const int32_t probe = kzg_calculate_roots_of_unity(ctx.handle(), length_of_data_after_padding, nullptr, 0, &n_out);             // the count, or the reference's error
+    if (probe != KZG_ERR_INVALID_ARG) detail::check(probe, ctx.handle());
+    std::vector<Fr> roots(n_out);
+    detail::check(kzg_calculate_roots_of_unity(ctx.handle(), length_of_data_after_padding, roots.data()->limbs.data(), roots.size(), &n_out), ctx.handle());
+    return roots;
+}
+// helpers.rs:328-337: the MSM of batch verification, on the device
+inline G1Affine g1_lincomb(const std::vector<G1Affine>& points, const std::vector<Fr>& scalars, const Context& ctx = Context::default_context()) {
+    G1Affine out; uint8_t inf = 0;
+    const int32_t rc = kzg_msm_g1(ctx.handle(), points.empty() ? nullptr : points.data()->xy.data(), points.size(), scalars.empty() ? nullptr : scalars.data()->limbs.data(),
+                                  scalars.size(), out.xy.data(), &inf);
+    if (rc == KZG_ERR_MSM_LENGTH_MISMATCH) throw KzgError::MsmError(std::to_string(points.size() < scalars.size() ? points.size() : scalars.size()));
+    detail::check(rc, ctx.handle());
+    return out;
+}
+// helpers.rs:239-261, :694-708 (cofactor 1: on the curve = in the subgroup; the identity passes)
+inline bool is_on_curve_g1(const G1Affine& g1) { return kzg_validate_g1_point(g1.xy.data()) == KZG_OK; }
+inline void validate_g1_point(const G1Affine& point) { if (!is_on_curve_g1(point)) throw KzgError::NotOnCurveError("G1 point not on curve"); }
+// helpers.rs:263-285
+inline bool is_on_curve_g2(const G2Affine& g2) { int32_t ok = 0; detail::check(kzg_g2_is_on_curve(g2.w.data(), &ok)); return ok != 0; }
+// helpers.rs:740-766
+inline void example_validate_g2_point(const G2Affine& point) {
+    int32_t reason = 0;
+    detail::check(kzg_validate_g2_point(point.w.data(), &reason));
+    switch (reason) {
+        case 1: throw KzgError::NotOnCurveError("G2 point not on curve");
+        case 2: throw KzgError::NotOnCurveError("G2 point is point at infinity");
+        case 3: throw KzgError::NotOnCurveError("G2 point not in correct subgroup");
+        case 4: throw KzgError::G2GeneratorNotAcceptedError("G2 point cannot be the generator point");
+        default: return;
+    }
+}
+// helpers.rs:392-398
+inline bool pairings_verify(const G1Affine& a1, const G2Affine& a2, const G1Affine& b1, const G2Affine& b2) {
+    int32_t ok = 0;
+    detail::check(kzg_pairings_verify(a1.xy.data(), a2.w.data(), b1.xy.data(), b2.w.data(), &ok));
+    return ok != 0;
+}
+// helpers.rs:151-173: y > (p - 1) / 2, y given in Montgomery form
+inline bool lexicographically_largest(const std::array<uint64_t, 4>& y_mont) {
+    using u128 = unsigned __int128;
+    static constexpr uint64_t P[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    static constexpr uint64_t HALF[4] = {0x9e10460b6c3e7ea3ull, 0xcbc0b548b438e546ull, 0xdc2822db40c0ac2eull, 0x183227397098d014ull};   // (p - 1) / 2
+    static constexpr uint64_t PINV = 0x87d20782e4866389ull;           // -p^-1 mod 2^64
+    uint64_t t[5] = {y_mont[0], y_mont[1], y_mont[2], y_mont[3], 0};
+    for (int i = 0; i < 4; ++i) {                                     // arith::montgomery_reduce: y 2^-256 mod p
+        const uint64_t m = t[0] * PINV;
+        u128 c = ((u128)m * P[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) { c += (u128)m * P[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[3] = (uint64_t)c; t[4] = (uint64_t)(c >> 64);
+    }
+    bool ge = t[4] != 0;
+    if (!ge) { ge = true; for (int j = 3; j >= 0; --j) if (t[j] != P[j]) { ge = t[j] > P[j]; break; } }
+    if (ge) { u128 br = 0; for (int j = 0; j < 4; ++j) { const u128 d = (u128)t[j] - P[j] - (uint64_t)br; t[j] = (uint64_t)d; br = (d >> 64) & 1; } }
+    for (int j = 3; j >= 0; --j) if (t[j] != HALF[j]) return t[j] > HALF[j];
+    return false;
+}
+// helpers.rs:175-227: one gnark-compressed point through the kernel that decodes a whole SRS file, and a read-back
+inline G1Affine read_g1_point_from_bytes_be(const std::vector<uint8_t>& g1_bytes_be, const Context& ctx = Context::default_context()) {
+    if (g1_bytes_be.size() != 32) throw KzgError::DeserializationError("not enough bytes for g1 point");
+    kzg_srs* h = nullptr;
+    uint64_t bad = 0;
+    const int32_t rc = kzg_srs_load_compressed_be(ctx.handle(), g1_bytes_be.data(), 1, &h, &bad);
+    if (rc == KZG_ERR_DESERIALIZE) throw KzgError::DeserializationError("point at infinity not coded properly for g1");
+    if (rc == KZG_ERR_NOT_ON_CURVE) throw KzgError::NotOnCurveError("compressed g1 point not on curve");
+    detail::check(rc, ctx.handle());
+    G1Affine out;
+    const int32_t rc2 = kzg_srs_download(ctx.handle(), h, 0, 1, out.xy.data());
+    kzg_srs_free(h);
+    detail::check(rc2, ctx.handle());
+    return out;
+}
 // helpers.rs:475-535
 inline Fr evaluate_polynomial_in_evaluation_form(const PolynomialEvalForm& polynomial, const Fr& z, const Context& ctx = Context::default_context()) {
     Fr y;
@@ -425,6 +605,19 @@ inline Fr compute_challenge(const Blob& blob, const G1Affine& commitment) {
     Fr z;
     detail::check(kzg_compute_challenge(blob.data().data(), blob.len(), commitment.xy.data(), z.limbs.data()));
     return z;
+}
+// helpers.rs:613-665: the transcripts on a pool of host threads, the evaluations as one batched launch
+inline std::pair<std::vector<Fr>, std::vector<Fr>> compute_challenges_and_evaluate_polynomial(const std::vector<Blob>& blobs, const std::vector<G1Affine>& commitments,
+                                                                                              const Context& ctx = Context::default_context()) {
+    if (blobs.size() != commitments.size() && !blobs.empty()) throw KzgError::GenericError("length's of the input are not the same or is empty");   // helpers.rs:618-622
+    std::vector<Fr> zs(blobs.size()), ys(blobs.size());
+    if (blobs.empty()) return {zs, ys};
+    std::vector<const uint8_t*> ptrs(blobs.size());
+    std::vector<size_t> lens(blobs.size());
+    for (size_t i = 0; i < blobs.size(); ++i) { ptrs[i] = blobs[i].data().data(); lens[i] = blobs[i].len(); }
+    detail::check(kzg_compute_challenges_and_evaluate_polynomial(ctx.handle(), ptrs.data(), lens.data(), commitments.data()->xy.data(), blobs.size(), zs.data()->limbs.data(),
+                                                                 ys.data()->limbs.data()), ctx.handle());
+    return {zs, ys};
 }
 }  // namespace helpers
 

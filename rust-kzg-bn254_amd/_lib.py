@@ -123,6 +123,8 @@ PROTOTYPES = {
     "kzg_g2_generator": (i32, [u64p]),
     "kzg_g2_tau_mainnet": (i32, [u64p]),
     "kzg_g2_mul_generator": (i32, [u64p, u64p]),
+    "kzg_validate_g1_point": (i32, [u64p]),
+    "kzg_hash_to_field_element": (i32, [u8p, C.c_size_t, u64p]),
     "kzg_g2_is_on_curve": (i32, [u64p, C.POINTER(i32)]),
     "kzg_validate_g2_point": (i32, [u64p, C.POINTER(i32)]),
     "kzg_compute_quotient_eval_on_domain": (i32, [vp, u64p, u64p, C.c_size_t, u64p, u64p]),

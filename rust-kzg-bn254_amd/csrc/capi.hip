@@ -1347,6 +1347,26 @@ size_t blob_padded_len(size_t len) { size_t e = (len + 31) / 32, p = 1; while (p
 
 }  // namespace
 
+int32_t kzg_validate_g1_point(const uint64_t xy_mont[8]) {
+    if (!xy_mont) return KZG_ERR_INVALID_ARG;
+    return kzg_host::g1_on_curve(kzg_host::g1_from_wire(xy_mont)) ? KZG_OK : KZG_ERR_G1_NOT_ON_CURVE;
+}
+
+int32_t kzg_hash_to_field_element(const uint8_t* msg, size_t len, uint64_t out_mont[4]) {
+    if (!out_mont || (len && !msg)) return KZG_ERR_INVALID_ARG;
+    using namespace kzg_host;
+    Sha256 sh;
+    sha256_init(sh);
+    if (len) sha256_update(sh, msg, len);
+    uint8_t dig[32];
+    sha256_final(sh, dig);
+    uint64_t w[4];
+    for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int b = 0; b < 8; ++b) v = (v << 8) | dig[8 * (3 - i) + b]; w[i] = v; }
+    while (fr_geq_r(w)) fr_sub_r(w);
+    fr_mul(w, FR_R2_WORDS, out_mont);
+    return KZG_OK;
+}
+
 int32_t kzg_compute_challenge(const uint8_t* blob_bytes, size_t len, const uint64_t commitment_xy_mont[8], uint64_t out_z_mont[4]) {
     if (!commitment_xy_mont || !out_z_mont || (len && !blob_bytes)) return KZG_ERR_INVALID_ARG;
     if ((len + 31) / 32 > ((size_t)1 << 28)) return KZG_ERR_TOO_LARGE;

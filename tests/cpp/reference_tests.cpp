@@ -228,6 +228,150 @@ static void test_blob_padding_and_validation() {
     CHECK(std::memcmp(round_trip.data(), first, 32) == 0);
 }
 
+// ---- primitives/tests/helpers_test.rs (the tests the C++ mirror's helpers namespace can run; the same tests through the Python mirror:
+// tests/test_reference_helpers.py) ----------------------------------------------------------------------------------------------------------
+static G1Affine random_g1() {                                        // [s]G1 for a random s: the commitment of the constant polynomial s over the test SRS
+    KZG kzg = KZG::new_();
+    uint8_t b[32]; for (auto& c : b) c = (uint8_t)rng();
+    return kzg.commit_coeff_form(PolynomialCoeffForm::new_({Fr::from_be_bytes_mod_order(b)}), *SRS_INSTANCE);
+}
+static G2Affine random_g2() { uint8_t b[32]; for (auto& c : b) c = (uint8_t)rng(); return G2Affine::mul_generator(Fr::from_be_bytes_mod_order(b)); }
+static void test_g2_is_on_curve() {                                  // :375-387 (64 points here)
+    for (int i = 0; i < 64; ++i) {
+        G2Affine point = random_g2();
+        CHECK(helpers::is_on_curve_g2(point));
+        G2Affine not_on_curve = point;
+        not_on_curve.w[0] ^= 1;                                      // another x.c0
+        CHECK(!helpers::is_on_curve_g2(not_on_curve));
+    }
+}
+static void test_get_num_element() { CHECK(helpers::get_num_element(1000, BYTES_PER_FIELD_ELEMENT) == 32); }      // :462-465
+static void test_pad_payload() {                                     // :468-521
+    const std::vector<uint8_t> padded = helpers::pad_payload({'h', 'i'});
+    std::vector<uint8_t> want(32, 0); want[1] = 104; want[2] = 105;
+    CHECK(padded == want);
+    std::vector<uint8_t> want_un(31, 0); want_un[0] = 104; want_un[1] = 105;
+    CHECK(helpers::remove_internal_padding(padded) == want_un);
+    const std::vector<uint8_t> un = helpers::remove_internal_padding(helpers::pad_payload(GETTYSBURG_ADDRESS_BYTES));
+    CHECK(un.size() == 1488 && GETTYSBURG_ADDRESS_BYTES.size() <= un.size());
+    CHECK(throws(KzgError::Kind::InvalidInputLength, "", [] { helpers::remove_internal_padding(std::vector<uint8_t>(33)); }));
+}
+static void test_to_fr_array() {                                     // :431-449
+    const std::vector<uint8_t> converted = helpers::pad_payload({42, 212, 238, 227, 192, 237, 178, 128, 19, 108, 50, 204, 87, 81, 63, 120, 232, 27, 116, 108, 74, 168, 109, 84,
+                                                                 89, 9, 6, 233, 144, 200, 125, 40});
+    CHECK(helpers::to_byte_array(helpers::to_fr_array(converted), converted.size()) == converted);
+    const std::vector<uint8_t> ga = helpers::pad_payload(GETTYSBURG_ADDRESS_BYTES);
+    CHECK(helpers::to_byte_array(helpers::to_fr_array(ga), ga.size()) == ga);
+}
+static void test_is_zeroed() {                                       // :524-584 (the six is_zeroed tests)
+    CHECK(helpers::is_zeroed(0, {0, 0, 0, 0, 0}));
+    CHECK(!helpers::is_zeroed(1, {0, 0, 0, 0, 0}));
+    CHECK(!helpers::is_zeroed(0, {0, 0, 1, 0, 0}));
+    CHECK(!helpers::is_zeroed(1, {0, 1, 0, 0, 0}));
+    CHECK(helpers::is_zeroed(0, {}));
+    CHECK(!helpers::is_zeroed(1, {}));
+}
+static void test_primitive_roots_of_unity() {                        // :587-628 through their defining property, and against the device's roots
+    CHECK(helpers::get_primitive_root_of_unity(0) == Fr::one());
+    Fr minus_one = helpers::get_primitive_root_of_unity(1);
+    CHECK(minus_one != Fr::one() && minus_one * minus_one == Fr::one());
+    for (size_t p = 1; p <= 28; ++p) {
+        const Fr w = helpers::get_primitive_root_of_unity(p);
+        CHECK(w * w == helpers::get_primitive_root_of_unity(p - 1));
+    }
+    const std::vector<Fr> roots = helpers::calculate_roots_of_unity(32 * 1024);
+    CHECK(roots.size() == 1024 && roots[0] == Fr::one() && roots[1] == helpers::get_primitive_root_of_unity(10));
+    CHECK(helpers::compute_powers(roots[1], 1024) == roots);
+    CHECK(throws(KzgError::Kind::GenericError, "power must be <= 28", [] { helpers::get_primitive_root_of_unity(29); }));
+}
+static void test_validate_g1_point_and_g2_point() {                  // :631-844 (valid / identity / invalid / generator, both groups, and the consistency test)
+    for (int i = 0; i < 5; ++i) { helpers::validate_g1_point(random_g1()); helpers::example_validate_g2_point(random_g2()); }
+    helpers::validate_g1_point(G1Affine::identity());                // :646-651: the identity passes validate_g1_point
+    G1Affine invalid; invalid.xy = random_g1().xy; invalid.xy[0] ^= 1;
+    CHECK(!helpers::is_on_curve_g1(invalid));
+    CHECK(throws(KzgError::Kind::NotOnCurveError, "G1 point not on curve", [&] { helpers::validate_g1_point(invalid); }));
+    CHECK(throws(KzgError::Kind::NotOnCurveError, "G2 point is point at infinity", [] { helpers::example_validate_g2_point(G2Affine::identity()); }));
+    G2Affine bad2 = random_g2(); bad2.w[8] ^= 1;
+    CHECK(throws(KzgError::Kind::NotOnCurveError, "G2 point not on curve", [&] { helpers::example_validate_g2_point(bad2); }));
+    CHECK(throws(KzgError::Kind::G2GeneratorNotAcceptedError, "G2 point cannot be the generator point", [] { helpers::example_validate_g2_point(G2Affine::generator()); }));
+    try { helpers::example_validate_g2_point(G2Affine::generator()); } catch (const KzgError& e) {
+        CHECK(std::string(e.what()) == "g2 generator not accepted error: G2 point cannot be the generator point");
+    }
+}
+static void test_compute_challenge_comprehensive() {                 // :847-949
+    const std::string text = "comprehensive test data for compute challenge validation";
+    const Blob blob = Blob::from_raw_data(std::vector<uint8_t>(text.begin(), text.end()));
+    CHECK(helpers::compute_challenge(blob, random_g1()) != Fr::zero());
+    helpers::compute_challenge(blob, G1Affine::identity());
+    G1Affine invalid; invalid.xy = random_g1().xy; invalid.xy[4] ^= 1;
+    CHECK(throws(KzgError::Kind::NotOnCurveError, "", [&] { helpers::compute_challenge(blob, invalid); }));
+    const G1Affine c = random_g1(), c2 = random_g1();
+    CHECK(helpers::compute_challenge(blob, c) == helpers::compute_challenge(blob, c));
+    CHECK(helpers::compute_challenge(blob, c) != helpers::compute_challenge(blob, c2));
+    const Blob other = Blob::from_raw_data({'s', 'e', 'c', 'o', 'n', 'd'});
+    CHECK(helpers::compute_challenge(blob, c) != helpers::compute_challenge(other, c));
+}
+static void test_compute_challenges_and_evaluate_polynomial() {      // :952-1040
+    const Blob blob1 = Blob::from_raw_data({'t', 'e', 's', 't', ' ', 'b', 'l', 'o', 'b', ' ', '1'});
+    const std::string t2 = "test blob 2 with more data";
+    const Blob blob2 = Blob::from_raw_data(std::vector<uint8_t>(t2.begin(), t2.end()));
+    const G1Affine commitment1 = random_g1(), commitment2 = random_g1();
+    auto r = helpers::compute_challenges_and_evaluate_polynomial({blob1, blob2}, {commitment1, commitment2});
+    CHECK(r.first.size() == 2 && r.second.size() == 2 && r.first[0] != r.first[1]);
+    r = helpers::compute_challenges_and_evaluate_polynomial({}, {});
+    CHECK(r.first.empty() && r.second.empty());
+    CHECK(throws(KzgError::Kind::GenericError, "length's of the input are not the same or is empty", [&] { helpers::compute_challenges_and_evaluate_polynomial({blob1, blob2}, {commitment1}); }));
+    CHECK(throws(KzgError::Kind::GenericError, "", [&] { helpers::compute_challenges_and_evaluate_polynomial({blob1}, {commitment1, commitment2}); }));
+    r = helpers::compute_challenges_and_evaluate_polynomial({blob2}, {commitment2});
+    CHECK(r.first.size() == 1 && r.second.size() == 1);
+    CHECK(r.first[0] == helpers::compute_challenge(blob2, commitment2));
+    CHECK(r.second[0] == helpers::evaluate_polynomial_in_evaluation_form(blob2.to_polynomial_eval_form(), r.first[0]));
+}
+static void test_read_g1_point_and_lincomb() {                       // helpers.rs:175-227, :328-337 against the points SRS::new decodes from the same file
+    const std::vector<uint8_t> raw = read_file(GOLDEN + "/g1.point");
+    const std::vector<G1Affine> pts = SRS::parallel_read_g1_points_native(GOLDEN + "/g1.point", 16, false);
+    for (size_t i : {(size_t)0, (size_t)5, (size_t)15})
+        CHECK(helpers::read_g1_point_from_bytes_be(std::vector<uint8_t>(raw.begin() + 32 * i, raw.begin() + 32 * i + 32)) == pts[i]);
+    CHECK(throws(KzgError::Kind::DeserializationError, "not enough bytes for g1 point", [&] { helpers::read_g1_point_from_bytes_be(std::vector<uint8_t>(31)); }));
+    std::vector<uint8_t> inf(32, 0); inf[0] = 0x40;
+    CHECK(helpers::read_g1_point_from_bytes_be(inf).is_zero());
+    inf[31] = 1;
+    CHECK(throws(KzgError::Kind::DeserializationError, "point at infinity not coded properly for g1", [&] { helpers::read_g1_point_from_bytes_be(inf); }));
+    // g1_lincomb([P, P], [a, b]) == g1_lincomb([P], [a + b]); a length mismatch is MsmError(min length)
+    uint8_t ab[32]; for (auto& c : ab) c = (uint8_t)rng();
+    const Fr a = Fr::from_be_bytes_mod_order(ab), b = Fr::from_u64(77);
+    CHECK(helpers::g1_lincomb({pts[1], pts[1]}, {a, b}) == helpers::g1_lincomb({pts[1]}, {Fr::add(a, b)}));
+    CHECK(throws(KzgError::Kind::MsmError, "1", [&] { helpers::g1_lincomb({pts[1], pts[2]}, {a}); }));
+    // e([a]G1, G2) == e(G1, [a]G2)
+    KZG kzg = KZG::new_();
+    const G1Affine g1 = SRS_INSTANCE->g1()[0], ag1 = kzg.commit_coeff_form(PolynomialCoeffForm::new_({a}), *SRS_INSTANCE);
+    CHECK(helpers::pairings_verify(ag1, G2Affine::generator(), g1, G2Affine::mul_generator(a)));
+    CHECK(!helpers::pairings_verify(ag1, G2Affine::generator(), g1, G2Affine::mul_generator(b)));
+    // hash_to_field_element / set_bytes_canonical / usize_to_be_bytes: SHA-256("abc") = ba7816bf...; bytes of any length
+    const Fr h = helpers::hash_to_field_element({'a', 'b', 'c'});
+    const uint8_t dig[32] = {0xba, 0x78, 0x16, 0xbf, 0x8f, 0x01, 0xcf, 0xea, 0x41, 0x41, 0x40, 0xde, 0x5d, 0xae, 0x22, 0x23, 0xb0, 0x03, 0x61, 0xa3, 0x96, 0x17, 0x7a, 0x9c,
+                             0xb4, 0x10, 0xff, 0x61, 0xf2, 0x00, 0x15, 0xad};
+    CHECK(h == Fr::from_be_bytes_mod_order(dig) && h == helpers::set_bytes_canonical(std::vector<uint8_t>(dig, dig + 32)));
+    CHECK(helpers::set_bytes_canonical({1, 0}) == Fr::from_u64(256));
+    CHECK((helpers::usize_to_be_bytes(0x0102) == std::array<uint8_t, 8>{0, 0, 0, 0, 0, 0, 1, 2}));
+    // lexicographically_largest: exactly one of y, -y for a point of the file (its compressed flag says which)
+    CHECK(helpers::lexicographically_largest({pts[0].xy[4], pts[0].xy[5], pts[0].xy[6], pts[0].xy[7]}) == ((raw[0] & 0xc0) == 0xc0));
+    CHECK(helpers::lexicographically_largest({pts[5].xy[4], pts[5].xy[5], pts[5].xy[6], pts[5].xy[7]}) == ((raw[32 * 5] & 0xc0) == 0xc0));
+}
+static void test_compute_quotient_eval_on_domain() {                 // kzg.rs:237-260: the quotient's evaluation AT the domain point z = w^7
+    KZG kzg = KZG::new_();
+    const Blob input = Blob::from_raw_data(GETTYSBURG_ADDRESS_BYTES);          // (the value printed below is checked against big integers by the Python driver)
+    const PolynomialEvalForm poly = input.to_polynomial_eval_form();
+    kzg.calculate_and_store_roots_of_unity(input.len());
+    const size_t m = 7;
+    const Fr z = *kzg.get_nth_root_of_unity(m), value = poly.evaluations()[m];
+    const Fr qm = kzg.compute_quotient_eval_on_domain(z, poly.evaluations(), value);
+    // the same sum with the roles swapped must differ; and a second call gives the same value
+    CHECK(qm == kzg.compute_quotient_eval_on_domain(z, poly.evaluations(), value));
+    CHECK(qm != kzg.compute_quotient_eval_on_domain(z, poly.evaluations(), Fr::add(value, Fr::one())));
+    std::printf("value quotient_eval_on_domain %s\n", hex(qm.limbs.data(), 4).c_str());
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: %s <tests/golden> <tau: 64 hex digits>\n", argv[0]); return 2; }
     GOLDEN = argv[1];
@@ -251,6 +395,17 @@ int main(int argc, char** argv) {
             {"test_multiple_proof_random_100_blobs", test_multiple_proof_random_100_blobs},
             {"test_kzg_batch_proof_invalid_curve_points", test_kzg_batch_proof_invalid_curve_points},
             {"test_blob_padding_and_validation", test_blob_padding_and_validation},
+            {"test_g2_is_on_curve", test_g2_is_on_curve},
+            {"test_get_num_element", test_get_num_element},
+            {"test_pad_payload", test_pad_payload},
+            {"test_to_fr_array", test_to_fr_array},
+            {"test_is_zeroed", test_is_zeroed},
+            {"test_primitive_roots_of_unity", test_primitive_roots_of_unity},
+            {"test_validate_g1_point_and_g2_point", test_validate_g1_point_and_g2_point},
+            {"test_compute_challenge_comprehensive", test_compute_challenge_comprehensive},
+            {"test_compute_challenges_and_evaluate_polynomial", test_compute_challenges_and_evaluate_polynomial},
+            {"test_read_g1_point_and_lincomb", test_read_g1_point_and_lincomb},
+            {"test_compute_quotient_eval_on_domain", test_compute_quotient_eval_on_domain},
         };
         for (const auto& t : tests) {
             const int before = failures;

@@ -21,7 +21,11 @@ TAU = int.from_bytes(hashlib.sha256(b"kzg-bn254-mi355x/srs/v1").digest(), "big")
 TESTS = ["test_srs_setup_errors", "test_evaluate_polynomial_in_evaluation_form_random_blob_all_indexes",
          "test_commit_coeff_form_and_eval_form_equivalence", "test_calculate_and_store_roots_of_unity", "test_g1_ifft_non_power_of_two_error",
          "test_compute_blob_proof_invalid_commitment", "test_compute_kzg_proof", "test_compute_kzg_proof_random_100_blobs", "test_kzg_zero_blob",
-         "test_multiple_proof_random_100_blobs", "test_kzg_batch_proof_invalid_curve_points", "test_blob_padding_and_validation"]
+         "test_multiple_proof_random_100_blobs", "test_kzg_batch_proof_invalid_curve_points", "test_blob_padding_and_validation",
+         # primitives/tests/helpers_test.rs through the C++ mirror's helpers namespace
+         "test_g2_is_on_curve", "test_get_num_element", "test_pad_payload", "test_to_fr_array", "test_is_zeroed", "test_primitive_roots_of_unity",
+         "test_validate_g1_point_and_g2_point", "test_compute_challenge_comprehensive", "test_compute_challenges_and_evaluate_polynomial",
+         "test_read_g1_point_and_lincomb", "test_compute_quotient_eval_on_domain"]
 
 
 def build(tmp_path):
@@ -59,6 +63,9 @@ def test_reference_tests_in_cpp_and_their_values(tmp_path):
     z7 = pow(w, 7, R_)
     q7 = (f_tau - evals[7]) * pow(TAU - z7, -1, R_) % R_
     assert vals["proof_index_7"] == wire_hex(pyref.point_to_wire(pyref.ec_mul(q7, g1)))
+    # KZG::compute_quotient_eval_on_domain (kzg.rs:237-260) at z = w^7, value = f_7: the literal sum over the other roots
+    q_dom = sum((evals[i] - evals[7]) * pow(w, i, R_) * pow((z7 - pow(w, i, R_)) * z7, -1, R_) for i in range(n) if i != 7) % R_
+    assert vals["quotient_eval_on_domain"] == wire_hex(pyref.fr_to_mont(q_dom))
     z = pyref.fr_from_mont(np.array([int(vals["challenge"][16 * i:16 * i + 16], 16) for i in range(4)], dtype=np.uint64))
     y = pyref.poly_eval(coeffs, z)
     qz = (f_tau - y) * pow(TAU - z, -1, R_) % R_
