@@ -65,6 +65,7 @@ class PartialGatherer:
     (most of it a synchronous pageable H2D copy) -> see tools/rehearse_rccl_world1.py.  CPU backends (gloo) take the list form."""
 
     MAX_BUCKET = 8          # partials one exchange can carry (commit_stream buckets several steps into one collective)
+    STREAM_PRIORITY = 0     # of the private stream (tools/probe_exchange_prio.py: high priority gains nothing measurable, for this stream or RCCL's)
 
     def __init__(self, world: int, device="cuda"):
         import sys
@@ -83,7 +84,7 @@ class PartialGatherer:
             self.pin_out = torch.empty(world * m, dtype=torch.int64).pin_memory()
             self.dev_in = torch.empty(m, dtype=torch.int64, device=device)
             self.dev_out = torch.empty(world * m, dtype=torch.int64, device=device)
-            self.stream = torch.cuda.Stream(device=self.dev_in.device)
+            self.stream = torch.cuda.Stream(device=self.dev_in.device, priority=self.STREAM_PRIORITY)
 
     def gather(self, partial):
         """One partial per rank, blocking: (world, 16)."""
