@@ -391,3 +391,33 @@ def test_compute_quotient_eval_on_domain(k, log_n):                           # 
         kzg.compute_quotient_eval_on_domain(pyref.fr_to_mont(0), pyref.frs_to_mont(evals), pyref.fr_to_mont(1))
     with pytest.raises(IndexError):
         kzg.compute_quotient_eval_on_domain(pyref.fr_to_mont(roots[0]), pyref.frs_to_mont(evals[:-1]) if n > 1 else np.zeros((0, 4), np.uint64), pyref.fr_to_mont(1))
+
+
+@pytest.mark.gpu
+def test_compute_quotient_eval_on_domain_2_18(k):                             # the same at 2^18 elements (many workgroups, the two-level sum): literal sum with one batched inversion
+    log_n = 18
+    n = 1 << log_n
+    rng = random.Random(2018)
+    kzg = k.KZG.new()
+    kzg.calculate_and_store_roots_of_unity(n * 32)
+    w = pyref.root_of_unity(log_n)
+    roots = [1] * n
+    for i in range(1, n):
+        roots[i] = roots[i - 1] * w % R_
+    evals = [rng.randrange(R_) for _ in range(n)]
+    wire = pyref.frs_to_mont(evals)
+    for m in (0, 12345, n - 1):
+        z, value = roots[m], evals[m]
+        dens = [(z - roots[i]) * z % R_ if i != m else 1 for i in range(n)]
+        pref = [1] * (n + 1)
+        for i in range(n):
+            pref[i + 1] = pref[i] * dens[i] % R_
+        inv_all = pow(pref[n], R_ - 2, R_)
+        want = 0
+        for i in range(n - 1, -1, -1):
+            inv_i = inv_all * pref[i] % R_
+            inv_all = inv_all * dens[i] % R_
+            if i != m:
+                want += (evals[i] - value) * roots[i] % R_ * inv_i
+        got = kzg.compute_quotient_eval_on_domain(pyref.fr_to_mont(z), wire, pyref.fr_to_mont(value))
+        assert pyref.fr_from_mont(got) == want % R_, m
