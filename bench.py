@@ -1065,6 +1065,18 @@ def main():
                 if n >= nn:
                     st = stats_ms(lambda: lib.kzg_g1_ifft(ctx.handle, srs.handle, nn, _lib.ptr(lag)), reps=9, warm=2)
                     small["g1_ifft_%d_ms" % nn] = st["median"]; small_stats["g1_ifft_%d" % nn] = st
+            # verifier/benches/bench_kzg_verify.rs:18-67: ONE verify_proof of a proof at a domain point (host only: [y]G1, [z]G2, two Miller loops, final exponentiation)
+            nn = 512
+            sc_s = np.ascontiguousarray(scalars[:nn])
+            roots_s = np.zeros((nn, 4), np.uint64); n_roots = C.c_size_t(0)
+            assert lib.kzg_calculate_roots_of_unity(ctx.handle, nn * 32, _lib.ptr(roots_s), nn, C.byref(n_roots)) == 0
+            z_v = np.ascontiguousarray(roots_s[123]); y_v = np.ascontiguousarray(sc_s[123])
+            c_v = np.zeros(8, np.uint64); p_v = np.zeros(8, np.uint64); ok_v = C.c_int32(0)
+            assert lib.kzg_commit_eval_form(ctx.handle, srs.handle, _lib.ptr(sc_s), nn, _lib.ptr(c_v), C.byref(oi)) == 0
+            assert lib.kzg_compute_proof(ctx.handle, srs.handle, _lib.ptr(sc_s), nn, None, nn, _lib.ptr(z_v), _lib.ptr(p_v), C.byref(oi), None) == 0
+            st = stats_ms(lambda: lib.kzg_verify_proof(_lib.ptr(c_v), _lib.ptr(p_v), _lib.ptr(y_v), _lib.ptr(z_v), _lib.ptr(tau_g2), C.byref(ok_v)), reps=60, warm=8)
+            assert ok_v.value == 1, "verify_proof rejected a correct proof"
+            small["verify_proof_ms"] = st["median"]; small_stats["verify_proof"] = st
             small["statistic"] = "median of the per-call wall times (60 calls per commit / proof shape, 9 per g1_ifft size); mean / p99 / min / max under reference_bench_shapes_stats"
             # sizes beyond the tables (parity: tests/test_gpu_large_sizes.py): the 2^20 step WITHOUT the 15.9 GiB of per-bit
             # tables (KZG_NO_NAF=1: fixed 17-bit windows over the 1 GiB window tables), a commitment over a 2^23-point SRS (window tables

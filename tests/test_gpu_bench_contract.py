@@ -55,6 +55,9 @@ def test_bench_emits_the_contract_line():
     sec = d["secondary"]
     assert sec["host_buffers_compute_proof_streamed_ms"] > 0 and sec["host_buffers_compute_proof_streamed_ifft_path_ms"] > 0
     assert sec["cached_lagrange_basis"]["host_buffers_compute_proof_ms"] > 0
+    shapes = sec["reference_bench_shapes"]               # every criterion harness of the reference has its line: commit / proof / g1_ifft / verify
+    for key in ("commit_coeff_512_ms", "compute_proof_512_ms", "g1_ifft_512_ms", "verify_proof_ms"):
+        assert shapes[key] > 0, key
     clk = d["gpu_clock_under_load"]                      # sysfs engine clock sampled in the untimed spin-up (None where sysfs does not show this GPU)
     assert clk is None or (200 < clk["sclk_mhz_min"] <= clk["sclk_mhz_mean"] <= clk["sclk_mhz_max"] < 4000 and clk["samples"] >= 1)
 
