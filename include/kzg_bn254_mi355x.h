@@ -330,13 +330,6 @@ int32_t kzg_commit_and_prove_lagrange_begin(kzg_ctx* ctx, const kzg_srs* lagrang
                                             size_t n, const uint64_t z_mont[4], int32_t commit_slot, int32_t proof_slot);
 int32_t kzg_commit_and_prove_lagrange_begin_device(kzg_ctx* ctx, const kzg_srs* lagrange_shard, size_t shard_lo, const void* d_evals_slice_mont, size_t len,
                                                    size_t n, const uint64_t z_mont[4], int32_t commit_slot, int32_t proof_slot);
-/* PAIRED launches (slices small enough for kzg_msm_batch_capacity(len) >= 4, i.e. up to 2^17 elements): two blobs begun GROUPED (commit_slot == proof_slot) on
- * slots a and b over the same shard and slice, both past kzg_compute_proof_lagrange_partial_y, continue TOGETHER -- their four MSMs (commitment a, proof a,
- * commitment b, proof b) leave as ONE batched launch on slot a: 0.151 ms per MSM in a stream of 2^17-pair MSMs where launches of two cost 0.185.  Collect with
- * kzg_commit_and_prove_lagrange_end_pair (the single-slot `end` calls refuse a paired slot); kzg_compute_proof_lagrange_abort on either slot gives up both. */
-int32_t kzg_commit_and_prove_lagrange_continue_pair(kzg_ctx* ctx, int32_t slot_a, const uint64_t y_a_mont[4], int32_t slot_b, const uint64_t y_b_mont[4]);
-int32_t kzg_commit_and_prove_lagrange_end_pair(kzg_ctx* ctx, int32_t slot_a, int32_t slot_b, uint64_t out_commit_a_xyzz_mont[16], uint64_t out_part_a[32],
-                                               uint64_t out_commit_b_xyzz_mont[16], uint64_t out_part_b[32]);
 int32_t kzg_compute_proof_lagrange_partial_y(kzg_ctx* ctx, int32_t slot, uint64_t out_ypart_mont[8]);
 int32_t kzg_compute_proof_lagrange_continue(kzg_ctx* ctx, int32_t slot, const uint64_t y_mont[4]);
 int32_t kzg_compute_proof_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t out_part[32]);

@@ -149,8 +149,6 @@ PROTOTYPES = {
     "kzg_compute_proof_lagrange_continue": (i32, [vp, i32, u64p]),
     "kzg_compute_proof_lagrange_end": (i32, [vp, i32, u64p]),
     "kzg_compute_proof_lagrange_abort": (i32, [vp, i32]),
-    "kzg_commit_and_prove_lagrange_continue_pair": (i32, [vp, i32, u64p, i32, u64p]),
-    "kzg_commit_and_prove_lagrange_end_pair": (i32, [vp, i32, i32, u64p, u64p, u64p, u64p]),
     "kzg_lagrange_fold_y": (i32, [u64p, sz, sz, u64p, u64p]),
     "kzg_lagrange_fold_proof": (i32, [u64p, sz, sz, u64p, u64p, u8p]),
     "kzg_commit_eval_form_rccl": (i32, [vp, vp, u64p, sz, vp, i32, u64p, u8p]),

@@ -65,8 +65,6 @@ int32_t lag_partial_y(kzg_ctx* ctx, int slot, uint64_t out[8]);
 int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]);
 int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32], uint64_t* out_commit);
 void lag_abort(kzg_ctx* ctx, int slot);
-int32_t lag_continue_pair(kzg_ctx* ctx, int slot_a, const uint64_t y_a[4], int slot_b, const uint64_t y_b[4]);
-int32_t lag_end_pair(kzg_ctx* ctx, int slot_a, int slot_b, uint64_t out_commit_a[16], uint64_t out_part_a[32], uint64_t out_commit_b[16], uint64_t out_part_b[32]);
 int32_t lag_quotient_eval_on_domain(kzg_ctx* ctx, const uint64_t z[4], const uint64_t* evals, size_t n, const uint64_t value[4], uint64_t out[4]);
 // (lag_fold_y / lag_fold_proof: host_lagrange.h)
 int32_t vb_evaluate_setup(kzg_ctx* ctx, size_t packed_len, size_t nb);
@@ -1087,19 +1085,6 @@ int32_t kzg_commit_and_prove_lagrange_end(kzg_ctx* ctx, int32_t slot, uint64_t o
     std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return lag_end(ctx, slot, out_part, out_commit_xyzz_mont);
-}
-int32_t kzg_commit_and_prove_lagrange_continue_pair(kzg_ctx* ctx, int32_t slot_a, const uint64_t y_a_mont[4], int32_t slot_b, const uint64_t y_b_mont[4]) {
-    if (!ctx || !y_a_mont || !y_b_mont) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return lag_continue_pair(ctx, slot_a, y_a_mont, slot_b, y_b_mont);
-}
-int32_t kzg_commit_and_prove_lagrange_end_pair(kzg_ctx* ctx, int32_t slot_a, int32_t slot_b, uint64_t out_commit_a_xyzz_mont[16], uint64_t out_part_a[32],
-                                               uint64_t out_commit_b_xyzz_mont[16], uint64_t out_part_b[32]) {
-    if (!ctx || !out_commit_a_xyzz_mont || !out_part_a || !out_commit_b_xyzz_mont || !out_part_b) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return lag_end_pair(ctx, slot_a, slot_b, out_commit_a_xyzz_mont, out_part_a, out_commit_b_xyzz_mont, out_part_b);
 }
 int32_t kzg_compute_proof_lagrange_abort(kzg_ctx* ctx, int32_t slot) {
     if (!ctx) return KZG_ERR_INVALID_ARG;

@@ -81,8 +81,6 @@ struct LagProof {
     uint32_t m = 0;
     bool msm_started = false;      // len > 0: an MSM is pending on the slot
     bool grouped = false;          // commitment and proof leave as ONE batched launch (two scalar sets) on this slot
-    int follower = -1;             // PAIRED launch (lag_continue_pair): this slot holds the launch of four scalar sets, two of them of slot `follower`
-    int leader = -1;               // ... and this slot's two sets left with slot `leader`'s launch
 };
 }
 #ifndef KZG_NUM_SLOTS

@@ -288,7 +288,6 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     if (lp.on_domain && lp.m >= base && lp.m - base < len)     // this slice owns f_m = y (helpers.rs:497-504)
         LAG_TRY(hipMemcpyAsync(pin + 96, reinterpret_cast<const uint8_t*>(d_ev) + (size_t)(lp.m - base) * 32, 32, hipMemcpyDeviceToHost, s1));
     LAG_TRY(hipEventRecord(ctx->lag_phase1[slot], s1));            // phase 2 (the slot's stream) and lag_partial_y wait for THIS proof's phase 1 only
-#undef LAG_TRY
     lp.phase = 1;
     return KZG_OK;
 }
@@ -305,24 +304,26 @@ int32_t lag_partial_y(kzg_ctx* ctx, int slot, uint64_t out[8]) {
     return KZG_OK;
 }
 
-// phase 2 of the proof on `slot` up to (not including) its MSM, enqueued on stream `st` (the slot's own, or -- paired launches -- the leader's): y up,
-// quotient evaluations of the slice into the slot's buffer c, T = sum q_i w^i down when z is a domain point.  *d_ev_out: the evaluations it read.
-static int32_t lag_enqueue_quotient(kzg_ctx* ctx, int slot, const uint64_t y[4], hipStream_t st, const uint4** d_ev_out) {
+int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]) {
+    if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->lag[slot].phase != 2) return KZG_ERR_INVALID_ARG;
     LagProof& lp = ctx->lag[slot];
+    if (lp.len == 0) { lp.phase = 3; return KZG_OK; }
+    hipStream_t st = nullptr;
+    (void)msm_slot_stream(ctx, slot, &st);
     PolySet& set = ctx->poly[slot];
     uint8_t* pin = static_cast<uint8_t*>(set.pinned);
     uint8_t* small = set.small.as<uint8_t>();
     NttTables tb;
     int32_t rc = ntt_get_tables(ctx, ilog2_sz(lp.n), false, &tb);
-    if (rc != KZG_OK) return rc;
-    auto fail = [&](hipError_t e, const char* where) { (void)hipStreamSynchronize(st); return set_error(ctx, e, where); };
-#define LAG_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(_e, #expr); } while (0)
+    if (rc != KZG_OK) { lp = LagProof(); return rc; }
+    auto fail = [&](hipError_t e, const char* where) { lp = LagProof(); (void)hipStreamSynchronize(st); return set_error(ctx, e, where); };
     memcpy(pin + 32, y, 32);
     LAG_TRY(hipStreamWaitEvent(st, ctx->lag_phase1[slot], 0));     // the inverses (already complete: lag_partial_y waited for the event)
     LAG_TRY(hipMemcpyAsync(small + 32, pin + 32, 32, hipMemcpyHostToDevice, st));
     const bool owner = lp.on_domain && lp.m >= lp.base && lp.m - lp.base < lp.len;
     const uint32_t m_slice = owner ? (uint32_t)(lp.m - lp.base) : NO_INDEX;
-    const uint32_t blocks = (uint32_t)((lp.len + LAG_BLOCK - 1) / LAG_BLOCK);       // same lanes-per-element shape as k_poly_quotient: four elements per lane
+    // same lanes-per-element shape as k_poly_quotient: four elements per lane
+    uint32_t blocks = (uint32_t)((lp.len + LAG_BLOCK - 1) / LAG_BLOCK);
     const uint4* d_ev = lp.d_evals ? static_cast<const uint4*>(lp.d_evals) : set.a.as<uint4>();
     hipLaunchKernelGGL(k_lag_quotient, dim3(blocks), dim3(POLY_THREADS), 0, st, d_ev, (uint32_t)lp.len, (uint32_t)lp.base, tb,
                        set.b.as<int32_t>(), reinterpret_cast<const uint4*>(small + 32), m_slice, lp.on_domain ? 1 : 0, set.c.as<uint4>(),
@@ -334,20 +335,6 @@ static int32_t lag_enqueue_quotient(kzg_ctx* ctx, int slot, const uint64_t y[4],
     }
     LAG_TRY(hipGetLastError());
 #undef LAG_TRY
-    *d_ev_out = d_ev;
-    return KZG_OK;
-}
-
-int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]) {
-    if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->lag[slot].phase != 2) return KZG_ERR_INVALID_ARG;
-    LagProof& lp = ctx->lag[slot];
-    if (lp.len == 0) { lp.phase = 3; return KZG_OK; }
-    hipStream_t st = nullptr;
-    (void)msm_slot_stream(ctx, slot, &st);
-    PolySet& set = ctx->poly[slot];
-    const uint4* d_ev = nullptr;
-    int32_t rc = lag_enqueue_quotient(ctx, slot, y, st, &d_ev);
-    if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(st); return rc; }
     if (lp.grouped) {                                           // commitment (the evaluations) and proof (the quotient) as ONE launch, in that order
         MsmBases b;
         b.points = srs_bits(lp.shard); b.table_stride = (uint32_t)lp.shard->n; b.c = 7; b.W = 255; b.naf = true;
@@ -362,68 +349,6 @@ int32_t lag_continue(kzg_ctx* ctx, int slot, const uint64_t y[4]) {
     return KZG_OK;
 }
 
-// PAIRED launch: the two MSMs of the blob on slot_a AND the two of the blob on slot_b (both begun grouped, over the same shard and slice) leave as ONE batched
-// launch of four scalar sets on slot_a -- a launch of four 2^17-pair MSMs costs 0.151 ms per MSM in a stream where launches of two cost 0.185
-// (tools/probe_shard_region.py).  Both quotients are computed on slot_a's stream; slot_b is busy until lag_end_pair.
-int32_t lag_continue_pair(kzg_ctx* ctx, int slot_a, const uint64_t y_a[4], int slot_b, const uint64_t y_b[4]) {
-    if (slot_a < 0 || slot_a >= KZG_NUM_SLOTS || slot_b < 0 || slot_b >= KZG_NUM_SLOTS || slot_a == slot_b) return KZG_ERR_INVALID_ARG;
-    LagProof& la = ctx->lag[slot_a];
-    LagProof& lb = ctx->lag[slot_b];
-    if (la.phase != 2 || lb.phase != 2 || !la.grouped || !lb.grouped || la.shard != lb.shard || la.len != lb.len || la.base != lb.base || la.n != lb.n) {
-        ctx->last_error = "a paired launch needs two grouped proofs in phase 2 over the same shard and slice";
-        return KZG_ERR_INVALID_ARG;
-    }
-    if (la.len && msm_batch_capacity(la.len) < 4) { ctx->last_error = "no room for four scalar sets in one launch (kzg_msm_batch_capacity)"; return KZG_ERR_INVALID_ARG; }
-    if (la.len == 0) { la.phase = lb.phase = 3; la.follower = slot_b; lb.leader = slot_a; return KZG_OK; }
-    hipStream_t st = nullptr;
-    (void)msm_slot_stream(ctx, slot_a, &st);
-    const uint4 *ev_a = nullptr, *ev_b = nullptr;
-    int32_t rc = lag_enqueue_quotient(ctx, slot_a, y_a, st, &ev_a);
-    if (rc == KZG_OK) rc = lag_enqueue_quotient(ctx, slot_b, y_b, st, &ev_b);
-    if (rc == KZG_OK) {
-        MsmBases b;
-        b.points = srs_bits(la.shard); b.table_stride = (uint32_t)la.shard->n; b.c = 7; b.W = 255; b.naf = true;
-        const void* sets[4] = {ev_a, ctx->poly[slot_a].c.p, ev_b, ctx->poly[slot_b].c.p};      // commitment a, proof a, commitment b, proof b
-        rc = msm_begin_batch(ctx, slot_a, b, sets, la.len, 4);
-    }
-    if (rc != KZG_OK) { la = LagProof(); lb = LagProof(); (void)hipStreamSynchronize(st); return rc; }
-    la.msm_started = true;
-    la.follower = slot_b; lb.leader = slot_a;
-    la.phase = lb.phase = 3;
-    return KZG_OK;
-}
-
-// the on-domain words of out_part for the proof that was on `slot` (state copy lp): T from the slot's pinned buffer, L_m when this slice owns m
-static int32_t lag_fill_on_domain(kzg_ctx* ctx, int slot, const LagProof& lp, uint64_t out_part[32]) {
-    if (!lp.on_domain) return KZG_OK;
-    const uint8_t* pin = static_cast<const uint8_t*>(ctx->poly[slot].pinned);
-    memcpy(out_part + 16, pin + 128, 32);
-    if (lp.m >= lp.base && lp.m - lp.base < lp.len) {
-        const int32_t rc = srs_download(ctx, lp.shard->d_points + 4 * (lp.m - lp.base), 1, out_part + 20);
-        if (rc != KZG_OK) return rc;
-        out_part[28] = 1;
-    }
-    return KZG_OK;
-}
-
-int32_t lag_end_pair(kzg_ctx* ctx, int slot_a, int slot_b, uint64_t out_commit_a[16], uint64_t out_part_a[32], uint64_t out_commit_b[16], uint64_t out_part_b[32]) {
-    if (slot_a < 0 || slot_a >= KZG_NUM_SLOTS || slot_b < 0 || slot_b >= KZG_NUM_SLOTS) return KZG_ERR_INVALID_ARG;
-    if (ctx->lag[slot_a].phase != 3 || ctx->lag[slot_a].follower != slot_b || ctx->lag[slot_b].phase != 3 || ctx->lag[slot_b].leader != slot_a) return KZG_ERR_INVALID_ARG;
-    const LagProof la = ctx->lag[slot_a], lb = ctx->lag[slot_b];
-    ctx->lag[slot_a] = LagProof(); ctx->lag[slot_b] = LagProof();
-    memset(out_commit_a, 0, 128); memset(out_commit_b, 0, 128);
-    memset(out_part_a, 0, 256); memset(out_part_b, 0, 256);
-    if (la.len == 0) return KZG_OK;
-    uint64_t four[64];
-    int32_t rc = msm_end_batch(ctx, slot_a, 4, nullptr, nullptr, four);          // waits for slot_a's stream: both T are in their pinned buffers as well
-    if (rc != KZG_OK) return rc;
-    memcpy(out_commit_a, four, 128); memcpy(out_part_a, four + 16, 128);
-    memcpy(out_commit_b, four + 32, 128); memcpy(out_part_b, four + 48, 128);
-    rc = lag_fill_on_domain(ctx, slot_a, la, out_part_a);
-    if (rc == KZG_OK) rc = lag_fill_on_domain(ctx, slot_b, lb, out_part_b);
-    return rc;
-}
-
 // out_part (32 words): [0,16) XYZZ partial | [16,20) T = sum_{i in slice, i != m} q_i w^i (z on the domain, else 0) | [20,28) L_m (wire; the
 // owner of m only, else 0) | [28] 1 if this slice owns m | [29,32) 0
 // out_commit (grouped launches only, else ignored): the commitment's XYZZ partial, 16 words
@@ -431,7 +356,6 @@ int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32], uint64_t* out_com
     if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->lag[slot].phase != 3) return KZG_ERR_INVALID_ARG;
     LagProof lp = ctx->lag[slot];
     if (lp.grouped && !out_commit) return KZG_ERR_INVALID_ARG;           // (left in flight: collect it with kzg_commit_and_prove_lagrange_end)
-    if (lp.follower >= 0 || lp.leader >= 0) return KZG_ERR_INVALID_ARG;  // (a paired launch: kzg_commit_and_prove_lagrange_end_pair)
     ctx->lag[slot] = LagProof();
     memset(out_part, 0, 256);
     if (out_commit) memset(out_commit, 0, 128);
@@ -445,7 +369,15 @@ int32_t lag_end(kzg_ctx* ctx, int slot, uint64_t out_part[32], uint64_t* out_com
         rc = msm_end(ctx, slot, nullptr, nullptr, out_part);             // waits for the slot's stream: T is in the pinned buffer as well
     }
     if (rc != KZG_OK) return rc;
-    return lag_fill_on_domain(ctx, slot, lp, out_part);
+    if (!lp.on_domain) return KZG_OK;
+    const uint8_t* pin = static_cast<const uint8_t*>(ctx->poly[slot].pinned);
+    memcpy(out_part + 16, pin + 128, 32);
+    if (lp.m >= lp.base && lp.m - lp.base < lp.len) {
+        rc = srs_download(ctx, lp.shard->d_points + 4 * (lp.m - lp.base), 1, out_part + 20);
+        if (rc != KZG_OK) return rc;
+        out_part[28] = 1;
+    }
+    return KZG_OK;
 }
 
 // KZG::compute_quotient_eval_on_domain (prover/src/kzg.rs:237-260): sum over the n roots w^i != z of (f_i - value) w^i / ((z - w^i) z), the quotient's
@@ -507,17 +439,14 @@ int32_t lag_quotient_eval_on_domain(kzg_ctx* ctx, const uint64_t z[4], const uin
 // the slot gives up whatever it has in flight (error paths of the hosts above: a peer failed between two phases)
 void lag_abort(kzg_ctx* ctx, int slot) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS) return;
-    if (ctx->lag[slot].leader >= 0) slot = ctx->lag[slot].leader;       // a paired launch is given up as a whole, from its leader
     LagProof lp = ctx->lag[slot];
     ctx->lag[slot] = LagProof();
-    if (lp.follower >= 0 && lp.follower < KZG_NUM_SLOTS) ctx->lag[lp.follower] = LagProof();
     hipStream_t st = nullptr;
     (void)msm_slot_stream(ctx, slot, &st);
     if (lp.phase >= 1 && lp.len && ctx->lag_phase1[slot]) (void)hipEventSynchronize(ctx->lag_phase1[slot]);
     if (lp.msm_started && ctx->slot_pending[slot]) {
         uint64_t sink[32];
-        if (lp.follower >= 0) { uint64_t sink4[64]; (void)msm_end_batch(ctx, slot, 4, nullptr, nullptr, sink4); }
-        else if (lp.grouped) (void)msm_end_batch(ctx, slot, 2, nullptr, nullptr, sink);
+        if (lp.grouped) (void)msm_end_batch(ctx, slot, 2, nullptr, nullptr, sink);
         else (void)msm_end(ctx, slot, nullptr, nullptr, sink);
     }
     else if (st) (void)hipStreamSynchronize(st);

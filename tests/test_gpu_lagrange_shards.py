@@ -329,34 +329,6 @@ def test_commit_and_prove_stream_one_rank(k, ref_srs, test_srs_wire):
     assert lib.kzg_commit_and_prove_lagrange_end(ctx.handle, 2, P(cpart), P(part)) == 0
     from rust_kzg_bn254_amd.sharding import fold_partials
     assert np.array_equal(fold_partials(cpart.reshape(1, 16)), wants[0][0])
-    # PAIRED launches through the C-ABI: blobs 0 (z off the domain) and 1 (z on it) on slots 1 and 3, their four MSMs as one launch on slot 1
-    def begin_to_y(slot, w_, z_):
-        assert lib.kzg_commit_and_prove_lagrange_begin(ctx.handle, sk.srs.handle, 0, P(w_), n, n, P(z_), slot, slot) == 0
-        yp_ = np.zeros(8, np.uint64); y_ = np.zeros(4, np.uint64)
-        assert lib.kzg_compute_proof_lagrange_partial_y(ctx.handle, slot, P(yp_)) == 0 and lib.kzg_lagrange_fold_y(P(yp_), 1, n, P(z_), P(y_)) == 0
-        return y_
-    (w0, z0), (w1, z1) = blobs[0], blobs[1]
-    y0, y1 = begin_to_y(1, w0, z0), begin_to_y(3, w1, z1)
-    assert np.array_equal(y0, wants[0][2]) and np.array_equal(y1, wants[1][2])
-    assert lib.kzg_commit_and_prove_lagrange_continue_pair(ctx.handle, 1, P(y0), 1, P(y0)) == k._lib.ERR_INVALID_ARG       # a slot with itself
-    assert lib.kzg_commit_and_prove_lagrange_continue_pair(ctx.handle, 1, P(y0), 2, P(y1)) == k._lib.ERR_INVALID_ARG       # slot 2 is idle
-    assert lib.kzg_commit_and_prove_lagrange_continue_pair(ctx.handle, 1, P(y0), 3, P(y1)) == 0
-    ca, cb = np.zeros(16, np.uint64), np.zeros(16, np.uint64)
-    pa, pb = np.zeros(32, np.uint64), np.zeros(32, np.uint64)
-    assert lib.kzg_commit_and_prove_lagrange_end(ctx.handle, 1, P(ca), P(pa)) == k._lib.ERR_INVALID_ARG                     # paired slots end together
-    assert lib.kzg_commit_and_prove_lagrange_end(ctx.handle, 3, P(cb), P(pb)) == k._lib.ERR_INVALID_ARG
-    assert lib.kzg_commit_and_prove_lagrange_end_pair(ctx.handle, 3, 1, P(ca), P(pa), P(cb), P(pb)) == k._lib.ERR_INVALID_ARG    # leader first
-    assert lib.kzg_commit_and_prove_lagrange_end_pair(ctx.handle, 1, 3, P(ca), P(pa), P(cb), P(pb)) == 0
-    for (cpart_, ppart_, z_, want) in ((ca, pa, z0, wants[0]), (cb, pb, z1, wants[1])):
-        assert np.array_equal(fold_partials(cpart_.reshape(1, 16)), want[0])
-        proof_ = np.zeros(8, np.uint64); inf_ = C.c_uint8(0)
-        assert lib.kzg_lagrange_fold_proof(P(ppart_), 1, n, P(z_), P(proof_), C.byref(inf_)) == 0
-        assert np.array_equal(proof_, want[1])
-    # a pair given up from its follower: both slots are free again
-    y0, y1 = begin_to_y(0, w0, z0), begin_to_y(2, w1, z1)
-    assert lib.kzg_commit_and_prove_lagrange_continue_pair(ctx.handle, 0, P(y0), 2, P(y1)) == 0
-    assert lib.kzg_compute_proof_lagrange_abort(ctx.handle, 2) == 0
-    assert lib.kzg_commit_and_prove_lagrange_end_pair(ctx.handle, 0, 2, P(ca), P(pa), P(cb), P(pb)) == k._lib.ERR_INVALID_ARG
     gen = sk.commit_and_prove_stream(blobs)
     first = next(gen); next(gen)
     gen.close()                                                         # blobs still in flight
