@@ -105,6 +105,7 @@ k_lag_inverses(const uint4* __restrict__ evals, uint32_t len, uint32_t base, Ntt
         const uint32_t i = i0 + (uint32_t)k * POLY_THREADS;
         if (i < len) {
             pl_store(inv, len, i, iv);
+            if (!evals) continue;                            // inverses only: the sum is k_lag_bary's (uniform across the grid)
             Fr f, w, term;
             wire_load(f, evals, i);
             domain_elem(w, tb, base + i);
@@ -114,10 +115,38 @@ k_lag_inverses(const uint4* __restrict__ evals, uint32_t len, uint32_t base, Ntt
             fe_norm(sum);                                    // four terms of (-m, 2m)
         }
     }
+    if (!evals) return;
     fe_reduce(sum);
     __syncthreads();                                         // the tree is dead: its first planes carry the workgroup sum
     block_sum(sum, tree);
     if (t == 0) pl_store(partial, gridDim.x, blockIdx.x, sum);
+}
+
+// ---- L1b: the slice's part of the barycentric sum from inverses that are already there (evaluations from a HOST buffer: the inverses need z
+// only, so k_lag_inverses(evals = nullptr) runs BESIDE the upload and this kernel behind both).  Same element-to-lane map as L1. ---------------
+__global__ void __launch_bounds__(POLY_THREADS)
+k_lag_bary(const uint4* __restrict__ evals, uint32_t len, uint32_t base, NttTables tb, const int32_t* __restrict__ inv, int32_t* __restrict__ partial) {
+    __shared__ int32_t lds[NL * POLY_THREADS];
+    const uint32_t i0 = blockIdx.x * LAG_BLOCK + threadIdx.x;
+    Fr sum;
+    fe_set_zero(sum);
+#pragma unroll
+    for (int k = 0; k < LAG_PER; ++k) {
+        const uint32_t i = i0 + (uint32_t)k * POLY_THREADS;
+        if (i < len) {
+            Fr f, w, iv, term;
+            wire_load(f, evals, i);
+            pl_load(iv, inv, len, i);
+            domain_elem(w, tb, base + i);
+            fe_mul(term, f, w);
+            fe_mul(term, term, iv);
+            fe_sub(sum, sum, term);                          // f_i w^i / (z - w^i) = -(f_i w^i inv_i)
+            fe_norm(sum);
+        }
+    }
+    fe_reduce(sum);
+    block_sum(sum, lds);
+    if (threadIdx.x == 0) pl_store(partial, gridDim.x, blockIdx.x, sum);
 }
 
 // ---- L2: sum of the per-workgroup partials -> one wire element -----------------------------------------------------------------------
@@ -263,13 +292,30 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     memcpy(pin + 160, &no_index, 4);
     LAG_TRY(hipMemcpyAsync(small, pin, 32, hipMemcpyHostToDevice, s1));
     LAG_TRY(hipMemcpyAsync(small + 64, pin + 160, 4, hipMemcpyHostToDevice, s1));
-    if (!on_device) LAG_TRY(hipMemcpyAsync(set.a.p, evals, len * 32, hipMemcpyHostToDevice, s1));
+    // Evaluations in HOST memory: the inverses need z only, so they are enqueued FIRST (auxiliary stream) and run while this thread sits in the pageable upload
+    // (the slot's stream); the sum waits for both.  Per-rank proof of a 2^17-element slice, one call at a time: 0.63 -> 0.56 ms.  KZG_LAG_SPLIT=0: one after the other.
+    static const bool split_off = []() { const char* e = getenv("KZG_LAG_SPLIT"); return e && atoi(e) == 0; }();
+    const bool split = !on_device && !split_off && s1 != st;
+    if (split) {
+        hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, s1, static_cast<const uint4*>(nullptr), (uint32_t)len, (uint32_t)base, tb,
+                           reinterpret_cast<const uint4*>(small), set.b.as<int32_t>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS),
+                           reinterpret_cast<uint32_t*>(small + 64));
+        LAG_TRY(hipGetLastError());
+        if (!ctx->lag_uploaded[slot]) LAG_TRY(hipEventCreateWithFlags(&ctx->lag_uploaded[slot], hipEventDisableTiming));
+        LAG_TRY(hipMemcpyAsync(set.a.p, evals, len * 32, hipMemcpyHostToDevice, st));
+        LAG_TRY(hipEventRecord(ctx->lag_uploaded[slot], st));
+        LAG_TRY(hipStreamWaitEvent(s1, ctx->lag_uploaded[slot], 0));
+    } else if (!on_device) {
+        LAG_TRY(hipMemcpyAsync(set.a.p, evals, len * 32, hipMemcpyHostToDevice, s1));
+    }
     const uint4* d_ev = on_device ? static_cast<const uint4*>(evals) : set.a.as<uint4>();     // resident evaluations are read in place
     if (commit_slot >= 0 && !grouped) {                         // the commitment of the same slice on its own slot, behind the upload
         hipStream_t st_c = nullptr;
         rc = msm_slot_stream(ctx, commit_slot, &st_c);
         if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(s1); return rc; }
-        if (!on_device && st_c != s1) {
+        if (split) {
+            if (st_c != st) LAG_TRY(hipStreamWaitEvent(st_c, ctx->lag_uploaded[slot], 0));      // (recorded on the proof slot's stream, behind the upload)
+        } else if (!on_device && st_c != s1) {
             if (!ctx->lag_uploaded[slot]) LAG_TRY(hipEventCreateWithFlags(&ctx->lag_uploaded[slot], hipEventDisableTiming));
             LAG_TRY(hipEventRecord(ctx->lag_uploaded[slot], s1));
             LAG_TRY(hipStreamWaitEvent(st_c, ctx->lag_uploaded[slot], 0));
@@ -278,9 +324,13 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
         if (rc != KZG_OK) { lp = LagProof(); (void)hipStreamSynchronize(s1); return rc; }
         commit_started = true;
     }
-    hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, s1, d_ev, (uint32_t)len, (uint32_t)base, tb,
-                       reinterpret_cast<const uint4*>(small), set.b.as<int32_t>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS),
-                       reinterpret_cast<uint32_t*>(small + 64));
+    if (split)
+        hipLaunchKernelGGL(k_lag_bary, dim3(blocks), dim3(POLY_THREADS), 0, s1, d_ev, (uint32_t)len, (uint32_t)base, tb, set.b.as<int32_t>(),
+                           reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS));
+    else
+        hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, s1, d_ev, (uint32_t)len, (uint32_t)base, tb,
+                           reinterpret_cast<const uint4*>(small), set.b.as<int32_t>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS),
+                           reinterpret_cast<uint32_t*>(small + 64));
     hipLaunchKernelGGL(k_lag_sum, dim3(1), dim3(POLY_THREADS), 0, s1, reinterpret_cast<const int32_t*>(small + LAG_SMALL_PARTIALS), blocks,
                        reinterpret_cast<uint4*>(small + 128));
     LAG_TRY(hipGetLastError());
