@@ -42,8 +42,8 @@ inline void h_fr_sub(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) 
     if (br) { hu128 c = 0; for (int i = 0; i < 4; ++i) { c += (hu128)t[i] + H_FR[i]; t[i] = (uint64_t)c; c >>= 64; } }
     memcpy(out, t, 32);
 }
-// a^(r-2), wire in / wire out
-inline void h_fr_inv(const uint64_t a[4], uint64_t out[4]) {
+// a^(r-2), wire in / wire out: 381 dependent products (kept as the cross-check of h_fr_inv below: tests/hostcheck/sanitize_main.cpp)
+inline void h_fr_inv_fermat(const uint64_t a[4], uint64_t out[4]) {
     uint64_t e[4] = {H_FR[0] - 2, H_FR[1], H_FR[2], H_FR[3]};
     uint64_t acc[4], base[4];
     const uint64_t one_int[4] = {1, 0, 0, 0};
@@ -54,6 +54,34 @@ inline void h_fr_inv(const uint64_t a[4], uint64_t out[4]) {
         h_fr_mul(base, base, base);
     }
     memcpy(out, acc, 32);
+}
+// Inverse, wire in / wire out (0 -> 0): binary extended Euclid on the plain integers -- at most 2 x 254 shift / subtract rounds on four words -- and two
+// Montgomery products by R^2 back into the form: a third of the Fermat form's time, on the host's critical path of every proof (the one inversion of the
+// coset chain, the folds of the sharded proofs).  Same construction as kzg_host::inv for Fq (host_curve.h).
+inline void h_fr_inv(const uint64_t a_in[4], uint64_t out[4]) {
+    uint64_t u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+    memcpy(u, a_in, 32);
+    for (int i = 0; i < 6 && h_geq_r(u); ++i) h_sub_r(u);                     // any 256-bit input: canonical first
+    if ((u[0] | u[1] | u[2] | u[3]) == 0) { memset(out, 0, 32); return; }
+    memcpy(v, H_FR, 32);
+    auto is_one = [](const uint64_t t[4]) { return t[0] == 1 && (t[1] | t[2] | t[3]) == 0; };
+    auto geq = [](const uint64_t a[4], const uint64_t b[4]) { for (int i = 3; i >= 0; --i) if (a[i] != b[i]) return a[i] > b[i]; return true; };
+    auto shr1 = [](uint64_t t[4]) { for (int i = 0; i < 3; ++i) t[i] = (t[i] >> 1) | (t[i + 1] << 63); t[3] >>= 1; };
+    auto sub_raw = [](uint64_t a[4], const uint64_t b[4]) { uint64_t br = 0; for (int i = 0; i < 4; ++i) { hu128 d = (hu128)a[i] - b[i] - br; a[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } };
+    auto half_mod_r = [&](uint64_t x[4]) {                                    // x / 2 mod r, x < r < 2^254
+        if (x[0] & 1) { hu128 c = 0; for (int i = 0; i < 4; ++i) { c += (hu128)x[i] + H_FR[i]; x[i] = (uint64_t)c; c >>= 64; } }
+        shr1(x);
+    };
+    for (int guard = 0; guard < 1024 && !is_one(u) && !is_one(v); ++guard) {   // gcd(a, r) = 1
+        while ((u[0] & 1) == 0) { shr1(u); half_mod_r(x1); }
+        while ((v[0] & 1) == 0) { shr1(v); half_mod_r(x2); }
+        if (geq(u, v)) { sub_raw(u, v); h_fr_sub(x1, x2, x1); }
+        else { sub_raw(v, u); h_fr_sub(x2, x1, x2); }
+    }
+    const uint64_t* b = is_one(u) ? x1 : x2;                                  // (a R)^-1 = a^-1 R^-1 as a plain integer < r
+    uint64_t t[4];
+    h_fr_mul(b, H_FR_R2, t);                                                  // . R^2 R^-1 = a^-1
+    h_fr_mul(t, H_FR_R2, out);                                                // . R^2 R^-1 = a^-1 R
 }
 // 1/(i - 1), -1/2, 1/(-i - 1) in wire form, i = 5^((r-1)/4) (= w_n^(n/4) for every n >= 4: arkworks' roots are powers of 5^((r-1)/2^28))
 inline const uint64_t* h_on_domain_constants() {

@@ -35,11 +35,18 @@ inline int32_t lag_fold_y(const uint64_t* parts, size_t count, size_t n, const u
     h_pow2k(z, log_n, zn);
     for (size_t g = 0; g < count; ++g) { h_fr_add(s, parts + 8 * g, s); h_fr_add(fm, parts + 8 * g + 4, fm); }
     if (h_is_one(zn)) { memcpy(out_y, fm, 32); return 0; }
-    uint64_t one[4], num[4], n_int[4] = {(uint64_t)n, 0, 0, 0}, n_w[4], n_inv[4];
+    uint64_t one[4], num[4], n_inv_int[4], n_inv[4];
     h_one(one);
     h_fr_sub(zn, one, num);                                   // z^n - 1
-    h_fr_mul(H_FR_R2, n_int, n_w);
-    h_fr_inv(n_w, n_inv);
+    // 1 / n for n = 2^k, k <= 28, without an inversion: n divides r - 1, and n (r - (r - 1) / n) = n r - (r - 1) = 1 mod r
+    {
+        uint64_t q[4] = {H_FR[0] - 1, H_FR[1], H_FR[2], H_FR[3]};
+        for (int i = 0; i < 4; ++i) q[i] = log_n ? ((q[i] >> log_n) | (i < 3 ? q[i + 1] << (64 - log_n) : 0)) : q[i];       // (r - 1) >> log_n
+        uint64_t br = 0;
+        for (int i = 0; i < 4; ++i) { hu128 d = (hu128)H_FR[i] - q[i] - br; n_inv_int[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+        if (log_n == 0) { n_inv_int[0] = 1; n_inv_int[1] = n_inv_int[2] = n_inv_int[3] = 0; }                               // n = 1: r - (r - 1) = 1
+    }
+    h_fr_mul(H_FR_R2, n_inv_int, n_inv);
     h_fr_mul(s, num, s);
     h_fr_mul(s, n_inv, out_y);
     return 0;

@@ -138,6 +138,43 @@ int main() {
         kzg::h_fr_inv(n_m, n_inv);
         orc_f_mul(1, want, sum, t); orc_f_mul(1, want, want, n_inv);
         CHECK(memcmp(y, want, 32) == 0);
+        // the host inversion (binary Euclid) against the Fermat form on every scalar at hand, on 0, 1, r - 1 and on words above r; and the fold's
+        // inversion-free 1 / n against it at every domain size
+        for (size_t i = 0; i + 4 <= sc.size() && i < 4 * 64; i += 4) {
+            uint64_t a[4], i1[4], i2[4], back[4];
+            orc_f_mul(1, a, sc.data() + i, FR_ONE_M);
+            kzg::h_fr_inv(a, i1); kzg::h_fr_inv_fermat(a, i2);
+            CHECK(memcmp(i1, i2, 32) == 0);
+            kzg::h_fr_mul(a, i1, back);
+            CHECK((a[0] | a[1] | a[2] | a[3]) == 0 || memcmp(back, FR_ONE_M, 32) == 0);
+        }
+        {
+            const uint64_t zero[4] = {0, 0, 0, 0}, big[4] = {~0ULL, ~0ULL, ~0ULL, ~0ULL};
+            uint64_t i1[4], i2[4], m1[4];
+            kzg::h_fr_inv(zero, i1); CHECK((i1[0] | i1[1] | i1[2] | i1[3]) == 0);
+            kzg::h_fr_inv(FR_ONE_M, i1); CHECK(memcmp(i1, FR_ONE_M, 32) == 0);
+            kzg::h_fr_sub(zero, FR_ONE_M, m1);
+            kzg::h_fr_inv(m1, i1); CHECK(memcmp(i1, m1, 32) == 0);              // (-1)^-1 = -1
+            kzg::h_fr_inv(big, i1);                                              // 2^256 - 1 = some residue above r: the same inverse as its canonical form
+            uint64_t canon[4]; memcpy(canon, big, 32);
+            while (kzg::h_geq_r(canon)) kzg::h_sub_r(canon);
+            kzg::h_fr_inv_fermat(canon, i2);
+            CHECK(memcmp(i1, i2, 32) == 0);
+        }
+        for (int lg = 0; lg <= 28; ++lg) {
+            uint64_t rows1[8] = {0}, yy[4], nm[4], ninv[4], zz[4], znn[4], tt[4], want2[4];
+            memcpy(rows1, S[0], 32);
+            orc_f_mul(1, zz, sc.data() + 8, FR_ONE_M);
+            CHECK(kzg::lag_fold_y(rows1, 1, (size_t)1 << lg, zz, yy) == 0);
+            const uint64_t np[4] = {(uint64_t)1 << lg, 0, 0, 0};
+            orc_f_mul(1, nm, np, FR_R2);
+            kzg::h_fr_inv_fermat(nm, ninv);
+            memcpy(znn, zz, 32);
+            for (int q = 0; q < lg; ++q) orc_f_mul(1, znn, znn, znn);
+            kzg::h_fr_sub(znn, FR_ONE_M, tt);
+            orc_f_mul(1, want2, S[0], tt); orc_f_mul(1, want2, want2, ninv);
+            CHECK(memcmp(yy, want2, 32) == 0);
+        }
         // z on the domain (z = 1 = w^0): y is the owner's f_m; the proof fold adds q_m L_m with q_m = -(1/z) sum_g T_g
         uint64_t rows2[3 * 8] = {0};
         memcpy(rows2 + 8 * 1 + 4, S[1], 32);                        // rank 1 owns m
