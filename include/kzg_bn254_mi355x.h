@@ -298,7 +298,9 @@ int32_t kzg_commit_eval_form_lagrange_partial_device(kzg_ctx* ctx, const kzg_srs
 /* KZG::compute_proof_impl (kzg.rs:128-178) on a slice, in four steps on `slot` (the asynchronous slots of kzg_msm_g1_srs_begin; several
  * proofs may be in flight on different slots):
  *   _begin       enqueue: upload of the slice (or, _device, the caller's resident buffer read in place: keep it untouched until _end),
- *                the inverses 1 / (w^i - z) of the slice (one inversion per 1 024 elements, side by side) and S_g.  shard_lo = index of the
+ *                the inverses 1 / (w^i - z) of the slice (one inversion per 1 024 elements, side by side; they need z only and run BESIDE the upload)
+ *                and S_g.  A pageable host buffer may be reused when _begin returns (the runtime has staged it); a PINNED one must stay valid and
+ *                unchanged until _partial_y has returned, as for kzg_msm_g1_srs_begin.  shard_lo = index of the
  *                slice's first evaluation; shard_lo + len <= n, len <= kzg_srs_len(lagrange_shard), n a power of two <= 2^28.
  *   _partial_y   waits for phase 1: out_ypart = 8 words, S_g | f_m (f_m only from the slice that owns m when z = w^m, else zero)
  *   kzg_lagrange_fold_y        (host only) y from the G gathered 8-word parts
