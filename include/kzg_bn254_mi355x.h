@@ -445,6 +445,30 @@ int32_t kzg_commit_and_prove_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_
                                   uint64_t out_commitment_xy_mont[8], uint8_t* out_commitment_is_infinity,
                                   uint64_t out_proof_xy_mont[8], uint8_t* out_proof_is_infinity,
                                   uint64_t* out_z_mont, uint64_t* out_y_mont);
+/* The same as a STREAM (round 6): KZG::commit_blob + KZG::compute_blob_proof (kzg.rs:182-185, :288-309) of many blobs with up to
+ * KZG_BLOB_JOBS of them in flight per context.  One call above is bound by ITS transcript -- SHA-256 over the whole blob is one
+ * sequential stream, 16-17 ms per 32 MiB on a core with SHA extensions, against ~2.9 ms of GPU work -- but the transcripts of different
+ * blobs are independent:
+ *   _begin(job)  starts the job's transcript prefix (helpers.rs:411-455: everything but the commitment) on a host thread of its own and
+ *                enqueues upload, bytes -> Fr and the commitment on one of the context's slots; returns without waiting for either.
+ *                commitment_xy_mont != NULL: KZG::compute_blob_proof as it stands -- the caller's commitment is validated (kzg.rs:295,
+ *                KZG_ERR_G1_NOT_ON_CURVE) and absorbed, none is computed.
+ *   _end(job)    returns the job's commitment, proof, z and y (any out pointer may be NULL); waits for whatever is still missing.
+ * EVERY begin / end call also moves every other job on as far as it can go without waiting (commitment collected -> 32 bytes appended
+ * to its finished prefix -> z -> proof enqueued), so with `begin(k + d); end(k)` in a loop, d >= 6, the hashes of d blobs run side by
+ * side and the GPU works through commitments and proofs back to back: ~3 ms per 32 MiB blob instead of ~20.  Results are bit-identical to
+ * kzg_commit_and_prove_blob / kzg_compute_blob_proof.  Same argument checks and statuses as those; blobs of up to 2^24 elements.
+ * LIFETIME: blob_bytes is read by the transcript thread until the job's _end call returns.  SLOTS: the jobs take the context's
+ * KZG_NUM_SLOTS slots phase by phase (a slot still held by another kzg_*_begin call of the caller is left alone; the synchronous calls,
+ * which run on slot 0, return KZG_ERR_INVALID_ARG while a job holds it -- collect the jobs first).  A failed job reports its status from
+ * _end and is idle afterwards.  kzg_ctx_destroy joins whatever is still in flight. */
+#ifndef KZG_BLOB_JOBS
+#define KZG_BLOB_JOBS 16
+#endif
+int32_t kzg_commit_and_prove_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_bytes, size_t len, size_t n_roots,
+                                        const uint64_t* commitment_xy_mont, int32_t job);
+int32_t kzg_commit_and_prove_blob_end(kzg_ctx* ctx, int32_t job, uint64_t* out_commitment_xy_mont, uint8_t* out_commitment_is_infinity,
+                                      uint64_t* out_proof_xy_mont, uint8_t* out_proof_is_infinity, uint64_t* out_z_mont, uint64_t* out_y_mont);
 /* helpers::evaluate_polynomial_in_evaluation_form (helpers.rs:475-535) on the domain of size n. */
 int32_t kzg_evaluate_polynomial_in_evaluation_form(kzg_ctx* ctx, const uint64_t* evals_mont, size_t n,
                                                    const uint64_t z_mont[4], uint64_t out_y_mont[4]);

@@ -32,6 +32,7 @@ ERR_ZERO_LENGTH = -13
 ERR_SRS_LENGTH = -14
 ERR_DESERIALIZE = -15
 ERR_NOT_ON_CURVE = -16
+BLOB_JOBS = 16                                                   # KZG_BLOB_JOBS of the header
 NUM_SLOTS = int(os.environ.get("KZG_NUM_SLOTS", "4"))          # KZG_NUM_SLOTS of the header (env: variant builds with more slots)
 ERR_G1_NOT_ON_CURVE = -17
 ERR_G2_TAU_NOT_ON_CURVE = -18
@@ -116,6 +117,8 @@ PROTOTYPES = {
     "kzg_compute_challenge": (i32, [u8p, sz, u64p, u64p]),
     "kzg_compute_blob_proof": (i32, [vp, vp, u8p, sz, sz, u64p, u64p, u8p, u64p, u64p]),
     "kzg_commit_and_prove_blob": (i32, [vp, vp, u8p, sz, sz, u64p, u8p, u64p, u8p, u64p, u64p]),
+    "kzg_commit_and_prove_blob_begin": (i32, [vp, vp, u8p, sz, sz, u64p, i32]),
+    "kzg_commit_and_prove_blob_end": (i32, [vp, i32, u64p, u8p, u64p, u8p, u64p, u64p]),
     "kzg_commit_eval_form_partial": (i32, [vp, vp, sz, u64p, sz, u64p]),
     "kzg_compute_proof_partial": (i32, [vp, vp, sz, u64p, sz, u64p, sz, u64p, u64p, u64p]),
     "kzg_evaluate_polynomial_in_evaluation_form": (i32, [vp, u64p, sz, u64p, u64p]),

@@ -56,7 +56,7 @@ int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where) {
 // polynomial pipeline (poly.hip)
 int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4],
                   uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y, bool want_proof, size_t coeff_lo, uint64_t* out_xyzz);
-int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot);
+int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot, const void* d_resident = nullptr);
 int32_t proof_end(kzg_ctx* ctx, int slot, uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_y);
 int32_t roots_run(kzg_ctx* ctx, uint64_t* out, size_t n);
 // Lagrange-sharded proofs (lagrange.hip)
@@ -151,6 +151,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto st : ctx->stream_x) if (st) (void)hipStreamSynchronize(st);
+    blob_stream_release(ctx);
     msm_drop_slots(ctx);
     ctx->last_sorted = nullptr; ctx->last_sorted_stream = nullptr;
     ctx->msm.release();
@@ -1276,9 +1277,11 @@ int32_t kzg_compute_proof_end(kzg_ctx* ctx, int32_t slot, uint64_t out_xy_mont[8
 
 // ---- Fiat-Shamir challenge and blob proofs (helpers.rs:411-472, kzg.rs:288-309) --------------------------------------------
 namespace {
-
 const char FS_DOMAIN[] = "EIGENDA_FSBLOBVERIFY_V1_";          // primitives/src/consts.rs:8 (24 bytes)
 const uint64_t FR_R2_WORDS[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};   // 2^512 mod r
+}  // namespace
+}  // extern "C"
+namespace kzg {   // (shared with blobstream.hip)
 
 // Absorbs  tag || u64be(n) || n x 32 bytes, the evaluations of Blob::to_polynomial_eval_form in to_byte_array form: every
 // 32-byte big-endian chunk of the blob reduced mod r (helpers.rs:40-57 -> :80-119), zero elements up to the next power of two.
@@ -1345,7 +1348,8 @@ void challenge_finish(kzg_host::Sha256& sh, const kzg_host::G1& commitment, uint
 }
 size_t blob_padded_len(size_t len) { size_t e = (len + 31) / 32, p = 1; while (p < e) p <<= 1; return p; }
 
-}  // namespace
+}  // namespace kzg
+extern "C" {
 
 int32_t kzg_validate_g1_point(const uint64_t xy_mont[8]) {
     if (!xy_mont) return KZG_ERR_INVALID_ARG;
@@ -1493,15 +1497,48 @@ void digest_to_fr_wire(const uint8_t dig[32], uint64_t out[4]) {            // h
 // Upper bound of the pool, whatever the core count (KZG_HOST_THREADS_MAX).  Measured on the 256-thread host of an MI355X box, 4 096-row batch verification
 // end to end (tools/trace_batch_verify.py): 32 threads 6.3-6.5 ms, 48 5.4-5.5, 64 5.3-5.6, 96 5.8-5.9, 128 6.0-6.5 (the transcripts scale, the upload and the
 // serial parts do not, and past 64 the pool's wake-ups cost more than they gain) -> 48.
+// CPUs this process may use on average: the CFS bandwidth quota of its cgroup (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us), 0 = none.
+// A pool wider than the quota allows runs fine for one call, but back-to-back calls then spend the period's budget early and the kernel
+// freezes EVERY thread of the cgroup until the next 100 ms period: that was the 20-34 ms tail of batch verification (1 call in 9; DESIGN.md
+// section 6, profiles/r06_batch_verify_tail.md: every slow call coincides with a throttled period in cpu.stat, none without).
+double cgroup_cpu_quota() {
+    static const double q = []() -> double {
+        auto read2 = [](const char* path, char a[64], char b[64]) {
+            FILE* f = fopen(path, "r");
+            if (!f) return 0;
+            const int got = fscanf(f, "%63s %63s", a, b);
+            fclose(f);
+            return got;
+        };
+        char a[64] = {0}, b[64] = {0};
+        if (read2("/sys/fs/cgroup/cpu.max", a, b) == 2 && strcmp(a, "max") != 0 && atof(b) > 0) return atof(a) / atof(b);
+        char c[64] = {0}, d[64] = {0};
+        if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", a, b) >= 1 && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", c, d) >= 1 && atof(a) > 0 && atof(c) > 0)
+            return atof(a) / atof(c);
+        return 0.0;
+    }();
+    return q;
+}
 unsigned host_threads_cap() {
-    static const unsigned cap = []() { const char* e = getenv("KZG_HOST_THREADS_MAX"); const int v = e ? atoi(e) : 48; return (unsigned)(v >= 1 && v <= 256 ? v : 48); }();
+    // 48 threads at most; under a CPU quota of Q, 1.25 Q: the pool is busy ~60 % of a call, so back-to-back calls average ~0.8 Q CPUs and
+    // leave the rest to the HIP runtime's threads (measured on a 16-CPU quota, 4 096 blobs per call, 60 calls each: 48 threads median 6.2 ms /
+    // max 24 / 123 ms of CPU per call; 32: 6.1 / 15 / 109; 24: 6.8 / 7.2 / 100; 20: 6.9 / 7.0 / 88; 16: 7.7 / 7.8 / 84; 12: 9.4 / 9.8 / 86).
+    // KZG_HOST_THREADS_MAX overrides.
+    static const unsigned cap = []() {
+        const char* e = getenv("KZG_HOST_THREADS_MAX");
+        if (e && atoi(e) >= 1 && atoi(e) <= 256) return (unsigned)atoi(e);
+        unsigned c = 48;
+        const double q = cgroup_cpu_quota();
+        if (q > 0) c = std::min<unsigned>(c, std::max<unsigned>(2u, (unsigned)(q * 1.25)));
+        return c;
+    }();
     return cap;
 }
 unsigned host_threads(size_t jobs) {
     unsigned t = std::thread::hardware_concurrency();
     if (t == 0) t = 4;
-    { const char* env = getenv("KZG_HOST_THREADS"); if (env && atoi(env) > 0) t = (unsigned)atoi(env); }
     if (t > host_threads_cap()) t = host_threads_cap();
+    { const char* env = getenv("KZG_HOST_THREADS"); if (env && atoi(env) > 0) t = (unsigned)atoi(env); }   // exactly that many (measurements)
     if ((size_t)t > jobs) t = (unsigned)jobs;
     return t ? t : 1;
 }
@@ -1824,8 +1861,8 @@ int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blob
     RoctxRange range_core("kzg:batch_verify:lincombs (GPU) + pairing (host)");
     const int32_t rc = verify_batch_core(ctx, commitments_xy_mont, zs.data(), ys.data(), proofs_xy_mont, rp.data(), n, g2_tau_mont, out_ok);   // batch.rs:62-68
     if (trace)
-        fprintf(stderr, "kzg_verify_blob_kzg_proof_batch n=%zu: point validation %.3f ms, challenges + evaluations %.3f ms, r_powers %.3f ms, lincombs + pairing %.3f ms\n",
-                n, ms(t_start, t_valid), ms(t_valid, t_eval), ms(t_eval, t_rp), ms(t_rp, now()));
+        fprintf(stderr, "kzg_verify_blob_kzg_proof_batch n=%zu: point validation %.3f ms, challenges + evaluations %.3f ms, r_powers %.3f ms, lincombs + pairing %.3f ms, call %.3f ms\n",
+                n, ms(t_start, t_valid), ms(t_valid, t_eval), ms(t_eval, t_rp), ms(t_rp, now()), ms(t_start, now()));
     return rc;
 }
 

@@ -71,6 +71,7 @@ struct NttWorkspace {
 
 namespace kzg {
 struct MsmPending;
+struct BlobStream;   // blob -> commitment + proof jobs in flight (blobstream.hip)
 // a proof over a slice of the evaluations and the matching slice of a Lagrange basis, in flight on one slot (lagrange.hip)
 struct LagProof {
     int phase = 0;                 // 0 idle; 1 inverses + partial barycentric sum enqueued; 2 partial collected, waiting for y; 3 quotient (+ MSM) enqueued
@@ -118,6 +119,7 @@ struct kzg_ctx {
     hipEvent_t lag_phase1[KZG_NUM_SLOTS] = {};     // behind phase 1 of the proof on that slot
     hipEvent_t lag_uploaded[KZG_NUM_SLOTS] = {};   // behind the slice's upload on the proof slot's stream: the commitment on another slot starts after it
     kzg::MsmWorkspace& slot_msm(int slot) { return slot ? msm_x[slot - 1] : msm; }
+    kzg::BlobStream* blob_stream = nullptr;    // kzg_commit_and_prove_blob_begin / _end: created on first use
     hipEvent_t last_sorted = nullptr;          // ev_sorted of the most recently enqueued MSM launch of this context ...
     hipStream_t last_sorted_stream = nullptr;  // ... and the stream it went to (msm.hip msm_enqueue)
     kzg::NttWorkspace& slot_ntt(int slot) { return slot ? ntt_x[slot - 1] : ntt; }
@@ -256,6 +258,9 @@ int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);
 int32_t ctx_aux_stream(kzg_ctx* ctx, hipStream_t fallback, hipStream_t* out);
 // the points only, no window / per-bit tables (set-up paths that need the points once: kzg_multi_cache_lagrange)
 int32_t srs_upload_plain(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);
+
+// joins the transcript threads and frees the buffers of the blob stream (kzg_ctx_destroy)
+void blob_stream_release(kzg_ctx* ctx);
 
 // process-wide caches keyed by device (NTT twiddles, g1_ifft scalar sets): released when the LAST context of a device is destroyed
 void ntt_release_device_caches(int dev);

@@ -720,8 +720,9 @@ int32_t blob_to_fr_run(kzg_ctx* ctx, const uint8_t* bytes, size_t len, size_t n_
 // stream has been synchronised); the quotient's coefficients are left in ps_set.c.
 // skip_intt: the caller commits the quotient's EVALUATIONS over a Lagrange basis (prover/src/kzg.rs:96-100 applied to the quotient, exactly
 // what the reference's compute_proof_impl does: kzg.rs:176-177), so they stay in set.c as they are.
+// d_resident: the n evaluations (wire) already on the device in a buffer of the caller's (the blob stream's jobs, capi.hip); read in place
 static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWorkspace* nttws, const uint64_t* evals, size_t n,
-                             const uint64_t z[4], bool want_proof, bool skip_intt = false) {
+                             const uint64_t z[4], bool want_proof, bool skip_intt = false, const uint4* d_resident = nullptr) {
     RoctxRange range(want_proof ? "kzg:proof:inverses + y + quotient + intt" : "kzg:evaluate:inverses + y");
     int log_n = ilog2_exact(n);
     NttTables tb;
@@ -732,7 +733,9 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     const int per_lane = 4;           // = the coset size of the last inversion level (k_poly_inverses)
     uint32_t blocks = (uint32_t)((n + (size_t)POLY_THREADS * per_lane - 1) / ((size_t)POLY_THREADS * per_lane));
     if (blocks == 0) blocks = 1;
-    KZG_HIP_TRY(ctx, set.a.reserve(n * 32));                 // evaluations (wire)
+    if (!d_resident) KZG_HIP_TRY(ctx, set.a.reserve(n * 32));                 // evaluations (wire)
+    if (d_resident) evals = nullptr;
+    const uint4* d_a = d_resident ? d_resident : set.a.as<uint4>();
     // inverses (planes) | level scratch: the smaller domains' inverses, two ping-pong plane sets of the small kernel
     // The one-workgroup kernel takes the chain up to 2^chain_small_log points, x4 levels on the whole chip go on from there: its late levels
     // keep all 16 waves of one CU busy, a x4 launch over many CUs costs about one of them.  KZG_POLY_SMALL_LOG (2..12), off-domain proofs of
@@ -815,10 +818,10 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         KZG_HIP_TRY(ctx, hipHostGetDevicePointer(&ps_host_dev, pin + 3072, 0));
         ProofScalars* ps_out = static_cast<ProofScalars*>(ps_host_dev);
         if (evals) KZG_HIP_TRY(ctx, hipMemcpyAsync(set.a.p, evals, n * 32, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_poly_quotient_table, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, t1, m_known,
+        hipLaunchKernelGGL(k_poly_quotient_table, dim3(blocks), dim3(POLY_THREADS), 0, st, d_a, (uint32_t)n, tb, t1, m_known,
                            set.c.as<uint4>(), partial, ps_out);
         if (blocks > 1)
-            hipLaunchKernelGGL(k_poly_quotient_on_domain_known, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, partial, blocks,
+            hipLaunchKernelGGL(k_poly_quotient_on_domain_known, dim3(1), dim3(POLY_THREADS), 0, st, d_a, (uint32_t)n, tb, partial, blocks,
                                m_known, ps_out, set.c.as<uint4>());
         KZG_HIP_TRY(ctx, hipGetLastError());
         return skip_intt ? KZG_OK : ntt_run(ctx, set.c.p, n, true, st, nttws);
@@ -870,15 +873,15 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         }
     }
     const int fused_y = blocks == 1 && !z_on_domain;         // one workgroup holds the whole barycentric sum: no second launch for y
-    hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, tb, d_z,
+    hipLaunchKernelGGL(k_poly_inverses, dim3(blocks), dim3(POLY_THREADS), 0, st, d_a, (uint32_t)n, log_n, tb, d_z,
                        next, direct, d_inv, partial, ps, fused_y);
     if (!fused_y)
-        hipLaunchKernelGGL(k_poly_finish_y, dim3(1), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, log_n, d_z,
+        hipLaunchKernelGGL(k_poly_finish_y, dim3(1), dim3(POLY_THREADS), 0, st, d_a, (uint32_t)n, log_n, d_z,
                            partial, blocks, ps);
     KZG_HIP_TRY(ctx, hipGetLastError());
     KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + 3072, ps, sizeof(ProofScalars), hipMemcpyDeviceToHost, st));
     if (!want_proof) return KZG_OK;
-    hipLaunchKernelGGL(k_poly_quotient, dim3(blocks), dim3(POLY_THREADS), 0, st, set.a.as<uint4>(), (uint32_t)n, tb, d_inv,
+    hipLaunchKernelGGL(k_poly_quotient, dim3(blocks), dim3(POLY_THREADS), 0, st, d_a, (uint32_t)n, tb, d_inv,
                        ps, set.c.as<uint4>(), partial);
     if (z_on_domain)                                         // (z off the domain: the kernel would return at once)
         hipLaunchKernelGGL(k_poly_quotient_on_domain, dim3(1), dim3(POLY_THREADS), 0, st, (uint32_t)n, tb, partial, blocks, ps,
@@ -932,14 +935,14 @@ int32_t proof_run(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_
 }
 
 // asynchronous form: everything on the slot's stream; proof_end collects the point and y
-int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot) {
+int32_t proof_begin(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* evals, size_t n, const uint64_t z[4], int slot, const void* d_resident) {
     if (slot < 0 || slot >= KZG_NUM_SLOTS || ctx->slot_pending[slot]) return KZG_ERR_INVALID_ARG;
     hipStream_t st = nullptr;
     int32_t rc = msm_slot_stream(ctx, slot, &st);
     if (rc != KZG_OK) return rc;
     PolySet& set = ctx->poly[slot];
     const kzg_srs* lag = proof_lagrange_basis(srs, n);
-    rc = proof_enqueue(ctx, set, st, &ctx->slot_ntt(slot), evals, n, z, true, lag != nullptr);
+    rc = proof_enqueue(ctx, set, st, &ctx->slot_ntt(slot), evals, n, z, true, lag != nullptr, static_cast<const uint4*>(d_resident));
     if (rc != KZG_OK) { (void)hipStreamSynchronize(st); return rc; }
     return msm_begin(ctx, slot, srs_bases(lag ? lag : srs, 0, n, ctx->msm_c_override == 0), set.c.p, n);
 }

@@ -375,6 +375,63 @@ class KZG:
         self._raise_proof_status(ctx, rc, blob, srs)
         return com, out, z, y
 
+    # the same as a stream (`kzg_commit_and_prove_blob_begin` / `_end`): up to _lib.BLOB_JOBS blobs in flight, their transcript hashes side by side
+    def commit_and_prove_blob_begin(self, blob, srs, job, commitment=None):
+        """Starts job `job` (0 .. BLOB_JOBS-1): the transcript prefix on a host thread of the library, upload + bytes -> Fr + commitment on the
+        GPU; returns at once.  `commitment` given: `compute_blob_proof` as it stands (validated, absorbed, not recomputed).  The blob's bytes are
+        kept alive here until the job's end call."""
+        ctx = self._ctx()
+        data = blob.data()
+        buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+        cptr = _lib.ptr(_lib.as_u64(commitment, 0).reshape(8)) if commitment is not None else None
+        rc = _lib.load().kzg_commit_and_prove_blob_begin(ctx.handle, srs.handle, buf.ctypes.data_as(_lib.u8p), len(data), len(self.expanded_roots_of_unity),
+                                                         cptr, job)
+        self._raise_proof_status(ctx, rc, blob, srs)
+        if not hasattr(self, "_blob_jobs"):
+            self._blob_jobs = {}
+        self._blob_jobs[job] = (buf, data, blob, srs)
+
+    def commit_and_prove_blob_end(self, job):
+        """(commitment, proof, z, y) of job `job`; waits for what is still missing and moves the other jobs on meanwhile."""
+        ctx = self._ctx()
+        com = np.zeros(8, dtype=np.uint64); cinf = C.c_uint8(0)
+        out = np.zeros(8, dtype=np.uint64); inf = C.c_uint8(0); z = np.zeros(4, dtype=np.uint64); y = np.zeros(4, dtype=np.uint64)
+        rc = _lib.load().kzg_commit_and_prove_blob_end(ctx.handle, job, _lib.ptr(com), C.byref(cinf), _lib.ptr(out), C.byref(inf), _lib.ptr(z), _lib.ptr(y))
+        held = getattr(self, "_blob_jobs", {}).pop(job, None)
+        if rc != _lib.OK and held is not None:
+            self._raise_proof_status(ctx, rc, held[2], held[3])
+        ctx.check_device(rc)
+        if rc != _lib.OK:
+            raise GenericError(ctx.last_error() or _lib.status_message(rc))
+        return com, out, z, y
+
+    def commit_and_prove_blobs(self, blobs, srs, inflight=8):
+        """Generator over an iterable of blobs: yields (commitment, proof, z, y) per blob, in order, with `inflight` jobs in flight."""
+        inflight = max(1, min(int(inflight), _lib.BLOB_JOBS))
+        pending = []                                   # job indices in begin order
+        free = list(range(inflight))
+        try:
+            for blob in blobs:
+                if not free:
+                    j = pending.pop(0)
+                    res = self.commit_and_prove_blob_end(j)
+                    free.append(j)
+                    yield res
+                j = free.pop(0)
+                self.commit_and_prove_blob_begin(blob, srs, j)
+                pending.append(j)
+            while pending:
+                j = pending.pop(0)
+                res = self.commit_and_prove_blob_end(j)
+                free.append(j)
+                yield res
+        finally:
+            for j in pending:                          # (an exception or an abandoned generator: nothing stays in flight)
+                try:
+                    self.commit_and_prove_blob_end(j)
+                except Exception:
+                    pass
+
     @staticmethod
     def _raise_proof_status(ctx, rc, blob, srs):
         if rc == _lib.OK:

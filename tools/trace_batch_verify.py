@@ -1,5 +1,5 @@
 """Phase times of kzg_verify_blob_kzg_proof_batch (BASELINE config 5, 4 096 rows) with KZG_VB_TRACE=1: the bench's workload (256 distinct blobs of
-35 .. 50 000 raw bytes, each used 16 times), 12 calls.  Usage (GPU box): KZG_VB_TRACE=1 python tools/trace_batch_verify.py"""
+35 .. 50 000 raw bytes, each used 16 times), TRACE_CALLS calls (default 60) with the cgroup's CPU-throttling counters beside every call.  Usage (GPU box): [KZG_VB_TRACE=1] [KZG_HOST_THREADS=16] python tools/trace_batch_verify.py"""
 import ctypes as C, hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch, bench
@@ -28,9 +28,42 @@ cm5 = np.ascontiguousarray(np.stack([r[1] for r in sel5])); pf5 = np.ascontiguou
 tau_g2 = np.zeros(16, np.uint64)
 lib.kzg_g2_mul_generator(_lib.ptr(k.fr.fr_from_int(tau)), _lib.ptr(tau_g2))
 ok5 = C.c_int32(0)
-ts = []
-for i in range(12):
+def cg(name):
+    """one file of this process's cgroup (v2), or None"""
+    for base in ("/sys/fs/cgroup", "/sys/fs/cgroup/cpu"):
+        try:
+            return open(os.path.join(base, name)).read()
+        except OSError:
+            pass
+    return None
+def throttled():
+    s = cg("cpu.stat") or ""
+    d = dict(l.split() for l in s.splitlines() if len(l.split()) == 2)
+    return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", d.get("throttled_time", 0)))
+calls = int(os.environ.get("TRACE_CALLS", "60"))
+gap_ms = float(os.environ.get("TRACE_GAP_MS", "0"))
+print("cpu.max:", (cg("cpu.max") or cg("cpu.cfs_quota_us") or "n/a").strip(), "| hardware threads", os.cpu_count(), "| affinity", len(os.sched_getaffinity(0)),
+      "| KZG_HOST_THREADS", os.environ.get("KZG_HOST_THREADS"), "KZG_HOST_THREADS_MAX", os.environ.get("KZG_HOST_THREADS_MAX"), flush=True)
+if os.environ.get("TRACE_GC", "1") == "0":
+    import gc
+    gc.disable()
+tracing = os.environ.get("KZG_VB_TRACE", "0") != "0"
+ts, thr, cpu = [], [], []
+for i in range(calls):
+    a = throttled()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     assert lib.kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs5, lens5, _lib.ptr(cm5), _lib.ptr(pf5), nb, _lib.ptr(tau_g2), C.byref(ok5)) == 0 and ok5.value == 1
     ts.append((time.perf_counter() - t0) * 1e3)
+    cpu.append((time.process_time() - c0) * 1e3)
+    if tracing:
+        print("  call %d seen from Python: %.3f ms" % (i, ts[-1]), file=sys.stderr, flush=True)
+    b = throttled()
+    thr.append((b[0] - a[0], (b[1] - a[1]) / 1e3))
+    if gap_ms: time.sleep(gap_ms / 1e3)
 print("per call ms:", " ".join("%.2f" % t for t in ts), "| blob MiB", sum(len(r[0]) for r in sel5) / 2 ** 20, flush=True)
+print("cgroup throttling per call (periods, ms):", " ".join("%d/%.1f" % t for t in thr), flush=True)
+print("process CPU ms per call: median %.1f  mean %.1f (all threads of the process; quota = cpu.max)" % (sorted(cpu)[len(cpu) // 2], sum(cpu) / len(cpu)), flush=True)
+ts = ts[int(os.environ.get("TRACE_SKIP", "2")):]                     # the first calls size the staging buffers and start the pool
+srt = sorted(ts)
+print("median %.2f  mean %.2f  p90 %.2f  p99 %.2f  max %.2f over %d calls" % (srt[len(srt) // 2], sum(ts) / len(ts), srt[int(len(srt) * 0.9)], srt[min(len(srt) - 1, int(len(srt) * 0.99))], srt[-1], len(ts)), flush=True)
