@@ -47,6 +47,20 @@ N_SIMDS = 1024
 N_BUFFERS = 8                  # distinct resident scalar buffers the timed steps rotate through
 
 
+def host_pool_threads():
+    """Threads of the library's host pool (capi.hip host_threads_cap): 48, the hardware threads, or 1.25 x the cgroup's CPU quota, whichever is least."""
+    if os.environ.get("KZG_HOST_THREADS_MAX"):
+        return int(os.environ["KZG_HOST_THREADS_MAX"])
+    cap = min(48, os.cpu_count() or 1)
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            cap = min(cap, max(2, int(float(a) / float(b) * 1.25)))
+    except (OSError, ValueError):
+        pass
+    return cap
+
+
 def pmc_traffic_bytes(log_n):
     """(HBM bytes per k_msm_accumulate launch, reason): from the committed rocprofv3 --pmc passes of this round (FETCH_SIZE +
     WRITE_SIZE, KB; tools/pmc_summarize.py documents the gfx950 correction).  Only valid for the workload it was measured on."""
@@ -991,6 +1005,35 @@ def main():
             assert np.array_equal(o8, want_proof), "streamed proof over the cached Lagrange basis differs"
             cb_lag_ms = avg_ms(lambda: lib.kzg_commit_blob(ctx.handle, srs.handle, blob_bytes.ctypes.data_as(u8p), blob_bytes.size, _lib.ptr(o8), C.byref(oi)), reps=5)
             assert np.array_equal(o8, want_blob), "blob commitment over the cached Lagrange basis differs"
+            # BASELINE config 4 read literally, as a STREAM (kzg_commit_and_prove_blob_begin / _end, csrc/blobstream.hip): blob bytes in host memory ->
+            # commitment + Fiat-Shamir challenge + proof, `depth` blobs in flight so that their transcript hashes (one sequential SHA-256 stream of
+            # 32 MiB each, compute_challenge_host_sha256_ms) run side by side on host threads while the GPU works through commitments and proofs.
+            # Two distinct blobs alternate; every result is compared with the one-call entry's (itself checked against big integers in tests/).
+            blob_b = np.ascontiguousarray(np.roll(blob_bytes.reshape(-1, 32), 12345, axis=0).reshape(-1))
+            want_cp = []
+            for bb in (blob_bytes, blob_b):
+                wc = np.zeros(8, np.uint64); wp = np.zeros(8, np.uint64); wz = np.zeros(4, np.uint64); wy = np.zeros(4, np.uint64)
+                assert lib.kzg_commit_and_prove_blob(ctx.handle, srs.handle, bb.ctypes.data_as(u8p), bb.size, n, _lib.ptr(wc), C.byref(oci), _lib.ptr(wp), C.byref(oi),
+                                                     _lib.ptr(wz), _lib.ptr(wy)) == 0
+                want_cp.append((wc, wp, wz, wy))
+            assert np.array_equal(want_cp[0][0], oc2) and np.array_equal(want_cp[0][1], ob2), "commit + proof over the cached Lagrange basis differs from the IFFT path"
+            def stream_commit_and_prove(total, depth):
+                sc = np.zeros(8, np.uint64); sp = np.zeros(8, np.uint64); sz_ = np.zeros(4, np.uint64); sy = np.zeros(4, np.uint64)
+                t0 = time.perf_counter()
+                for i in range(total + depth):
+                    if i >= depth:
+                        assert lib.kzg_commit_and_prove_blob_end(ctx.handle, (i - depth) % depth, _lib.ptr(sc), C.byref(oci), _lib.ptr(sp), C.byref(oi), _lib.ptr(sz_), _lib.ptr(sy)) == 0
+                        w = want_cp[(i - depth) & 1]
+                        assert np.array_equal(sc, w[0]) and np.array_equal(sp, w[1]) and np.array_equal(sz_, w[2]) and np.array_equal(sy, w[3]), "streamed commitment / proof differs"
+                    if i < total:
+                        bb = blob_b if i & 1 else blob_bytes
+                        assert lib.kzg_commit_and_prove_blob_begin(ctx.handle, srs.handle, bb.ctypes.data_as(u8p), bb.size, n, None, i % depth) == 0
+                return (time.perf_counter() - t0) / total * 1e3
+            cps = {}
+            for depth in (8, 12):
+                stream_commit_and_prove(depth, depth)
+                cps[depth] = min(stream_commit_and_prove(24, depth) for _ in range(2))
+            cp_stream_ms = cps[8]
             assert lib.kzg_srs_drop_lagrange(ctx.handle, srs.handle) == 0
             # config 5 shape: verify_kzg_proof_batch core at n = 4096 (three 4096-point MSMs batched on the GPU + host pairing check)
             nb = 4096
@@ -1028,7 +1071,7 @@ def main():
             cm5 = np.ascontiguousarray(np.stack([r[1] for r in sel5])); pf5 = np.ascontiguousarray(np.stack([r[2] for r in sel5]))
             ok5 = C.c_int32(0)
             e2e_stats = stats_ms(lambda: lib.kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs5, lens5, _lib.ptr(cm5), _lib.ptr(pf5), nb, _lib.ptr(tau_g2),
-                                                                             C.byref(ok5)), reps=9, warm=2)
+                                                                             C.byref(ok5)), reps=40, warm=3)
             e2e_ms = e2e_stats["median"]
             assert ok5.value == 1, "the 4096-row batch did not verify"
             pf5[nb - 1] = pf5[0]
@@ -1037,6 +1080,7 @@ def main():
             # the reference's own commit / proof bench shapes (prover/benches/bench_kzg_commit.rs:17-42, bench_kzg_proof.rs:17-58: 10 000 .. 50 000
             # byte blobs = 512 .. 2 048 coefficients) from host buffers against the loaded SRS, one call at a time, and g1_ifft(2048)
             small, small_stats = {}, {}
+            large_commit, setup_sample = {}, None
             for nn in (512, 1024, 2048):
                 sc_s = np.ascontiguousarray(scalars[:nn]); zq_s = np.ascontiguousarray(scalars_b[77])
                 def put(name, st):
@@ -1077,6 +1121,51 @@ def main():
             st = stats_ms(lambda: lib.kzg_verify_proof(_lib.ptr(c_v), _lib.ptr(p_v), _lib.ptr(y_v), _lib.ptr(z_v), _lib.ptr(tau_g2), C.byref(ok_v)), reps=60, warm=8)
             assert ok_v.value == 1, "verify_proof rejected a correct proof"
             small["verify_proof_ms"] = st["median"]; small_stats["verify_proof"] = st
+            # prover/benches/bench_kzg_commit_large_blobs.rs:17-37: commit_coeff_form of an 8 000 000- / 16 252 000-byte blob = 258 065 / 524 259 blob-like
+            # coefficients padded to 2^18 / 2^19, from a host buffer, one call at a time
+            for name, n_el in (("commit_8mb", 258065), ("commit_16mb", 524259)):
+                n_el = n_el if LOG_N >= 20 else max(1, n_el >> (20 - LOG_N))      # (reduced runs of the contract test: the same shapes, scaled)
+                npad = 1
+                while npad < n_el:
+                    npad <<= 1
+                sc_l = np.zeros((npad, 4), np.uint64); sc_l[:n_el] = scalars[:n_el]
+                st = stats_ms(lambda: lib.kzg_commit_coeff_form(ctx.handle, srs.handle, _lib.ptr(sc_l), npad, _lib.ptr(o8), C.byref(oi)), reps=30, warm=4)
+                small[name + "_ms"] = st["median"]; small_stats[name] = st
+                large_commit[name] = (sc_l, o8.copy())
+            # prover/benches/bench_kzg_setup.rs:6-15: SRS::new(g1.32mb.point, 268435456, 524288) = 524 288 gnark-compressed points (16 MiB) -> decompressed,
+            # validated, resident SRS with its window and per-bit tables.  The file is synthetic: the first 2^19 points of the bench's SRS re-encoded.
+            n_setup = 524288 if LOG_N >= 20 else max(64, n >> 1)
+            P_ = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+            rinv = pow(1 << 256, -1, P_)
+            wire = np.zeros((n_setup, 8), np.uint64)
+            assert lib.kzg_srs_download(ctx.handle, srs.handle, 0, n_setup, _lib.ptr(wire)) == 0
+            wb = wire.tobytes()
+            enc = bytearray(32 * n_setup)
+            half = (P_ - 1) // 2
+            for i in range(n_setup):
+                x = int.from_bytes(wb[64 * i:64 * i + 32], "little") * rinv % P_
+                y = int.from_bytes(wb[64 * i + 32:64 * i + 64], "little") * rinv % P_
+                e = x.to_bytes(32, "big")
+                enc[32 * i:32 * i + 32] = e
+                enc[32 * i] |= 0xC0 if y > half else 0x80        # helpers.rs:175-226: 0b11 = larger y, 0b10 = smaller y
+            enc = np.frombuffer(bytes(enc), dtype=np.uint8)
+            def setup_once():
+                h = C.c_void_p(); bad = C.c_uint64(0)
+                assert lib.kzg_srs_load_compressed_be(ctx.handle, enc.ctypes.data_as(u8p), n_setup, C.byref(h), C.byref(bad)) == 0
+                return h
+            h0 = setup_once()
+            back = np.zeros((n_setup, 8), np.uint64)
+            assert lib.kzg_srs_download(ctx.handle, h0, 0, n_setup, _lib.ptr(back)) == 0 and np.array_equal(back, wire), "decompressed SRS differs from the points it was encoded from"
+            lib.kzg_srs_free(h0)
+            ts_setup = []
+            for _ in range(5):
+                t = time.perf_counter(); hh = setup_once(); ts_setup.append((time.perf_counter() - t) * 1e3); lib.kzg_srs_free(hh)
+            ts_setup.sort()
+            small["kzg_setup_%d_ms" % n_setup] = ts_setup[len(ts_setup) // 2]
+            small_stats["kzg_setup_%d" % n_setup] = {"median": ts_setup[len(ts_setup) // 2], "mean": sum(ts_setup) / len(ts_setup), "min": ts_setup[0], "max": ts_setup[-1], "calls": len(ts_setup)}
+            small["kzg_setup_is"] = ("%d gnark-compressed points (%.1f MiB) in host memory -> decompressed (square roots on the GPU), curve-checked, resident, window + per-bit "
+                                     "tables built (%.1f GiB)" % (n_setup, n_setup * 32 / 2.0 ** 20, (255 + 15 + 17) * n_setup * 64 / 2.0 ** 30))
+            setup_sample = (enc[:32 * min(4096, n_setup)].tobytes(), n_setup)
             small["statistic"] = "median of the per-call wall times (60 calls per commit / proof shape, 9 per g1_ifft size); mean / p99 / min / max under reference_bench_shapes_stats"
             # sizes beyond the tables (parity: tests/test_gpu_large_sizes.py): the 2^20 step WITHOUT the 15.9 GiB of per-bit
             # tables (KZG_NO_NAF=1: fixed 17-bit windows over the 1 GiB window tables), a commitment over a 2^23-point SRS (window tables
@@ -1119,10 +1208,13 @@ def main():
                 "host_buffers_commit_coeff_streamed_ms": cc_stream_ms,
                 "commit_blob_from_host_bytes_ms": cb_ms, "commit_blob_from_host_bytes_streamed_ms": cb_stream_ms,
                 "compute_blob_proof_from_host_bytes_ms": bp_ms, "commit_and_prove_blob_from_host_bytes_ms": cp_ms,
+                "commit_and_prove_blob_streamed_ms": cp_stream_ms, "commit_and_prove_blob_streamed_by_jobs_in_flight_ms": {str(d): v for d, v in cps.items()},
+                "commit_and_prove_blob_streamed_is": "32 MiB blobs in host memory -> commitment, challenge and proof per blob, 8 jobs in flight (kzg_commit_and_prove_blob_begin / _end): "
+                                                     "the transcript hashes of the jobs run side by side on host threads; cached Lagrange basis; every result compared",
                 "compute_challenge_host_sha256_ms": ch_ms,
                 "batch_verify_4096_core_ms": bv_ms, "batch_verify_4096_three_msms_ms": m3_ms,
                 "batch_verify_4096_end_to_end_ms": e2e_ms, "batch_verify_4096_end_to_end_stats": e2e_stats, "batch_verify_4096_end_to_end_blob_MiB": e2e_bytes / 2.0 ** 20,
-                "batch_verify_4096_end_to_end_host_threads": min(int(os.environ.get("KZG_HOST_THREADS_MAX", "48")), os.cpu_count() or 1),
+                "batch_verify_4096_end_to_end_host_threads": host_pool_threads(),
                 "reference_bench_shapes": small, "reference_bench_shapes_stats": small_stats, "beyond_the_tables": beyond,
                 "measured_d2d_copy_GBps": copy_gbs,
                 "fr_ntt_ms": ntt_ms, "fr_intt_ms": intt_ms,
@@ -1154,6 +1246,27 @@ def main():
             cpu1_s = time.perf_counter() - t1
             out["cpu_baseline"]["single_thread"] = {"value": m1 / cpu1_s, "unit": "pairs/s", "cores": 1,
                                                     "sample": "2^16-pair MSM, same port, 1 thread, %.2f s wall" % cpu1_s}
+            # the oracle port beside the reference's bench_kzg_commit_large_blobs / bench_kzg_setup shapes (same inputs as the GPU figures above)
+            if not args.no_secondary:
+                shapes_cpu = {}
+                for name, (sc_l, got_pt) in large_commit.items():
+                    t1 = time.perf_counter()
+                    want_l = orc.msm_pippenger(g1[:len(sc_l)], sc_l, threads=cores)
+                    shapes_cpu[name + "_ms"] = (time.perf_counter() - t1) * 1e3
+                    if not np.array_equal(want_l, got_pt):
+                        out["config"]["bit_exact_vs_oracle"] = False
+                        exit_code = 3
+                if setup_sample is not None:
+                    t1 = time.perf_counter()
+                    sample_bytes, n_setup_pts = setup_sample
+                    for i in range(0, len(sample_bytes), 32):
+                        orc.g1_decompress_be(sample_bytes[i:i + 32])
+                    per_point = (time.perf_counter() - t1) / (len(sample_bytes) // 32)
+                    shapes_cpu["kzg_setup_%d_ms" % n_setup_pts] = per_point * n_setup_pts * 1e3
+                    shapes_cpu["kzg_setup_is"] = "%d points decompressed one at a time by the oracle (1 thread, %.1f us per point incl. the ctypes call), scaled to %d" % (
+                        len(sample_bytes) // 32, per_point * 1e6, n_setup_pts)
+                shapes_cpu["commit_is"] = "oracle/ signed-window Pippenger, one thread per window (17 of %d hardware threads), result compared with the GPU's" % cores
+                out["secondary"]["reference_bench_shapes_cpu_port"] = shapes_cpu
             # CPU baseline of the Fr NTT (primitives/src/polynomial.rs:130-140, :241-251): radix-2, every layer chunked over the cores
             t1 = time.perf_counter()
             cpu_f = orc.fr_ntt_mt(scalars_b, inverse=False, threads=cores)

@@ -9,13 +9,16 @@
 //     end:    proof collected
 // with KZG_BLOB_JOBS jobs in flight per context.  The jobs own their device buffers (bytes, evaluations); the MSM / polynomial
 // workspaces are those of the context's KZG_NUM_SLOTS slots, taken per phase.  Every call advances every job that can advance
-// without waiting ("pump"), so proofs of earlier jobs are enqueued behind the commitment of the job just begun.
+// without waiting ("pump"), so proofs of earlier jobs are enqueued behind the commitment of the job just begun; the transcript thread
+// pumps too when it finishes (if the context is not busy in another call), and an end call waits OUTSIDE the context's lock, so a
+// proof is enqueued the moment its challenge exists and not at the caller's next call.
 #include "engine.h"
 #include "host_curve.h"
 #include "host_pairing.h"
 #include "host_sha256.h"
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -109,7 +112,7 @@ static int acquire_slot(kzg_ctx* ctx, BlobStream& bs) {
 
 // JOB_WAIT_HASH with the prefix hashed: z, then the proof on `slot`
 static void job_start_proof(kzg_ctx* ctx, BlobStream& bs, BlobJob& j, int slot) {
-    if (j.hasher.joinable()) j.hasher.join();
+    if (j.hasher.joinable() && j.hasher.get_id() != std::this_thread::get_id()) j.hasher.join();   // (the transcript thread itself may be the one pumping)
     challenge_finish(j.sh, j.commitment, j.z);
     hipStream_t st = nullptr;
     int32_t rc = msm_slot_stream(ctx, slot, &st);
@@ -194,10 +197,30 @@ int32_t kzg_commit_and_prove_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const 
     int32_t rc = msm_slot_stream(ctx, slot, &st);
     if (rc != KZG_OK) return rc;
     if (!j.ev_evals) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&j.ev_evals, hipEventDisableTiming));
+    // the transcript prefix on a thread of its own (it reads the caller's buffer until the job's end call returns)
+    kzg_host::sha256_init(j.sh);
+    j.hash_done.store(0, std::memory_order_relaxed);
+    BlobJob* jp = &j;
+    try {
+        j.hasher = std::thread([ctx, jp, blob_bytes, len, n] {
+            challenge_absorb_prefix(jp->sh, blob_bytes, len, n);
+            jp->hash_done.store(1, std::memory_order_release);
+            // the proof goes out now if the context is free (an end call waits outside the lock); try_lock, never lock: a caller may be joining
+            // this thread while it holds the lock, and whoever holds it pumps on its way out anyway
+            if (ctx->mu.try_lock()) {
+                if (ctx->blob_stream && hipSetDevice(ctx->device) == hipSuccess) pump(ctx, *ctx->blob_stream);
+                ctx->mu.unlock();
+            }
+        });
+    } catch (...) {
+        ctx->last_error = "could not start the transcript thread of a blob job";
+        return KZG_ERR_DEVICE;
+    }
+    // from here on a failure has to wait for that thread (job_reset joins it): it reads the caller's buffer
     void* d_evals = nullptr;
     rc = blob_to_fr_run(ctx, blob_bytes, len, n, &d_evals, st, &j.d_bytes, &j.d_evals);              // Blob::to_polynomial_eval_form
-    if (rc != KZG_OK) return rc;
-    KZG_HIP_TRY(ctx, hipEventRecord(j.ev_evals, st));
+    if (rc == KZG_OK && hipEventRecord(j.ev_evals, st) != hipSuccess) rc = set_error(ctx, hipGetLastError(), "hipEventRecord(blob job)");
+    if (rc != KZG_OK) { job_reset(j); return rc; }
     j.srs = srs;
     j.n = n;
     j.seq = bs.next_seq++;
@@ -211,9 +234,10 @@ int32_t kzg_commit_and_prove_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const 
             rc = msm_begin(ctx, slot, srs_bases(cached, 0, n, ctx->msm_c_override == 0), d_evals, n);
         } else {
             MsmWorkspace& ws = ctx->slot_msm(slot);
-            KZG_HIP_TRY(ctx, ws.scalars.reserve(n * 32 + 32));
-            KZG_HIP_TRY(ctx, hipMemcpyAsync(ws.scalars.p, d_evals, n * 32, hipMemcpyDeviceToDevice, st));
-            if (n > 1) {
+            hipError_t e = ws.scalars.reserve(n * 32 + 32);
+            if (e == hipSuccess) e = hipMemcpyAsync(ws.scalars.p, d_evals, n * 32, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) rc = set_error(ctx, e, "blob job: copy of the evaluations");
+            if (rc == KZG_OK && n > 1) {
                 NttTables tb;
                 int log_n = 0; while (((size_t)1 << log_n) < n) ++log_n;
                 rc = ntt_get_tables(ctx, log_n, true, &tb);
@@ -221,25 +245,10 @@ int32_t kzg_commit_and_prove_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const 
             }
             if (rc == KZG_OK) rc = msm_begin(ctx, slot, srs_bases(srs, 0, n, ctx->msm_c_override == 0), ws.scalars.p, n);
         }
-        if (rc != KZG_OK) { (void)hipStreamSynchronize(st); return rc; }
+        if (rc != KZG_OK) { (void)hipStreamSynchronize(st); job_reset(j); return rc; }
         j.slot = slot;
         bs.owner[slot] = job;
         j.state = JOB_COMMIT;
-    }
-    // the transcript prefix on a thread of its own (it reads the caller's buffer until the job's end call returns)
-    kzg_host::sha256_init(j.sh);
-    j.hash_done.store(0, std::memory_order_relaxed);
-    BlobJob* jp = &j;
-    try {
-        j.hasher = std::thread([jp, blob_bytes, len, n] {
-            challenge_absorb_prefix(jp->sh, blob_bytes, len, n);
-            jp->hash_done.store(1, std::memory_order_release);
-        });
-    } catch (...) {
-        if (j.slot >= 0) job_collect(ctx, bs, j);
-        job_reset(j);
-        ctx->last_error = "could not start the transcript thread of a blob job";
-        return KZG_ERR_DEVICE;
     }
     return KZG_OK;
 }
@@ -247,39 +256,51 @@ int32_t kzg_commit_and_prove_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const 
 int32_t kzg_commit_and_prove_blob_end(kzg_ctx* ctx, int32_t job, uint64_t* out_commitment_xy_mont, uint8_t* out_commitment_is_infinity,
                                       uint64_t* out_proof_xy_mont, uint8_t* out_proof_is_infinity, uint64_t* out_z_mont, uint64_t* out_y_mont) {
     if (!ctx || job < 0 || job >= KZG_BLOB_JOBS) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->blob_stream || ctx->blob_stream->job[job].state == JOB_IDLE) {
-        ctx->last_error = "no blob job in flight under this index";
-        return KZG_ERR_INVALID_ARG;
-    }
-    BlobStream& bs = *ctx->blob_stream;
-    BlobJob& j = bs.job[job];
     for (;;) {
-        pump(ctx, bs);
-        if (j.state == JOB_DONE) {
-            if (out_commitment_xy_mont) memcpy(out_commitment_xy_mont, j.cxy, 64);
-            if (out_commitment_is_infinity) *out_commitment_is_infinity = j.cinf;
-            if (out_proof_xy_mont) memcpy(out_proof_xy_mont, j.pxy, 64);
-            if (out_proof_is_infinity) *out_proof_is_infinity = j.pinf;
-            if (out_z_mont) memcpy(out_z_mont, j.z, 32);
-            if (out_y_mont) memcpy(out_y_mont, j.y, 32);
-            job_reset(j);
-            return KZG_OK;
+        hipEvent_t wait_event = nullptr;                 // what this call waits for next, outside the lock: a phase on the device ...
+        BlobJob* wait_hash = nullptr;                    // ... or the job's transcript prefix
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+            if (!ctx->blob_stream || ctx->blob_stream->job[job].state == JOB_IDLE) {
+                ctx->last_error = "no blob job in flight under this index";
+                return KZG_ERR_INVALID_ARG;
+            }
+            BlobStream& bs = *ctx->blob_stream;
+            BlobJob& j = bs.job[job];
+            pump(ctx, bs);
+            if (j.state == JOB_WAIT_HASH && j.hash_done.load(std::memory_order_acquire)) {
+                // challenge ready but every slot taken: collect older jobs until one is free (acquire_slot only collects jobs that hold a slot: not this one)
+                const int slot = acquire_slot(ctx, bs);
+                if (slot < 0) { job_fail(bs, j, KZG_ERR_INVALID_ARG); ctx->last_error = "no slot free: every slot is held by another kzg_*_begin call"; }
+                else if (j.state == JOB_WAIT_HASH) job_start_proof(ctx, bs, j, slot);
+            }
+            if (j.state == JOB_DONE) {
+                if (out_commitment_xy_mont) memcpy(out_commitment_xy_mont, j.cxy, 64);
+                if (out_commitment_is_infinity) *out_commitment_is_infinity = j.cinf;
+                if (out_proof_xy_mont) memcpy(out_proof_xy_mont, j.pxy, 64);
+                if (out_proof_is_infinity) *out_proof_is_infinity = j.pinf;
+                if (out_z_mont) memcpy(out_z_mont, j.z, 32);
+                if (out_y_mont) memcpy(out_y_mont, j.y, 32);
+                job_reset(j);
+                return KZG_OK;
+            }
+            if (j.state == JOB_FAILED) {
+                const int32_t rc = j.rc;
+                job_reset(j);
+                return rc;
+            }
+            if (j.state == JOB_COMMIT || j.state == JOB_PROOF) wait_event = ctx->slot_msm(j.slot).ev_done;
+            else wait_hash = &j;
+            if ((j.state == JOB_COMMIT || j.state == JOB_PROOF) && !wait_event) { job_collect(ctx, bs, j); continue; }
         }
-        if (j.state == JOB_FAILED) {
-            const int32_t rc = j.rc;
-            job_reset(j);
-            return rc;
+        // Outside the lock: the transcript threads of other jobs can pump meanwhile.  The event may be re-recorded for another phase if this job is
+        // collected by such a pump -- then the wait is a little longer than needed and the state is looked at again.
+        if (wait_event) {
+            if (hipEventSynchronize(wait_event) != hipSuccess) (void)hipGetLastError();   // (an error surfaces in the collecting call under the lock)
+        } else {
+            while (!wait_hash->hash_done.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
-        if (j.state == JOB_COMMIT || j.state == JOB_PROOF) { job_collect(ctx, bs, j); continue; }
-        // JOB_WAIT_HASH: wait for the prefix (the only wait on the host's hash here), then the proof on a slot -- collecting older jobs if none is free
-        if (j.hasher.joinable()) j.hasher.join();
-        pump(ctx, bs);                                                               // (older jobs first; this one too if a slot is free)
-        if (j.state != JOB_WAIT_HASH) continue;
-        const int slot = acquire_slot(ctx, bs);
-        if (slot < 0) { job_fail(bs, j, KZG_ERR_INVALID_ARG); ctx->last_error = "no slot free: every slot is held by another kzg_*_begin call"; continue; }
-        if (j.state == JOB_WAIT_HASH) job_start_proof(ctx, bs, j, slot);             // (acquire_slot only collects jobs that hold a slot: not this one)
     }
 }
 

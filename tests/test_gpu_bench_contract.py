@@ -58,6 +58,13 @@ def test_bench_emits_the_contract_line():
     shapes = sec["reference_bench_shapes"]               # every criterion harness of the reference has its line: commit / proof / g1_ifft / verify
     for key in ("commit_coeff_512_ms", "compute_proof_512_ms", "g1_ifft_512_ms", "verify_proof_ms"):
         assert shapes[key] > 0, key
+    # round 6: the rest of the reference's criterion suite (bench_kzg_setup, bench_kzg_commit_large_blobs; scaled with the reduced size here) with the
+    # oracle port beside it, the blob -> commitment + proof stream, batch verification over >= 30 calls
+    assert shapes["commit_8mb_ms"] > 0 and shapes["commit_16mb_ms"] > 0 and shapes["kzg_setup_%d_ms" % (1 << 13)] > 0
+    cpu_shapes = sec["reference_bench_shapes_cpu_port"]
+    assert cpu_shapes["commit_8mb_ms"] > 0 and cpu_shapes["commit_16mb_ms"] > 0 and cpu_shapes["kzg_setup_%d_ms" % (1 << 13)] > 0
+    assert sec["commit_and_prove_blob_streamed_ms"] > 0 and sorted(sec["commit_and_prove_blob_streamed_by_jobs_in_flight_ms"]) == ["12", "8"]
+    assert sec["batch_verify_4096_end_to_end_stats"]["calls"] >= 30
     clk = d["gpu_clock_under_load"]                      # sysfs engine clock sampled in the untimed spin-up (None where sysfs does not show this GPU)
     assert clk is None or (200 < clk["sclk_mhz_min"] <= clk["sclk_mhz_mean"] <= clk["sclk_mhz_max"] < 4000 and clk["samples"] >= 1)
 
