@@ -371,10 +371,15 @@ int32_t kzg_srs_load_packed(kzg_ctx* ctx, const char* path, size_t points_to_loa
         memcpy(&n64, head + 8, 8);
         if (n64 > ((uint64_t)1 << 28)) rc = KZG_ERR_TOO_LARGE;
     }
+    if (rc == KZG_OK) {                                            // the header's count is believed only if the file has exactly that many bytes
+        const long here = ftell(f);
+        long size = -1;
+        if (here >= 0 && fseek(f, 0, SEEK_END) == 0) { size = ftell(f); if (fseek(f, here, SEEK_SET) != 0) size = -1; }
+        if (size < 0 || (uint64_t)size != (uint64_t)PACKED_HEADER + n64 * 64) rc = KZG_ERR_DESERIALIZE;   // truncated, or bytes behind the payload
+    }
     if (rc == KZG_OK) {
-        pts.resize((size_t)n64 * 8 + 1);
-        uint8_t extra;
-        if ((n64 && fread(pts.data(), 64, (size_t)n64, f) != (size_t)n64) || fread(&extra, 1, 1, f) != 0) rc = KZG_ERR_DESERIALIZE;   // truncated, or bytes behind the payload
+        try { pts.resize((size_t)n64 * 8 + 1); } catch (const std::bad_alloc&) { rc = KZG_ERR_TOO_LARGE; }
+        if (rc == KZG_OK && n64 && fread(pts.data(), 64, (size_t)n64, f) != (size_t)n64) rc = KZG_ERR_DESERIALIZE;
     }
     fclose(f);
     if (rc == KZG_OK) {
@@ -594,12 +599,12 @@ int32_t kzg_msm_g1_batch(kzg_ctx* ctx, const uint64_t* bases_xy_mont, const uint
 
 constexpr size_t MSM_SPLIT_MAX = (size_t)1 << 21;     // halves of up to 2^20 pairs: one launch each
 
-static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
+// (the caller holds ctx->mu)
+static int32_t msm_srs_locked(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
                               uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
     if (!ctx || !srs || srs->ctx->device != ctx->device || (!out_xy && !out_xyzz)) return KZG_ERR_INVALID_ARG;   // an SRS may be shared by the contexts of its GPU
     if (n && !scalars) return KZG_ERR_INVALID_ARG;
     if (offset > srs->n || n > srs->n - offset) return KZG_ERR_MSM_LENGTH_MISMATCH;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n == 0) { write_identity(out_xy, out_inf, out_xyzz); return KZG_OK; }
     const void* d_scalars = scalars;
@@ -649,6 +654,12 @@ static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, c
         if (rc != KZG_OK) return rc;
     }
     return msm_run(ctx, srs_bases(srs, offset, n, ctx->msm_c_override == 0), d_scalars, n, out_xy, out_inf, out_xyzz);
+}
+static int32_t msm_srs_common(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const void* scalars, bool on_device, size_t n,
+                              uint64_t out_xy[8], uint8_t* out_inf, uint64_t* out_xyzz) {
+    if (!ctx) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return msm_srs_locked(ctx, srs, offset, scalars, on_device, n, out_xy, out_inf, out_xyzz);
 }
 
 int32_t kzg_msm_g1_srs(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, const uint64_t* scalars_mont, size_t n,
@@ -913,9 +924,9 @@ int32_t kzg_commit_eval_form(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* e
     if (n > srs->n) return KZG_ERR_SRS_CAPACITY_EXCEEDED;             // kzg.rs:89-94
     if (n == 0 || (n & (n - 1)) != 0) return KZG_ERR_NOT_POWER_OF_TWO; // kzg.rs:265-269 (g1_ifft)
     if (n > ((size_t)1 << 28)) return KZG_ERR_DOMAIN;
+    std::lock_guard<std::mutex> lk(ctx->mu);                            // (taken BEFORE the cache is looked at: kzg_srs_drop_lagrange frees the basis under this lock)
     if (const kzg_srs* cached = srs_cached_lagrange(srs, n))            // the reference's literal form: MSM over the Lagrange basis (kzg.rs:98-100);
-        return msm_srs_common(ctx, cached, 0, evals_mont, false, n, out_xy_mont, out_is_infinity, nullptr);   // large ones in two parts, the second upload hidden
-    std::lock_guard<std::mutex> lk(ctx->mu);
+        return msm_srs_locked(ctx, cached, 0, evals_mont, false, n, out_xy_mont, out_is_infinity, nullptr);   // large ones in two parts, the second upload hidden
     KZG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     KZG_HIP_TRY(ctx, ctx->poly[0].a.reserve(n * 32));
     KZG_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly[0].a.p, evals_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));

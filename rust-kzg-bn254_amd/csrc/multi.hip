@@ -374,7 +374,11 @@ double exchange_timeout_s() {
 // One all-gather of `bytes` <= 256 payload bytes per rank (+ the status word).  local_rc != KZG_OK: this rank sends POISON.
 // gathered = world x bytes (payload only).  Returns KZG_OK, the rank's own local_rc (it was the one that failed), KZG_ERR_PEER,
 // KZG_ERR_EXCHANGE_TIMEOUT, or an argument / device error.  Caller holds no lock; takes ctx->mu.
-int32_t rccl_exchange(kzg_ctx* ctx, void* comm, int32_t world, const void* payload, size_t bytes, int32_t local_rc, std::vector<uint64_t>& gathered) {
+// *issued (optional): the collective went onto the stream -- the peers are (or will be) in it too.  A caller with a further collective in the same
+// call must skip that one only when this one was NOT issued or timed out; a status that merely echoes local_rc says nothing about that.
+int32_t rccl_exchange(kzg_ctx* ctx, void* comm, int32_t world, const void* payload, size_t bytes, int32_t local_rc, std::vector<uint64_t>& gathered,
+                      bool* issued = nullptr) {
+    if (issued) *issued = false;
     if (!ctx || !comm || world < 1 || world > 4096 || bytes > ROW_PAYLOAD_MAX || (bytes & 7)) return KZG_ERR_INVALID_ARG;
     Rccl& r = rccl();
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -389,7 +393,11 @@ int32_t rccl_exchange(kzg_ctx* ctx, void* comm, int32_t world, const void* paylo
             return KZG_ERR_INVALID_ARG;
         }
     }
-    static const bool poison_self = []() { const char* e = getenv("KZG_RCCL_TEST_POISON"); return e && atoi(e) != 0; }();   // test hook: a healthy rank that reports failure
+#ifdef KZG_TEST_HOOKS        // libkzg_bn254_mi355x_hooks.so only (make hooks; tests/test_gpu_rccl_cabi.py): a healthy rank that reports failure
+    static const bool poison_self = []() { const char* e = getenv("KZG_RCCL_TEST_POISON"); return e && atoi(e) != 0; }();
+#else
+    constexpr bool poison_self = false;
+#endif
     const size_t row = 8 + bytes, need = row * ((size_t)world + 1);
     kzg::DeviceBuffer& d = ctx->rccl_buf;
     KZG_HIP_TRY(ctx, d.reserve(need + 256));
@@ -410,6 +418,7 @@ int32_t rccl_exchange(kzg_ctx* ctx, void* comm, int32_t world, const void* paylo
         ctx->last_error = std::string("ncclAllGather: ") + (r.err ? r.err(rc) : "error");
         return KZG_ERR_DEVICE;
     }
+    if (issued) *issued = true;
     KZG_HIP_TRY(ctx, hipMemcpyAsync(pin + row, dev + row, row * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
     // bounded wait: a peer that never issues its collective must not block this rank for ever
     {
@@ -502,9 +511,15 @@ static int32_t compute_proof_rccl_common(kzg_ctx* ctx, const kzg_srs* lagrange_s
     bool in_flight = local == KZG_OK;
     if (local == KZG_OK) { local = kzg_compute_proof_lagrange_partial_y(ctx, slot, ypart); if (local != KZG_OK) in_flight = false; }
     std::vector<uint64_t> got;
-    int32_t rc = rccl_exchange(ctx, nccl_comm, world, ypart, sizeof ypart, local, got);
-    if (rc == KZG_ERR_EXCHANGE_TIMEOUT || rc == KZG_ERR_DEVICE || rc == KZG_ERR_INVALID_ARG) { if (in_flight) (void)kzg_compute_proof_lagrange_abort(ctx, slot); return rc; }
-    int32_t first = rc;                                               // KZG_OK, this rank's own error, or KZG_ERR_PEER: the second collective is issued all the same
+    bool issued = false;
+    const bool own_failure = local != KZG_OK;
+    std::string own_error = own_failure ? ctx->last_error : std::string();
+    int32_t rc = rccl_exchange(ctx, nccl_comm, world, ypart, sizeof ypart, local, got, &issued);
+    // The second collective is skipped ONLY when the first never went out (bad communicator, no RCCL: the same on every rank) or timed out (the
+    // communicator is gone).  A status that echoes this rank's own failure -- KZG_ERR_DEVICE from an allocation, KZG_ERR_INVALID_ARG from a slot
+    // in flight -- came back AFTER the collective: the peers hold KZG_ERR_PEER and are about to issue the second one, so this rank joins it too.
+    if (!issued || rc == KZG_ERR_EXCHANGE_TIMEOUT) { if (in_flight) (void)kzg_compute_proof_lagrange_abort(ctx, slot); return rc; }
+    int32_t first = rc;                                               // KZG_OK, this rank's own error, KZG_ERR_PEER, or a device error behind the collective
     if (first == KZG_OK) {
         local = kzg_lagrange_fold_y(got.data(), (size_t)world, n, z_mont, y);
         if (local == KZG_OK) local = kzg_compute_proof_lagrange_continue(ctx, slot, y);
@@ -514,7 +529,11 @@ static int32_t compute_proof_rccl_common(kzg_ctx* ctx, const kzg_srs* lagrange_s
         if (in_flight) (void)kzg_compute_proof_lagrange_abort(ctx, slot);
         local = first;
     }
-    rc = rccl_exchange(ctx, nccl_comm, world, part, sizeof part, local == KZG_ERR_PEER ? KZG_OK : local, got);
+    rc = rccl_exchange(ctx, nccl_comm, world, part, sizeof part, local == KZG_ERR_PEER ? KZG_OK : local, got, &issued);
+    if (own_failure) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->last_error = own_error + (issued ? " [this rank joined both collectives of the call with poisoned rows]" : " [the second collective could not be issued]");
+    }
     if (first != KZG_OK) return first;
     if (rc != KZG_OK) return rc;
     if (out_y_mont) memcpy(out_y_mont, y, 32);

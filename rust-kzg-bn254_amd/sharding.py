@@ -816,6 +816,8 @@ class ShardedKzgLagrange:
                     if state["bad"]:
                         inflight.append((cs, ps, z, None))
                         drain_and_raise()
+                # (buffer lifetime: the host slice `sl` is read by an asynchronous copy on the slot's stream; partial_y below waits for phase 1, which is
+                # behind that copy, BEFORE the generator is asked for its next item -- a producer that refills one pinned buffer per blob is safe)
                 ypart = np.zeros(16, dtype=np.uint64)                           # 8 words used: S_g | f_m
                 guard(lib.kzg_compute_proof_lagrange_partial_y, self.ctx.handle, ps, _lib.ptr(ypart))
                 y = np.zeros(4, dtype=np.uint64)

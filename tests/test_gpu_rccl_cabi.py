@@ -123,6 +123,13 @@ big = np.zeros((m + 1, 4), np.uint64)
 assert lib.kzg_commit_eval_form_rccl(ctx.handle, lag.handle, _lib.ptr(big), m + 1, comm, 1, _lib.ptr(g4), C.byref(inf)) == _lib.ERR_SRS_CAPACITY_EXCEEDED
 assert lib.kzg_compute_proof_rccl(ctx.handle, lag.handle, 0, _lib.ptr(big), m + 1, 2 * m, _lib.ptr(z), comm, 1, _lib.ptr(g4), C.byref(inf), None) == _lib.ERR_SRS_CAPACITY_EXCEEDED
 assert lib.kzg_commit_coeff_form_rccl(ctx.handle, srs.handle, d, n + 1, comm, 1, _lib.ptr(got2), C.byref(inf)) == _lib.ERR_MSM_LENGTH_MISMATCH
+# a local failure that comes back as KZG_ERR_INVALID_ARG (slot 0 still holds an MSM of the caller's) must NOT be taken for "no collective issued":
+# the rank joins BOTH exchanges of the call with poisoned rows (ADVICE r5: it used to skip the second one and leave its peers in it for 60 s)
+assert lib.kzg_msm_g1_srs_begin(ctx.handle, srs.handle, 0, _lib.ptr(wire), n, 0) == 0
+rc = lib.kzg_compute_proof_rccl(ctx.handle, lag.handle, 0, _lib.ptr(ev4), m, m, _lib.ptr(z), comm, 1, _lib.ptr(g4), C.byref(inf), None)
+assert rc == _lib.ERR_INVALID_ARG, rc
+assert b"joined both collectives" in lib.kzg_ctx_last_error(ctx.handle), lib.kzg_ctx_last_error(ctx.handle)
+assert lib.kzg_msm_g1_srs_end(ctx.handle, 0, _lib.ptr(got2), C.byref(inf), None) == 0 and np.array_equal(got2, want)
 # ... and the context is usable afterwards (no slot left in flight)
 assert lib.kzg_compute_proof_rccl(ctx.handle, lag.handle, 0, _lib.ptr(ev4), m, m, _lib.ptr(z), comm, 1, _lib.ptr(gp4), C.byref(inf), None) == 0
 lag.close()
@@ -133,7 +140,7 @@ print("rccl c-abi ok")
 
 
 POISONED = r'''
-# KZG_RCCL_TEST_POISON=1 (test hook of csrc/multi.hip): this healthy rank marks every row it sends as failed -> every rank of a call returns
+# KZG_RCCL_TEST_POISON=1 (test hook of csrc/multi.hip, compiled into libkzg_bn254_mi355x_hooks.so only): this healthy rank marks every row it sends as failed -> every rank of a call returns
 # KZG_ERR_PEER after the SAME collectives a successful call issues, and nothing stays in flight
 inf = C.c_uint8(0)
 part = np.zeros(16, np.uint64)
@@ -171,4 +178,8 @@ def test_rccl_exchange_behind_the_c_abi_one_rank():
 
 
 def test_rccl_failure_protocol_poisoned_rank():
-    assert "poison path ok" in run_child(POISONED, KZG_RCCL_TEST_POISON="1")
+    hooks = os.path.join(ROOT, "rust-kzg-bn254_amd", "libkzg_bn254_mi355x_hooks.so")
+    assert os.path.exists(hooks), "make -C rust-kzg-bn254_amd/csrc hooks (__graft_entry__.build() does it)"
+    assert "poison path ok" in run_child(POISONED, KZG_RCCL_TEST_POISON="1", KZG_LIB_PATH=hooks)
+    # the shipped library has no such switch: the same child, same variable, healthy results
+    assert "rccl c-abi ok" in run_child(HEALTHY, KZG_RCCL_TEST_POISON="1")
