@@ -77,3 +77,36 @@ def test_patch_touches_the_call_sites_of_the_boundary():
     for call in ("mi355x::commit_eval_form(", "mi355x::commit_coeff_form(", "mi355x::g1_ifft(", "mi355x::compute_proof(", "mi355x::fr_ntt(&self.evaluations, true)",
                  "mi355x::fr_ntt(&self.coeffs, false)", "mi355x::msm(points, scalars)"):
         assert call in plus, call
+
+
+def test_transcript_pin_in_the_patch_is_what_the_library_computes():
+    """the one convention no reference vector pins -- ark-serialize's compressed G1 flags inside compute_challenge /
+    compute_r_powers -- is planted in the reference tree as Rust tests whose constants come from THIS library (host-only entry points, no
+    GPU).  Here: the constants in the patch equal a fresh run (integration/make_transcript_pin.py), and the test sources use nothing but the
+    reference's own functions, so the first `cargo test` of a maintainer closes the pin."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
+    import make_transcript_pin as pin
+    c = pin.constants()
+    plus = "".join(added_lines())
+    for name in ("CHALLENGE_G", "CHALLENGE_NEG_G", "CHALLENGE_IDENTITY", "R_POWER_1"):
+        m = re.search(r'const %s: &str = "(\d+)";' % name, plus)
+        assert m and m.group(1) == c[name], name
+    for name in ("COMPRESSED_G", "COMPRESSED_NEG_G", "COMPRESSED_IDENTITY"):
+        m = re.search(r"const %s: \[u8; 32\] = \[([^\]]*)\];" % name, plus)
+        assert m and bytes(int(v, 16) for v in m.group(1).split(",")) == c[name], name
+    # the three encodings cover both flag bits and the no-flag case; the challenges differ pairwise, so a wrong flag cannot go unnoticed
+    assert c["COMPRESSED_G"][31] == 0x00 and c["COMPRESSED_NEG_G"][31] == 0x80 and c["COMPRESSED_IDENTITY"][31] == 0x40
+    assert len({c["CHALLENGE_G"], c["CHALLENGE_NEG_G"], c["CHALLENGE_IDENTITY"]}) == 3
+    assert pin.primitives_test(c) in plus.replace("\r", "") or all(ln in plus for ln in pin.primitives_test(c).splitlines() if ln.strip())
+    assert "fn mi355x_pin_compute_r_powers()" in plus and "primitives/tests/mi355x_transcript_pin.rs" in open(PATCH).read()
+    # independent of the library: the same transcript through hashlib and the Python mirror's serialisation (layout slips)
+    import hashlib
+    import rust_kzg_bn254_amd as k
+    from rust_kzg_bn254_amd import helpers
+    data = helpers.pad_payload(pin.RAW)
+    n = 1
+    while n < len(data) // 32:
+        n <<= 1
+    msg = b"EIGENDA_FSBLOBVERIFY_V1_" + n.to_bytes(8, "big") + data + bytes(32 * n - len(data)) + c["COMPRESSED_NEG_G"]
+    assert str(int.from_bytes(hashlib.sha256(msg).digest(), "big") % k.consts.FR_MODULUS) == c["CHALLENGE_NEG_G"]
