@@ -76,7 +76,11 @@ k_lag_inverses(const uint4* __restrict__ evals, uint32_t len, uint32_t base, Ntt
         Fr root, ri;
 #pragma unroll
         for (int j = 0; j < NL; ++j) root.l[j] = tree[j * S + 1];
+#ifdef KZG_PROBE_NO_LAG_INVERSION      // measurement build only (tools/build_variant.sh): the inversion priced at ZERO -- WRONG results; bounds what any faster inversion could gain
+        ri = root;
+#else
         fe_inverse_safegcd(ri, root);
+#endif
 #pragma unroll
         for (int j = 0; j < NL; ++j) tree[j * S + 1] = ri.l[j];
     }

@@ -173,9 +173,7 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [64, 5, 1])
-def test_sharded_msm_allgather_and_fold_world2(n):
-    world = 2
+def _run_msm_world(world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -186,9 +184,22 @@ def test_sharded_msm_allgather_and_fold_world2(n):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(r[0] for r in res) == [0, 1]
+    assert sorted(r[0] for r in res) == list(range(world))
     for _, ok, shape in res:
-        assert ok and tuple(shape) == (2, 16)
+        assert ok and tuple(shape) == (world, 16)
+
+
+@pytest.mark.parametrize("n", [64, 5, 1])
+def test_sharded_msm_allgather_and_fold_world2(n):
+    _run_msm_world(2, n)
+
+
+def test_sharded_msm_allgather_and_fold_world8():
+    """The rank count of the driver's SCALE run (N = 8), which a one-GPU box cannot rehearse with the GPU (at most 6 processes may use the
+    card there): the same host protocol -- shard bounds, bucketed all-gathers, grouped launches, mid-stream failures on one rank -- over
+    gloo with eight ranks and 64 / 20 pairs (20: shards of 2 and 3 pairs)."""
+    _run_msm_world(8, 64)
+    _run_msm_world(8, 20)
 
 
 def test_shard_bounds_cover_everything():

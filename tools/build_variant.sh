@@ -4,7 +4,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 B=/tmp/kzg_variant_$NAME; mkdir -p $B $ROOT/gpurun_variants
-for f in msm ntt poly lagrange srs g1fft capi multi ubench; do
+for f in msm ntt poly lagrange srs g1fft capi blobstream multi ubench; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $ROOT/rust-kzg-bn254_amd/csrc/$f.hip -o $B/$f.o &
 done
 wait
