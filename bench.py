@@ -48,14 +48,14 @@ N_BUFFERS = 8                  # distinct resident scalar buffers the timed step
 
 
 def host_pool_threads():
-    """Threads of the library's host pool (capi.hip host_threads_cap): 48, the hardware threads, or 1.25 x the cgroup's CPU quota, whichever is least."""
+    """Threads of the library's host pool (capi.hip host_threads_cap): 48, the hardware threads, or the cgroup's CPU quota, whichever is least."""
     if os.environ.get("KZG_HOST_THREADS_MAX"):
         return int(os.environ["KZG_HOST_THREADS_MAX"])
     cap = min(48, os.cpu_count() or 1)
     try:
         a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if a != "max":
-            cap = min(cap, max(2, int(float(a) / float(b) * 1.25)))
+            cap = min(cap, max(2, int(float(a) / float(b))))
     except (OSError, ValueError):
         pass
     return cap
@@ -889,7 +889,7 @@ def main():
             mix_floor_ms = entries / 64.0 * mix_ns / N_SIMDS * 1e-6
             out["roofline"]["valu"] = {"mixed_adds_per_launch": entries, "mixed_adds_per_pair": entries / max(1.0, units_per_launch),
                                        "mixed_adds_source": "sorted entries of the profiled launches, counted on the device (per-bit SRS tables, width-18 NAF digits: "
-                                                            "~13.8 per scalar; 15 with the fixed 17-bit windows, KZG_NAF_OFF=1)",
+                                                            "~13.8 per scalar; 15 with the fixed 17-bit windows of an SRS uploaded under KZG_NO_NAF=1)",
                                        "mads_per_mixed_add": MADS_PER_MIXED_ADD,
                                        "mad_issue_floor_ms": floor_ms, "frac_of_mad_issue_floor": floor_ms / acc_ms,
                                        "instruction_issue_floor_ms": mix_floor_ms, "frac_of_instruction_issue_floor": mix_floor_ms / acc_ms,
@@ -1269,6 +1269,7 @@ def main():
                 out["secondary"]["reference_bench_shapes_cpu_port"] = shapes_cpu
             # CPU baseline of the Fr NTT (primitives/src/polynomial.rs:130-140, :241-251): radix-2, every layer chunked over the cores
             t1 = time.perf_counter()
+            cores = orc.host_cpus()                                # (the layers are chunked over the CPUs the cgroup's quota really grants: 256 threads under a 16-CPU quota run slower)
             cpu_f = orc.fr_ntt_mt(scalars_b, inverse=False, threads=cores)
             ntt_all_s = time.perf_counter() - t1
             t1 = time.perf_counter()

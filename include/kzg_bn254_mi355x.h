@@ -18,6 +18,16 @@
  * A context is bound to one GPU; calls on one context are serialised internally, different
  * contexts may be used concurrently from different threads.  There is NO CPU fallback: without a
  * usable HIP device kzg_ctx_create fails with KZG_ERR_NO_DEVICE.
+ *
+ * ENVIRONMENT.  The library reads eleven variables and no others (csrc/engine.h `kzg::Opts`):
+ *   KZG_NO_PRECOMPUTE=1, KZG_NO_NAF=1     SRS uploads without any tables / without the per-bit tables (read at every upload)
+ *   KZG_HOST_THREADS_MAX, KZG_HOST_THREADS cap of (default min(48, hardware threads, the cgroup's CPU quota)) / exact width of the host pool
+ *   KZG_VB_GROUP_BYTES, KZG_VB_CHUNK_BYTES, KZG_VB_TRACE   batch verification: bytes per GPU round / per upload chunk; phase times on stderr
+ *   KZG_ROCTX=1                           roctx ranges around the host phases (rocprofv3 --marker-trace)
+ *   KZG_NTT_TILE_LOG=10 / 11              one tile size of the Fr NTT at every transform size
+ *   KZG_EXCHANGE_TIMEOUT_S, KZG_RCCL_LIB  the _rccl entries: seconds to wait for a collective (60); the RCCL to dlopen
+ * Per-context settings are calls (kzg_ctx_set_msm_window, kzg_ctx_set_reduction_lanes).  Entry points marked MEASUREMENT ONLY below
+ * (kzg_ctx_set_profiling, kzg_ctx_get_msm_profile*, kzg_ctx_measure_valu_rates) exist for bench.py's roofline figures; a host binding can leave them out.
  */
 #ifndef KZG_BN254_MI355X_H
 #define KZG_BN254_MI355X_H
@@ -73,7 +83,7 @@ int32_t kzg_ctx_set_msm_window(kzg_ctx* ctx, int32_t c_bits, int32_t segment_len
 /* Lanes per point of the table-mode bucket-reduction kernels: 0 = automatic (lane quads for an MSM that runs alone, lane pairs
  * beside another MSM in flight), 2 = always pairs, 4 = always quads.  Results are identical; a test / measurement hook. */
 int32_t kzg_ctx_set_reduction_lanes(kzg_ctx* ctx, int32_t lanes);
-/* Measurement aid: when enabled, every MSM launch is bracketed phase by phase with HIP events on the
+/* MEASUREMENT ONLY (bench.py's roofline): when enabled, every MSM launch is bracketed phase by phase with HIP events on the
  * context's launch stream.  phase_ms_out[0..7] = accumulated milliseconds of: digits, bucket scan, scatter,
  * segment map, bucket ACCUMULATE (the dominant kernel), bucket finalise, window reduction, whole device span;
  * *launches / *pairs = launches and (scalar, point) pairs covered.  Enabling resets the counters. */
@@ -82,7 +92,7 @@ int32_t kzg_ctx_get_msm_profile(kzg_ctx* ctx, double phase_ms_out[8], uint64_t* 
 /* *entries = sorted entries (= mixed additions of the accumulate kernel) of the launches profiled since kzg_ctx_set_profiling(ctx, 1):
  * windows x pairs with the fixed-window tables, data dependent (~254 / (w + 1) + 1/2 per scalar) in the NAF mode of the per-bit tables. */
 int32_t kzg_ctx_get_msm_profile_entries(kzg_ctx* ctx, uint64_t* entries);
-/* Measurement aid: issue rate of the instruction classes the MSM accumulate kernel consists of, on this device, with
+/* MEASUREMENT ONLY: issue rate of the instruction classes the MSM accumulate kernel consists of, on this device, with
  * `waves_per_simd` waves per SIMD (the kernel runs 3): out_ns[0..5] = nanoseconds per wave-instruction per SIMD of
  * v_mad_i64_i32, v_mul_lo_u32, v_ashrrev_i64, v_and_b32, v_sub_u32 (the plain 32-bit class), s_nop.  ~60 ms of GPU time. */
 int32_t kzg_ctx_measure_valu_rates(kzg_ctx* ctx, int32_t waves_per_simd, double out_ns[6]);
@@ -525,7 +535,7 @@ int32_t kzg_compute_r_powers(const uint64_t* commitments_xy_mont, const uint64_t
 /* helpers::compute_challenges_and_evaluate_polynomial (primitives/src/helpers.rs:613-662) for n blobs in ONE call:
  * out_zs[i] = compute_challenge(blob_i, commitment_i) (helpers.rs:411-472), out_ys[i] = p_i(z_i) (helpers.rs:475-535).
  * blobs[i] / blob_lens[i] = the padded bytes of blob i (Blob::data()).  The n transcripts are hashed on a pool of host threads
- * (KZG_HOST_THREADS, default: all cores up to 48 = KZG_HOST_THREADS_MAX); the n barycentric evaluations run as one batched GPU launch for blobs of up to
+ * (KZG_HOST_THREADS_MAX, default min(48, hardware threads, the cgroup's CPU quota)); the n barycentric evaluations run as one batched GPU launch for blobs of up to
  * 4096 field elements (one workgroup per blob, one inversion per blob) and through the single-polynomial path beyond.  Errors, for
  * the first failing blob in order: KZG_ERR_TOO_LARGE (polynomial.rs:42-46), KZG_ERR_G1_NOT_ON_CURVE (helpers.rs:413),
  * KZG_ERR_ZERO_LENGTH (empty blob: helpers.rs:554-558). */

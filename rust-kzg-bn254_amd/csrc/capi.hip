@@ -26,8 +26,7 @@ struct RoctxApi {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
     RoctxApi() {
-        const char* e = getenv("KZG_ROCTX");
-        if (!e || atoi(e) == 0) return;
+        if (!opts().roctx) return;
         void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
@@ -42,6 +41,27 @@ const RoctxApi& roctx_api() { static const RoctxApi api; return api; }
 }  // namespace
 void roctx_push(const char* name) { const RoctxApi& a = roctx_api(); if (a.push) (void)a.push(name); }
 void roctx_pop() { const RoctxApi& a = roctx_api(); if (a.pop) (void)a.pop(); }
+
+// ---- the environment variables of the library, all of them (engine.h Opts; documented in the header and in INTEGRATION.md) ------------------
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
+const Opts& opts() {
+    static const Opts o = []() {
+        Opts v;
+        v.host_threads_max = env_int("KZG_HOST_THREADS_MAX", 0);
+        v.host_threads = env_int("KZG_HOST_THREADS", 0);
+        v.vb_trace = env_int("KZG_VB_TRACE", 0);
+        { const char* e = getenv("KZG_VB_GROUP_BYTES"); v.vb_group_bytes = e && atol(e) > 0 ? (size_t)atol(e) : 0; }
+        { const char* e = getenv("KZG_VB_CHUNK_BYTES"); v.vb_chunk_bytes = e && atol(e) > 0 ? (size_t)atol(e) : 0; }
+        v.roctx = env_int("KZG_ROCTX", 0) != 0;
+        { const char* e = getenv("KZG_EXCHANGE_TIMEOUT_S"); const double t = e ? atof(e) : 60.0; v.exchange_timeout_s = t > 0 ? t : 60.0; }
+        { const char* e = getenv("KZG_RCCL_LIB"); v.rccl_lib = e && *e ? e : nullptr; }
+        v.ntt_tile_log = env_int("KZG_NTT_TILE_LOG", 0);
+        return v;
+    }();
+    return o;
+}
+bool opt_no_precompute() { return env_int("KZG_NO_PRECOMPUTE", 0) != 0; }
+bool opt_no_naf() { return env_int("KZG_NO_NAF", 0) != 0; }
 
 int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where) {
     if (ctx) {
@@ -134,8 +154,6 @@ int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
             ctx->acc_wave_slots = (uint32_t)cus * 4u * 3u;                // k_msm_accumulate: 3 waves per SIMD (KZG_ACC_WAVES)
         else (void)hipGetLastError();
-        const char* env = getenv("KZG_ACC_SLOTS");
-        if (env && atoi(env) > 0) { ctx->acc_wave_slots = (uint32_t)atoi(env); ctx->acc_slots_forced = true; }
     }
     {
         std::lock_guard<std::mutex> lk(g_ctx_count_mu);          // (taken before the handle exists: no call on it can reach a cache that kzg_ctx_destroy is freeing)
@@ -614,14 +632,11 @@ static int32_t msm_srs_locked(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, c
         // partial sums are added on the host.  Resident, two halves cost what the whole costs (tools/probe_split_lone.py: 2^19 0.872 against
         // 0.887 ms, 2^20 1.444 against 1.445) -- so the hidden part of the upload is the gain: 2^19 1.15 -> 1.07 ms, 2^20 2.00 -> 1.76.
         // Below 2^19 pairs the second bucket set costs more than the hidden copy (2^18: 0.601 against 0.553 resident).  KZG_SPLIT_UPLOAD=0: off.
-        static const bool split_on = []() { const char* e = getenv("KZG_SPLIT_UPLOAD"); return !(e && atoi(e) == 0); }();
         // share of the FIRST half (the smaller it is, the sooner the GPU starts and the more of the upload is hidden; too small and the second MSM runs alone):
         // measured from host buffers, 0.375 / 0.44 / 0.5 / 0.56: 2^19 1.116 / 1.070 / 1.084 / 1.111 ms (unsplit 1.148), 2^20 1.756 / 1.786 / 1.901 / 1.863 (unsplit 2.000)
-        static const double frac_env = []() { const char* e = getenv("KZG_SPLIT_FRAC"); const double v = e ? atof(e) : 0.0; return v > 0.05 && v < 0.95 ? v : 0.0; }();
-        const double split_frac = frac_env > 0.0 ? frac_env : (n >= ((size_t)1 << 20) ? 0.375 : 0.44);
+        const double split_frac = n >= ((size_t)1 << 20) ? 0.375 : 0.44;
         const bool idle = !ctx->slot_pending[0] && !ctx->slot_pending[1] && ctx->lag[0].phase == 0 && ctx->lag[1].phase == 0;
-        static const size_t split_min = []() { const char* e = getenv("KZG_SPLIT_MIN_LOG"); const int v = e ? atoi(e) : 19; return (size_t)1 << (v >= 14 && v <= 21 ? v : 19); }();
-        if (split_on && idle && n >= split_min && n <= MSM_SPLIT_MAX && ctx->msm_c_override == 0 && srs_bits(srs)) {
+        if (idle && n >= ((size_t)1 << 19) && n <= MSM_SPLIT_MAX && ctx->msm_c_override == 0 && srs_bits(srs)) {
             const size_t half = ((size_t)((double)n * split_frac) + 255) / 256 * 256;
             const uint64_t* sc = static_cast<const uint64_t*>(scalars);
             const size_t lo[2] = {0, half}, len[2] = {half, n - half};
@@ -1160,9 +1175,8 @@ int32_t kzg_commit_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_t* blob_by
     {
         // over the cached Lagrange basis a large blob goes in TWO parts on two slots, as msm_srs_common does for scalars: bytes -> Fr and the MSM of the
         // first part run while this thread sits in the upload of the second (no IFFT ties the parts together)
-        static const bool split_on = []() { const char* e = getenv("KZG_SPLIT_UPLOAD"); return !(e && atoi(e) == 0); }();
         const bool idle = !ctx->slot_pending[0] && !ctx->slot_pending[1] && ctx->lag[0].phase == 0 && ctx->lag[1].phase == 0;
-        if (cached && split_on && idle && n >= ((size_t)1 << 19) && n <= MSM_SPLIT_MAX && ctx->msm_c_override == 0 && srs_bits(cached)) {
+        if (cached && idle && n >= ((size_t)1 << 19) && n <= MSM_SPLIT_MAX && ctx->msm_c_override == 0 && srs_bits(cached)) {
             const size_t half = ((size_t)((double)n * (n >= ((size_t)1 << 20) ? 0.375 : 0.44)) + 255) / 256 * 256;
             const size_t e_lo[2] = {0, half}, e_n[2] = {half, n - half};
             int32_t rc = KZG_OK;
@@ -1531,16 +1545,15 @@ double cgroup_cpu_quota() {
     return q;
 }
 unsigned host_threads_cap() {
-    // 48 threads at most; under a CPU quota of Q, 1.25 Q: the pool is busy ~60 % of a call, so back-to-back calls average ~0.8 Q CPUs and
-    // leave the rest to the HIP runtime's threads (measured on a 16-CPU quota, 4 096 blobs per call, 60 calls each: 48 threads median 6.2 ms /
-    // max 24 / 123 ms of CPU per call; 32: 6.1 / 15 / 109; 24: 6.8 / 7.2 / 100; 20: 6.9 / 7.0 / 88; 16: 7.7 / 7.8 / 84; 12: 9.4 / 9.8 / 86).
+    // 48 threads at most; under a CPU quota of Q, Q threads: the pool then never draws more than the quota, whatever else the process runs (HIP's
+    // helper threads, the caller's own).  Measured on a 16-CPU quota, 4 096 blobs per call, 60 calls each: 48 threads median 6.2 ms / max 24 / 123 ms of CPU per
+    // call; 32: 6.1 / 15 / 109; 24: 6.8 / 7.2 / 100; 20: 6.9 / 7.0 / 88 (but 13.7 once in 40 calls inside bench.py); 16: 7.7 / 7.8 / 84; 12: 9.4 / 9.8 / 86.
     // KZG_HOST_THREADS_MAX overrides.
     static const unsigned cap = []() {
-        const char* e = getenv("KZG_HOST_THREADS_MAX");
-        if (e && atoi(e) >= 1 && atoi(e) <= 256) return (unsigned)atoi(e);
+        if (opts().host_threads_max >= 1 && opts().host_threads_max <= 256) return (unsigned)opts().host_threads_max;
         unsigned c = 48;
         const double q = cgroup_cpu_quota();
-        if (q > 0) c = std::min<unsigned>(c, std::max<unsigned>(2u, (unsigned)(q * 1.25)));
+        if (q > 0) c = std::min<unsigned>(c, std::max<unsigned>(2u, (unsigned)q));
         return c;
     }();
     return cap;
@@ -1549,7 +1562,7 @@ unsigned host_threads(size_t jobs) {
     unsigned t = std::thread::hardware_concurrency();
     if (t == 0) t = 4;
     if (t > host_threads_cap()) t = host_threads_cap();
-    { const char* env = getenv("KZG_HOST_THREADS"); if (env && atoi(env) > 0) t = (unsigned)atoi(env); }   // exactly that many (measurements)
+    if (opts().host_threads > 0) t = (unsigned)opts().host_threads;                                         // exactly that many (measurements)
     if ((size_t)t > jobs) t = (unsigned)jobs;
     return t ? t : 1;
 }
@@ -1629,9 +1642,9 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
     std::vector<int32_t> status(n, KZG_OK);
     std::vector<VbMeta> meta(n);
     std::vector<size_t> group_end;                            // blob index where each GPU round ends
-    // (KZG_VB_GROUP_BYTES / KZG_VB_CHUNK_BYTES: test hooks that make small batches take the multi-round / multi-chunk paths)
-    static const size_t group_bytes = []() { const char* e = getenv("KZG_VB_GROUP_BYTES"); return e && atol(e) > 0 ? (size_t)atol(e) : VB_GROUP_BYTES; }();
-    static const size_t chunk_bytes = []() { const char* e = getenv("KZG_VB_CHUNK_BYTES"); return e && atol(e) > 0 ? (size_t)atol(e) : ((size_t)16 << 20); }();
+    // (KZG_VB_GROUP_BYTES / KZG_VB_CHUNK_BYTES: staging granularity; tests shrink them so that small batches take the multi-round / multi-chunk paths)
+    const size_t group_bytes = opts().vb_group_bytes ? opts().vb_group_bytes : VB_GROUP_BYTES;
+    const size_t chunk_bytes = opts().vb_chunk_bytes ? opts().vb_chunk_bytes : ((size_t)16 << 20);
     size_t off = 0;
     for (size_t i = 0; i < n; ++i) {
         const size_t elems = (lens[i] + 31) / 32;
@@ -1684,7 +1697,7 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
         std::vector<std::atomic<uint32_t>> left(chunk_lo.size());
         for (size_t c = 0; c < chunk_lo.size(); ++c) left[c].store((uint32_t)(chunk_hi[c] - chunk_lo[c]));
         std::atomic<int32_t> enqueue_rc{KZG_OK};
-        static const bool trace_chunks = []() { const char* e = getenv("KZG_VB_TRACE"); return e && atoi(e) >= 2; }();
+        const bool trace_chunks = opts().vb_trace >= 2;
         std::vector<double> enq_at(chunk_lo.size(), 0.0), enq_took(chunk_lo.size(), 0.0);
         std::vector<hipEvent_t> chunk_ev(trace_chunks ? chunk_lo.size() : 0);
         hipEvent_t ev0 = nullptr;
@@ -1743,7 +1756,7 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
         if (rc != KZG_OK) return rc;
         for (size_t i = g0; i < g1; ++i) if (status[i] != KZG_OK) return status[i];      // the first failing blob, in order
         {
-            static const bool trace = []() { const char* e = getenv("KZG_VB_TRACE"); return e && atoi(e) != 0; }();
+            const bool trace = opts().vb_trace != 0;
             if (trace)
                 fprintf(stderr, "  blobs [%zu, %zu): %zu packed bytes in %zu chunks; transcripts + pack %.3f ms (%u host threads, uploads and kernels beside them), "
                         "the rest of the GPU work + D2H %.3f ms\n", g0, g1, bytes, chunk_lo.size(),
@@ -1841,7 +1854,7 @@ int32_t kzg_verify_blob_kzg_proof_batch(kzg_ctx* ctx, const uint8_t* const* blob
     if (!ctx || !out_ok) return KZG_ERR_INVALID_ARG;
     if (n && (!blobs || !blob_lens || !commitments_xy_mont || !proofs_xy_mont)) return KZG_ERR_INVALID_ARG;
     using namespace kzg_host;
-    static const bool trace = []() { const char* e = getenv("KZG_VB_TRACE"); return e && atoi(e) != 0; }();   // phase times on stderr
+    const bool trace = opts().vb_trace != 0;                                                                   // phase times on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_start = now();

@@ -99,8 +99,7 @@ struct kzg_ctx {
     bool profiling = false;
     bool lds_attr_set = false;
     bool poly_lds_attr_set = false;
-    uint32_t acc_wave_slots = 3 * 1024;   // resident waves of the accumulate kernel on this device: 3 per SIMD x 4 SIMDs x CUs (set at kzg_ctx_create)
-    bool acc_slots_forced = false;         // KZG_ACC_SLOTS given: use exactly that many (else make_plan takes 2 of the 3 per SIMD where that pays)
+    uint32_t acc_wave_slots = 3 * 1024;   // resident waves of the accumulate kernel on this device: 3 per SIMD x 4 SIMDs x CUs (set at kzg_ctx_create; make_plan takes 2 of the 3 per SIMD where that pays)
     kzg::MsmWorkspace msm;
     kzg::MsmWorkspace msm_x[KZG_NUM_SLOTS - 1];   // workspaces of slots 1.. of the asynchronous calls
     hipStream_t stream_x[KZG_NUM_SLOTS - 1] = {}; // one stream per slot (slot 0: `stream`), created on first use
@@ -171,10 +170,8 @@ constexpr size_t SRS_NAF_MIN = (size_t)1 << 11;       // an SRS of at least this
 constexpr size_t MSM_NAF_MIN = (size_t)1 << 14;       // MSMs of at least this many pairs use them (width-w NAF digits): one at a time 2^14 0.296 -> 0.273 ms; 2^13 0.241 -> 0.273: not below
 // bucket bits (c: 2^(c-1) buckets, NAF width c + 1) of an MSM of n pairs over the per-bit tables: the window policy of srs_precompute, by MSM length
 inline int srs_naf_c(size_t n) {
-    static const int forced = []() { const char* e = getenv("KZG_NAF_C"); return e ? atoi(e) : 0; }();
-    if (forced == 13 || (forced >= 15 && forced <= 17)) return forced;          // (13: 32 digit words per scalar; 15..17: 16)
-    if (n < ((size_t)1 << 15)) return 13;
-    // measured (tools/time_shard_inflight.py, KZG_NAF_C = 15 / 16 / 17, two or three MSMs in flight, ms per MSM): 2^17 0.257 / 0.264 / 0.284,
+    if (n < ((size_t)1 << 15)) return 13;                                       // (13: 32 digit words per scalar; 15..17: 16)
+    // measured (tools/time_shard_inflight.py, c = 15 / 16 / 17, two or three MSMs in flight, ms per MSM): 2^17 0.257 / 0.264 / 0.284,
     // 2^18 0.362 / 0.355 / 0.404, 2^19 0.678 / 0.631 / 0.629, 2^20 1.307 / 1.227 / 1.188 (profiles/r03_naf.md)
     return n >= ((size_t)1 << 20) ? 17 : n >= ((size_t)1 << 18) ? 16 : 15;
 }
@@ -193,13 +190,11 @@ inline MsmBases srs_bases(const kzg_srs* srs, size_t offset, size_t n, bool allo
     if (allow_tables && srs->pre_W > 0) {
         b.table_stride = (uint32_t)srs->n; b.c = srs->pre_c; b.W = srs->pre_W;
         if (srs->d_small && n <= SRS_SMALL_MAX) { b.points = srs->d_small + 4 * offset; b.c = srs->small_c; b.W = srs->small_W; }
-        static const bool naf_off = []() { const char* e = getenv("KZG_NAF_OFF"); return e && atoi(e) != 0; }();   // A/B: tables built, not used
-        static const size_t naf_min = []() { const char* e = getenv("KZG_NAF_MIN_LOG"); return e && atoi(e) >= 10 && atoi(e) <= 24 ? (size_t)1 << atoi(e) : MSM_NAF_MIN; }();
-        static const size_t bitsum_max = []() { const char* e = getenv("KZG_BITSUM_MAX"); return e ? (size_t)atoi(e) : (size_t)4096; }();   // 0: off; measured, one commitment at a time: 2^9 0.108 -> 0.066 ms, 2^10 0.120 -> 0.077, 2^11 0.157 -> 0.100, 2^12 0.176 -> 0.135, 2^13 0.197 -> 0.204
-        if (srs->d_bits && n <= bitsum_max && n <= 8192 && !naf_off) {
+        // bit sums up to 4 096 pairs; measured, one commitment at a time: 2^9 0.108 -> 0.066 ms, 2^10 0.120 -> 0.077, 2^11 0.157 -> 0.100, 2^12 0.176 -> 0.135, 2^13 0.197 -> 0.204
+        if (srs->d_bits && n <= 4096) {
             b.points = srs->d_bits + 4 * offset; b.c = 0; b.W = 255; b.bitsum = true;
         }
-        if (srs->d_bits && n >= naf_min && !naf_off) {
+        if (srs->d_bits && n >= MSM_NAF_MIN) {
             b.points = srs->d_bits + 4 * offset; b.c = srs_naf_c(n); b.W = 255; b.naf = true;
         }
     }
@@ -261,6 +256,23 @@ int32_t srs_upload_plain(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_poin
 
 // joins the transcript threads and frees the buffers of the blob stream (kzg_ctx_destroy)
 void blob_stream_release(kzg_ctx* ctx);
+
+// Every environment variable the library reads (capi.hip opts(); header: "ENVIRONMENT").  Read once per process, except the two SRS switches,
+// which are read at every upload so that a host can load one SRS with and one without tables (bench.py does).
+struct Opts {
+    int host_threads_max = 0;        // KZG_HOST_THREADS_MAX: cap of the host pool (transcripts of batch verification); 0 = min(48, the cgroup's CPU quota)
+    int host_threads = 0;            // KZG_HOST_THREADS: exactly that many pool threads (measurements)
+    int vb_trace = 0;                // KZG_VB_TRACE: 1 = phase times of batch verification on stderr, 2 = per upload chunk
+    size_t vb_group_bytes = 0;       // KZG_VB_GROUP_BYTES: packed blob bytes per GPU round of batch verification (default 256 MiB)
+    size_t vb_chunk_bytes = 0;       // KZG_VB_CHUNK_BYTES: bytes per upload chunk inside a round (default 16 MiB)
+    bool roctx = false;              // KZG_ROCTX: roctx ranges around the host phases (rocprofv3 --marker-trace)
+    double exchange_timeout_s = 60;  // KZG_EXCHANGE_TIMEOUT_S: bound of the wait for a collective of the _rccl entries
+    const char* rccl_lib = nullptr;  // KZG_RCCL_LIB: the RCCL to dlopen instead of the one already in the process
+    int ntt_tile_log = 0;            // KZG_NTT_TILE_LOG: 10 / 11 = one NTT tile size at every transform size (0: by size)
+};
+const Opts& opts();
+bool opt_no_precompute();            // KZG_NO_PRECOMPUTE=1: SRS uploads build no window tables (and no per-bit tables): 64 B per point
+bool opt_no_naf();                   // KZG_NO_NAF=1: SRS uploads build no per-bit tables (16 KiB per point saved; fixed-window MSMs)
 
 // process-wide caches keyed by device (NTT twiddles, g1_ifft scalar sets): released when the LAST context of a device is destroyed
 void ntt_release_device_caches(int dev);

@@ -778,16 +778,6 @@ k_g1fft_bits(const uint4* __restrict__ bits, uint32_t stride, const uint4* __res
     }
     if (pair == 0) half_store(partial, (size_t)n * waves_per_out, (size_t)o * waves_per_out + wv, acc, odd);
 }
-// scalars of the transform as n MSMs of n pairs (the batched table mode of msm.hip): out[o n + j] = w^(-o j) / n, wire words
-__global__ void __launch_bounds__(256)
-k_g1fft_expand_scalars(const uint4* __restrict__ tab_wire, uint32_t n, uint4* __restrict__ out) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * n) return;
-    const uint32_t o = (uint32_t)(t / n), j = (uint32_t)(t - (size_t)o * n);
-    const uint32_t e = (uint32_t)((unsigned long long)o * j) & (n - 1);
-    out[2 * t] = tab_wire[2 * (size_t)e];
-    out[2 * t + 1] = tab_wire[2 * (size_t)e + 1];
-}
 // y[o] = sum of the waves_per_out (<= 32) partial sums of output o: one wave per output
 __global__ void __launch_bounds__(256)
 k_g1fft_sum_partials(const int32_t* __restrict__ partial, uint32_t waves_per_out, uint32_t n, int32_t* __restrict__ y) {
@@ -949,14 +939,12 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
     if (rc == KZG_OK) rc = get_scalars(ctx, log_n, true, &scal_n);
     if (rc != KZG_OK) return rc;
     const int32_t* result = bufA;
-    // 64 .. 256 points of an SRS with per-bit tables: the whole transform as sums of table points (k_g1fft_bits; KZG_G1FFT_BITS=0: off);
+    // 64 .. 256 points of an SRS with per-bit tables: the whole transform as sums of table points (k_g1fft_bits);
     // 512 .. 2048 points: the FIRST STAGE that way (radix 2^K0 over the SRS points: n 2^K0 x 64 mixed additions at the chip's throughput
-    // instead of a 127-step scalar-multiplication chain), the rest as one direct stage on lane pairs (KZG_G1FFT_BITS_FIRST=0: off)
-    static const bool use_bits = []() { const char* e = getenv("KZG_G1FFT_BITS"); return !(e && atoi(e) == 0); }();
-    static const bool use_bits_first = []() { const char* e = getenv("KZG_G1FFT_BITS_FIRST"); return !(e && atoi(e) == 0); }();
+    // instead of a 127-step scalar-multiplication chain), the rest as one or two direct stages on lane quads
     uint4* const d_bits = srs_bits(srs);
-    const bool whole_by_bits = use_bits && d_bits && srs->lagrange_of == 0 && n >= 64 && n <= 256;
-    const bool first_by_bits = use_bits && use_bits_first && d_bits && srs->lagrange_of == 0 && n >= 512 && n <= G1FFT_T3_MAX;
+    const bool whole_by_bits = d_bits && srs->lagrange_of == 0 && n >= 64 && n <= 256;
+    const bool first_by_bits = d_bits && srs->lagrange_of == 0 && n >= 512 && n <= G1FFT_T3_MAX;
     uint4* d_t3 = nullptr;
     uint32_t t3_points = 0;
     if (whole_by_bits || first_by_bits) {
@@ -1004,30 +992,18 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
     if (first_by_bits) {
         // Plan (bits of the stages, first one through the per-bit tables): the later stages are one 127-step GLV chain deep each, pure latency
         // while they fit one wave per SIMD (65 536 lanes = 16 384 quads = n 2^K <= 16 384).  512 = 2^4 . 2^5, 1024 = 2^6 . 2^4, 2048 = 2^5 . 2^3 . 2^3
-        // (measured, tools/time_g1ifft.py; KZG_G1FFT_PLAN="k0,k1[,k2]" overrides, KZG_G1FFT_QUADS=0: the later stages on lane pairs, K <= 5).
+        // (measured against 5,4 / 3,3,3 / 5,5 / 4,3,3 / 6,5 / 7,4 and against the later stages on lane pairs: tools/time_g1ifft.py, profiles/r03d_quad.md).
         int plan[4] = {0, 0, 0, 0}, np = 0;
-        static const bool use_quads = []() { const char* e = getenv("KZG_G1FFT_QUADS"); return !(e && atoi(e) == 0); }();
-        if (const char* e = getenv("KZG_G1FFT_PLAN")) {
-            int a0 = 0, a1 = 0, a2 = 0;
-            const int got = sscanf(e, "%d,%d,%d", &a0, &a1, &a2);
-            if (got >= 2 && a0 >= 1 && a0 <= 7 && a1 >= 1 && a1 <= 5 && (got < 3 || (a2 >= 1 && a2 <= 5)) && a0 + a1 + (got == 3 ? a2 : 0) == log_n) {
-                plan[0] = a0; plan[1] = a1; np = 2;
-                if (got == 3) { plan[2] = a2; np = 3; }
-            }
-        }
-        if (np == 0) {
-            if (!use_quads) { plan[1] = std::min(5, log_n - 1); plan[0] = log_n - plan[1]; np = 2; }
-            else if (log_n == 9) { plan[0] = 4; plan[1] = 5; np = 2; }
-            else if (log_n == 10) { plan[0] = 6; plan[1] = 4; np = 2; }
-            else { plan[0] = 5; plan[1] = 3; plan[2] = 3; np = 3; }
-        }
+        if (log_n == 9) { plan[0] = 4; plan[1] = 5; np = 2; }
+        else if (log_n == 10) { plan[0] = 6; plan[1] = 4; np = 2; }
+        else { plan[0] = 5; plan[1] = 3; plan[2] = 3; np = 3; }
         const int K0 = plan[0];
 #if !defined(KZG_G1FFT_QUAD_LDS) || defined(KZG_G1FFT_QUAD_W1)
         constexpr size_t QUAD_TAB_LDS = 0;
 #else
         constexpr size_t QUAD_TAB_LDS = (size_t)16 * NL * 256 * 4;     // entries 1 .. 15 of every lane (entry 0 unused): 144 KiB of the CU's 160
         static bool quad_attr_set = false;
-        if (use_quads && !quad_attr_set) {
+        if (!quad_attr_set) {
             KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1fft_mul_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUAD_TAB_LDS));
             quad_attr_set = true;
         }
@@ -1053,14 +1029,9 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
             const int log_s = log_n - done;
             const bool last = i == np - 1;
             const size_t slots = n << K;
-            if (use_quads) {
-                hipLaunchKernelGGL(k_g1fft_mul_quads, dim3((unsigned)((4 * slots + 255) / 256)), dim3(256), QUAD_TAB_LDS, st, src, partial, (uint32_t)n, log_n, K, log_s,
-                                   last ? scal_n : scal, last ? 1 : 0);
-                hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, (uint32_t)1 << K, (uint32_t)n, dst);
-            } else {
-                hipLaunchKernelGGL(k_g1fft_direct_pairs, dim3((unsigned)((2 * slots + 255) / 256)), dim3(256), 0, st, src, dst, (uint32_t)n, log_n, K, log_s,
-                                   last ? scal_n : scal, last ? 1 : 0);
-            }
+            hipLaunchKernelGGL(k_g1fft_mul_quads, dim3((unsigned)((4 * slots + 255) / 256)), dim3(256), QUAD_TAB_LDS, st, src, partial, (uint32_t)n, log_n, K, log_s,
+                               last ? scal_n : scal, last ? 1 : 0);
+            hipLaunchKernelGGL(k_g1fft_sum_partials, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, partial, (uint32_t)1 << K, (uint32_t)n, dst);
             std::swap(src, dst);
         }
         KZG_HIP_TRY(ctx, hipGetLastError());
@@ -1073,14 +1044,12 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
     // wave already issues most of what its SIMD can: two pair waves per SIMD took 1.44 ms).  Candidates:
     //   direct stages of radix 2^K (one lane or pair per (output, term): n 2^K lanes or pairs), K <= 5
     //   radix-2 butterflies (n / 2 lanes or pairs, work bound: one multiplication per two outputs)
-    static const int force_pairs = []() { const char* e = getenv("KZG_G1FFT_PAIRS"); return e ? atoi(e) : -1; }();   // 0 / 1: force one mode (A/B)
     int kmax = 0;
     bool pairs = false;
     {
         const double t_lane = 1.25, t_pair = 0.83, cap = 65536.0;
         double best = 1e300;
         for (int mode = 0; mode < 2; ++mode) {                        // 0: one lane per point, 1: lane pairs
-            if (force_pairs >= 0 && mode != (force_pairs ? 1 : 0)) continue;
             const double t1 = mode ? t_pair : t_lane, width = mode ? 2.0 : 1.0;
             for (int K = 2; K <= 5 && K <= std::max(log_n, 2); ++K) {  // direct stages
                 const double lanes = (double)n * (double)(1u << K) * width;
@@ -1092,17 +1061,14 @@ static int32_t g1_ifft_stages(kzg_ctx* ctx, const kzg_srs* srs, size_t n, const 
             if (cost2 < best) { best = cost2; kmax = 0; pairs = mode != 0; }
         }
     }
-    const char* env = getenv("KZG_G1FFT_RADIX_BITS");
-    if (env) kmax = std::max(0, std::min(5, atoi(env)));
     if (log_n == 0) {
         hipLaunchKernelGGL(k_g1fft_load, dim3(gn), dim3(256), 0, st, srs->d_points, (uint32_t)n, bufA, 0);
     } else if (kmax >= 2) {
         const int stages = (log_n + kmax - 1) / kmax;
         // the first stage through the SRS window tables when the SRS has them and the stage fits four waves per SIMD
-        // (KZG_G1FFT_TABLES=0: off).  Prefers the narrow (c = 15) set: fewer double-and-add steps per digit.
-        static const bool use_tables = []() { const char* e = getenv("KZG_G1FFT_TABLES"); return !(e && atoi(e) == 0); }();
+        // Prefers the narrow (c = 15) set: fewer double-and-add steps per digit.
         const uint4* tab = nullptr; int tab_c = 0, tab_W = 0;
-        if (use_tables && srs->lagrange_of == 0) {
+        if (srs->lagrange_of == 0) {
             if (srs->d_small) { tab = srs->d_small; tab_c = srs->small_c; tab_W = srs->small_W; }
             else if (srs->pre_W > 0) { tab = srs->d_points; tab_c = srs->pre_c; tab_W = srs->pre_W; }
         }
@@ -1170,39 +1136,7 @@ int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out,
 // on the device it is a 380-multiplication chain on lone lanes, 0.2 ms whatever n -- two thirds of a g1_ifft of 2..32 points.
 constexpr size_t G1FFT_HOST_AFFINE_MAX = 256;
 
-// The transform as n MSMs of n pairs over the per-bit tables: L_o = sum_j [w^(-o j) / n] P_j is the "commitment" of the scalar row o,
-// so the batched table mode of the MSM engine (msm.hip msm_run_batch_tables: width-8 NAF digits, 64 buckets per output, one sort, the
-// accumulate kernel, one reduction group per output) computes all n outputs in one kernel sequence: n^2 x 28.7 mixed additions instead
-// of the n^2 x 85 of k_g1fft_bits.  The n^2 scalars are expanded once per size (32 n^2 bytes: 8 MiB at 512 points) and kept.
-static std::map<std::pair<int, int>, uint4*> g_expanded;
-static int32_t g1_ifft_as_batched_msm(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy) {
-    int log_n = 0;
-    while (((size_t)1 << log_n) < n) ++log_n;
-    const uint4* tabw = nullptr;
-    int32_t rc = get_scalars(ctx, log_n, true, &tabw, 2);
-    if (rc != KZG_OK) return rc;
-    uint4* exp = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_scal_mu);
-        auto key = std::make_pair(ctx->device, log_n);
-        auto it = g_expanded.find(key);
-        if (it != g_expanded.end()) exp = it->second;
-        else {
-            KZG_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&exp), n * n * 32));
-            hipLaunchKernelGGL(k_g1fft_expand_scalars, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, tabw, (uint32_t)n, exp);
-            hipError_t e = hipGetLastError();
-            // the cache is shared by every context (and stream) of the device: complete before anyone else can find it
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) { (void)hipFree(exp); return set_error(ctx, e, "expanding the scalars of g1_ifft"); }
-            g_expanded[key] = exp;
-        }
-    }
-    MsmBases b;
-    b.points = srs_bits(srs); b.table_stride = (uint32_t)srs->n; b.c = 7; b.W = 255; b.naf = true;
-    return msm_run_batch_tables(ctx, b, exp, n, n, out_xy, nullptr);
-}
-
-// the last context of device `dev` is gone: free the scalar tables, digit lists and expanded scalar sets g1_ifft cached for it
+// the last context of device `dev` is gone: free the scalar tables and digit lists g1_ifft cached for it
 void g1fft_release_device_caches(int dev) {
     std::lock_guard<std::mutex> lk(g_scal_mu);
     for (auto it = g_scal.begin(); it != g_scal.end();) {
@@ -1211,22 +1145,11 @@ void g1fft_release_device_caches(int dev) {
     for (auto it = g_naf2.begin(); it != g_naf2.end();) {
         if (std::get<0>(it->first) == dev) { (void)hipFree(it->second.list); (void)hipFree(it->second.cnt); it = g_naf2.erase(it); } else ++it;
     }
-    for (auto it = g_expanded.begin(); it != g_expanded.end();) {
-        if (it->first.first == dev) { (void)hipFree(it->second); it = g_expanded.erase(it); } else ++it;
-    }
 }
 
 int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy) {
-    // sizes the batched MSM wins at (measured, tools/time_g1ifft.py): KZG_G1FFT_BATCH="lo,hi" overrides, "0" switches it off
-    static const std::pair<size_t, size_t> batch_range = []() {
-        // 64 / 128 / 256 / 512 / 1024 points: 0.49 / 0.55 / 0.70 / 1.08 / 3.0 ms this way.  Round 3 took it at 512 points (staged: 1.84 ms); since
-        // round 4 the table first stage + one quad stage does 512 points in 0.86 ms, so the default range is empty (KZG_G1FFT_BATCH=512 restores it)
-        size_t lo = 1, hi = 0;
-        if (const char* e = getenv("KZG_G1FFT_BATCH")) { unsigned long a = 0, b2 = 0; int k = sscanf(e, "%lu,%lu", &a, &b2); lo = a; hi = k == 2 ? b2 : a; if (a == 0) { lo = 1; hi = 0; } }
-        return std::make_pair(lo, hi);
-    }();
-    if (srs_bits(srs) && srs->lagrange_of == 0 && n >= batch_range.first && n <= batch_range.second && n <= 1024 && !ctx->slot_pending[0])
-        return g1_ifft_as_batched_msm(ctx, srs, n, out_xy);
+    // (the transform as n batched MSMs of n pairs over the per-bit tables -- round 3's form at 512 points, 1.08 ms -- lost to the table first stage + one quad
+    // stage, 0.68 ms, and was removed in round 6: docs/history, profiles/r03_g1ifft.txt)
     if (n <= G1FFT_HOST_AFFINE_MAX) {
         const int32_t* result = nullptr;
         int32_t rc = g1_ifft_stages(ctx, srs, n, &result);

@@ -221,10 +221,9 @@ constexpr size_t LAG_SMALL_PARTIALS = 4096;
 // work waits for.  Phase 1 of every Lagrange-sharded proof of a context (upload, inverses, partial sum: ~0.1 ms on few waves) runs here, and so
 // does the coset inversion chain of poly.hip's proofs (beside the upload of the evaluations).  On the slot's stream it shared a hardware queue with other slots' MSM kernels (HIP maps its streams onto a
 // handful of queues) and sat behind them: in a stream of 2^17-element proofs the host waited 0.45 ms per blob for a 0.1 ms phase
-// (tools/trace_config4_stream.py).  KZG_LAG_PRIO=0: the slot's stream (A/B).
+// (tools/trace_config4_stream.py).
 int32_t ctx_aux_stream(kzg_ctx* ctx, hipStream_t slot_stream, hipStream_t* out) {
-    static const bool off = []() { const char* e = getenv("KZG_LAG_PRIO"); return e && atoi(e) == 0; }();
-    if (off) { *out = slot_stream; return KZG_OK; }
+    (void)slot_stream;
     if (!ctx->lag_stream) {
         int least = 0, greatest = 0;
         KZG_HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -297,9 +296,8 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     LAG_TRY(hipMemcpyAsync(small, pin, 32, hipMemcpyHostToDevice, s1));
     LAG_TRY(hipMemcpyAsync(small + 64, pin + 160, 4, hipMemcpyHostToDevice, s1));
     // Evaluations in HOST memory: the inverses need z only, so they are enqueued FIRST (auxiliary stream) and run while this thread sits in the pageable upload
-    // (the slot's stream); the sum waits for both.  Per-rank proof of a 2^17-element slice, one call at a time: 0.63 -> 0.56 ms.  KZG_LAG_SPLIT=0: one after the other.
-    static const bool split_off = []() { const char* e = getenv("KZG_LAG_SPLIT"); return e && atoi(e) == 0; }();
-    const bool split = !on_device && !split_off && s1 != st;
+    // (the slot's stream); the sum waits for both.  Per-rank proof of a 2^17-element slice, one call at a time: 0.63 -> 0.56 ms.
+    const bool split = !on_device && s1 != st;
     if (split) {
         hipLaunchKernelGGL(k_lag_inverses, dim3(blocks), dim3(POLY_THREADS), 0, s1, static_cast<const uint4*>(nullptr), (uint32_t)len, (uint32_t)base, tb,
                            reinterpret_cast<const uint4*>(small), set.b.as<int32_t>(), reinterpret_cast<int32_t*>(small + LAG_SMALL_PARTIALS),

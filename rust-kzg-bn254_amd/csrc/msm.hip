@@ -57,7 +57,6 @@ struct Plan {
     bool fused;          // sparse table-mode MSM: the first reduction level adds the sorted entries itself; its group g holds the buckets gp * G1 + g (set by msm_enqueue)
     bool quad;           // reduction levels on lane quads (curve_quad.h): no other MSM in flight when this one was planned
     bool alone = false;  // planned with no other MSM of this context in flight
-    bool dual1;          // first reduction level on two groups per workgroup (k_msm_bucket_bits1p_dual): fewer instructions, longer alone -> with another MSM in flight
     bool sort2;          // two-level sort (table mode, index fits 24 bits)
     bool sort_small;     // global-atomic sort (few entries)
     uint32_t Hb, tile1, tiles1, tiles2cap;
@@ -77,8 +76,6 @@ static int generic_window(size_t n, uint32_t batch) {
 // Batched table mode: bucket bits per polynomial by its length (width c + 1 digits over the per-bit tables).  Short polynomials: 64
 // buckets, one group of the first reduction level each; from 2^13 coefficients whole units of 4 096 buckets, reduced like a single MSM.
 static int batch_bucket_bits(size_t poly_len) {
-    static const int forced = []() { const char* e = getenv("KZG_BATCH_C"); return e ? atoi(e) : 0; }();
-    if (forced == 7 || (forced >= 13 && forced <= 16)) return forced;    // (c = 12 would be 0 units of 4 096 buckets per polynomial: ADVICE r4)
     if (poly_len < ((size_t)1 << 13)) return 7;
     if (poly_len < ((size_t)1 << 15)) return 13;
     if (poly_len < ((size_t)1 << 18)) return 15;
@@ -91,16 +88,14 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
     p.tables = bases.table_stride != 0;
     p.naf = p.tables && bases.naf;
     p.polys = p.naf ? polys : 0;
-    p.dual1 = false;
     p.fused = false;
     p.bitsum = false;
     {
         // lane quads for the two reduction levels when this MSM runs alone (0.7 of the pair form's dependent instructions, twice its lanes);
-        // with another MSM in flight the SIMDs are shared and the pair form's fewer instructions count.  KZG_QUAD_REDUCE=0 / 1: never / always.
-        static const int quad_env = []() { const char* e = getenv("KZG_QUAD_REDUCE"); return e ? atoi(e) : -1; }();
+        // with another MSM in flight the SIMDs are shared and the pair form's fewer instructions count (kzg_ctx_set_reduction_lanes forces either).
         bool other_in_flight = false;
         for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) other_in_flight |= ctx->slot_pending[sl] != nullptr;
-        p.quad = p.tables && (quad_env > 0 || (quad_env < 0 && !other_in_flight));
+        p.quad = p.tables && !other_in_flight;
         if (ctx->reduction_lanes) p.quad = p.tables && ctx->reduction_lanes == 4;
         p.alone = !other_in_flight;
     }
@@ -111,12 +106,10 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         c = bases.c;
         // NAF mode, 2^18 .. 2^19 - 1 pairs, nothing else in flight (the reference's bench_kzg_commit_8mb shape): 2^14 buckets instead of 2^15 --
         // alone, the reductions cost their latency, not their instructions: 0.551 -> 0.525 ms at 2^18 (with other MSMs in flight 16 stays
-        // ahead, engine.h srs_naf_c; tools/archive/sweep_naf_c_alone.py).  An explicit KZG_NAF_C wins.
-        static const bool naf_c_forced = getenv("KZG_NAF_C") != nullptr;
-        if (p.naf && c == 16 && p.alone && !naf_c_forced && n < ((size_t)1 << 19)) c = 15;
+        // ahead, engine.h srs_naf_c; tools/archive/sweep_naf_c_alone.py).
+        if (p.naf && c == 16 && p.alone && n < ((size_t)1 << 19)) c = 15;
     } else {
         c = ctx->msm_c_override;
-        if (c == 0) { const char* env = getenv("KZG_MSM_C"); if (env) c = atoi(env); }
         if (c == 0) c = generic_window(n, batch);
         c = std::min(16, std::max(2, c));
     }
@@ -133,8 +126,7 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         // lane with the same trip count.  Small MSMs: at least Lmin entries per lane -- short trips keep them from serialising
         // ~100 dependent mixed adds (10 us each) in a handful of waves; from 2^21 entries on, below 24 entries per lane the
         // folding of the lane partials costs more than the extra waves buy (measured in round 1: 15 -> 0.655 ms, 24 -> 0.582 ms).
-        int L = ctx->msm_seg_override;
-        if (L == 0) { const char* env = getenv("KZG_MSM_SEG"); if (env) L = atoi(env); }
+        const int L = ctx->msm_seg_override;
         size_t lanes;
         if (L > 0) {
             lanes = (entries + (size_t)L - 1) / (size_t)L;                 // forced trip count (tests, sweeps): no cap
@@ -143,25 +135,18 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
             // Round 3: TWO waves per SIMD (of the three the 168-VGPR kernel could hold) unless this is a large MSM running alone.
             // A grid that fills all three slots leaves no registers for any other kernel on the chip, so the sort and the reductions
             // of the other MSM in flight only ran in the tail of this kernel; with a third of the slots free they run beside it:
-            // pipelined step 1.183-1.192 -> 1.160-1.166 ms (same box, KZG_ACC_SLOTS=3072 / 2048; 2560 = 2.5 waves per SIMD: 1.17-1.18),
+            // pipelined step 1.183-1.192 -> 1.160-1.166 ms (same box, 3072 / 2048 wave slots; 2560 = 2.5 waves per SIMD: 1.17-1.18),
             // and below 2^19 pairs fewer lanes also mean fewer partial sums for the first reduction level (2^16: 0.464 -> 0.403 ms,
             // 2^17: 0.534 -> 0.486).  Alone, a 2^19 / 2^20-pair MSM is 2-3 % faster on three (0.929 / 1.474 against 0.961 / 1.496 ms).
             size_t slots = ctx->acc_wave_slots;
             {
-                bool busy = false;
-                for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) busy |= ctx->slot_pending[sl] != nullptr;
-                static const int dual_env = []() { const char* e = getenv("KZG_BITS1_DUAL"); return e ? atoi(e) : -1; }();   // 0 / 1: never / always (A/B)
-                (void)busy;
-                p.dual1 = p.tables && p.B >= 8192 && dual_env > 0;      // off: measured no gain (same-box A/B 1.169-1.181 without, 1.174-1.179 with it whenever another MSM is in flight)
-            }
-            if (!ctx->acc_slots_forced) {
                 bool other_in_flight = false;
                 for (int sl = 0; sl < KZG_NUM_SLOTS; ++sl) other_in_flight |= ctx->slot_pending[sl] != nullptr;
                 if (other_in_flight || entries < ((size_t)1 << 23)) slots = slots / 3 * 2;
                 // below 2^22 entries (2^15 .. 2^17 pairs; 2^18 is even) ONE wave per SIMD: the kernel is not throughput bound there (the same
                 // 0.20 ms at 2^17 pairs with 65 536 lanes of 30 entries as with 131 072 of 15), half the lanes leave half the partial sums
                 // to the first reduction level (0.097 -> 0.084 ms) and room for the other MSMs in flight: three in flight 2^15 0.154 ->
-                // 0.136, 2^16 0.191 -> 0.160, 2^17 0.245 -> 0.211 ms per MSM (KZG_ACC_SLOTS sweep, profiles/r03_naf.md)
+                // 0.136, 2^16 0.191 -> 0.160, 2^17 0.245 -> 0.211 ms per MSM (wave-slot sweep, profiles/r03_naf.md)
                 if (entries < ((size_t)1 << 22)) slots = ctx->acc_wave_slots / 3;
             }
             lanes = std::min<size_t>(slots * 64, (entries + lmin - 1) / lmin);
@@ -179,30 +164,24 @@ static Plan make_plan(const kzg_ctx* ctx, size_t n, const MsmBases& bases, uint3
         }
     }
     // single-pass sort tiles: large against the bucket count (one contiguous flush of B counters per tile), and not too many
-    size_t mult = 2;
-    { const char* env = getenv("KZG_SORT_TILE_MULT"); if (env && atoi(env) > 0) mult = (size_t)atoi(env); }
-    size_t tile = std::max<size_t>(4096, mult * p.B);
+    size_t tile = std::max<size_t>(4096, 2 * (size_t)p.B);
     while (tile < p.set_len && ((size_t)p.set_len + tile - 1) / tile * p.sets > 1024) tile *= 2;   // (many small sets: one tile per set)
     p.tile_len = (uint32_t)tile;
     p.tiles_per_set = (uint32_t)(((size_t)p.set_len + tile - 1) / tile);
     p.tiles = p.tiles_per_set * p.sets;
     {
-        const char* env = getenv("KZG_SORT2");
-        const bool want = !(env && atoi(env) == 0);
         const bool lds_fits = (size_t)p.B * 4 <= SORT1_MAX_LDS;            // single-pass sort: one LDS counter per bucket
         p.sort_small = !p.naf && entries < ((size_t)1 << 18);
         const bool can2 = p.tables && (p.c - 1 > SORT2_LO_BITS || p.polys) && (p.B >> SORT2_LO_BITS) <= SORT2_MAX_BINS &&
                           (p.naf ? (size_t)NAF_POSITIONS * p.idx_stride < ((size_t)1 << 31)
                                  : (size_t)p.W * p.idx_stride <= ((size_t)1 << SORT2_IDX_BITS));
-        int min_log = 18;                                                  // (was 2^23: the scalar-tile pass 1 and the per-bin pass 2 win from the first size the single-pass sort is not "small" for)
-        { const char* e2 = getenv("KZG_SORT2_MIN_LOG"); if (e2 && atoi(e2) >= 18 && atoi(e2) <= 30) min_log = atoi(e2); }
-        p.sort2 = !p.sort_small && can2 && ((want && entries >= ((size_t)1 << min_log)) || !lds_fits || p.naf);
+        // from 2^18 entries (was 2^23): the scalar-tile pass 1 and the per-bin pass 2 win from the first size the single-pass sort is not "small" for
+        p.sort2 = !p.sort_small && can2 && (entries >= ((size_t)1 << 18) || !lds_fits || p.naf);
         if (!p.sort2 && !lds_fits) p.sort_small = true;                    // (slow but correct: a forced odd configuration)
         p.Hb = p.sort2 ? (p.B >> SORT2_LO_BITS) : 0;
         p.tile1 = n >= ((size_t)1 << 19) ? 2048 : 1024;                    // SCALARS per pass-1 tile (W entries each)
         if (p.naf) {                                                       // the recoding is a long dependent chain per scalar: more, smaller tiles
-            static const int naf_tile = []() { const char* e = getenv("KZG_NAF_TILE"); return e ? atoi(e) : 0; }();
-            p.tile1 = naf_tile >= 256 && naf_tile <= 4096 ? (uint32_t)naf_tile : 512;
+            p.tile1 = 512;
             if (p.polys) p.tile1 = 2048;                                    // (twice the entries per scalar: fewer, larger tiles)
         }
         p.tiles1 = (uint32_t)((n + p.tile1 - 1) / p.tile1);
@@ -233,61 +212,6 @@ struct MsmPending {
     Pending part[MSM_MAX_PARTS];
     uint32_t n_parts = 0;
 };
-
-// KZG_DEBUG_SORT=1 (diagnostic): after the sort of a table-mode MSM, recompute every scalar's digits on the host and compare the
-// device's sorted entries with them bucket by bucket (as multisets).  Slow; reports the first differences on stderr.
-static int32_t debug_check_sort(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const Plan& p, const uint4* d_scalars) {
-    KZG_HIP_TRY(ctx, hipStreamSynchronize(st));
-    std::vector<uint64_t> sc((size_t)p.n * 4);
-    std::vector<uint32_t> offs((size_t)p.G + 1);
-    KZG_HIP_TRY(ctx, hipMemcpy(sc.data(), d_scalars, sc.size() * 8, hipMemcpyDeviceToHost));
-    KZG_HIP_TRY(ctx, hipMemcpy(offs.data(), ws.offs.p, offs.size() * 4, hipMemcpyDeviceToHost));
-    const uint32_t E = offs[p.G];
-    std::vector<uint32_t> sorted(E ? E : 1);
-    if (E) KZG_HIP_TRY(ctx, hipMemcpy(sorted.data(), ws.sorted.p, (size_t)E * 4, hipMemcpyDeviceToHost));
-    std::vector<std::vector<uint32_t>> want(p.G);
-    for (uint32_t i = 0; i < p.n; ++i) {
-        uint64_t k64[4];
-        kzg_host::fr_wire_to_canonical(&sc[(size_t)i * 4], k64);
-        uint32_t k[8];
-        memcpy(k, k64, 32);
-        if (p.naf) {
-            naf_for_digits(k, p.c + 1, [&](uint32_t pos, uint32_t key, uint32_t neg) { want[naf_bucket(key, p.c - 1)].push_back((neg << 31) | (pos * p.idx_stride + i)); });
-        } else {
-            const uint32_t mask = (1u << p.c) - 1u, half = 1u << (p.c - 1);
-            uint32_t carry = 0;
-            for (int w = 0; w < p.W; ++w) {
-                const uint32_t raw = (k[0] & mask) + carry;
-                for (int j = 0; j < 7; ++j) k[j] = (k[j] >> p.c) | (k[j + 1] << (32 - p.c));
-                k[7] >>= p.c;
-                const uint32_t neg = raw > half, mag = neg ? (1u << p.c) - raw : raw;
-                carry = neg;
-                if (mag) want[mag - 1].push_back((neg << 31) | ((uint32_t)w * p.idx_stride + i));
-            }
-        }
-    }
-    size_t total = 0, bad = 0;
-    for (uint32_t g = 0; g < p.G; ++g) {
-        total += want[g].size();
-        const uint32_t lo = offs[g], hi = offs[g + 1];
-        bool ok = hi >= lo && hi - lo == want[g].size() && hi <= E;
-        if (ok) {
-            std::vector<uint32_t> got(sorted.begin() + lo, sorted.begin() + hi);
-            std::sort(got.begin(), got.end());
-            std::sort(want[g].begin(), want[g].end());
-            ok = got == want[g];
-            if (!ok && bad < 8)
-                for (size_t q = 0; q < got.size(); ++q)
-                    if (got[q] != want[g][q]) { fprintf(stderr, "KZG_DEBUG_SORT: bucket %u entry %zu: device %08x host %08x\n", g, q, got[q], want[g][q]); break; }
-        } else if (bad < 8) {
-            fprintf(stderr, "KZG_DEBUG_SORT: bucket %u: device range [%u, %u) host count %zu (E = %u)\n", g, lo, hi, want[g].size(), E);
-        }
-        if (!ok) ++bad;
-    }
-    fprintf(stderr, "KZG_DEBUG_SORT: n = %u c = %d naf = %d: E device %u host %zu, %zu of %u buckets differ\n", p.n, p.c, (int)p.naf, E, total, bad, p.G);
-    if (bad || total != E) { ctx->last_error = "KZG_DEBUG_SORT: the sorted entries differ from the host's digits"; return KZG_ERR_DEVICE; }
-    return KZG_OK;
-}
 
 // Enqueue every kernel of one MSM (or batch) plus the D2H copy of its O(100) result points on `st`, using `ws`.
 static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmBases& bases, const uint4* d_scalars, size_t n,
@@ -351,8 +275,6 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     const uint32_t G1 = p.B / 64, G1p = (G1 + 63) / 64;
     if (p.tables && G1 > 1 && 13 * G1p > MSM_MAX_OUT) return KZG_ERR_INVALID_ARG;
 
-    static const bool enq_trace = []() { const char* e = getenv("KZG_ENQ_TRACE"); return e && atoi(e) != 0; }();   // diagnostic: host time of this function's parts
-    const auto tq0 = std::chrono::steady_clock::now();
     if (!p.sort2) KZG_HIP_TRY(ctx, ws.digits.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.sorted.reserve(entries * 4));
     KZG_HIP_TRY(ctx, ws.count.reserve((size_t)p.G * 4 + 16));
@@ -392,7 +314,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     // The last kernel of the sequence stores the O(200) result points straight into the pinned host buffer (coherent host memory, read
     // after the event behind that kernel).  A device-to-host copy of them cost ~10 us per MSM -- and above ~16 KiB (208 points at 2^16
     // buckets: every batched launch) hipMemcpyAsync takes the SDMA path, whose set-up after a device-wide synchronisation blocked the
-    // enqueueing thread for 5.6-7 ms (tools/trace_group.py with KZG_ENQ_TRACE=1; gone with HSA_ENABLE_SDMA=0).
+    // enqueueing thread for 5.6-7 ms (gone with HSA_ENABLE_SDMA=0).
     uint32_t* d_out = reinterpret_cast<uint32_t*>(ws.pinned_out_dev) + (size_t)out_off * 32;
     if (!ctx->lds_attr_set) {
         KZG_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SORT1_MAX_LDS));
@@ -406,21 +328,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         ctx->lds_attr_set = true;
     }
 
-    const auto tq1 = std::chrono::steady_clock::now();
-    auto tq_last = tq1;
-    auto tick = [&](int phase) {                          // KZG_ENQ_TRACE: host time of the runtime calls of one phase when they block
-        if (!enq_trace) return;
-        const auto now = std::chrono::steady_clock::now();
-        const double ms = std::chrono::duration<double, std::milli>(now - tq_last).count();
-        if (ms > 0.3) fprintf(stderr, "KZG_ENQ_TRACE:   the calls before mark %d took %.2f ms on the host\n", phase, ms);
-        tq_last = now;
-    };
     const bool prof = ctx->profiling;
     if (prof && !ws.ev_ready) {
         for (auto& e : ws.ev) KZG_HIP_TRY(ctx, hipEventCreate(&e));
         ws.ev_ready = true;
     }
-#define KZG_MARK(i) do { tick(i); if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[i], st)); } while (0)
+#define KZG_MARK(i) do { if (prof) KZG_HIP_TRY(ctx, hipEventRecord(ws.ev[i], st)); } while (0)
 
     // Staggered start.  Two MSMs enqueued back to back on two streams (the fill of a pipeline) run their phases in lock-step: both sort
     // (memory-bound) and then both accumulate (VALU-bound), instead of one sorting beside the other's accumulate as in steady state,
@@ -429,9 +342,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     // 20-step regions (profiles/r04_ab_msm_stagger.txt): 2^17-pair steps, four per launch, 0.188 -> 0.183 ms per step; 2^18 / 2^19, two per launch,
     // -0.7 %; long regions unchanged.  Only GROUPED launches wait (the sharded streams): a single 2^20-pair MSM planned alone lost 0.7 %
     // (1.115 -> 1.122: its successor's sort starts 0.2 ms later and the first MSM runs on three wave slots either way).
-    // KZG_MSM_STAGGER=0: off, =2: every table-mode launch.
-    static const int stagger_env = []() { const char* e = getenv("KZG_MSM_STAGGER"); return e ? atoi(e) : 1; }();
-    const bool stagger = p.tables && (stagger_env >= 2 || (stagger_env == 1 && p.polys >= 2));
+    const bool stagger = p.tables && p.polys >= 2;
     if (stagger && ctx->last_sorted && ctx->last_sorted_stream != st) KZG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_sorted, 0));
 
     uint32_t* d_offs = ws.offs.as<uint32_t>();
@@ -451,8 +362,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     // what an earlier small sort left of `count` (see k_scan_counts_1wg<true>); every other path writes the counters as it likes
     const uint32_t clean_g = ws.count_zero_ptr == ws.count.p ? ws.count_zero_g : 0;
     ws.count_zero_g = 0;
-    static const bool lean_on = []() { const char* e = getenv("KZG_LEAN_SORT"); return !(e && atoi(e) == 0); }();
-    const bool lean_sort = lean_on && !p.sort2 && p.sort_small && p.tables && batch == 1 && p.G == p.B && p.G <= SCAN1_MAX;
+    const bool lean_sort = !p.sort2 && p.sort_small && p.tables && batch == 1 && p.G == p.B && p.G <= SCAN1_MAX;
     const uint32_t n_total = p.n * batch;
     const uint32_t gn = (n_total + 255) / 256;
     const size_t lds_bytes = (size_t)p.B * 4;
@@ -480,7 +390,6 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
                            ws.blockbase.as<uint32_t>(), (const uint32_t*)nullptr, p.idx_stride, (uint32_t*)nullptr);
         KZG_MARK(1);
         hipLaunchKernelGGL(k_sort2_scan, dim3(1), dim3(512), 0, st, ccount, p.Hb, cstart, tstart, tile_bin, ws.count.as<uint32_t>(), bin_cap);
-        static const bool direct_scatter = []() { const char* e = getenv("KZG_SORT2_DIRECT"); return e && atoi(e) != 0; }();   // A/B: pass 1 without the LDS staging
         if (p.naf) {
             const size_t lds1 = ((size_t)3 * p.Hb + (size_t)SORT2_P1_THREADS * p.W) * 4 + (size_t)SORT2_P1_THREADS * p.W * 2;
             if (ND == 32)
@@ -489,7 +398,7 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
             else
             hipLaunchKernelGGL(k_sort2_scatter1_lds<true>, dim3(p.tiles1), dim3(SORT2_P1_THREADS), lds1, st, ws.digits.as<uint4>(), p.n, p.c, p.W, p.tile1, p.Hb,
                                ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>(), tmpk, poly_len);
-        } else if (direct_scatter || p.W > 31) {
+        } else if (p.W > 31) {                              // (more windows than the LDS staging holds: pass 1 scatters directly)
             hipLaunchKernelGGL(k_sort2_scalars<true>, dim3(p.tiles1), dim3(256), (size_t)p.Hb * 4, st, d_scalars, p.n, p.c, p.W, p.tile1, p.Hb, ccount,
                                ws.blockbase.as<uint32_t>(), (const uint32_t*)cstart, p.idx_stride, ws.sort_tmp.as<uint32_t>());
         } else {
@@ -553,26 +462,19 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         KZG_MARK(3);
     }
     KZG_MARK(4);
-    if (stagger_env >= 1 && p.tables) {                     // (recorded by every table-mode launch: the NEXT launch decides whether it waits)
+    if (p.tables) {                                         // (recorded by every table-mode launch: the NEXT launch decides whether it waits)
         if (!ws.ev_sorted) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_sorted, hipEventDisableTiming));
         KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_sorted, st));
         ctx->last_sorted = ws.ev_sorted;
         ctx->last_sorted_stream = st;
     }
-    static const bool debug_sort = []() { const char* e = getenv("KZG_DEBUG_SORT"); return e && atoi(e) != 0; }();
-    if (debug_sort && p.tables && batch == 1 && !p.polys) {
-        int32_t rc = debug_check_sort(ctx, ws, st, p, d_scalars);
-        if (rc != KZG_OK) return rc;
-    }
     phases.begin("kzg:msm:accumulate");
-    // the two reduction levels: on lane pairs (curve_pair.h; one 128-thread workgroup per 64 buckets, then per two groups of 64 sums) unless KZG_PAIR_REDUCE=0
-    static const bool pair_reduce = []() { const char* e = getenv("KZG_PAIR_REDUCE"); return !(e && atoi(e) == 0); }();
-    // sparse table-mode MSMs (at most KZG_FUSED_PER_BUCKET = 2.5 entries per bucket on average: commitments of <= 2^11 coefficients on
+    // the two reduction levels run on lane pairs (curve_pair.h; one 128-thread workgroup per 64 buckets, then per two groups of 64 sums) or lane quads
+    // sparse table-mode MSMs (at most 2.5 entries per bucket on average: commitments of <= 2^11 coefficients on
     // the c = 15 tables): the first reduction level adds the entries itself (k_msm_bucket_bits1p_fused), there is no accumulate kernel and
     // there are no partial sums.  Measured (tools/phases_small.py, same box, device time of one commitment): 2^8 170 -> 125 us, 2^9 163 -> 128,
     // 2^10 165 -> 152, 2^11 199 -> 195; at 2^12 (4.25 per bucket) 206 -> 261: a wave waits for its fullest bucket, the equal split does not.
-    static const double fused_per_bucket = []() { const char* e = getenv("KZG_FUSED_PER_BUCKET"); return e ? atof(e) : 2.5; }();
-    const bool fused = p.tables && !p.naf && pair_reduce && (double)entries <= fused_per_bucket * (double)p.B;
+    const bool fused = p.tables && !p.naf && (double)entries <= 2.5 * (double)p.B;
     p.fused = fused;
     // (64- and 128-thread workgroups measured the same as 256)
     if (!fused)
@@ -588,18 +490,12 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
         else if (fused)
             hipLaunchKernelGGL(k_msm_bucket_bits1p_fused, dim3(G1), dim3(128), 0, st, bases.points, ws.sorted.as<uint32_t>(), d_offs, p.B, p.idx_log,
                                p.stride_adj, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
-        else if (pair_reduce && p.dual1 && (G1 & 1u) == 0)
-            hipLaunchKernelGGL(k_msm_bucket_bits1p_dual, dim3(G1 / 2), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
-                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1);
-        else if (pair_reduce && p.quad && (G1 <= 512 || ctx->reduction_lanes == 4))
+        else if (p.quad && (G1 <= 512 || ctx->reduction_lanes == 4))
             // (at 2^16 buckets the level is 4 096 quad waves of ~11 000 instructions: throughput bound, 0.121 against 0.114 ms on pairs)
             hipLaunchKernelGGL(k_msm_bucket_bits1q, dim3(G1), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
-        else if (pair_reduce)
-            hipLaunchKernelGGL(k_msm_bucket_bits1p, dim3(G1), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
-                               ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
         else
-            hipLaunchKernelGGL(k_msm_bucket_bits1, dim3((G1 * 64 + 255) / 256), dim3(256), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
+            hipLaunchKernelGGL(k_msm_bucket_bits1p, dim3(G1), dim3(128), 0, st, d_offs, p.B, p.nl, ws.head.as<int32_t>(), (size_t)p.G,
                                ws.cont.as<int32_t>(), (size_t)p.nl, G1, ws.chunkS.as<int32_t>(), (size_t)7 * G1, d_out);
         KZG_MARK(6);
         if (p.polys && p.c == 7) {
@@ -609,13 +505,10 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
             n_out = 7;
         } else {
             const uint32_t waves2 = 7 * G1p;
-            if (pair_reduce && p.quad)
+            if (p.quad)
                 hipLaunchKernelGGL(k_red_bits2q, dim3(waves2), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, d_out);
-            else if (pair_reduce)
-                hipLaunchKernelGGL(k_red_bits2p, dim3((waves2 + 1) / 2), dim3(128), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, d_out);
             else
-                hipLaunchKernelGGL(k_red_bits2, dim3((waves2 * 64 + 255) / 256), dim3(256), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p,
-                                   d_out);
+                hipLaunchKernelGGL(k_red_bits2p, dim3((waves2 + 1) / 2), dim3(128), 0, st, ws.chunkS.as<int32_t>(), (size_t)7 * G1, G1, G1p, d_out);
             n_out = 13 * G1p;
         }
     } else {
@@ -649,11 +542,6 @@ static int32_t msm_enqueue(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const
     if (!ws.ev_done) KZG_HIP_TRY(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
     KZG_HIP_TRY(ctx, hipEventRecord(ws.ev_done, st));        // msm_finish waits for THIS launch, not for the stream: a later MSM may already be queued behind it
 #undef KZG_MARK
-    if (enq_trace) {
-        const auto tq2 = std::chrono::steady_clock::now();
-        const double a = std::chrono::duration<double, std::milli>(tq1 - tq0).count(), b = std::chrono::duration<double, std::milli>(tq2 - tq1).count();
-        if (a + b > 0.5) fprintf(stderr, "KZG_ENQ_TRACE: n %zu polys %u: buffers %.2f ms, launches + copies %.2f ms\n", n, p.polys, a, b);
-    }
     pend->p = p;
     pend->n_out = n_out;
     pend->batch = batch;
@@ -670,13 +558,6 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     (void)st;
     {
         RoctxRange range_wait("kzg:msm:wait");
-        static const int poll = []() { const char* e = getenv("KZG_EVENT_POLL"); return e ? atoi(e) : 0; }();
-        if (poll) {
-            hipError_t q;
-            while ((q = hipEventQuery(ws.ev_done)) == hipErrorNotReady) __builtin_ia32_pause();
-            (void)hipGetLastError();
-            KZG_HIP_TRY(ctx, q);
-        } else
         KZG_HIP_TRY(ctx, hipEventSynchronize(ws.ev_done));
     }
     RoctxRange range_epi("kzg:msm:host epilogue");
@@ -817,10 +698,6 @@ int32_t msm_slot_stream(kzg_ctx* ctx, int slot, hipStream_t* out) {
     // queues (4 by default, shared with every other stream of the process): at 2^17 pairs per MSM, depth 2 gives 0.43-0.45 ms per
     // MSM, depth 3 0.37-0.38 (0.5 in one mapping), depth 4 anything from 0.34 to 0.46.  Sharing streams between slots (2 or 3
     // streams for 4 slots, any assignment) made depth 4 mapping-independent but no faster than depth 2-3 (tools/queue_probe.py).
-    // KZG_SLOT_STREAMS=k (experiment, default = one stream per slot): slot s runs on stream s mod k, so that with more slots than streams the
-    // next MSM of a stream is already enqueued behind the one in flight (no host round trip between them) while only k MSMs compete for the chip
-    static const int n_streams = []() { const char* e = getenv("KZG_SLOT_STREAMS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= KZG_NUM_SLOTS ? v : KZG_NUM_SLOTS; }();
-    slot %= n_streams;
     if (slot == 0) { *out = ctx->stream; return KZG_OK; }
     if (!ctx->stream_x[slot - 1]) KZG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_x[slot - 1], hipStreamNonBlocking));
     *out = ctx->stream_x[slot - 1];

@@ -1155,18 +1155,6 @@ k_red_window_sum(int32_t* __restrict__ a, size_t stride, uint32_t T, uint32_t* _
 // Superset-sum ("zeta") transform over the 64 lanes of a wave: after the 6 steps lane x holds the sum of the values
 // of all lanes l with (l & x) == x.  Lane 0 = total T; lane 2^k = S_k (sum over the lanes whose index has bit k set):
 // all seven sums the bucket reduction needs from a group of 64 buckets come out of 6 wave-wide additions.
-__device__ __forceinline__ void wave_zeta(Xyzz& v, uint32_t lane) {
-#pragma unroll 1
-    for (int k = 0; k < 6; ++k) {
-        Xyzz u;
-        xyzz_shfl_down(u, v, 1 << k);
-        if (((lane >> k) & 1u) == 0) {
-            Xyzz r;
-            xyzz_add<true>(r, v, u);
-            v = r;
-        }
-    }
-}
 __device__ __forceinline__ int zeta_role(uint32_t lane) {       // lane 0 -> role 6 (total), lane 2^k -> role k, else -1
     if (lane == 0) return 6;
     if ((lane & (lane - 1)) != 0) return -1;
@@ -1178,58 +1166,12 @@ __device__ __forceinline__ void xyzz_store_wire(uint32_t* __restrict__ out_wire,
 #pragma unroll
     for (int j = 0; j < 32; j += 4) *reinterpret_cast<uint4*>(out_wire + i * 32 + j) = make_uint4(w[j], w[j + 1], w[j + 2], w[j + 3]);
 }
-// level 1, fused with the bucket sums (one launch instead of bucket_fin + heavy + bits1): one wave per group g of 64 buckets;
-// lane = bucket: sum of its partials (bucket_sum_wave), then the zeta transform.  X1[role * G1 + g]: role k < 6 = S_k, role 6 = T.
-// With a single group (B = 64) the seven results leave as wire words at once.
-// (<= 168 VGPRs like the accumulate kernel: a wave of this kernel fits beside two accumulate waves of the other MSM in flight)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_msm_bucket_bits1(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
-                   const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride,
-                   uint32_t* __restrict__ out_wire /* G1 == 1 only */) {
-    latency_bound_kernel();
-    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (g >= G1) return;                               // wave-uniform
-    const uint32_t L = acc_seg_len(offs[B], nl);
-    const uint32_t bkt = g * 64 + lane;
-    BucketSpan s;
-    s.g = bkt; s.t1 = 0; s.np = 0; s.long_run = false;
-    if (bkt < B && L) s = bucket_span(offs, bkt, L);
-    Xyzz v;
-    bucket_sum_wave(v, s, lane, head, head_stride, cont, cont_stride);
-    wave_zeta(v, lane);
-    const int role = zeta_role(lane);
-    if (role < 0) return;
-    if (G1 == 1) xyzz_store_wire(out_wire, (size_t)role, v);
-    else xyzz_store(x1, x_stride, (size_t)role * G1 + g, v);
-}
-// level 2 (one launch, two kinds of job), results straight to wire words: with G1p = ceil(G1 / 64)
-//   wave <  6 G1p : out[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                                  (a < 6: finishes bits 0..5)
-//   wave >= 6 G1p : out[6 G1p + role * G1p + g2], role 0..6, zeta transform of the totals X1[6][g2 * 64 .. +64)  (bits 6..11, totals)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_red_bits2(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
-    latency_bound_kernel();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= 7u * G1p) return;
-    const bool sum_job = wave < 6u * G1p;
-    const uint32_t a = sum_job ? wave / G1p : 6u;
-    const uint32_t g = sum_job ? wave % G1p : wave - 6u * G1p;
-    const uint32_t cnt = G1 - g * 64 < 64 ? G1 - g * 64 : 64;
-    Xyzz v;
-    if (lane < cnt) xyzz_load(v, x1, x_stride, (size_t)a * G1 + (size_t)g * 64 + lane);
-    else xyzz_set_inf(v);
-    wave_zeta(v, lane);
-    if (sum_job) {
-        if (lane == 0) xyzz_store_wire(out_wire, wave, v);
-    } else {
-        const int role = zeta_role(lane);
-        if (role >= 0) xyzz_store_wire(out_wire, (size_t)6 * G1p + (size_t)role * G1p + g, v);
-    }
-}
-
+// (the one-lane kernels of this form -- one wave per group of 64 buckets, X1[role * G1 + g]: role k < 6 = S_k, role 6 = T; then one launch that finishes
+// bits 0..5 and transforms the group totals -- were the round-1 reduction; the lane-pair and lane-quad kernels below replaced them: history section 4b)
 // -------------------------------------------------------------------------------------------------
 // 6c. the same two reduction levels on LANE PAIRS (curve_pair.h): one point per pair of lanes, 7 multiplications per lane and
 //     addition instead of 14; 64 values = one workgroup of two waves (32 pairs each).  Same inputs, same X1 / out_wire layout
-//     and the same group elements as 6b (-DKZG_NO_PAIR_REDUCE / KZG_PAIR_REDUCE=0: the one-lane kernels).
+//     and the same group elements as the one-lane form of 6b.
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bucket_partial_half(HalfXyzz& v, const BucketSpan& s, uint32_t k, const int32_t* __restrict__ head, size_t head_stride,
                                                     const int32_t* __restrict__ cont, size_t cont_stride, bool odd) {
@@ -1492,38 +1434,10 @@ __device__ __forceinline__ void group_zeta64_dual(HalfXyzz& vA, HalfXyzz& vB, ui
         half_select(vB, bit, r, vB);
     }
 }
-// Level 1 with TWO groups of 64 buckets per two-wave workgroup (groups 2 blk and 2 blk + 1; pair gp holds bucket gp of the first and
-// bucket 63 - gp of the second): the transform of both takes six additions per pair instead of twelve -- 3 of the ~8 additions per bucket
-// this level costs.  Half the waves and twice the serial work per wave: SLOWER alone (0.123 -> 0.207 ms at 2^20 pairs), but with another
-// MSM in flight the step is the sum of everybody's VALU instructions (rocprofv3 SQ_INSTS_VALU per kernel, tools/prof_valu_by_kernel.sh:
-// this level is 8 % of the accumulate kernel's count).  Measured: NO gain -- same-box A/B of the pipelined 2^20 step 1.169-1.181 ms
-// without, 1.174-1.179 with this form whenever another MSM was in flight: the level's instructions already run in issue slots the
-// accumulate waves leave empty.  Kept behind KZG_BITS1_DUAL=1 (parity-tested), off by default.  G1 even.
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
-k_msm_bucket_bits1p_dual(const uint32_t* __restrict__ offs, uint32_t B, uint32_t nl, const int32_t* __restrict__ head, size_t head_stride,
-                         const int32_t* __restrict__ cont, size_t cont_stride, uint32_t G1, int32_t* __restrict__ x1, size_t x_stride) {
-    latency_bound_kernel();
-    __shared__ int32_t lds[2 * 2 * NL * 64];
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, gp = w * 32 + (lane >> 1);
-    const bool odd = (lane & 1u) != 0;
-    const uint32_t L = acc_seg_len(offs[B], nl);
-    HalfXyzz v[2];
-#pragma unroll 1
-    for (int which = 0; which < 2; ++which) {
-        const uint32_t bkt = (2 * blockIdx.x + which) * 64 + (which ? 63 - gp : gp);
-        BucketSpan s;
-        s.g = bkt; s.t1 = 0; s.np = 0; s.long_run = false;
-        if (bkt < B && L) s = bucket_span(offs, bkt, L);
-        bucket_sum_pairs(v[which], s, lane, odd, head, head_stride, cont, cont_stride);
-    }
-    group_zeta64_dual(v[0], v[1], lane, w, odd, lds);
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        const int role = zeta_role(which ? 63 - gp : gp);
-        if (role >= 0) half_store(x1, x_stride, (size_t)role * G1 + 2 * blockIdx.x + which, v[which], odd);
-    }
-}
-// level 2: one two-wave workgroup per TWO jobs of k_red_bits2 (jobs 2 blk and 2 blk + 1)
+// level 2 (one launch, two kinds of job), results straight to wire words: with G1p = ceil(G1 / 64)
+//   job <  6 G1p : out[a * G1p + g'] = sum of X1[a][g' * 64 .. +64)                                  (a < 6: finishes bits 0..5)
+//   job >= 6 G1p : out[6 G1p + role * G1p + g2], role 0..6, zeta transform of the totals X1[6][g2 * 64 .. +64)  (bits 6..11, totals)
+// one two-wave workgroup per TWO jobs (jobs 2 blk and 2 blk + 1)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(KZG_PAIR_WAVES, KZG_PAIR_WAVES)))
 k_red_bits2p(const int32_t* __restrict__ x1, size_t x_stride, uint32_t G1, uint32_t G1p, uint32_t* __restrict__ out_wire) {
     latency_bound_kernel();

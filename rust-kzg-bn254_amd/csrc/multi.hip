@@ -341,7 +341,7 @@ Rccl& rccl() {
     std::lock_guard<std::mutex> lk(mu);
     if (!r.tried) {
         r.tried = true;
-        const char* env = getenv("KZG_RCCL_LIB");
+        const char* env = kzg::opts().rccl_lib;
         if (env && *env) { r.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL); r.have = r.lib != nullptr; r.how = "KZG_RCCL_LIB"; }
         if (!r.have && dlsym(RTLD_DEFAULT, "ncclAllGather")) { r.lib = RTLD_DEFAULT; r.have = true; r.how = "the RCCL already in the process (global scope)"; }
         if (!r.have) {
@@ -366,9 +366,7 @@ constexpr uint64_t ROW_OK = 0, ROW_POISON = 0xFFFFFFFFFFFFFFFFULL;
 constexpr size_t ROW_PAYLOAD_MAX = 256;
 
 double exchange_timeout_s() {
-    const char* e = getenv("KZG_EXCHANGE_TIMEOUT_S");
-    const double v = e ? atof(e) : 60.0;
-    return v > 0 ? v : 60.0;
+    return kzg::opts().exchange_timeout_s;
 }
 
 // One all-gather of `bytes` <= 256 payload bytes per rank (+ the status word).  local_rc != KZG_OK: this rank sends POISON.

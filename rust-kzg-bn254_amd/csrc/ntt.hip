@@ -474,7 +474,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
     uint4* bufs[2] = {ws->data.as<uint4>(), ws->tmp.as<uint4>()};
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    static const int tile_env = []() { const char* e = getenv("KZG_NTT_TILE_LOG"); return e ? atoi(e) : 0; }();    // 10 / 11: force one tile size (A/B)
+    const int tile_env = opts().ntt_tile_log;                       // KZG_NTT_TILE_LOG = 10 / 11: one tile size at every transform size (tests cover both kernels everywhere)
     const bool small_tile = tile_env == NTT_TILE_LOG_SMALL || (tile_env != NTT_TILE_LOG_BIG && ntt_small_tile_pays(log_n));
     const int tile_log = small_tile ? NTT_TILE_LOG_SMALL : NTT_TILE_LOG_BIG;
     int log_ncur = 0;

@@ -738,9 +738,10 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     const uint4* d_a = d_resident ? d_resident : set.a.as<uint4>();
     // inverses (planes) | level scratch: the smaller domains' inverses, two ping-pong plane sets of the small kernel
     // The one-workgroup kernel takes the chain up to 2^chain_small_log points, x4 levels on the whole chip go on from there: its late levels
-    // keep all 16 waves of one CU busy, a x4 launch over many CUs costs about one of them.  KZG_POLY_SMALL_LOG (2..12), off-domain proofs of
+    // keep all 16 waves of one CU busy, a x4 launch over many CUs costs about one of them.  Chain lengths 2..12, off-domain proofs of
     // 2^11 / 2^12 / 2^14 evaluations (tools/time_proof_sizes.py, same box): 12 -> 0.231 / 0.295 / 0.426 ms, 9 -> 0.226 / 0.281 / 0.414, 7 -> 0.230 / 0.286 / 0.422
-    static const int chain_small_log = []() { const char* e = getenv("KZG_POLY_SMALL_LOG"); const int v = e ? atoi(e) : 9; return v >= 2 && v <= (int)POLY_SMALL_MAX_LOG ? v : 9; }();
+    constexpr int chain_small_log = 9;
+    static_assert(chain_small_log >= 2 && chain_small_log <= (int)POLY_SMALL_MAX_LOG, "the one-workgroup kernel holds the chain's first levels in LDS");
     const size_t chain_small_max = (size_t)1 << chain_small_log;
     const size_t n1 = n > chain_small_max ? n / 4 : 0;       // the level above the last one (0: the small kernel gives all n inverses)
     const size_t lvl_words = n1 ? (n1 + n1 / 2) * NL + 64 : 0;          // sum over n/4, n/16, ... < n1 * 4/3
@@ -789,10 +790,9 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
         ctx->poly_lds_attr_set = true;
     }
     // z = w^m on a domain of at most 4 096 points (compute_proof_with_known_z_fr_index at the reference's bench sizes): the host finds m,
-    // the inverses come from the domain's table 1 / (w^k - 1) -- no inversion chain, no barycentric sum (KZG_ONDOMAIN_TABLE=0: the chain)
-    static const bool table_path = []() { const char* e = getenv("KZG_ONDOMAIN_TABLE"); return !(e && atoi(e) == 0); }();
+    // the inverses come from the domain's table 1 / (w^k - 1) -- no inversion chain, no barycentric sum
     uint32_t m_known = NO_INDEX;
-    if (table_path && want_proof && z_on_domain && n >= 2 && n <= POLY_SMALL_MAX && h_domain_index(z, log_n, &m_known)) {
+    if (want_proof && z_on_domain && n >= 2 && n <= POLY_SMALL_MAX && h_domain_index(z, log_n, &m_known)) {
         int32_t*& t1 = ctx->ondomain_inv[log_n];
         if (!t1) {                                           // once per domain size: the chain below at z = 1
             std::vector<uint64_t> z1((size_t)(2 * log_n + 6) * 4, 0);
@@ -831,10 +831,8 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     memset(pin + sizeof(ProofScalars), 0, 1024 - sizeof(ProofScalars));
     // The chain below needs z only, not the evaluations: for a proof from HOST evaluations it is enqueued FIRST, on the context's auxiliary stream, and
     // runs while this thread is inside the pageable upload of the evaluations (0.6 ms at 2^20; the chain: six launches, ~0.09 ms of latency).
-    // KZG_PROOF_CHAIN_AUX=0: everything on the slot's stream, chain behind the upload (A/B).
-    static const bool chain_aux = []() { const char* e = getenv("KZG_PROOF_CHAIN_AUX"); return !(e && atoi(e) == 0); }();
     hipStream_t sc = st;
-    if (chain_aux && evals && n > chain_small_max) {
+    if (evals && n > chain_small_max) {
         int32_t rca = ctx_aux_stream(ctx, st, &sc);
         if (rca != KZG_OK) return rca;
     }
@@ -890,10 +888,9 @@ static int32_t proof_enqueue(kzg_ctx* ctx, PolySet& set, hipStream_t st, NttWork
     // commit_eval_form(quotient): coefficients = IFFT(q), then MSM over the monomial SRS (kzg.rs:176-177)
     return skip_intt ? KZG_OK : ntt_run(ctx, set.c.p, n, true, st, nttws);
 }
-// The cached Lagrange basis of exactly n points, if the SRS carries one (KZG_PROOF_LAGRANGE=0: never -- the IFFT + monomial-basis form, A/B)
+// The cached Lagrange basis of exactly n points, if the SRS carries one (without one: the IFFT + monomial-basis form)
 static const kzg_srs* proof_lagrange_basis(const kzg_srs* srs, size_t n) {
-    static const bool off = []() { const char* e = getenv("KZG_PROOF_LAGRANGE"); return e && atoi(e) == 0; }();
-    if (off || n < 2 || srs->lagrange_of != 0) return nullptr;
+    if (n < 2 || srs->lagrange_of != 0) return nullptr;
     return srs_cached_lagrange(srs, n);
 }
 static void proof_read_y(const PolySet& set, uint64_t* out_y) {

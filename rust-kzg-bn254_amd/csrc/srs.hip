@@ -361,8 +361,7 @@ int32_t srs_generate(kzg_ctx* ctx, const uint64_t tau[4], uint64_t first_power, 
 // Window tables T_w = 2^(c w) * SRS for w < W, contiguous after the SRS itself.  Spends HBM capacity (W x 64 B per
 // point: 0.94 GiB for 2^20 points at c = 17) to turn the MSM into W n mixed adds into a single bucket set.
 int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
-    const char* env = getenv("KZG_NO_PRECOMPUTE");
-    if (env && atoi(env) != 0) return KZG_OK;
+    if (opt_no_precompute()) return KZG_OK;
     const size_t n = srs->n;
     if (n < 128) return KZG_OK;
     int lg = 0;
@@ -377,8 +376,6 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
     int c = 13;
     if (lg >= 14) c = 15;
     if (lg >= 18) c = 17;
-    const char* envc = getenv("KZG_TABLE_C");
-    if (envc && atoi(envc) >= 7 && atoi(envc) <= 17) c = atoi(envc);
     // tables T_w = 2^(cw) * SRS, w < W, as one allocation (table 0 = a copy of the SRS); nullptr when they do not fit
     auto build = [&](int cw, uint4** out, int* out_W) -> int32_t {
         *out = nullptr;
@@ -406,9 +403,8 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
     // A second, narrower table set for SMALL MSMs over this SRS: every launch pays for all 2^(c-1) buckets (scan, empty-bucket
     // walks, 2^(c-7) reduction waves), which a 2^11..2^13-coefficient commitment does not amortise -- 0.36..0.42 ms on the c = 17
     // tables of a 2^20-point SRS, 0.27..0.31 ms on c = 15 ones (tools/time_commit_sizes.py).  HBM is plentiful (another 1.06 GiB
-    // at 2^20 points), so both are kept and srs_bases() picks per launch.  KZG_NO_SMALL_TABLES=1: only the main set.
-    const char* env_small = getenv("KZG_NO_SMALL_TABLES");
-    if (c > SRS_SMALL_C && !(env_small && atoi(env_small) != 0)) {
+    // at 2^20 points), so both are kept and srs_bases() picks per launch.
+    if (c > SRS_SMALL_C) {
         uint4* t2 = nullptr; int W2 = 0;
         int32_t rc = build(SRS_SMALL_C, &t2, &W2);
         if (rc != KZG_OK) { (void)hipFree(table); return rc; }
@@ -427,8 +423,7 @@ int32_t srs_precompute(kzg_ctx* ctx, kzg_srs* srs) {
 // Built for SRS of 2^11 .. 2^22 points when they fit beside a quarter of the free memory; KZG_NO_NAF=1: never.
 // force: also for an SRS below SRS_NAF_MIN points (the batched commitments build them on first use: 16 KiB per point)
 int32_t srs_build_bit_tables(kzg_ctx* ctx, kzg_srs* srs, bool force) {
-    const char* env = getenv("KZG_NO_NAF");
-    if (env && atoi(env) != 0) return KZG_OK;
+    if (opt_no_naf()) return KZG_OK;
     const size_t n = srs->n;
     std::lock_guard<std::mutex> lazy(srs->lazy_mu);           // two contexts asking at once: the second finds the tables built
     if (n == 0 || (n < SRS_NAF_MIN && !force) || n > ((size_t)1 << 22) || srs->d_bits) return KZG_OK;

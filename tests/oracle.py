@@ -131,6 +131,23 @@ def msm_naive(bases, scalars):
     lib().orc_msm_naive(_p(bases), _p(scalars), C.c_size_t(len(scalars)), _p(out)); return out
 
 
+def host_cpus():
+    """CPUs this process may really use: hardware threads, capped by its affinity mask and by the cgroup's CFS quota (a GPU box shows 256 hardware
+    threads under a 16-CPU quota: 256 oracle threads there are throttled by the kernel and run SLOWER than 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            n = min(n, max(1, int(float(a) / float(b))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def msm_pippenger(bases, scalars, threads=None):
     bases = _u64(bases, (-1, 8)); scalars = _u64(scalars, (-1, 4)); out = np.zeros(8, np.uint64)
     n = min(len(bases), len(scalars))
@@ -153,7 +170,7 @@ def fr_ntt(data, inverse=False):
 def fr_ntt_mt(data, inverse=False, threads=None):
     """The same transform, every layer chunked over `threads` pthreads (CPU baseline of the NTT)."""
     a = _u64(data, (-1, 4)).copy()
-    rc = lib().orc_fr_ntt_mt(_p(a), C.c_size_t(len(a)), int(inverse), int(threads or os.cpu_count() or 1))
+    rc = lib().orc_fr_ntt_mt(_p(a), C.c_size_t(len(a)), int(inverse), int(threads or host_cpus()))
     if rc:
         raise ValueError("oracle NTT: length is not a power of two <= 2^28")
     return a

@@ -104,7 +104,7 @@ def test_bench_without_launcher_refuses_more_ranks_than_gpus_over_rccl():
 def test_bench_self_launch_propagates_a_failing_rank():
     """A rank that exits non-zero makes the launcher-less bench exit non-zero, and the surviving rank (waiting in the rendezvous for
     its peer) is ended after the grace period instead of hanging the run."""
-    env = dict(os.environ, KZG_BENCH_LOG_N="12", KZG_BENCH_BACKEND="gloo", KZG_BENCH_RANK_GRACE_S="5", KZG_BENCH_FAIL_RANK="1")
+    env = dict(os.environ, KZG_BENCH_LOG_N="12", KZG_BENCH_BACKEND="gloo", KZG_BENCH_RANK_GRACE_S="2", KZG_BENCH_FAIL_RANK="1")
     for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(key, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-secondary"],

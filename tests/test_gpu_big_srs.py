@@ -114,6 +114,6 @@ def test_randomised_soak_of_the_srs_msm_entry_points():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SOAK_SECONDS="6", SOAK_SEED="20260102", SOAK_SRS_LOG="18")
+    env = dict(os.environ, SOAK_SECONDS="4", SOAK_SEED="20260102", SOAK_SRS_LOG="18")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_msm.py")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-400:] + r.stderr[-400:]

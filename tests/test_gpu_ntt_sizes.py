@@ -148,10 +148,10 @@ def test_commit_and_proofs_on_k9_transform_sizes(k, srs19, log_n):
 
 
 def test_randomised_soak_of_commit_and_proof():
-    """tools/soak_proof.py for ten seconds with a fixed seed: random domain sizes 2^0 .. 2^14 (2^9 among them), dense / sparse /
+    """tools/soak_proof.py for four seconds with a fixed seed: random domain sizes 2^0 .. 2^14 (2^9 among them), dense / sparse /
     few-valued evaluations, z on and off the domain, every result against big-integer arithmetic."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SOAK_SECONDS="10", SOAK_SEED="20261004")
+    env = dict(os.environ, SOAK_SECONDS="4", SOAK_SEED="20261004")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_proof.py")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-400:] + r.stderr[-400:]
 
@@ -163,7 +163,7 @@ import numpy as np
 import oracle as orc
 import rust_kzg_bn254_amd as k
 k.load(); ctx = k.default_context(); lib = k._lib.load()
-for log_n in list(range(0, 22)) + [24]:
+for log_n in range(0, 23):
     n = 1 << log_n
     rng = np.random.default_rng(4000 + log_n)
     a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1)
@@ -179,7 +179,7 @@ print("tile %%s ok" %% os.environ["KZG_NTT_TILE_LOG"])
 @pytest.mark.parametrize("tile_log", [10, 11])
 def test_both_ntt_tile_sizes_at_every_transform_size(tile_log):
     """The pass kernel exists for tiles of 1 024 and of 2 048 elements and the library picks one by transform size (ntt.hip
-    ntt_small_tile_pays); here each is FORCED for every log n 0 .. 21 and 24 (KZG_NTT_TILE_LOG, read when the library loads: a child process
+    ntt_small_tile_pays); here each is FORCED for every log n 0 .. 22 (KZG_NTT_TILE_LOG, read when the library loads: a child process
     per tile size) and compared with the oracle in both directions -- sizes the default never runs on that tile included."""
     env = dict(os.environ, KZG_NTT_TILE_LOG=str(tile_log))
     res = subprocess.run([sys.executable, "-c", NTT_TILE_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=900, env=env)

@@ -1,6 +1,6 @@
 """Randomised soak of KZG::g1_ifft against the closed form on known-tau point sets: P_j = tau^(f + j) G  =>
 L_i = tau^f (tau^n - 1) / n * w^i / (tau - w^i) G.  Random n = 2^1 .. 2^12, random first power f, SRS with and without per-bit tables (the
-table paths need >= 2^15 points), the alternative paths of the library (KZG_G1FFT_* switches are read per call).  SOAK_SECONDS (default 60)."""
+table paths need >= 2^15 points), the library's g1_ifft (its KZG_G1FFT_* A/B switches went in round 6).  SOAK_SECONDS (default 60)."""
 import hashlib, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,8 +16,7 @@ print("seed", seed, flush=True)
 G = (1, 2)
 kzg = k.KZG.new(ctx)
 t_end = time.time() + float(os.environ.get("SOAK_SECONDS", "60"))
-SWITCHES = [{}, {"KZG_G1FFT_BITS": "0"}, {"KZG_G1FFT_BITS_FIRST": "0"}, {"KZG_G1FFT_QUADS": "0"}, {"KZG_G1FFT_RADIX_BITS": "0"}, {"KZG_G1FFT_RADIX_BITS": "2"},
-            {"KZG_G1FFT_BATCH": "512"}, {"KZG_G1FFT_PAIRS": "0"}, {"KZG_G1FFT_PAIRS": "1"}]
+SWITCHES = [{}]                                        # (round 6 removed the KZG_G1FFT_* switches with the rejected paths: the default path is what ships)
 cases = 0
 while time.time() < t_end:
     tau = rnd.randrange(2, R_)

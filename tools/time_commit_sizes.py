@@ -1,5 +1,5 @@
 """Latency of one commitment of n coefficients (device-resident scalars) against ONE loaded SRS of 2^SRS_LOG points, n = 2^11 .. 2^SRS_LOG:
-the table window bits c are fixed by the SRS size (or KZG_TABLE_C), so this shows what a given c costs the small blobs."""
+the table window bits c are fixed by the SRS size, so this shows what a given c costs the small blobs."""
 import ctypes as C, hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,4 +22,4 @@ for log_n in range(11, srs_log + 1):
     t0 = time.perf_counter()
     for _ in range(30): one()
     row.append("2^%d %.3f" % (log_n, (time.perf_counter() - t0) / 30 * 1e3))
-print("SRS 2^%d c=%s | ms per commitment: " % (srs_log, os.environ.get("KZG_TABLE_C", "auto")) + "  ".join(row), flush=True)
+print("SRS 2^%d c=%s | ms per commitment: " % (srs_log, "auto") + "  ".join(row), flush=True)
