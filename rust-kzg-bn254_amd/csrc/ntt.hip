@@ -200,6 +200,24 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
         }
         __syncthreads();
         KZG_NTT_STAMP(1);                                  // wait for the tile's words + unpack + LDS fill
+        // ---- this tile's inter-pass twiddle words (the STORE phase multiplies by them): with the 1 024-element tile they are issued now and are in
+        // flight during the butterfly stages; fetched at the store they are a dependent global load in front of every output product.  Same-box A/B
+        // (round 6, tools/time_ntt.py, ms per transform early / at the store): 2^12 0.0364 / 0.0386, 2^16 0.0425 / 0.0453, 2^18 0.0528 / 0.0551,
+        // 2^21 0.2646 / 0.2788, 2^22 0.5085 / 0.5323 -- but the 2 048-element tile LOSES (2^19 0.0784 / 0.0768, 2^20 0.1390 / 0.1333), so it keeps the late read.
+        constexpr bool TW_EARLY = TILE_LOG == NTT_TILE_LOG_SMALL;
+        uint4 twpre[NTT_EPT][2];
+        if (TW_EARLY && !last && next_tw) {
+#pragma unroll
+            for (int k = 0; k < NTT_EPT; ++k) {
+                const uint32_t t = tid + k * NTT_THREADS;
+                const uint32_t uu = t & (C - 1), j = t >> log_c;
+                const uint32_t u = tile_u0 + uu;
+                if (u < n_units) {
+                    const size_t idx = (size_t)u + ((size_t)j << (log_n - K));
+                    twpre[k][0] = next_tw[2 * idx]; twpre[k][1] = next_tw[2 * idx + 1];
+                } else { twpre[k][0] = make_uint4(0, 0, 0, 0); twpre[k][1] = make_uint4(0, 0, 0, 0); }
+            }
+        }
         // ---- prefetch the next tile's words: in flight during the butterfly stages ---------------
         {
             const uint32_t nt = tile + gridDim.x;
@@ -331,7 +349,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
                 const uint32_t E = (uint32_t)(((unsigned long long)pn * jn) << a.next_log_s) & (N - 1);
                 Fr w;
                 if (next_tw) {             // one coalesced 32-byte read (same access pattern as the data) instead of a two-level lookup + multiply
-                    const uint4 ta = next_tw[2 * idx], tb2 = next_tw[2 * idx + 1];
+                    const uint4 ta = TW_EARLY ? twpre[k][0] : next_tw[2 * idx], tb2 = TW_EARLY ? twpre[k][1] : next_tw[2 * idx + 1];
                     const uint32_t tw32[8] = {ta.x, ta.y, ta.z, ta.w, tb2.x, tb2.y, tb2.z, tb2.w};
                     fe_unpack(w, tw32);
                 } else if (E != 0) twiddle(w, tlo, lo_len, lo_bits, thi, hi_len, E);
