@@ -511,9 +511,16 @@ def main():
         gc.disable()
     barrier()
     spinup_steps = int(os.environ.get("KZG_BENCH_SPINUP_STEPS", str(min(48 * world, 384))))
+    # what a COLD service sees: the first 20 steps after the idle set-up, before the clock has settled -- reported, never `value`
+    cold_n = min(20, spinup_steps)
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    run_steps(cold_n, rot_ptrs, depth_used)
+    torch.cuda.synchronize()
+    cold_ms_per_step = (time.perf_counter() - t_cold) / max(1, cold_n) * 1e3
     clocks = ClockSampler(local_rank)                                  # engine clock under this very load, sampled in the UNTIMED spin-up only:
     with clocks:                                                        # inside a timed region the sysfs reads cost 4-10 % (1.15 -> 1.27 ms per step at 20 steps)
-        run_steps(spinup_steps, rot_ptrs, depth_used)
+        run_steps(spinup_steps - cold_n, rot_ptrs, depth_used)
     run_steps(args.warmup, rot_ptrs, depth_used)                        # the W untimed warm-up steps
     timed_results = []
     elapsed, result = timed(args.steps, rot_ptrs, depth_used, keep=timed_results)    # THE timed region: exactly --steps steps, step k on buffer k mod N_BUFFERS
@@ -859,6 +866,8 @@ def main():
                        "sharding": "by scalar index over %d GPU(s); all-gather of XYZZ partials + host fold" % world,
                        "host_gc_in_timed_region": os.environ.get("KZG_BENCH_GC", "0") != "0",
                        "pipeline_depth": sh.group_depth(depth_used, GROUP), "steps_per_launch": GROUP,
+                       "cold_start_ms_per_step": cold_ms_per_step,
+                       "cold_start_is": "the first %d steps after the idle set-up (engine clock not yet settled), this rank; untimed, reported only" % cold_n,
                        "untimed_before_warmup": "set-up: %d steps (workspaces), the first device-wide synchronisation, %d steps (clock ramp); then the %d warm-up steps" % (depth_used, spinup_steps, args.warmup),
                        "latency_ms_is": "one commitment at a time (depth 1, one exchange per step), %d steps" % side_steps,
                        "bit_exact_vs_oracle": exact,
