@@ -35,7 +35,7 @@ LOG_N = int(os.environ.get("KZG_BENCH_LOG_N", "20"))
 DEPTH = int(os.environ["KZG_BENCH_DEPTH"]) if os.environ.get("KZG_BENCH_DEPTH") else None    # MSMs in flight (default: sharding.py)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 BYTES_PER_PAIR = 96            # 64 B packed affine point + 32 B scalar, each read once
-PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
 MADS_PER_MIXED_ADD = 1467      # v_mad_i64_i32 per xyzz_madd (8 x 162 + 2 x 126 - 81 for the fused Y3)
 # The instruction stream of one mixed addition on the fast path of k_msm_accumulate's loop, by class: v_mad_i64_i32, v_mul_lo_u32, 64-bit
 # shifts, v_and_b32, every other instruction (32-bit VALU / SALU / loads), s_nop.  REGENERATED from the compiler's listing by
