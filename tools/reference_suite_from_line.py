@@ -40,7 +40,7 @@ for nn in (512, 1024, 2048):
     row("bench_g1_ifft (%d)" % nn, "", "g1_ifft_%d" % nn)
 row("bench_kzg_verify_*", "one `verify_proof` (host pairing check, O(1))", "verify_proof")
 print()
-print("Beyond the harnesses, same line: blob -> commitment + proof streamed %.2f ms per 32 MiB blob (8 jobs in flight; one call at a time %.1f ms); batch verification of 4 096 blobs "
+print("Beyond the harnesses, same line: blob -> commitment + proof streamed %.2f ms per 32 MiB blob (12 jobs in flight; one call at a time %.1f ms); batch verification of 4 096 blobs "
       "median %.2f ms, max %.2f over %d calls; 2^20-pair MSM step %.4f ms." % (sec["commit_and_prove_blob_streamed_ms"], sec["commit_and_prove_blob_from_host_bytes_ms"],
                                                                               sec["batch_verify_4096_end_to_end_stats"]["median"], sec["batch_verify_4096_end_to_end_stats"]["max"],
                                                                               sec["batch_verify_4096_end_to_end_stats"]["calls"], d["ms_per_step"]))
