@@ -2,7 +2,8 @@
  *   1. generate a small known-tau SRS on the device (a real host would kzg_srs_upload its own points),
  *   2. commit to a blob given as bytes (KZG::commit_blob),
  *   3. compute an opening proof at z (KZG::compute_proof) and check it with the verifier entry point against [tau]G2,
- *   4. stream four coefficient-form commitments through two asynchronous slots.
+ *   4. stream four coefficient-form commitments through two asynchronous slots,
+ *   5. batch-verify 16 blobs in one call, 6. recompute their commitments and blob proofs as a stream of jobs.
  * Build: gcc -O2 -Iinclude examples/commit_and_verify.c -Lrust-kzg-bn254_amd -lkzg_bn254_mi355x -Wl,-rpath,$PWD/rust-kzg-bn254_amd -o commit_and_verify */
 #include <stdint.h>
 #include <stdio.h>
@@ -87,6 +88,26 @@ int main(void) {
     CHECK(kzg_verify_blob_kzg_proof_batch(ctx, (const uint8_t* const*)blobs, lens, cs, ps, NB, g2_tau, &ok));
     printf("verify_blob_kzg_proof_batch of %d blobs: %s\n", NB, ok ? "batch verifies" : "BATCH REJECTED");
     if (!ok) return 6;
+    /* 6. the same commitments and proofs as a STREAM of jobs (kzg_commit_and_prove_blob_begin / _end): begin(b + 4) before end(b), the
+     *    transcript hashes of the jobs in flight run side by side on host threads of the library */
+    {
+        enum { DEPTH = 4 };
+        int same = 0;
+        for (int b = 0; b < NB + DEPTH; ++b) {
+            if (b >= DEPTH) {
+                const int j = b - DEPTH;
+                uint64_t c2[8], p2[8]; uint8_t ci = 0, pi = 0;
+                CHECK(kzg_commit_and_prove_blob_end(ctx, j % DEPTH, c2, &ci, p2, &pi, NULL, NULL));
+                same += memcmp(c2, cs + 8 * j, 64) == 0 && memcmp(p2, ps + 8 * j, 64) == 0;
+            }
+            if (b < NB) {
+                size_t np = 1; while (np < lens[b] / 32) np <<= 1;
+                CHECK(kzg_commit_and_prove_blob_begin(ctx, srs, blobs[b], lens[b], np, NULL, b % DEPTH));
+            }
+        }
+        printf("streamed commitments + blob proofs equal the one-call ones: %d / %d\n", same, NB);
+        if (same != NB) return 8;
+    }
     blobs[7][33] ^= 1;
     CHECK(kzg_verify_blob_kzg_proof_batch(ctx, (const uint8_t* const*)blobs, lens, cs, ps, NB, g2_tau, &ok));
     if (ok) { fprintf(stderr, "a corrupted blob verified\n"); return 7; }

@@ -19,6 +19,7 @@ def test_c_example_builds_and_runs(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
     assert "proof verifies" in res.stdout and "4 / 4" in res.stdout and "batch verifies" in res.stdout
+    assert "streamed commitments + blob proofs equal the one-call ones: 16 / 16" in res.stdout
 
 
 def test_multi_device_c_example(tmp_path):
