@@ -204,9 +204,10 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
         // flight during the butterfly stages; fetched at the store they are a dependent global load in front of every output product.  Same-box A/B
         // (round 6, tools/time_ntt.py, ms per transform early / at the store): 2^12 0.0364 / 0.0386, 2^16 0.0425 / 0.0453, 2^18 0.0528 / 0.0551,
         // 2^21 0.2646 / 0.2788, 2^22 0.5085 / 0.5323 -- but the 2 048-element tile LOSES (2^19 0.0784 / 0.0768, 2^20 0.1390 / 0.1333), so it keeps the late read.
+        // Reading them in front of radix-4 step 1 .. 4 of the 2 048-element tile instead: 0.1319-0.1336 ms at 2^20 against 0.1327 at the store -- noise.
         constexpr bool TW_EARLY = TILE_LOG == NTT_TILE_LOG_SMALL;
         uint4 twpre[NTT_EPT][2];
-        if (TW_EARLY && !last && next_tw) {
+        auto fetch_tw = [&]() {
 #pragma unroll
             for (int k = 0; k < NTT_EPT; ++k) {
                 const uint32_t t = tid + k * NTT_THREADS;
@@ -217,7 +218,8 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
                     twpre[k][0] = next_tw[2 * idx]; twpre[k][1] = next_tw[2 * idx + 1];
                 } else { twpre[k][0] = make_uint4(0, 0, 0, 0); twpre[k][1] = make_uint4(0, 0, 0, 0); }
             }
-        }
+        };
+        if (TW_EARLY && !last && next_tw) fetch_tw();
         // ---- prefetch the next tile's words: in flight during the butterfly stages ---------------
         {
             const uint32_t nt = tile + gridDim.x;
