@@ -60,6 +60,7 @@ struct BlobStream {
     BlobJob job[KZG_BLOB_JOBS];
     uint64_t next_seq = 1;
     int owner[KZG_NUM_SLOTS];          // job holding the slot, or -1
+    bool closing = false;              // kzg_ctx_destroy is under way: transcript threads no longer pump (nothing new may reach the streams)
     BlobStream() { for (int& o : owner) o = -1; }
 };
 
@@ -149,9 +150,16 @@ static void job_reset(BlobJob& j) {
     j.hash_done.store(0, std::memory_order_relaxed);
 }
 
+// kzg_ctx_destroy, BEFORE it drains the streams: from here on no transcript thread enqueues anything; they are joined (they read the callers' blobs),
+// then the context's streams are synchronised and the buffers go
 void blob_stream_release(kzg_ctx* ctx) {
     BlobStream* bs = ctx->blob_stream;
     if (!bs) return;
+    { std::lock_guard<std::mutex> lk(ctx->mu); bs->closing = true; }
+    for (BlobJob& j : bs->job) if (j.hasher.joinable()) j.hasher.join();
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto st : ctx->stream_x) if (st) (void)hipStreamSynchronize(st);
     for (BlobJob& j : bs->job) {
         if (j.hasher.joinable()) j.hasher.join();
         if (j.ev_evals) (void)hipEventDestroy(j.ev_evals);
@@ -208,7 +216,7 @@ int32_t kzg_commit_and_prove_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const 
             // the proof goes out now if the context is free (an end call waits outside the lock); try_lock, never lock: a caller may be joining
             // this thread while it holds the lock, and whoever holds it pumps on its way out anyway
             if (ctx->mu.try_lock()) {
-                if (ctx->blob_stream && hipSetDevice(ctx->device) == hipSuccess) pump(ctx, *ctx->blob_stream);
+                if (ctx->blob_stream && !ctx->blob_stream->closing && hipSetDevice(ctx->device) == hipSuccess) pump(ctx, *ctx->blob_stream);
                 ctx->mu.unlock();
             }
         });

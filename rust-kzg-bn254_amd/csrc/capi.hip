@@ -167,9 +167,10 @@ int32_t kzg_ctx_create(int32_t device_id, kzg_ctx** out) {
 void kzg_ctx_destroy(kzg_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    blob_stream_release(ctx);                       // first: joins the transcript threads of blob jobs still in flight (they may enqueue work until then)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto st : ctx->stream_x) if (st) (void)hipStreamSynchronize(st);
-    blob_stream_release(ctx);
+    if (ctx->lag_stream) (void)hipStreamSynchronize(ctx->lag_stream);
     msm_drop_slots(ctx);
     ctx->last_sorted = nullptr; ctx->last_sorted_stream = nullptr;
     ctx->msm.release();

@@ -188,3 +188,15 @@ def test_stream_2_20_known_tau(k):
         assert pyref.fr_from_mont(y) == yi
         assert pyref.point_from_wire(proof) == expect_point(proof_scalar(ftau, yi, zi))
     srs.close()
+
+
+def test_randomised_soak_of_the_blob_stream():
+    """tools/soak_blob_stream.py for four seconds with a fixed seed (profiles/r06_soak.txt holds the long runs): random lengths, 1 .. 16 jobs in flight, shuffled end
+    order, given commitments, cached bases, a slot held by the caller -- every job bit for bit against the one-call entries."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOAK_SECONDS="4", SOAK_SEED="20261005", SOAK_MAX_LOG="14")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_blob_stream.py")], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0 and "blob stream soak ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
