@@ -47,9 +47,9 @@ constexpr int NTT_TILE_LOG_BIG = 11, NTT_TILE_LOG_SMALL = 10;
 // measured per call, small / big tile (tools/archive/time_ntt_variants.py, KZG_NTT_TILE_LOG=10 / 11): 2^10 0.034 / 0.043, 2^14 0.045 / 0.058,
 // 2^17 0.055 / 0.067, 2^18 0.059 / 0.071, 2^19 0.086 / 0.082, 2^20 0.155 / 0.136, 2^21 0.280 / 0.297, 2^22 0.537 / 0.562, 2^23 1.195 /
 // 1.246, 2^24 2.46 / 2.52, 2^25 5.31 / 5.34, 2^26 12.1 / 11.1 ms
-inline bool ntt_small_tile_pays(int log_n) { return log_n <= 18 || (log_n >= 21 && log_n <= 24); }
+// round 6: 2^25 moved to the small tile (its passes are 9 + 8 + 8 bits: the slim instantiation below, three workgroups per CU: 5.24 -> 4.95 ms; 2^26 stays: 10.9 against 11.5)
+inline bool ntt_small_tile_pays(int log_n) { return log_n <= 18 || (log_n >= 21 && log_n <= 25); }
 constexpr int NTT_LO_BITS = 10;
-constexpr int NTT_TW = 1 << (NTT_KMAX - 1);        // per-tile twiddles w_R^t, t < R/2
 
 // ---- twiddle tables: planes[9][len] of w^(t * step), internal Montgomery form -----------------------
 __device__ __forceinline__ void fr_pow_root(Fr& out, int log_n, bool inverse, uint32_t e) {
@@ -131,7 +131,9 @@ __device__ __forceinline__ size_t ntt_in_index(const NttPassArgs& a, int tile_lo
     return (size_t)q + ((size_t)(R * p + j) << a.log_s);
 }
 
-template <int TILE_LOG>
+// KMAX_T: largest radix 2^K this instantiation takes -- its per-workgroup twiddle table holds 2^(KMAX_T - 1) entries (18 KB at 10, 2.3 KB at 7: the
+// three-pass plan of round 6, whose workgroups then fit three per CU)
+template <int TILE_LOG, int KMAX_T = NTT_KMAX>
 __global__ void __launch_bounds__(NttTile<TILE_LOG>::THREADS)
 k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, NttPassArgs a,
            const int32_t* __restrict__ tlo, uint32_t lo_len, int lo_bits, const int32_t* __restrict__ thi, uint32_t hi_len,
@@ -142,6 +144,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
            ) {
     constexpr int NTT_TILE_LOG = TILE_LOG, NTT_TILE = NttTile<TILE_LOG>::TILE, NTT_PL = NttTile<TILE_LOG>::PL, NTT_THREADS = NttTile<TILE_LOG>::THREADS;
     __shared__ int32_t lds[NL * NTT_PL];
+    constexpr int NTT_TW = 1 << (KMAX_T - 1);
     __shared__ int32_t twl[NL * NTT_TW];
     const int K = a.K, log_n = a.log_n;
     const uint32_t N = 1u << log_n, R = 1u << K;
@@ -205,7 +208,7 @@ k_ntt_pass(const uint4* __restrict__ in_words, uint4* __restrict__ out_words, Nt
         // (round 6, tools/time_ntt.py, ms per transform early / at the store): 2^12 0.0364 / 0.0386, 2^16 0.0425 / 0.0453, 2^18 0.0528 / 0.0551,
         // 2^21 0.2646 / 0.2788, 2^22 0.5085 / 0.5323 -- but the 2 048-element tile LOSES (2^19 0.0784 / 0.0768, 2^20 0.1390 / 0.1333), so it keeps the late read.
         // Reading them in front of radix-4 step 1 .. 4 of the 2 048-element tile instead: 0.1319-0.1336 ms at 2^20 against 0.1327 at the store -- noise.
-        constexpr bool TW_EARLY = TILE_LOG == NTT_TILE_LOG_SMALL;
+        constexpr bool TW_EARLY = TILE_LOG == NTT_TILE_LOG_SMALL && KMAX_T == NTT_KMAX;    // (the three-pass instantiation keeps 145 VGPRs: three waves per SIMD)
         uint4 twpre[NTT_EPT][2];
         auto fetch_tw = [&]() {
 #pragma unroll
@@ -485,7 +488,9 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
     if (rc != KZG_OK) return rc;
     int lo_bits = log_n < NTT_LO_BITS ? log_n : NTT_LO_BITS;
 
-    const int P = (log_n + NTT_KMAX - 1) / NTT_KMAX;
+    int P = (log_n + NTT_KMAX - 1) / NTT_KMAX;
+    // (2^20 as THREE passes of 7 + 7 + 6 bits on slim workgroups: 0.1305 / 0.1322 ms against 0.1333 for 10 + 10 -- 1.5 % for 60 % more HBM traffic: not taken;
+    //  2^15 .. 2^19 lose 2 .. 13 % that way)
     int Ks[4];
     for (int pi = 0; pi < P; ++pi) Ks[pi] = log_n / P + (pi < log_n % P ? 1 : 0);
     // buffers: data -> A -> (B ->) data; a single pass works in place (one tile holds the whole transform)
@@ -495,7 +500,15 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const int tile_env = opts().ntt_tile_log;                       // KZG_NTT_TILE_LOG = 10 / 11: one tile size at every transform size (tests cover both kernels everywhere)
+    int kmax = 0;
+    for (int pi = 0; pi < P; ++pi) kmax = std::max(kmax, log_n / P + (pi < log_n % P ? 1 : 0));
+    // Round 6: the radix bits of the widest pass decide the per-workgroup twiddle table.  With K <= 9 a 1 024-element workgroup needs 41.5 / 43.8 / 48.4 KB of LDS
+    // instead of 57.6, THREE fit a CU and at 145 VGPRs run three waves per SIMD -- the instantiations k_ntt_pass<10, 7 / 8 / 9>; fill and drain of one tile then
+    // overlap the butterfly stages of two others.  Same-box A/B against the KMAX = 10 instantiation (two per CU, early twiddle read), ms per transform
+    // (tools/time_ntt.py): 2^8 0.0267 -> 0.0254, 2^12 0.0385 -> 0.0372, 2^16 0.0450 -> 0.0430, 2^18 0.0552 -> 0.0531, 2^21 0.2723 -> 0.2423, 2^22 0.5213 -> 0.4880,
+    // 2^23 1.168 -> 1.082, 2^24 2.430 -> 2.268, 2^25 5.24 (2 048-element tile) -> 4.95.  2^10, 2^19, 2^20 and 2^26 .. 2^30 have a 10-bit pass and stay as they were.
     const bool small_tile = tile_env == NTT_TILE_LOG_SMALL || (tile_env != NTT_TILE_LOG_BIG && ntt_small_tile_pays(log_n));
+    const int slim = small_tile && kmax <= 9 ? std::max(kmax, 7) : 0;
     const int tile_log = small_tile ? NTT_TILE_LOG_SMALL : NTT_TILE_LOG_BIG;
     int log_ncur = 0;
     bool scale_folded = false;      // the inverse transform's 1 / n went into the twiddle array of the last pass boundary
@@ -515,7 +528,7 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
         const uint4* src = pi == 0 ? reinterpret_cast<const uint4*>(d_data) : bufs[(pi - 1) & 1];
         uint4* dst = last ? reinterpret_cast<uint4*>(d_data) : bufs[pi & 1];
         // big tile: one workgroup per CU (97 KB of LDS); small tile: two (58 KB each); a workgroup walks its tiles with the next one's words prefetched
-        const uint32_t grid = std::min<uint32_t>(a.n_tiles, (uint32_t)cus * (small_tile ? 2u : 1u));
+        const uint32_t grid = std::min<uint32_t>(a.n_tiles, (uint32_t)cus * (slim ? 3u : small_tile ? 2u : 1u));
         const uint4* next_tw = nullptr;
         if (!last && log_n <= NTT_FULL_TW_MAX_LOG) {
             const bool fold = inverse && pi == P - 2;          // the boundary in front of the last pass carries the scaling
@@ -532,7 +545,13 @@ int32_t ntt_run(kzg_ctx* ctx, void* d_data, size_t n, bool inverse, hipStream_t 
         else
             hipLaunchKernelGGL(k_ntt_pass<NTT_TILE_LOG_BIG>, dim3(grid), dim3(NttTile<NTT_TILE_LOG_BIG>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw, d_stamps + (size_t)pi * 1024 * 8);
 #else
-        if (small_tile)
+        if (slim == 7)
+            hipLaunchKernelGGL((k_ntt_pass<NTT_TILE_LOG_SMALL, 7>), dim3(grid), dim3(NttTile<NTT_TILE_LOG_SMALL>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
+        else if (slim == 8)
+            hipLaunchKernelGGL((k_ntt_pass<NTT_TILE_LOG_SMALL, 8>), dim3(grid), dim3(NttTile<NTT_TILE_LOG_SMALL>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
+        else if (slim == 9)
+            hipLaunchKernelGGL((k_ntt_pass<NTT_TILE_LOG_SMALL, 9>), dim3(grid), dim3(NttTile<NTT_TILE_LOG_SMALL>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
+        else if (small_tile)
             hipLaunchKernelGGL(k_ntt_pass<NTT_TILE_LOG_SMALL>, dim3(grid), dim3(NttTile<NTT_TILE_LOG_SMALL>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
         else
             hipLaunchKernelGGL(k_ntt_pass<NTT_TILE_LOG_BIG>, dim3(grid), dim3(NttTile<NTT_TILE_LOG_BIG>::THREADS), 0, st, src, dst, a, tb.lo, tb.lo_len, lo_bits, tb.hi, tb.hi_len, next_tw);
