@@ -3,6 +3,7 @@
 #include "host_curve.h"
 #include "host_pairing.h"
 #include "host_sha256.h"
+#include "host_transcript.h"
 #include "host_lagrange.h"
 
 #include <algorithm>
@@ -1303,7 +1304,6 @@ int32_t kzg_compute_proof_end(kzg_ctx* ctx, int32_t slot, uint64_t out_xy_mont[8
 
 // ---- Fiat-Shamir challenge and blob proofs (helpers.rs:411-472, kzg.rs:288-309) --------------------------------------------
 namespace {
-const char FS_DOMAIN[] = "EIGENDA_FSBLOBVERIFY_V1_";          // primitives/src/consts.rs:8 (24 bytes)
 const uint64_t FR_R2_WORDS[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};   // 2^512 mod r
 }  // namespace
 }  // extern "C"
@@ -1313,40 +1313,8 @@ namespace kzg {   // (shared with blobstream.hip)
 // 32-byte big-endian chunk of the blob reduced mod r (helpers.rs:40-57 -> :80-119), zero elements up to the next power of two.
 // Canonical chunks (the normal case) are hashed straight from the caller's buffer.
 void challenge_absorb_prefix(kzg_host::Sha256& sh, const uint8_t* blob, size_t len, size_t n_padded) {
-    using namespace kzg_host;
-    sha256_update(sh, reinterpret_cast<const uint8_t*>(FS_DOMAIN), 24);
-    uint8_t nb[8];
-    for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)((uint64_t)n_padded >> (8 * (7 - i)));
-    sha256_update(sh, nb, 8);
-    const size_t n_full = len / 32;
-    uint8_t r_be[32];
-    for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) r_be[8 * i + b] = (uint8_t)(FR_MODULUS_WORDS[3 - i] >> (8 * (7 - b)));
-    auto reduce_and_absorb = [&](const uint8_t chunk[32]) {
-        uint64_t w[4];
-        for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int b = 0; b < 8; ++b) v = (v << 8) | chunk[8 * (3 - i) + b]; w[i] = v; }
-        while (fr_geq_r(w)) fr_sub_r(w);                                            // value < 2^256 < 6 r
-        uint8_t out[32];
-        for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) out[8 * i + b] = (uint8_t)(w[3 - i] >> (8 * (7 - b)));
-        sha256_update(sh, out, 32);
-    };
-    size_t run = 0;                                                                  // first chunk of the pending canonical run
-    for (size_t i = 0; i < n_full; ++i) {
-        if (memcmp(blob + 32 * i, r_be, 32) >= 0) {                                  // chunk >= r: flush the run, reduce this one
-            if (i > run) sha256_update(sh, blob + 32 * run, 32 * (i - run));
-            reduce_and_absorb(blob + 32 * i);
-            run = i + 1;
-        }
-    }
-    if (n_full > run) sha256_update(sh, blob + 32 * run, 32 * (n_full - run));
-    size_t done = n_full;
-    if (len % 32) {                                                                  // ragged tail: right-padded with zeros (helpers.rs:48-52)
-        uint8_t chunk[32] = {0};
-        memcpy(chunk, blob + 32 * n_full, len % 32);
-        reduce_and_absorb(chunk);
-        ++done;
-    }
-    static const uint8_t zeros[4096] = {0};
-    for (size_t left = (n_padded - done) * 32; left;) { size_t t = left < sizeof zeros ? left : sizeof zeros; sha256_update(sh, zeros, t); left -= t; }
+    kzg_host::TranscriptPrefix gen(blob, len, n_padded);                             // host_transcript.h
+    kzg_host::sha256_absorb(sh, gen);
 }
 // ark-serialize compressed G1Affine (helpers.rs:456-459): x little-endian, bit 7 of the last byte = y is the larger root, bit 6 = infinity
 void g1_serialize_compressed_ark(const kzg_host::G1& p, uint8_t out[32]) {
@@ -1703,9 +1671,27 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
         std::vector<hipEvent_t> chunk_ev(trace_chunks ? chunk_lo.size() : 0);
         hipEvent_t ev0 = nullptr;
         if (trace_chunks) { for (auto& e : chunk_ev) (void)hipEventCreate(&e); (void)hipEventCreate(&ev0); (void)hipEventRecord(ev0, ctx->stream); }
-        parallel_for(nb, [&](size_t k) {
-            const size_t i = g0 + k;
-            auto done = [&] {
+        // Pool jobs: PAIRS of blobs of one upload chunk with similar transcript lengths (sorted inside the chunk), so that the two SHA-256 streams of a
+        // job run interleaved in one thread to the end (host_transcript.h: 1.5 x the single-stream rate); chunks stay in index order, so they still
+        // complete -- and go up -- roughly in order.  A blob that is not hashed (bad status, no commitments) rides along as a job of its own.
+        std::vector<std::pair<uint32_t, uint32_t>> jobs;                 // blob indices relative to g0; second = UINT32_MAX: a single
+        jobs.reserve(nb / 2 + chunk_lo.size() + 1);
+        {
+            std::vector<uint32_t> order;
+            for (size_t c = 0; c < chunk_lo.size(); ++c) {
+                order.clear();
+                for (size_t k = chunk_lo[c]; k < chunk_hi[c]; ++k) order.push_back((uint32_t)k);
+                std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                    const size_t lx = lens[g0 + x], ly = lens[g0 + y];
+                    return lx != ly ? lx > ly : x < y;
+                });
+                for (size_t q = 0; q < order.size(); q += 2)
+                    jobs.emplace_back(order[q], q + 1 < order.size() && commitments ? order[q + 1] : UINT32_MAX);
+                if (!commitments) for (size_t q = 1; q < order.size(); q += 2) jobs.emplace_back(order[q], UINT32_MAX);
+            }
+        }
+        parallel_for(jobs.size(), [&](size_t jdx) {
+            auto done = [&](size_t k) {
                 const size_t c = chunk_of[k];
                 if (left[c].fetch_sub(1, std::memory_order_acq_rel) == 1) {
                     const auto e0 = std::chrono::steady_clock::now();
@@ -1718,28 +1704,49 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
                     }
                 }
             };
-            if (status[i] != KZG_OK) { done(); return; }
-            G1 c;
-            if (commitments) {
-                c = g1_from_wire(commitments + 8 * i);
-                if (!validated && !g1_on_curve(c)) { status[i] = KZG_ERR_G1_NOT_ON_CURVE; done(); return; }
+            // per blob: guards in the reference's order, packing; returns the bytes to hash (nullptr: nothing to hash for this blob)
+            auto prepare = [&](size_t k, G1& c) -> const uint8_t* {
+                const size_t i = g0 + k;
+                if (status[i] != KZG_OK) return nullptr;
+                if (commitments) {
+                    c = g1_from_wire(commitments + 8 * i);
+                    if (!validated && !g1_on_curve(c)) { status[i] = KZG_ERR_G1_NOT_ON_CURVE; return nullptr; }
+                }
+                if (lens[i] == 0) { status[i] = KZG_ERR_ZERO_LENGTH; return nullptr; }
+                const uint8_t* src = blobs[i];
+                if (meta[i].log_n != 99u) {                       // pack (zero-filled to the 32-byte chunk) and hash the packed copy
+                    uint8_t* dst = stage + meta[i].off;
+                    const size_t span = (lens[i] + 31) / 32 * 32;
+                    memcpy(dst, blobs[i], lens[i]);
+                    if (span > lens[i]) memset(dst + lens[i], 0, span - lens[i]);
+                    src = dst;
+                }
+                return commitments ? src : nullptr;
+            };
+            const size_t ka = jobs[jdx].first, kb = jobs[jdx].second;
+            G1 ca, cb;
+            const uint8_t* pa = prepare(ka, ca);
+            const uint8_t* pb = kb != UINT32_MAX ? prepare(kb, cb) : nullptr;
+            if (pa && pb) {
+                Sha256 sa, sb;
+                sha256_init(sa); sha256_init(sb);
+                TranscriptPrefix ga(pa, lens[g0 + ka], blob_padded_len(lens[g0 + ka])), gb(pb, lens[g0 + kb], blob_padded_len(lens[g0 + kb]));
+                sha256_absorb_x2(sa, ga, sb, gb);
+                challenge_finish(sa, ca, zs + 4 * (g0 + ka));
+                challenge_finish(sb, cb, zs + 4 * (g0 + kb));
+            } else {
+                for (int w = 0; w < 2; ++w) {
+                    const uint8_t* p1 = w ? pb : pa;
+                    if (!p1) continue;
+                    const size_t k1 = w ? kb : ka;
+                    Sha256 sh;
+                    sha256_init(sh);
+                    challenge_absorb_prefix(sh, p1, lens[g0 + k1], blob_padded_len(lens[g0 + k1]));
+                    challenge_finish(sh, w ? cb : ca, zs + 4 * (g0 + k1));
+                }
             }
-            if (lens[i] == 0) { status[i] = KZG_ERR_ZERO_LENGTH; done(); return; }
-            const uint8_t* src = blobs[i];
-            if (meta[i].log_n != 99u) {                       // pack (zero-filled to the 32-byte chunk) and hash the packed copy
-                uint8_t* dst = stage + meta[i].off;
-                const size_t span = (lens[i] + 31) / 32 * 32;
-                memcpy(dst, blobs[i], lens[i]);
-                if (span > lens[i]) memset(dst + lens[i], 0, span - lens[i]);
-                src = dst;
-            }
-            if (commitments) {
-                Sha256 sh;
-                sha256_init(sh);
-                challenge_absorb_prefix(sh, src, lens[i], blob_padded_len(lens[i]));
-                challenge_finish(sh, c, zs + 4 * i);
-            }
-            done();
+            done(ka);
+            if (kb != UINT32_MAX) done(kb);
         });
         const auto t_hash_done = std::chrono::steady_clock::now();
         rc = vb_evaluate_finish(ctx, nb, ys + 4 * g0, fallback.data() + g0);         // (also drains the stream before any early return below)

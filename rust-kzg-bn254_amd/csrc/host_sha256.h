@@ -106,6 +106,56 @@ __attribute__((target("sha,sse4.1,ssse3"))) inline void sha256_blocks_shani(uint
     _mm_storeu_si128((__m128i*)&h[0], st0);
     _mm_storeu_si128((__m128i*)&h[4], st1);
 }
+// TWO independent messages, n_blocks each, interleaved in one instruction stream: a single stream is bound by the latency of its sha256rnds2
+// chain (two dependent instructions per four rounds), a second message fills the empty issue slots (tools/ubench/sha_x2.cpp measures the ratio).
+__attribute__((target("sha,sse4.1,ssse3"))) inline void sha256_blocks_shani_x2(uint32_t ha[8], const uint8_t* pa, uint32_t hb[8], const uint8_t* pb, size_t n_blocks) {
+    const __m128i shuf = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+    __m128i a0, a1, b0, b1;
+    {
+        __m128i tmp = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i*)&ha[0]), 0xB1), s1 = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i*)&ha[4]), 0x1B);
+        a0 = _mm_alignr_epi8(tmp, s1, 8); a1 = _mm_blend_epi16(s1, tmp, 0xF0);
+        tmp = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i*)&hb[0]), 0xB1); s1 = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i*)&hb[4]), 0x1B);
+        b0 = _mm_alignr_epi8(tmp, s1, 8); b1 = _mm_blend_epi16(s1, tmp, 0xF0);
+    }
+    for (; n_blocks; --n_blocks, pa += 64, pb += 64) {
+        const __m128i sa0 = a0, sa1 = a1, sb0 = b0, sb1 = b1;
+        __m128i x0 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 0)), shuf), x1 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 16)), shuf);
+        __m128i x2 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 32)), shuf), x3 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 48)), shuf);
+        __m128i y0 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 0)), shuf), y1 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 16)), shuf);
+        __m128i y2 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 32)), shuf), y3 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 48)), shuf);
+        __m128i ma, mb, kk;
+#define KZG_SHA_RND2(xi, yi, kidx)                                                         \
+        kk = _mm_loadu_si128((const __m128i*)&SHA256_K[kidx]);                             \
+        ma = _mm_add_epi32(xi, kk); mb = _mm_add_epi32(yi, kk);                            \
+        a1 = _mm_sha256rnds2_epu32(a1, a0, ma); b1 = _mm_sha256rnds2_epu32(b1, b0, mb);    \
+        ma = _mm_shuffle_epi32(ma, 0x0E); mb = _mm_shuffle_epi32(mb, 0x0E);                \
+        a0 = _mm_sha256rnds2_epu32(a0, a1, ma); b0 = _mm_sha256rnds2_epu32(b0, b1, mb);
+#define KZG_SHA_NEXT2(a, b, c, d) a = _mm_sha256msg2_epu32(_mm_add_epi32(_mm_sha256msg1_epu32(a, b), _mm_alignr_epi8(d, c, 4)), d);
+        KZG_SHA_RND2(x0, y0, 0) KZG_SHA_RND2(x1, y1, 4) KZG_SHA_RND2(x2, y2, 8) KZG_SHA_RND2(x3, y3, 12)
+        KZG_SHA_NEXT2(x0, x1, x2, x3) KZG_SHA_NEXT2(y0, y1, y2, y3) KZG_SHA_RND2(x0, y0, 16)
+        KZG_SHA_NEXT2(x1, x2, x3, x0) KZG_SHA_NEXT2(y1, y2, y3, y0) KZG_SHA_RND2(x1, y1, 20)
+        KZG_SHA_NEXT2(x2, x3, x0, x1) KZG_SHA_NEXT2(y2, y3, y0, y1) KZG_SHA_RND2(x2, y2, 24)
+        KZG_SHA_NEXT2(x3, x0, x1, x2) KZG_SHA_NEXT2(y3, y0, y1, y2) KZG_SHA_RND2(x3, y3, 28)
+        KZG_SHA_NEXT2(x0, x1, x2, x3) KZG_SHA_NEXT2(y0, y1, y2, y3) KZG_SHA_RND2(x0, y0, 32)
+        KZG_SHA_NEXT2(x1, x2, x3, x0) KZG_SHA_NEXT2(y1, y2, y3, y0) KZG_SHA_RND2(x1, y1, 36)
+        KZG_SHA_NEXT2(x2, x3, x0, x1) KZG_SHA_NEXT2(y2, y3, y0, y1) KZG_SHA_RND2(x2, y2, 40)
+        KZG_SHA_NEXT2(x3, x0, x1, x2) KZG_SHA_NEXT2(y3, y0, y1, y2) KZG_SHA_RND2(x3, y3, 44)
+        KZG_SHA_NEXT2(x0, x1, x2, x3) KZG_SHA_NEXT2(y0, y1, y2, y3) KZG_SHA_RND2(x0, y0, 48)
+        KZG_SHA_NEXT2(x1, x2, x3, x0) KZG_SHA_NEXT2(y1, y2, y3, y0) KZG_SHA_RND2(x1, y1, 52)
+        KZG_SHA_NEXT2(x2, x3, x0, x1) KZG_SHA_NEXT2(y2, y3, y0, y1) KZG_SHA_RND2(x2, y2, 56)
+        KZG_SHA_NEXT2(x3, x0, x1, x2) KZG_SHA_NEXT2(y3, y0, y1, y2) KZG_SHA_RND2(x3, y3, 60)
+#undef KZG_SHA_NEXT2
+#undef KZG_SHA_RND2
+        a0 = _mm_add_epi32(a0, sa0); a1 = _mm_add_epi32(a1, sa1);
+        b0 = _mm_add_epi32(b0, sb0); b1 = _mm_add_epi32(b1, sb1);
+    }
+    {
+        __m128i tmp = _mm_shuffle_epi32(a0, 0x1B), s1 = _mm_shuffle_epi32(a1, 0xB1);
+        _mm_storeu_si128((__m128i*)&ha[0], _mm_blend_epi16(tmp, s1, 0xF0)); _mm_storeu_si128((__m128i*)&ha[4], _mm_alignr_epi8(s1, tmp, 8));
+        tmp = _mm_shuffle_epi32(b0, 0x1B); s1 = _mm_shuffle_epi32(b1, 0xB1);
+        _mm_storeu_si128((__m128i*)&hb[0], _mm_blend_epi16(tmp, s1, 0xF0)); _mm_storeu_si128((__m128i*)&hb[4], _mm_alignr_epi8(s1, tmp, 8));
+    }
+}
 inline bool sha256_have_shani() {
     static const bool have = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
     return have;

@@ -81,3 +81,46 @@ def test_challenge_canonical_blob_sign_flag_identity_and_errors(lib):
     pt = pyref.ec_mul(9, (1, 2))
     rc, z = challenge(lib, edge, pyref.point_to_wire(pt))
     assert rc == 0 and pyref.fr_from_mont(z) == transcript_py(edge, pt)
+
+
+def test_transcript_prefix_two_streams_at_once(tmp_path):
+    """csrc/host_transcript.h (round 6): the prefix tag || u64be(n) || n x 32 B as a segment generator, and SHA-256 over TWO prefixes interleaved in one
+    thread (sha256rnds2 of two independent messages; what a pool job of the batch verifier does for a pair of blobs) -- every digest against hashlib over
+    the prefix built in plain Python, for pairs of very different and of equal lengths, canonical and non-canonical chunks, ragged tails."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(os.path.dirname(here), "rust-kzg-bn254_amd", "csrc")
+    so = str(tmp_path / "libtranscriptcheck.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + csrc, os.path.join(here, "hostcheck", "transcriptcheck.cpp"), "-o", so])
+    tc = C.CDLL(so)
+    u8p = C.POINTER(C.c_uint8)
+    tc.tc_prefix_digests.argtypes = [u8p, C.c_size_t, C.c_size_t, u8p, C.c_size_t, C.c_size_t, u8p, u8p, u8p]
+
+    def prefix_py(blob):
+        n_el = -(-len(blob) // 32)
+        n = pyref.next_pow2(n_el)
+        padded = blob + bytes(n_el * 32 - len(blob))
+        evals = [int.from_bytes(padded[32 * i:32 * i + 32], "big") % R_ for i in range(n_el)] + [0] * (n - n_el)
+        return n, hashlib.sha256(TAG + n.to_bytes(8, "big") + b"".join(v.to_bytes(32, "big") for v in evals)).digest()
+
+    rnd = random.Random(62)
+
+    def blob_of(length, canonical):
+        raw = bytearray(rnd.randrange(256) for _ in range(length))
+        if canonical:
+            for i in range(0, length, 32):
+                raw[i] &= 0x1F
+        elif length >= 64:
+            raw[32:64] = (R_ + 5).to_bytes(32, "big")                       # a chunk just above r between two runs
+        return bytes(raw)
+
+    lengths = [1, 31, 32, 33, 64, 65, 96, 127, 1000, 4096, 32 * 100 + 7, 32 * 1024, 50000]
+    for la in lengths:
+        for lb in (lengths[(lengths.index(la) * 5 + 3) % len(lengths)], la, 32 * 2048 + 1):
+            a, b = blob_of(la, rnd.random() < 0.5), blob_of(lb, rnd.random() < 0.5)
+            (na, da), (nb_, db) = prefix_py(a), prefix_py(b)
+            ba, bb = np.frombuffer(a, np.uint8).copy(), np.frombuffer(b, np.uint8).copy()
+            o1, o2, o3 = (np.zeros(32, np.uint8) for _ in range(3))
+            tc.tc_prefix_digests(ba.ctypes.data_as(u8p), la, na, bb.ctypes.data_as(u8p), lb, nb_, o1.ctypes.data_as(u8p), o2.ctypes.data_as(u8p), o3.ctypes.data_as(u8p))
+            assert o1.tobytes() == da and o2.tobytes() == da and o3.tobytes() == db, (la, lb)
