@@ -633,7 +633,7 @@ static int32_t msm_srs_locked(kzg_ctx* ctx, const kzg_srs* srs, size_t offset, c
         // thread sits in it) runs beside the kernels of the first half, and the first half's accumulate beside the second half's sort; the two
         // partial sums are added on the host.  Resident, two halves cost what the whole costs (tools/probe_split_lone.py: 2^19 0.872 against
         // 0.887 ms, 2^20 1.444 against 1.445) -- so the hidden part of the upload is the gain: 2^19 1.15 -> 1.07 ms, 2^20 2.00 -> 1.76.
-        // Below 2^19 pairs the second bucket set costs more than the hidden copy (2^18: 0.601 against 0.553 resident).  KZG_SPLIT_UPLOAD=0: off.
+        // Below 2^19 pairs the second bucket set costs more than the hidden copy (2^18: 0.601 against 0.553 resident).
         // share of the FIRST half (the smaller it is, the sooner the GPU starts and the more of the upload is hidden; too small and the second MSM runs alone):
         // measured from host buffers, 0.375 / 0.44 / 0.5 / 0.56: 2^19 1.116 / 1.070 / 1.084 / 1.111 ms (unsplit 1.148), 2^20 1.756 / 1.786 / 1.901 / 1.863 (unsplit 2.000)
         const double split_frac = n >= ((size_t)1 << 20) ? 0.375 : 0.44;

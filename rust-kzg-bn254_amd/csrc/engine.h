@@ -249,7 +249,7 @@ int32_t g1_ifft_run(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint64_t* out_xy
 int32_t g1_ifft_device(kzg_ctx* ctx, const kzg_srs* srs, size_t n, uint4* d_out, bool wire);
 
 int32_t set_error(kzg_ctx* ctx, hipError_t e, const char* where);
-// the context's high-priority auxiliary stream (lagrange.hip), or `fallback` with KZG_LAG_PRIO=0
+// the context's high-priority auxiliary stream (lagrange.hip)
 int32_t ctx_aux_stream(kzg_ctx* ctx, hipStream_t fallback, hipStream_t* out);
 // the points only, no window / per-bit tables (set-up paths that need the points once: kzg_multi_cache_lagrange)
 int32_t srs_upload_plain(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);

@@ -273,7 +273,7 @@ int32_t lag_begin(kzg_ctx* ctx, const kzg_srs* shard, size_t base, const void* e
     rc = ntt_get_tables(ctx, log_n, false, &tb);
     if (rc != KZG_OK) { lp = LagProof(); return rc; }
     const uint32_t blocks = (uint32_t)((len + LAG_BLOCK - 1) / LAG_BLOCK);
-    hipStream_t s1 = nullptr;                                    // phase 1's stream (high priority; KZG_LAG_PRIO=0: = st)
+    hipStream_t s1 = nullptr;                                    // phase 1's stream (high priority)
     bool commit_started = false;                                 // a failure after the commitment's MSM was enqueued collects it, so that no slot stays pending without an owner
     auto fail = [&](hipError_t e, const char* where) {
         lp = LagProof();

@@ -21,7 +21,7 @@ KZG_NAF_HD void naf_for_digits(uint32_t k[8], int w, F&& f) {
     // ONE loop with one exit and one conditional block (the callback), everything else selects.  The first form of this function
     // (a `continue` for the 32-bit skip beside the digit branch, which hipcc turned into nested loops) lost one digit per pair of
     // lanes in k_sort2_scalars when neighbouring lanes took different paths (2^253 - 1 beside 2^36 - 1: found by
-    // tests/test_gpu_parity.py::test_msm_adversarial_digit_patterns, located with KZG_DEBUG_SORT=1).
+    // tests/test_gpu_parity.py::test_msm_adversarial_digit_patterns, located with the host-side sort checker of rounds 3-5).
     const uint32_t mask = (1u << w) - 1u, half = 1u << (w - 1);
     uint32_t pos = 0, carry = 0;
     for (;;) {

@@ -985,7 +985,7 @@ int32_t vb_evaluate_enqueue(kzg_ctx* ctx, const uint8_t* packed, const void* met
 #define VB_TRY(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); if (up) (void)hipEventDestroy(up); return KZG_ERR_DEVICE; } } while (0)
     VB_TRY(hipSetDevice(ctx->device));
     PolySet& set = ctx->poly[0];
-    hipStream_t st = ctx->stream, st_copy = ctx->stream_x[0] ? ctx->stream_x[0] : ctx->stream;   // slot 1's stream exists since vb_evaluate_setup (KZG_SLOT_STREAMS=1: the slots share ctx->stream)
+    hipStream_t st = ctx->stream, st_copy = ctx->stream_x[0] ? ctx->stream_x[0] : ctx->stream;   // slot 1's stream exists since vb_evaluate_setup
     // the blob bytes go up on a second stream (slot 1's): k_vb_prep is one inversion deep (~0.2 ms on a few lone waves, whatever the
     // chunk size) and needs the challenges only, so it runs while the chunk's bytes are still on the bus; k_vb_eval waits for them
     NttTables tb;
