@@ -27,3 +27,32 @@ int tc_have_shani(void) {
 #endif
 }
 }
+
+#ifdef TRANSCRIPT_SELF_CHECK
+// self-check under the sanitizers (tests/test_sanitizers_host.py): the two-stream form against the one-stream form over pseudo-random pairs of lengths,
+// canonical and non-canonical chunks (buffers sized exactly: an over-read of a segment trips ASAN)
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+int main() {
+    uint64_t x = 88172645463325252ULL;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    int cases = 0;
+    for (int it = 0; it < 300; ++it) {
+        const size_t la = 1 + rnd() % (it % 7 == 0 ? 70000 : 3000), lb = it % 5 == 0 ? la : 1 + rnd() % 5000;
+        std::vector<uint8_t> a(la), b(lb);
+        for (auto& v : a) v = (uint8_t)rnd();
+        for (auto& v : b) v = (uint8_t)rnd();
+        if (it & 1) for (size_t i = 0; i < la; i += 32) a[i] &= 0x1F;
+        if (it & 2) for (size_t i = 0; i < lb; i += 32) b[i] &= 0x1F;
+        auto np = [](size_t len) { size_t e = (len + 31) / 32, p = 1; while (p < e) p <<= 1; return p; };
+        uint8_t a1[32], a2[32], b2[32], b1[32], t1[32], t2[32];
+        tc_prefix_digests(a.data(), la, np(la), b.data(), lb, np(lb), a1, a2, b2);
+        tc_prefix_digests(b.data(), lb, np(lb), a.data(), la, np(la), b1, t1, t2);
+        if (memcmp(a1, a2, 32) || memcmp(b1, b2, 32) || memcmp(t1, b1, 32) || memcmp(t2, a1, 32)) { printf("MISMATCH at case %d (%zu, %zu)\n", it, la, lb); return 1; }
+        ++cases;
+    }
+    printf("transcript self-check ok: %d pairs, SHA extensions %d\n", cases, tc_have_shani());
+    return 0;
+}
+#endif

@@ -33,3 +33,11 @@ def test_device_math_host_form_sha256_fold_and_oracle_under_asan_ubsan(tmp_path)
                            os.path.join(HERE, "hostcheck", "sanitize_main.cpp"), *objs, "-lpthread", "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=600)
     assert r.returncode == 0 and "sanitize ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_transcript_generator_and_two_stream_sha_under_asan_ubsan(tmp_path):
+    """csrc/host_transcript.h + host_sha256.h (round 6: the transcript prefix as segments, two SHA-256 streams interleaved): 300 pairs of exactly-sized buffers."""
+    exe = str(tmp_path / "transcriptcheck_san")
+    subprocess.check_call(["g++", "-std=c++17", *SAN, "-DTRANSCRIPT_SELF_CHECK", "-I" + CSRC, os.path.join(HERE, "hostcheck", "transcriptcheck.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=600)
+    assert r.returncode == 0 and "transcript self-check ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
