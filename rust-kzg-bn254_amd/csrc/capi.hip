@@ -881,7 +881,9 @@ static int32_t verify_batch_core(kzg_ctx* ctx, const uint64_t* commitments_xy_mo
     uint64_t sums[3 * 8];
     uint8_t infs[3];
     uint32_t off_curve = 0;
+    const auto t_c0 = std::chrono::steady_clock::now();
     int32_t rc = msm_g1_batch_impl(ctx, bases.data(), scalars.data(), n, 3, sums, infs, &off_curve);
+    const auto t_c1 = std::chrono::steady_clock::now();
     if (rc != KZG_OK) return rc;
     if (off_curve) return KZG_ERR_G1_NOT_ON_CURVE;
     if (!g2_ok) return KZG_ERR_G2_TAU_NOT_ON_CURVE;
@@ -889,7 +891,13 @@ static int32_t verify_batch_core(kzg_ctx* ctx, const uint64_t* commitments_xy_mo
     uint64_t s_int[4];
     fr_wire_to_canonical(s, s_int);
     G1 rhs = g1_add(g1_add(c_lincomb, g1_neg(g1_mul_generator(s_int))), proof_z_lincomb);   // batch.rs:249
+    const auto t_c2 = std::chrono::steady_clock::now();
     *out_ok = pairings_verify(proof_lincomb, g2_tau, rhs, g2_generator()) ? 1 : 0;         // batch.rs:253-254
+    if (opts().vb_trace) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "  verify_batch_core n=%zu: three MSMs (upload, kernels, host Horner) %.3f ms, [s]G + point sums %.3f ms, pairing check %.3f ms\n", n, ms(t_c0, t_c1), ms(t_c1, t_c2),
+                ms(t_c2, std::chrono::steady_clock::now()));
+    }
     return KZG_OK;
 }
 
@@ -1596,6 +1604,11 @@ private:
     bool stop_ = false;
 };
 void parallel_for(size_t n, const std::function<void(size_t)>& job) { HostPool::get().run(n, job); }
+}  // namespace
+}  // extern "C"
+namespace kzg { void host_parallel_for(size_t n, const std::function<void(size_t)>& job) { parallel_for(n, job); } }
+extern "C" {
+namespace {
 
 // The data-parallel front end of verify_blob_kzg_proof_batch: z_i = compute_challenge(blob_i, C_i), y_i = p_i(z_i) for all n blobs.
 // Transcripts: n independent SHA-256 streams on a pool of host threads (each also packs its blob into the pinned staging buffer);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -254,6 +255,8 @@ int32_t ctx_aux_stream(kzg_ctx* ctx, hipStream_t fallback, hipStream_t* out);
 // the points only, no window / per-bit tables (set-up paths that need the points once: kzg_multi_cache_lagrange)
 int32_t srs_upload_plain(kzg_ctx* ctx, const uint64_t* g1_xy_mont, size_t n_points, kzg_srs** out);
 
+// job(i) for i < n on the library's persistent host pool (capi.hip HostPool; the calling thread takes part)
+void host_parallel_for(size_t n, const std::function<void(size_t)>& job);
 // joins the transcript threads and frees the buffers of the blob stream (kzg_ctx_destroy)
 void blob_stream_release(kzg_ctx* ctx);
 

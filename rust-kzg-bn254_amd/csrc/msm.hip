@@ -583,8 +583,10 @@ static int32_t msm_finish(kzg_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const 
     const uint64_t* w = reinterpret_cast<const uint64_t*>(ws.pinned_out) + 16 * (size_t)pend.out_off;
     for (uint32_t i = 0; i < n_out; ++i) memcpy(&vals[i], w + 16 * i, 128);
     if (!p.tables) {
-        for (uint32_t b = 0; b < batch; ++b)
-            result[b] = kzg_host::horner_windows(vals + (size_t)b * p.W, p.W, p.c);   // sum_w 2^(c w) S_w: <= 255 doublings
+        // sum_w 2^(c w) S_w: <= 255 doublings + W additions per MSM on the host (~0.1 ms).  The MSMs of a batch -- the three linear combinations of batch
+        // verification -- take theirs side by side on the host pool (round 6: 0.31 -> 0.11 ms of the 1.7 ms verification core)
+        if (batch > 1) host_parallel_for(batch, [&](size_t b) { result[b] = kzg_host::horner_windows(vals + b * p.W, p.W, p.c); });
+        else result[0] = kzg_host::horner_windows(vals, p.W, p.c);
         return KZG_OK;
     }
     if (p.bitsum) {
