@@ -841,6 +841,18 @@ int32_t kzg_verify_proof(const uint64_t commitment_xy_mont[8], const uint64_t pr
 }  // extern "C"
 namespace { void parallel_for(size_t n, const std::function<void(size_t)>& job); }   // the host pool (defined with the batch verifier's front end below)
 extern "C" {
+// helpers::pairings_verify for the batch verifier: the two Miller loops on the persistent host pool (a parked worker wakes in ~20 us; host_pairing.h's own
+// form starts a std::thread per call), then the one final exponentiation.  Same Fq12 values, bit for bit.
+static bool pairings_verify_pooled(const kzg_host::G1& a1, const kzg_host::G2& a2, const kzg_host::G1& b1, const kzg_host::G2& b2) {
+    using namespace kzg_host;
+    G1 ps[2] = {a1, g1_neg(b1)};
+    G2 qs[2] = {a2, b2};
+    Fq12 f[2];
+    bool bad[2] = {false, false};
+    parallel_for(2, [&](size_t k) { f[k] = miller_ate_product(ps + k, qs + k, 1, &bad[k]); });
+    if (bad[0] || bad[1]) return false;
+    return fq12_is_one(final_exponentiation_x(mul(f[0], f[1])));
+}
 static int32_t verify_batch_core(kzg_ctx* ctx, const uint64_t* commitments_xy_mont, const uint64_t* zs_mont, const uint64_t* ys_mont,
                                  const uint64_t* proofs_xy_mont, const uint64_t* r_powers_mont, size_t n,
                                  const uint64_t* g2_tau_mont, int32_t* out_ok) {
@@ -892,7 +904,7 @@ static int32_t verify_batch_core(kzg_ctx* ctx, const uint64_t* commitments_xy_mo
     fr_wire_to_canonical(s, s_int);
     G1 rhs = g1_add(g1_add(c_lincomb, g1_neg(g1_mul_generator(s_int))), proof_z_lincomb);   // batch.rs:249
     const auto t_c2 = std::chrono::steady_clock::now();
-    *out_ok = pairings_verify(proof_lincomb, g2_tau, rhs, g2_generator()) ? 1 : 0;         // batch.rs:253-254
+    *out_ok = pairings_verify_pooled(proof_lincomb, g2_tau, rhs, g2_generator()) ? 1 : 0;  // batch.rs:253-254
     if (opts().vb_trace) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "  verify_batch_core n=%zu: three MSMs (upload, kernels, host Horner) %.3f ms, [s]G + point sums %.3f ms, pairing check %.3f ms\n", n, ms(t_c0, t_c1), ms(t_c1, t_c2),
