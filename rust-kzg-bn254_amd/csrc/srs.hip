@@ -152,8 +152,8 @@ k_srs_window_step(const uint4* __restrict__ prev, uint4* __restrict__ next, size
 // One level of the per-bit tables: next[i] = 2 * prev[i], affine in, affine out (y^2 = x^3 + 3: lambda = 3 x^2 / (2 y),
 // x3 = lambda^2 - 2 x, y3 = lambda (x - x3) - y; no point of BN254 G1 has y = 0, the group order is odd).  The inversions are
 // batched: a lane owns BITS_K points (a grid stride apart, so the loads of a wave stay contiguous), keeps the running products
-// of their denominators in LDS, inverts the last one (Fermat, 381 products) and walks back: 7 products per point + 381 / BITS_K
-// instead of the 400 of k_srs_window_step's one-inversion-per-point form.  255 levels of a 2^20-point SRS: ~0.1 s, once.
+// of their denominators in LDS, inverts the last one (division steps, fe_invert.h: ~63 products' worth of cheap instructions; a^(m-2) before round 4) and
+// walks back: 7 products per point + one inversion per BITS_K points instead of k_srs_window_step's one inversion per point.  255 levels of a 2^20-point SRS: ~0.1 s, once.
 constexpr int BITS_K = 7;                               // 7 x 9 limbs x 256 lanes x 4 B = 63 KiB of LDS
 __global__ void __launch_bounds__(256)
 k_srs_double_batch(const uint4* __restrict__ prev, uint4* __restrict__ next, size_t n) {
