@@ -47,6 +47,19 @@ N_SIMDS = 1024
 N_BUFFERS = 8                  # distinct resident scalar buffers the timed steps rotate through
 
 
+def cgroup_nr_throttled():
+    """nr_throttled of this process's cgroup (v2 /sys/fs/cgroup/cpu.stat, v1 under cpu/), None where there is none: how many CFS periods froze the process so far."""
+    for base in ("/sys/fs/cgroup", "/sys/fs/cgroup/cpu"):
+        try:
+            for ln in open(os.path.join(base, "cpu.stat")):
+                f = ln.split()
+                if len(f) == 2 and f[0] == "nr_throttled":
+                    return int(f[1])
+        except OSError:
+            pass
+    return None
+
+
 def host_pool_threads():
     """Threads of the library's host pool (capi.hip host_threads_cap): 48, the hardware threads, or the cgroup's CPU quota, whichever is least."""
     if os.environ.get("KZG_HOST_THREADS_MAX"):
@@ -926,11 +939,18 @@ def main():
                 few calls is owned by a single stall (0.214 ms at 512 coefficients against a 0.068 ms median)."""
                 for _ in range(warm):
                     fn()
-                ts = []
+                ts = []; thr = []
                 for _ in range(reps):
+                    th0 = cgroup_nr_throttled()
                     t = time.perf_counter(); fn(); ts.append((time.perf_counter() - t) * 1e3)
+                    thr.append(th0 is not None and cgroup_nr_throttled() > th0)
+                slowest_throttled = thr[max(range(len(ts)), key=ts.__getitem__)]
                 ts.sort()
-                return {"median": ts[len(ts) // 2], "mean": sum(ts) / len(ts), "p99": ts[min(len(ts) - 1, int(0.99 * len(ts)))], "min": ts[0], "max": ts[-1], "calls": len(ts)}
+                out = {"median": ts[len(ts) // 2], "mean": sum(ts) / len(ts), "p99": ts[min(len(ts) - 1, int(0.99 * len(ts)))], "min": ts[0], "max": ts[-1], "calls": len(ts)}
+                if cgroup_nr_throttled() is not None:
+                    # CFS bandwidth control (DESIGN.md 6.3): calls during which the cgroup's nr_throttled moved, and whether the slowest call was one of them
+                    out["calls_in_a_throttled_period"] = sum(thr); out["slowest_call_throttled"] = bool(slowest_throttled)
+                return out
             d_ntt = d_scalars.clone()
             ntt_ms = avg_ms(lambda: lib.kzg_fr_ntt_device(ctx.handle, C.c_void_p(d_ntt.data_ptr()), n, 0))
             intt_ms = avg_ms(lambda: lib.kzg_fr_ntt_device(ctx.handle, C.c_void_p(d_ntt.data_ptr()), n, 1))
