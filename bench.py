@@ -60,6 +60,20 @@ def cgroup_nr_throttled():
     return None
 
 
+def runqueue_wait_ns_by_thread():
+    """/proc/self/task/<tid>/schedstat, second field: ns each thread of this process has spent RUNNABLE BUT WAITING for a CPU.  {} where the kernel does not keep it."""
+    out = {}
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                out[tid] = int(open("/proc/self/task/%s/schedstat" % tid).read().split()[1])
+            except (OSError, ValueError, IndexError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
 def host_pool_threads():
     """Threads of the library's host pool (capi.hip host_threads_cap): 48, the hardware threads, or the cgroup's CPU quota, whichever is least."""
     if os.environ.get("KZG_HOST_THREADS_MAX"):
@@ -934,22 +948,32 @@ def main():
                     fn()
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t) / reps * 1e3
-            def stats_ms(fn, reps=50, warm=5):
+            def stats_ms(fn, reps=50, warm=5, sched=False):
                 """Per-call wall times of a SYNCHRONOUS library call: median (the figure reported), mean, p99, min, max.  A mean over a
                 few calls is owned by a single stall (0.214 ms at 512 coefficients against a 0.068 ms median)."""
                 for _ in range(warm):
                     fn()
-                ts = []; thr = []
+                ts = []; thr = []; rq = []
                 for _ in range(reps):
+                    w0 = runqueue_wait_ns_by_thread() if sched else {}
                     th0 = cgroup_nr_throttled()
                     t = time.perf_counter(); fn(); ts.append((time.perf_counter() - t) * 1e3)
                     thr.append(th0 is not None and cgroup_nr_throttled() > th0)
-                slowest_throttled = thr[max(range(len(ts)), key=ts.__getitem__)]
+                    if sched:
+                        w1 = runqueue_wait_ns_by_thread()
+                        rq.append(max([(w1[k_] - w0[k_]) / 1e6 for k_ in w1 if k_ in w0] or [float("nan")]))
+                slowest = max(range(len(ts)), key=ts.__getitem__)
+                slowest_throttled = thr[slowest]
+                slowest_rq = rq[slowest] if rq else None
+                rq_median = sorted(rq)[len(rq) // 2] if rq else None
                 ts.sort()
                 out = {"median": ts[len(ts) // 2], "mean": sum(ts) / len(ts), "p99": ts[min(len(ts) - 1, int(0.99 * len(ts)))], "min": ts[0], "max": ts[-1], "calls": len(ts)}
                 if cgroup_nr_throttled() is not None:
                     # CFS bandwidth control (DESIGN.md 6.3): calls during which the cgroup's nr_throttled moved, and whether the slowest call was one of them
                     out["calls_in_a_throttled_period"] = sum(thr); out["slowest_call_throttled"] = bool(slowest_throttled)
+                if slowest_rq is not None and slowest_rq == slowest_rq:
+                    # the longest any ONE thread of the process sat runnable without a CPU during the slowest call (and the median over the calls): the host's scheduler, not the library
+                    out["slowest_call_longest_runqueue_wait_ms"] = slowest_rq; out["median_call_longest_runqueue_wait_ms"] = rq_median
                 return out
             d_ntt = d_scalars.clone()
             ntt_ms = avg_ms(lambda: lib.kzg_fr_ntt_device(ctx.handle, C.c_void_p(d_ntt.data_ptr()), n, 0))
@@ -1100,7 +1124,7 @@ def main():
             cm5 = np.ascontiguousarray(np.stack([r[1] for r in sel5])); pf5 = np.ascontiguousarray(np.stack([r[2] for r in sel5]))
             ok5 = C.c_int32(0)
             e2e_stats = stats_ms(lambda: lib.kzg_verify_blob_kzg_proof_batch(ctx.handle, ptrs5, lens5, _lib.ptr(cm5), _lib.ptr(pf5), nb, _lib.ptr(tau_g2),
-                                                                             C.byref(ok5)), reps=40, warm=3)
+                                                                             C.byref(ok5)), reps=40, warm=3, sched=True)
             e2e_ms = e2e_stats["median"]
             assert ok5.value == 1, "the 4096-row batch did not verify"
             pf5[nb - 1] = pf5[0]

@@ -48,8 +48,22 @@ if os.environ.get("TRACE_GC", "1") == "0":
     import gc
     gc.disable()
 tracing = os.environ.get("KZG_VB_TRACE", "0") != "0"
-ts, thr, cpu = [], [], []
+def sched_of_threads():
+    """/proc/self/task/<tid>/schedstat of every thread: tid -> (ns on a CPU, ns RUNNABLE BUT WAITING for one, time slices); {} where the kernel does not keep it"""
+    out = {}
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                f = open("/proc/self/task/%s/schedstat" % tid).read().split()
+                out[tid] = (int(f[0]), int(f[1]), int(f[2]))
+            except (OSError, ValueError, IndexError):
+                pass
+    except OSError:
+        pass
+    return out
+ts, thr, cpu, waits = [], [], [], []
 for i in range(calls):
+    s0 = sched_of_threads()
     a = throttled()
     c0 = time.process_time()
     t0 = time.perf_counter()
@@ -61,9 +75,14 @@ for i in range(calls):
         print("  call %d seen from Python: %.3f ms" % (i, ts[-1]), file=sys.stderr, flush=True)
     b = throttled()
     thr.append((b[0] - a[0], (b[1] - a[1]) / 1e3))
+    s1 = sched_of_threads()
+    dw = [(s1[t][1] - s0[t][1]) / 1e6 for t in s1 if t in s0]
+    waits.append((max(dw) if dw else float("nan"), sum(dw), len(dw)))
     if gap_ms: time.sleep(gap_ms / 1e3)
 print("per call ms:", " ".join("%.2f" % t for t in ts), "| blob MiB", sum(len(r[0]) for r in sel5) / 2 ** 20, flush=True)
 print("cgroup throttling per call (periods, ms):", " ".join("%d/%.1f" % t for t in thr), flush=True)
+print("runqueue wait per call, ms (the longest any one thread of the process sat runnable without a CPU / summed over its %d threads):" % waits[-1][2],
+      " ".join("%.2f/%.2f" % (w[0], w[1]) for w in waits), flush=True)
 print("process CPU ms per call: median %.1f  mean %.1f (all threads of the process; quota = cpu.max)" % (sorted(cpu)[len(cpu) // 2], sum(cpu) / len(cpu)), flush=True)
 ts = ts[int(os.environ.get("TRACE_SKIP", "2")):]                     # the first calls size the staging buffers and start the pool
 srt = sorted(ts)
