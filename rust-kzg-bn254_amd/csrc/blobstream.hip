@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cstring>
 #include <new>
+#include <pthread.h>
 #include <thread>
 
 namespace kzg {
@@ -217,6 +218,7 @@ int32_t kzg_commit_and_prove_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const 
     } else
     try {
         j.hasher = std::thread([ctx, jp, blob_bytes, len, n] {
+            pthread_setname_np(pthread_self(), "kzg-hash");
             challenge_absorb_prefix(jp->sh, blob_bytes, len, n);
             jp->hash_done.store(1, std::memory_order_release);
             // the proof goes out now if the context is free (an end call waits outside the lock); try_lock, never lock: a caller may be joining

@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <functional>
 #include <new>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -1588,7 +1589,10 @@ private:
         cv_work_.notify_all();
         for (auto& t : threads_) t.join();
     }
-    void ensure(unsigned count) { while (threads_.size() < count) threads_.emplace_back([this] { loop(); }); }
+    void ensure(unsigned count) {
+        while (threads_.size() < count)
+            threads_.emplace_back([this] { pthread_setname_np(pthread_self(), "kzg-pool"); loop(); });     // visible in /proc/<pid>/task/*/comm (tools/trace_batch_verify.py)
+    }
     void work() { for (;;) { const size_t i = next_.fetch_add(1, std::memory_order_relaxed); if (i >= n_) return; (*job_)(i); } }
     void loop() {
         uint64_t seen = 0;

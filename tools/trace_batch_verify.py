@@ -61,7 +61,7 @@ def sched_of_threads():
     except OSError:
         pass
     return out
-ts, thr, cpu, waits = [], [], [], []
+ts, thr, cpu, waits, waiters = [], [], [], [], []
 for i in range(calls):
     s0 = sched_of_threads()
     a = throttled()
@@ -78,11 +78,19 @@ for i in range(calls):
     s1 = sched_of_threads()
     dw = [(s1[t][1] - s0[t][1]) / 1e6 for t in s1 if t in s0]
     waits.append((max(dw) if dw else float("nan"), sum(dw), len(dw)))
+    if dw and max(dw) > 1.0:                                          # who waited: the thread's name (the pool's are "kzg-pool", the caller is the process's main thread)
+        tid = max((t for t in s1 if t in s0), key=lambda t: s1[t][1] - s0[t][1])
+        try:
+            who = open("/proc/self/task/%s/comm" % tid).read().strip() + ("(main)" if int(tid) == os.getpid() else "")
+        except OSError:
+            who = "?"
+        waiters.append((i, who, max(dw), ts[-1]))
     if gap_ms: time.sleep(gap_ms / 1e3)
 print("per call ms:", " ".join("%.2f" % t for t in ts), "| blob MiB", sum(len(r[0]) for r in sel5) / 2 ** 20, flush=True)
 print("cgroup throttling per call (periods, ms):", " ".join("%d/%.1f" % t for t in thr), flush=True)
 print("runqueue wait per call, ms (the longest any one thread of the process sat runnable without a CPU / summed over its %d threads):" % waits[-1][2],
       " ".join("%.2f/%.2f" % (w[0], w[1]) for w in waits), flush=True)
+print("threads that waited > 1 ms for a CPU (call: thread name, its wait ms, the call's ms):", " ".join("%d:%s,%.1f,%.1f" % w for w in waiters) or "none", flush=True)
 print("process CPU ms per call: median %.1f  mean %.1f (all threads of the process; quota = cpu.max)" % (sorted(cpu)[len(cpu) // 2], sum(cpu) / len(cpu)), flush=True)
 ts = ts[int(os.environ.get("TRACE_SKIP", "2")):]                     # the first calls size the staging buffers and start the pool
 srt = sorted(ts)
