@@ -64,7 +64,13 @@ def test_bench_emits_the_contract_line():
     cpu_shapes = sec["reference_bench_shapes_cpu_port"]
     assert cpu_shapes["commit_8mb_ms"] > 0 and cpu_shapes["commit_16mb_ms"] > 0 and cpu_shapes["kzg_setup_%d_ms" % (1 << 13)] > 0
     assert sec["commit_and_prove_blob_streamed_ms"] > 0 and sorted(sec["commit_and_prove_blob_streamed_by_jobs_in_flight_ms"]) == ["12", "8"]
-    assert sec["batch_verify_4096_end_to_end_stats"]["calls"] >= 30
+    bv = sec["batch_verify_4096_end_to_end_stats"]
+    assert bv["calls"] >= 30
+    # where the kernel keeps them: the throttled periods of the process's cgroup and the slowest call's longest runqueue wait ride with the statistics
+    if "calls_in_a_throttled_period" in bv:
+        assert 0 <= bv["calls_in_a_throttled_period"] <= bv["calls"] and isinstance(bv["slowest_call_throttled"], bool)
+    if "slowest_call_longest_runqueue_wait_ms" in bv:
+        assert 0 <= bv["slowest_call_longest_runqueue_wait_ms"] <= bv["max"] + 2.0     # (the reads bracket the call: a little more than the call itself is possible)
     clk = d["gpu_clock_under_load"]                      # sysfs engine clock sampled in the untimed spin-up (None where sysfs does not show this GPU)
     assert clk is None or (200 < clk["sclk_mhz_min"] <= clk["sclk_mhz_mean"] <= clk["sclk_mhz_max"] < 4000 and clk["samples"] >= 1)
 
