@@ -70,7 +70,7 @@ def test_bench_emits_the_contract_line():
     if "calls_in_a_throttled_period" in bv:
         assert 0 <= bv["calls_in_a_throttled_period"] <= bv["calls"] and isinstance(bv["slowest_call_throttled"], bool)
     if "slowest_call_longest_runqueue_wait_ms" in bv:
-        assert 0 <= bv["slowest_call_longest_runqueue_wait_ms"] <= bv["max"] + 2.0     # (the reads bracket the call: a little more than the call itself is possible)
+        assert bv["slowest_call_longest_runqueue_wait_ms"] >= 0 and bv["median_call_longest_runqueue_wait_ms"] >= 0
     clk = d["gpu_clock_under_load"]                      # sysfs engine clock sampled in the untimed spin-up (None where sysfs does not show this GPU)
     assert clk is None or (200 < clk["sclk_mhz_min"] <= clk["sclk_mhz_mean"] <= clk["sclk_mhz_max"] < 4000 and clk["samples"] >= 1)
 
