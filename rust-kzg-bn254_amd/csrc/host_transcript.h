@@ -33,10 +33,12 @@ public:
                 case 0: stage_ = 1; s = ShaSeg{hdr_, 32}; return true;
                 case 1: {                                                                 // whole chunks: runs of canonical ones, reduced ones singly
                     if (pending_reduced_) { pending_reduced_ = false; s = ShaSeg{red_, 32}; return true; }
+                    // (a run is handed out after RUN_MAX chunks at the latest: the hash then reads them from the cache the scan left them in, not from memory again)
                     size_t i = run_;
-                    while (i < n_full_ && memcmp(blob_ + 32 * i, r_be_, 32) < 0) ++i;
-                    const size_t first = run_;
-                    if (i < n_full_) { reduce(blob_ + 32 * i); pending_reduced_ = true; run_ = i + 1; }
+                    const size_t first = run_, stop = n_full_ - first > RUN_MAX ? first + RUN_MAX : n_full_;
+                    while (i < stop && below_r(blob_ + 32 * i)) ++i;
+                    if (i < stop) { reduce(blob_ + 32 * i); pending_reduced_ = true; run_ = i + 1; }
+                    else if (i < n_full_) run_ = i;
                     else { run_ = n_full_; stage_ = 2; }
                     if (i > first) { s = ShaSeg{blob_ + 32 * first, 32 * (i - first)}; return true; }
                     continue;
@@ -72,6 +74,23 @@ public:
     static size_t blocks(size_t n_padded) { return (32 + 32 * n_padded) / 64 + 1; }
 
 private:
+#ifdef KZG_TRANSCRIPT_WHOLE_RUNS                                                             // measurement build: the scan as it was (whole runs, memcmp per chunk)
+    static constexpr size_t RUN_MAX = ~(size_t)0;
+#else
+    static constexpr size_t RUN_MAX = 512;                                                // chunks per run: 16 KiB
+#endif
+    // chunk < r as 32-byte big-endian numbers.  The top eight bytes decide unless they equal r's (2^-64 for random data): one load, one byte swap, one compare per
+    // chunk instead of a 32-byte memcmp call.
+    bool below_r(const uint8_t* c) const {
+#ifdef KZG_TRANSCRIPT_WHOLE_RUNS
+        return memcmp(c, r_be_, 32) < 0;
+#endif
+        uint64_t top;
+        memcpy(&top, c, 8);
+        top = __builtin_bswap64(top);
+        if (top != FR_MODULUS_WORDS[3]) return top < FR_MODULUS_WORDS[3];
+        return memcmp(c, r_be_, 32) < 0;
+    }
     void reduce(const uint8_t chunk[32]) {                                               // big-endian chunk mod r -> red_ (value < 2^256 < 6 r)
         uint64_t w[4];
         for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int b = 0; b < 8; ++b) v = (v << 8) | chunk[8 * (3 - i) + b]; w[i] = v; }

@@ -124,3 +124,20 @@ def test_transcript_prefix_two_streams_at_once(tmp_path):
             o1, o2, o3 = (np.zeros(32, np.uint8) for _ in range(3))
             tc.tc_prefix_digests(ba.ctypes.data_as(u8p), la, na, bb.ctypes.data_as(u8p), lb, nb_, o1.ctypes.data_as(u8p), o2.ctypes.data_as(u8p), o3.ctypes.data_as(u8p))
             assert o1.tobytes() == da and o2.tobytes() == da and o3.tobytes() == db, (la, lb)
+
+    # the run cap (512 chunks) and the top-word comparison of host_transcript.h: a chunk >= r AT, before and after every cap boundary of a long canonical run, and
+    # chunks whose top eight bytes EQUAL r's (decided by the lower 24 bytes: r - 1 is canonical, r and r + 1 are reduced)
+    base = bytearray(blob_of(32 * 1600 + 13, True))
+    specials = {510: R_ + 7, 511: R_, 512: R_ - 1, 513: (1 << 256) - 1, 1023: R_ + 1, 1024: R_, 1025: R_ - 1, 1535: R_ - 1, 1536: R_ + (1 << 190), 1599: R_}
+    for pos, v in specials.items():
+        base[32 * pos:32 * pos + 32] = v.to_bytes(32, "big")
+    variants = [bytes(base)]
+    for pos in (511, 512, 1024):                                              # one special chunk alone in an otherwise canonical blob
+        one = bytearray(blob_of(32 * 1600, True)); one[32 * pos:32 * pos + 32] = (R_ + 3).to_bytes(32, "big"); variants.append(bytes(one))
+    for a in variants:
+        b = blob_of(len(a) - 32 * 7, True)
+        (na, da), (nb_, db) = prefix_py(a), prefix_py(b)
+        ba, bb = np.frombuffer(a, np.uint8).copy(), np.frombuffer(b, np.uint8).copy()
+        o1, o2, o3 = (np.zeros(32, np.uint8) for _ in range(3))
+        tc.tc_prefix_digests(ba.ctypes.data_as(u8p), len(a), na, bb.ctypes.data_as(u8p), len(b), nb_, o1.ctypes.data_as(u8p), o2.ctypes.data_as(u8p), o3.ctypes.data_as(u8p))
+        assert o1.tobytes() == da and o2.tobytes() == da and o3.tobytes() == db
