@@ -457,7 +457,7 @@ int32_t kzg_commit_and_prove_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_
                                   uint64_t* out_z_mont, uint64_t* out_y_mont);
 /* The same as a STREAM (round 6): KZG::commit_blob + KZG::compute_blob_proof (kzg.rs:182-185, :288-309) of many blobs with up to
  * KZG_BLOB_JOBS of them in flight per context.  One call above is bound by ITS transcript -- SHA-256 over the whole blob is one
- * sequential stream, 16-17 ms per 32 MiB on a core with SHA extensions, against ~2.9 ms of GPU work -- but the transcripts of different
+ * sequential stream, 14-15 ms per 32 MiB on a core with SHA extensions, against ~2.9 ms of GPU work -- but the transcripts of different
  * blobs are independent:
  *   _begin(job)  starts the job's transcript prefix (helpers.rs:411-455: everything but the commitment) on a host thread of its own and
  *                enqueues upload, bytes -> Fr and the commitment on one of the context's slots; returns without waiting for either.

@@ -1,7 +1,7 @@
 // blobstream.hip — blob -> commitment + proof as a STREAM of jobs (prover/src/kzg.rs:182-185 + :288-309 on many blobs).
 //
 // One call of KZG::compute_blob_proof is bound by its Fiat-Shamir transcript: SHA-256 over tag || n || 32 n bytes || commitment
-// (primitives/src/helpers.rs:411-472) is ONE sequential hash stream, 16-17 ms for a 32 MiB blob on a core with SHA extensions, against
+// (primitives/src/helpers.rs:411-472) is ONE sequential hash stream, 14-15 ms for a 32 MiB blob on a core with SHA extensions, against
 // ~2.9 ms of GPU work for commitment + proof.  The hashes of DIFFERENT blobs are independent, so a job here is
 //     begin:  transcript prefix on a host thread of its own  |  upload, bytes -> Fr, commitment MSM on a slot of the context
 //     ...     (the caller begins further jobs: their hashes run side by side, the GPU works through commitments and proofs)
