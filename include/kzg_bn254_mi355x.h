@@ -466,7 +466,7 @@ int32_t kzg_commit_and_prove_blob(kzg_ctx* ctx, const kzg_srs* srs, const uint8_
  *   _end(job)    returns the job's commitment, proof, z and y (any out pointer may be NULL); waits for whatever is still missing.
  * EVERY begin / end call also moves every other job on as far as it can go without waiting (commitment collected -> 32 bytes appended
  * to its finished prefix -> z -> proof enqueued), so with `begin(k + d); end(k)` in a loop the hashes of d blobs run side by
- * side and the GPU works through commitments and proofs back to back: 3.0-3.2 ms per 32 MiB blob at d = 12 (3.4-3.7 at d = 8) instead of ~20.  Results are bit-identical to
+ * side and the GPU works through commitments and proofs back to back: 2.9-3.1 ms per 32 MiB blob at d = 12 (3.1 at d = 8) instead of 16-17.  Results are bit-identical to
  * kzg_commit_and_prove_blob / kzg_compute_blob_proof.  Same argument checks and statuses as those; blobs of up to 2^24 elements.
  * LIFETIME: blob_bytes is read by the transcript thread until the job's _end call returns.  SLOTS: the jobs take the context's
  * KZG_NUM_SLOTS slots phase by phase (a slot still held by another kzg_*_begin call of the caller is left alone; the synchronous calls,
