@@ -224,7 +224,9 @@ int32_t kzg_commit_and_prove_blob_begin(kzg_ctx* ctx, const kzg_srs* srs, const 
             // the proof goes out now if the context is free (an end call waits outside the lock); try_lock, never lock: a caller may be joining
             // this thread while it holds the lock, and whoever holds it pumps on its way out anyway
             if (ctx->mu.try_lock()) {
-                if (ctx->blob_stream && !ctx->blob_stream->closing && hipSetDevice(ctx->device) == hipSuccess) pump(ctx, *ctx->blob_stream);
+                try {
+                    if (ctx->blob_stream && !ctx->blob_stream->closing && hipSetDevice(ctx->device) == hipSuccess) pump(ctx, *ctx->blob_stream);
+                } catch (...) { }                                   // (an allocation failure here must not end the process: the next begin / end call pumps again and reports it)
                 ctx->mu.unlock();
             }
         });
